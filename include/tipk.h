@@ -1,0 +1,184 @@
+/* tipk.h -- C ABI of libtipk.so: the MI355X (gfx950) kernels behind the TIP hot path.
+ *
+ * The reference (NYXFLOWER/TIP) has no FFI/plugin layer for this path: its boundary is the Python
+ * `nn.Module` surface of `src/layers.py`, and all device arithmetic is delegated to torch, PyG 2.0.1
+ * and torch-scatter 2.0.8.  Each entry point below therefore names the reference call site whose
+ * implicit torch/PyG kernels it replaces (paths relative to the reference root; K-numbers are
+ * SURVEY.md section 2.1).  `tip_amd/_lib.py` binds every symbol with ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked host; fp32 values, int32 indices (the Python
+ *     side narrows the reference's int64 tensors once, when it builds a plan);
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream); calls only enqueue work: they
+ *     never allocate, free, synchronise or throw, so a caller may capture them into a hipGraph;
+ *   - return value: TIPK_OK, TIPK_EINVAL / TIPK_EUNSUPPORTED for bad arguments, or
+ *     -(1000 + hipError_t) when a HIP runtime call failed; `tipk_strerror` names it;
+ *   - workspaces (`partial`, slabs) are supplied by the caller; the library borrows pointers for the
+ *     duration of the call only;
+ *   - thread safety: re-entrant per (device, stream); one process per GPU for multi-GPU jobs.
+ */
+#ifndef TIPK_H
+#define TIPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIPK_ABI_VERSION 1
+
+#define TIPK_OK            0
+#define TIPK_EINVAL      (-1)
+#define TIPK_EUNSUPPORTED (-2)
+#define TIPK_EHIP_BASE   (-1000)      /* status = TIPK_EHIP_BASE - hipError_t */
+
+typedef void* tipk_stream_t;          /* hipStream_t */
+
+int         tipk_abi_version(void);
+const char* tipk_strerror(int status);
+/* host query: fills whatever is non-NULL; returns TIPK_OK or a HIP error (e.g. no device). */
+int         tipk_device_info(int device, int* n_cu, int* lds_bytes_per_cu, int* wavefront, char* arch, int arch_len);
+
+/* --------------------------------------------------------------------------------------------
+ * 1. Segmented gather-sum -- the one sparse-aggregation kernel of the path.
+ *
+ *      out[row(w)] (or partial[slot(w)]) = sum_{e in [begin_w, end_w)} edge_w[e] * table[row_id[e]]
+ *
+ * replaces PyG `MessagePassing.propagate` = `index_select` + `torch_scatter.scatter` at
+ *   GCNConv            src/layers.py:392,394   (K1: P-P aggregation, edge_w = gcn norm)
+ *   MyHierarchyConv    src/layers.py:229-233   (K2: P->D mean)
+ *   MyRGCNConv2/Conv   src/layers.py:159-180 / :78-86  (K5/K6: D-D aggregation over Y = att.XB)
+ * and their autograd backward (the transposed plan).
+ *
+ * A *plan* (built once per static graph by tip_amd/plan.py) sorts the edges by output row and cuts
+ * every row's edge list into work items of at most `chunk` edges:
+ *   items[w] = { begin, end, target, flags }     int32 x 4, items ordered by decreasing length
+ *     flags bit0 = 1: the row has one item; `target` is the output row and the epilogue
+ *                     (row_scale, bias, relu) is applied here;
+ *     flags bit0 = 0: the row is split; `target` is a slot of `partial` ([n_slots x d], dense);
+ *                     `tipk_gather_sum_finalize` adds the row's slots in order (deterministic).
+ * d = floats per row (d % 4 == 0: 4..256, or any d <= 64); ld_* = row strides in floats
+ * (multiples of 4 when d % 4 == 0; table/out/partial 16-byte aligned in that case).
+ */
+int tipk_gather_sum(const float* table, int64_t ld_table,
+                    const int32_t* row_id, const float* edge_w /* nullable */,
+                    const int32_t* items, int64_t n_items,
+                    float* out, int64_t ld_out,
+                    float* partial /* nullable when no item is split */,
+                    const float* row_scale /* nullable, per out row */,
+                    const float* bias /* nullable, [d] */, int relu,
+                    int d, tipk_stream_t stream);
+
+/* rows[m] = { out_row, first_slot, end_slot } int32 x 3: out[out_row] = epi(sum partial[slots]) */
+int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t n_rows,
+                             float* out, int64_t ld_out,
+                             const float* row_scale, const float* bias, int relu,
+                             int d, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+ *
+ *   C[z] = relu?( alpha * sum_{q<kbatch} A[z,q] (m x k) . B[z,q] (k x n) + C_in[z] ),  z < batch
+ *
+ * With ksplit > 1 the k range is cut into `ksplit` slabs: slab s holds the partial product over
+ * its k range at c + s*c_ss (c_in/relu must be unset); `tipk_sum_slabs` combines them in order.
+ *
+ * replaces the `torch.matmul`/`mm` calls of the path:
+ *   W = att @ basis.view(B,-1), x_j[s:e] @ w[et], x @ root   src/layers.py:163-172,184  (K4,K5,K7)
+ *   aggr_out[n_src:] @ weight                                 src/layers.py:239          (K2)
+ *   GCNConv.lin                                               src/layers.py:392,394      (K1)
+ * and their backward products.  Element (i,j) of A[z,q] is a[z*a_sz + q*a_sq + i*a_sm + j*a_sk]
+ * (strides in floats, so transposes and the basis-decomposition reshapes need no copies).
+ */
+typedef struct tipk_gemm_desc {
+    int64_t m, n, k;
+    int64_t batch, kbatch;
+    int64_t ksplit;                                /* >= 1: split K into this many slabs */
+    const float* a; int64_t a_sm, a_sk, a_sq, a_sz;
+    const float* b; int64_t b_sk, b_sn, b_sq, b_sz;
+    float*       c; int64_t c_sm, c_sz, c_ss;      /* C row-major (column stride 1); c_ss = slab stride */
+    const float* c_in; int64_t cin_sm, cin_sz;     /* nullable; may alias c */
+    float alpha;
+    int   relu;
+} tipk_gemm_desc;
+
+int tipk_gemm_f32(const tipk_gemm_desc* desc /* host */, tipk_stream_t stream);
+
+/* out[i] = alpha * sum_{s<n_slabs} in[s*slab_stride + i] (+ out[i] if accumulate), i < count.
+ * Ordered (deterministic) reduction of split-K slabs / per-workgroup partials. */
+int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count,
+                   float alpha, int accumulate, float* out, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).
+ */
+/* out[c, r] = in[r, c]  -- `lin(x)` for identity features is W^T (src/layers.py:392 with
+ * prepare.py:22-23), and dW = (dXlin)^T on the way back. */
+int tipk_transpose(const float* in, int64_t rows, int64_t cols, float* out, tipk_stream_t stream);
+
+/* out[r, c] (+)= in[r, c] * (row_mul ? row_mul[r] : 1) / (row_div ? row_div[r] : 1)
+ *               * (gate ? (gate[r, c] > 0) : 1)
+ * covers x/d_norm + cat/add (src/layers.py:534-539), 1/deg scaling of upstream gradients and the
+ * ReLU backward gate (src/layers.py:393,547). */
+int tipk_rows_affine(const float* in, int64_t ld_in,
+                     const float* row_mul, const float* row_div,
+                     const float* gate, int64_t ld_gate,
+                     float* out, int64_t ld_out,
+                     int64_t rows, int64_t cols, int accumulate, tipk_stream_t stream);
+
+/* out[c] = sum_r in[r, c]  (bias gradients of GCNConv).  `scratch` holds >= 256*cols floats. */
+int tipk_col_sum(const float* in, int64_t ld_in, int64_t rows, int64_t cols,
+                 float* scratch, float* out, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 4. DistMult decoder  score(u,v,r) = sigma( sum_k z[u,k] z[v,k] w[r,k] )
+ *    replaces MultiInnerProductDecoder.forward, src/layers.py:590-592 (K9) and its backward.
+ *    idx_bytes / et_bytes: 4 (int32) or 8 (int64, the reference's dtype) -- read in place.
+ */
+int tipk_distmult_fwd(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                      const void* idx_u, const void* idx_v, int idx_bytes,
+                      const void* edge_type, int et_bytes, int64_t n_triples,
+                      int sigmoid, float* score, tipk_stream_t stream);
+
+/* g_z [n_nodes x k] and g_w [n_rel x k] are ACCUMULATED into (caller zeroes them);
+ * `score` is the forward output when sigmoid != 0 (unused otherwise). */
+int tipk_distmult_bwd(const float* g_score, const float* score,
+                      const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                      const void* idx_u, const void* idx_v, int idx_bytes,
+                      const void* edge_type, int et_bytes, int64_t n_triples,
+                      int sigmoid, float* g_z, float* g_w, tipk_stream_t stream);
+
+/* Fused training objective of TIP.forward (src/layers.py:335-340, K9+K10): one pass over the
+ * positive triples and their negatives (same relation per position):
+ *   loss = -mean log(sigma(pos)+1e-13) - mean log(1-sigma(neg)+1e-13)
+ * loss_out[0] += loss (caller zeroes); if g_z/g_w are non-NULL they receive d loss / d z, d w
+ * (accumulated; caller zeroes), so the backward pass is a scale by the upstream scalar. */
+int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                       const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
+                       int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
+                       float* loss_out, float* g_z, float* g_w, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 5. Typed negative sampling on device -- replaces typed_negative_sampling / negative_sampling,
+ *    src/neg_sampling.py:5-26 (K11: host numpy + one D2H copy per relation).
+ *
+ * For every positive position e of relation r (rel_ptr[r] <= e < rel_ptr[r+1]) draw a pair
+ * uniformly from n_nodes^2 (with replacement, self pairs allowed, as np.random.choice does) and
+ * redraw while it equals a positive pair OF THE SAME RELATION.  Randomness: Philox4x32-10,
+ * counter = (e, attempt, 0, 0), key = (seed_lo, seed_hi); candidate = mulhi64(r0 | r1<<32, n^2)
+ * -- specified bit-exactly in oracle/philox_sampler.py.  `pos_key_sorted` holds u*n+v of each
+ * relation's positives sorted ascending within the relation (int64).  After 64 rejected attempts
+ * the 64th candidate is kept (probability < density^64).
+ */
+int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
+                                 int64_t n_rel, int64_t n_nodes, uint64_t seed,
+                                 void* out_u, void* out_v, int idx_bytes,
+                                 int64_t n_positions /* = rel_ptr[n_rel], host copy */,
+                                 tipk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIPK_H */

@@ -1,0 +1,242 @@
+"""-m gpu: the `tip_amd.layers` modules (reference `forward()` signatures) against the golden
+vectors recorded from the reference's own code, and against the oracle at BioSNAP scale."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import tip_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(got, want, rtol=2e-4, atol=None):
+    want = want.detach().to('cpu', torch.float64)
+    got = got.detach().to('cpu', torch.float64)
+    if atol is None:
+        atol = 2e-5 * max(1.0, float(want.abs().max()))
+    torch.testing.assert_close(got, want, rtol=rtol, atol=atol)
+
+
+def load_params(module, g, prefix=''):
+    sd = module.state_dict()
+    for k in sd:
+        sd[k] = g[prefix + k].clone()
+    module.load_state_dict(sd)                        # reference state_dict names load unchanged
+    return module.to(DEV)
+
+
+@pytest.mark.parametrize('name', ['rgcn_sym', 'rgcn_directed'])
+def test_rgcn_layers(name):
+    from tip_amd.layers import MyRGCNConv, MyRGCNConv2
+    g = load_golden(name)
+    nb, d_in, d_out = g['basis'].shape
+    r = g['att'].shape[0]
+    for cls in (MyRGCNConv2, MyRGCNConv):
+        m = load_params(cls(d_in, d_out, r, nb, after_relu=False), g)
+        x = g['x'].to(DEV).requires_grad_(True)
+        ei, et, rg = g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV)
+        out = m(x, ei, et, rg) if cls is MyRGCNConv2 else m(x, ei, et)
+        close(out, g['out'])
+        (out * g['upstream'].to(DEV)).sum().backward()
+        close(x.grad, g['grad_x'])
+        for k in ('basis', 'att', 'root'):
+            close(getattr(m, k).grad, g['grad.' + k])
+        out2 = m(x, ei, et, rg) if cls is MyRGCNConv2 else m(x, ei, et)     # cached plans, same bits
+        assert torch.equal(out, out2)
+
+
+def test_hierarchy_conv():
+    from tip_amd.layers import MyHierarchyConv
+    g = load_golden('hier_conv')
+    n_src = g['n_source']
+    m = load_params(MyHierarchyConv(16, 8, n_src, g['x'].shape[0] - n_src), g)
+    x = g['x'].to(DEV).requires_grad_(True)
+    out = m(x, g['dp_idx'].to(DEV), None)
+    close(out, g['out'])
+    (out * g['upstream'].to(DEV)).sum().backward()
+    close(x.grad, g['grad_x'])
+    close(m.weight.grad, g['grad.weight'])
+
+
+def test_pp_encoder_identity_sparse_dense_features():
+    from tip_amd.layers import PPEncoder
+    from tip_amd.utils import sparse_id
+    g = load_golden('pp_encoder')
+    n = g['n_prot']
+    m = load_params(PPEncoder(n), g)
+    out = m(sparse_id(n).to(DEV), g['pp_idx'].to(DEV))
+    close(out, g['out'])
+    (out * g['upstream'].to(DEV)).sum().backward()
+    for k in ('conv1.lin.weight', 'conv1.bias', 'conv2.lin.weight', 'conv2.bias'):
+        mod, attr = k.rsplit('.', 1)
+        close(getattr(m.get_submodule(mod), attr).grad, g['grad.' + k])
+    # a general sparse feature matrix (identity with shuffled storage + explicit values) and the
+    # dense path give the same numbers through the plan-based SpMM / GEMM
+    perm = torch.randperm(n)
+    sp = torch.sparse_coo_tensor(torch.stack([perm, perm]), torch.ones(n), (n, n)).to(DEV)
+    sp._tipk_identity = False
+    m2 = load_params(PPEncoder(n), g)
+    close(m2(sp, g['pp_idx'].to(DEV)), g['out'])
+    gd = load_golden('pp_encoder_dense')
+    m3 = load_params(PPEncoder(24), gd)
+    x = gd['x'].to(DEV).requires_grad_(True)
+    out3 = m3(x, gd['pp_idx'].to(DEV))
+    close(out3, gd['out'])
+    (out3 * gd['upstream'].to(DEV)).sum().backward()
+    close(x.grad, gd['grad_x'])
+    close(m3.conv1.lin.weight.grad, gd['grad.conv1.lin.weight'])
+
+
+def test_decoder_module_and_loss():
+    from tip_amd.layers import MultiInnerProductDecoder
+    g = load_golden('decoder')
+    m = load_params(MultiInnerProductDecoder(4, g['weight'].shape[0]), g)
+    ei, et = g['dd_idx'].to(DEV), g['dd_et'].to(DEV)
+    for sig in (True, False):
+        z = g['z'].to(DEV).requires_grad_(True)
+        m.weight.grad = None
+        s = m(z, ei, et, sigmoid=sig)
+        close(s, g['score_%d' % sig])
+        (s * g['upstream'].to(DEV)).sum().backward()
+        close(z.grad, g['grad_z_%d' % sig])
+        close(m.weight.grad, g['grad_weight_%d' % sig])
+    for fused in (True, False):
+        z = g['z'].to(DEV).requires_grad_(True)
+        m.weight.grad = None
+        neg = g['neg_idx'].to(DEV)
+        if fused:
+            loss = m.objective(z, ei, neg, et)
+        else:
+            loss = -torch.log(m(z, ei, et) + 1e-13).mean() - torch.log(1 - m(z, neg, et) + 1e-13).mean()
+        close(loss, g['loss'], rtol=2e-5)
+        (loss * 1.0).backward()
+        close(z.grad, g['loss_grad_z'], atol=1e-6)
+        close(m.weight.grad, g['loss_grad_weight'], atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['encoder_cat_small', 'encoder_add_small'])
+def test_fm_encoder_golden(name):
+    from tip_amd.layers import FMEncoder
+    from tip_amd.utils import sparse_id
+    g = load_golden(name)
+    mod = str(g['mod'])
+    cfg = {k[4:]: int(v) for k, v in g.items() if isinstance(k, str) and k.startswith('cfg.')}
+    enc = FMEncoder(DEV, g['n_drug'], g['n_rel'], g['n_prot'], g['n_prot'], g['n_drug'], mod=mod, **cfg)
+    enc = load_params(enc, g)
+    z = enc(sparse_id(g['n_drug']).to(DEV), g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV),
+            g['d_norm'].to(DEV), sparse_id(g['n_prot']).to(DEV), g['pp_idx'].to(DEV), g['dp_idx'].to(DEV), None)
+    close(z, g['z'])
+    (z * g['upstream'].to(DEV)).sum().backward()
+    for k, p in enc.named_parameters():
+        close(p.grad, g['grad.' + k])
+
+
+def test_tip_end_to_end_small():
+    """TIP(...) construction, forward() loss with the recorded negatives, backward, test()."""
+    from tip_amd.layers import TIP, Setting
+    g = load_golden('tip_add_small')
+    keys = ['dd_train_idx', 'dd_train_et', 'dd_train_range', 'dd_test_idx', 'dd_test_et', 'dd_test_range',
+            'pp_train_indices', 'dp_edge_index', 'dp_range_list', 'd_norm']
+    from tip_amd.utils import sparse_id
+    d = {k: g[k] for k in keys}
+    d.update(n_drug=g['n_drug'], n_prot=g['n_prot'], n_dd_et=g['n_dd_et'], n_drug_feat=g['n_drug'],
+             d_feat=sparse_id(g['n_drug']), p_feat=sparse_id(g['n_prot']))
+    st = Setting(sp_rate=0.9, lr=0.01, prot_drug_dim=8, n_embed=8, n_hid1=8, n_hid2=4, num_base=3)
+    for fused in (True, False):
+        model = TIP(st, torch.device(DEV), mod='add', data=d, fused_loss=fused)
+        assert model.embeddings.shape == (g['n_drug'], 4) and model.test_neg_index.shape == g['test_neg'].shape
+        sd = model.state_dict()
+        assert set(sd) == {k for k in g if isinstance(k, str) and (k.startswith('encoder.') or k.startswith('decoder.'))}
+        load_params(model, g)
+        loss = model(neg_index=g['train_neg'].to(DEV))
+        close(loss, g['loss'], rtol=2e-5)
+        close(model.embeddings, g['embeddings'])
+        loss.backward()
+        for k, p in model.named_parameters():
+            close(p.grad, g['grad.' + k], rtol=5e-4, atol=2e-6)
+        model.test_neg_index = g['test_neg'].to(DEV)
+        rec = model.test(print_output=False)
+        np.testing.assert_allclose(rec, g['record'].numpy(), rtol=1e-4, atol=1e-4)
+        # default path: negatives drawn on device, loss finite and close to the recorded one
+        assert abs(float(model()) - float(g['loss'])) < 0.5
+
+
+def test_biosnap_slice_against_reference_golden():
+    from tip_amd.data import build_data_dict, Data
+    from tip_amd.layers import FMEncoder
+    g = load_golden('biosnap_slice8')
+    dd = build_data_dict(max_relations=8)
+    p = O.init_params(dd['n_drug'], dd['n_prot'], 8, seed=g['param_seed'])
+    enc = FMEncoder(DEV, dd['n_drug'], 8, dd['n_prot'], dd['n_prot'], dd['n_drug'], prot_drug_dim=16, num_base=32,
+                    n_embed=48, n_hid1=32, n_hid2=16, mod='cat')
+    enc = load_params(enc, p)
+    d = Data.from_dict(dd).to(DEV)
+    z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices,
+            d.dp_edge_index, d.dp_range_list)
+    close(z, g['z'], rtol=1e-3)
+    (z * g['upstream'].to(DEV)).sum().backward()
+    for k, prm in enc.named_parameters():
+        if k == 'pp_encoder.conv1.lin.weight':
+            close(prm.grad[:, ::16], g['grad.' + k + '[:, ::16]'], rtol=2e-3, atol=1e-6)
+            close(prm.grad.sum(1), g['grad.' + k + '.rowsum'], rtol=2e-3, atol=1e-5)
+        else:
+            close(prm.grad, g['grad.' + k], rtol=2e-3, atol=1e-6)
+
+
+@pytest.fixture(scope='module')
+def biosnap_full():
+    from tip_amd.data import build_data_dict
+    return build_data_dict()
+
+
+@pytest.mark.parametrize('mod', ['cat', 'add'])
+def test_full_biosnap_encoder_vs_oracle(biosnap_full, mod):
+    """BASELINE configs 2 and 3 at full size: z and all parameter gradients vs the CPU oracle."""
+    from tip_amd.data import Data
+    from tip_amd.layers import FMEncoder
+    dd = biosnap_full
+    R = dd['n_dd_et']
+    dims = dict(prot_drug_dim=16, n_embed=48) if mod == 'cat' else dict(prot_drug_dim=64, n_embed=64)
+    p = O.init_params(dd['n_drug'], dd['n_prot'], R, mod=mod, seed=1111, **dims)
+    enc = FMEncoder(DEV, dd['n_drug'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], num_base=32, n_hid1=32,
+                    n_hid2=16, mod=mod, **dims)
+    enc = load_params(enc, p)
+    d = Data.from_dict(dd).to(DEV)
+    z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices,
+            d.dp_edge_index, d.dp_range_list)
+    torch.manual_seed(0)
+    up = torch.randn(dd['n_drug'], 16)
+    (z * up.to(DEV)).sum().backward()
+    zo, saved = O.fm_encoder_fwd(p, dd, mod)
+    go = O.fm_encoder_bwd(up, p, dd, saved, mod)
+    close(z, zo, rtol=1e-3)
+    for k, prm in enc.named_parameters():
+        close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+
+
+def test_full_biosnap_size_independent_properties(biosnap_full):
+    """Linearity and symmetry of the D-D aggregation at full size (no oracle needed):
+    rgcn(a x1 + b x2) = a rgcn(x1) + b rgcn(x2);  <A x, y> = <x, A^T y> via autograd."""
+    from tip_amd.layers import MyRGCNConv2
+    dd = biosnap_full
+    R, N = dd['n_dd_et'], dd['n_drug']
+    torch.manual_seed(1)
+    m = MyRGCNConv2(64, 32, R, 32, after_relu=False).to(DEV)
+    ei, et, rg = dd['dd_train_idx'].to(DEV), dd['dd_train_et'].to(DEV), dd['dd_train_range'].to(DEV)
+    x1, x2 = torch.randn(N, 64, device=DEV), torch.randn(N, 64, device=DEV)
+    with torch.no_grad():
+        lhs = m(0.3 * x1 - 1.7 * x2, ei, et, rg)
+        rhs = 0.3 * m(x1, ei, et, rg) - 1.7 * m(x2, ei, et, rg)
+    close(lhs, rhs, rtol=1e-3, atol=1e-4)
+    x = x1.clone().requires_grad_(True)
+    y = torch.randn(N, 32, device=DEV)
+    out = m(x, ei, et, rg)
+    (out * y).sum().backward()
+    # adjoint identity: <J x', y> == <x', J^T y> for a fresh direction x'
+    with torch.no_grad():
+        jx = m(x2, ei, et, rg)
+    a = float((jx.double() * y.double()).sum())
+    b = float((x2.double() * x.grad.double()).sum())
+    assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (a, b)

@@ -1,0 +1,174 @@
+"""CPU tests of the host side: plans, edge bookkeeping, metrics, data ingest, C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import tip_oracle as O
+from tip_amd import _lib, utils
+from tip_amd.data import build_data_dict, synthetic_data_dict, Data
+from tip_amd.plan import build_gather_plan, execute_plan_reference
+
+
+# ------------------------------------------------------------------ plans
+@pytest.mark.parametrize('chunk', [1, 4, 128])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_gather_plan_semantics(chunk, weighted):
+    g = torch.Generator().manual_seed(chunk)
+    n_out, n_tab, E, d = 23, 31, 500, 6
+    out_row = torch.randint(0, n_out - 3, (E,), generator=g)          # last rows empty
+    out_row[:200] = 5                                                 # one very heavy row
+    tab_row = torch.randint(0, n_tab, (E,), generator=g)
+    w = torch.rand(E, generator=g) if weighted else None
+    table = torch.randn(n_tab, d, generator=g, dtype=torch.float64)
+    plan = build_gather_plan(out_row, tab_row, n_out, n_tab, w, chunk)
+    got = execute_plan_reference(plan, table)
+    want = O.gather_sum(table, tab_row, out_row, n_out, None if w is None else w.double())
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-9)
+    it = plan.items.long()
+    lens = it[:, 1] - it[:, 0]
+    assert int(lens.max()) <= chunk and bool((lens[:-1] >= lens[1:]).all())      # sorted by length
+    assert int(lens.sum()) == E
+    # every output row is covered: direct rows + split rows partition range(n_out)
+    direct_rows = set(it[it[:, 3] == 1, 2].tolist())
+    split_rows = set(plan.split_rows[:, 0].tolist())
+    assert direct_rows | split_rows == set(range(n_out)) and not (direct_rows & split_rows)
+    # slots of split rows tile [0, n_slots)
+    if plan.n_slots:
+        sr = plan.split_rows.long()
+        assert int((sr[:, 2] - sr[:, 1]).sum()) == plan.n_slots
+    assert plan.items.dtype == torch.int32 and plan.row_id.dtype == torch.int32
+
+
+def test_gather_plan_empty_and_bounds():
+    plan = build_gather_plan(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 4, 3)
+    assert plan.items.shape == (4, 4) and plan.n_slots == 0
+    assert execute_plan_reference(plan, torch.ones(3, 2)).abs().sum() == 0
+    with pytest.raises(IndexError):
+        build_gather_plan(torch.tensor([0, 9]), torch.tensor([0, 1]), 4, 3)
+
+
+# ------------------------------------------------------------------ edge bookkeeping (vs the reference's recorded split)
+def test_process_edges_replays_reference_split():
+    """Same legacy generator state -> same six tensors as the reference produced (golden)."""
+    g = load_golden('tip_add_small')
+    rng = np.random.RandomState(18)
+    n_drug = g['n_drug']
+    raw = []
+    for s in (30, 25, 120, 60):                       # the generator recipe of oracle/make_golden.py
+        u = rng.randint(0, n_drug, s)
+        v = rng.randint(0, n_drug, s)
+        raw.append(torch.from_numpy(np.stack([np.minimum(u, v), np.maximum(u, v)]).astype(np.int64)))
+    out = utils.process_edges(raw, rng=np.random.RandomState(18))
+    for got, key in zip(out, ['dd_train_idx', 'dd_train_et', 'dd_train_range', 'dd_test_idx', 'dd_test_et',
+                              'dd_test_range']):
+        assert torch.equal(got, g[key]), key
+
+
+def test_bidirection_helpers():
+    e = torch.tensor([[5, 1, 2], [3, 4, 2]])
+    both = utils.to_bidirection(e)
+    assert both.tolist() == [[5, 1, 2, 3, 4, 2], [3, 4, 2, 5, 1, 2]]
+    kept = utils.remove_bidirection(both)
+    assert kept.tolist() == [[5, 4], [3, 1]]
+    sp = utils.sparse_id(4)
+    assert sp.is_sparse and torch.equal(sp.to_dense(), torch.eye(4))
+
+
+# ------------------------------------------------------------------ metrics vs sklearn (the reference's estimator)
+@pytest.mark.parametrize('ties', [False, True])
+def test_metrics_match_sklearn(ties):
+    rng = np.random.RandomState(3)
+    y = (rng.rand(400) < 0.4).astype(np.float64)
+    s = rng.rand(400) + 0.3 * y
+    if ties:
+        s = np.round(s, 1)
+    got = utils.auprc_auroc_ap(y, s)
+    want = O.auprc_auroc_ap(y, s)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+
+
+def test_metrics_by_range_matches_reference_record():
+    g = load_golden('tip_add_small')
+    p = {k[len('encoder.'):]: v for k, v in g.items() if isinstance(k, str) and k.startswith('encoder.')}
+    data = dict(dd_train_idx=g['dd_train_idx'], dd_train_range=g['dd_train_range'], d_norm=g['d_norm'],
+                pp_train_indices=g['pp_train_indices'], dp_edge_index=g['dp_edge_index'],
+                n_drug=g['n_drug'], n_prot=g['n_prot'])
+    z, _ = O.fm_encoder_fwd(p, data, 'add')
+    ps = O.distmult_fwd(z, g['dd_test_idx'], g['dd_test_et'], g['decoder.weight'])
+    ns = O.distmult_fwd(z, g['test_neg'], g['dd_test_et'], g['decoder.weight'])
+    rec = utils.auprc_auroc_ap_by_range(ps, ns, g['dd_test_range'])
+    np.testing.assert_allclose(rec, g['record'].numpy(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ data ingest
+def test_biosnap_data_dict_schema_and_sizes():
+    d = build_data_dict(max_relations=5)
+    assert d['n_drug'] == 645 and d['n_prot'] == 19081 and d['n_dd_et'] == 5
+    E = d['dd_train_idx'].shape[1]
+    assert d['dd_train_et'].shape == (E,) and d['dd_train_range'].shape == (5, 2)
+    assert int(d['dd_train_range'][-1, 1]) == E
+    for r, (a, b) in enumerate(d['dd_train_range'].tolist()):
+        blk = d['dd_train_idx'][:, a:b]
+        h = (b - a) // 2
+        assert torch.equal(blk[:, :h], blk[:, h:].flip(0))           # [u<v half | mirrored half]
+        assert bool((blk[0, :h] < blk[1, :h]).all())
+        assert bool((d['dd_train_et'][a:b] == r).all())
+    assert d['pp_train_indices'].shape[0] == 2 and d['dp_edge_index'].shape == (2, 18596)
+    assert int(d['dp_edge_index'][1].min()) >= d['n_prot']
+    assert d['d_feat'].is_sparse and d['d_norm'].shape == (645,)
+    # same seed -> same split; different seed -> different split
+    assert torch.equal(build_data_dict(max_relations=5)['dd_train_idx'], d['dd_train_idx'])
+    assert build_data_dict(max_relations=5, seed=1)['dd_train_idx'].shape != d['dd_train_idx'].shape or \
+        not torch.equal(build_data_dict(max_relations=5, seed=1)['dd_train_idx'], d['dd_train_idx'])
+    moved = Data.from_dict(d).to('cpu')
+    assert moved.n_drug == 645 and isinstance(moved.dd_edge_index, list)
+
+
+def test_synthetic_graph_shape():
+    d = synthetic_data_dict(n_drug=200, n_rel=17, n_edges=20000, seed=3)
+    E = d['dd_train_idx'].shape[1]
+    assert E == 20000 and d['dd_train_range'].shape == (17, 2) and int(d['dd_train_range'][-1, 1]) == E
+    assert bool((d['dd_train_idx'][0] != d['dd_train_idx'][1]).all())
+    sizes = (d['dd_train_range'][:, 1] - d['dd_train_range'][:, 0])
+    assert int(sizes.min()) >= 2 and int(sizes.max()) > 4 * int(sizes.median())    # skewed
+
+
+# ------------------------------------------------------------------ C ABI surface
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'tipk.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tipk_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    names = _declared_symbols()
+    assert names and set(names) == set(_lib.SIGNATURES), (names, sorted(_lib.SIGNATURES))
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), n
+    L = _lib.lib()
+    assert L.tipk_abi_version() == _lib.ABI_VERSION
+    assert L.tipk_strerror(0) == b'ok' and b'invalid' in L.tipk_strerror(-1)
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, 'tip_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'import oracle' not in src and 'from oracle' not in src, fn
+
+
+def test_ops_refuse_cpu_tensors():
+    from tip_amd import ops
+    plan = build_gather_plan(torch.tensor([0, 1]), torch.tensor([1, 0]), 2, 2)
+    with pytest.raises(_lib.TipkError):
+        ops.gather_sum(plan, torch.ones(2, 4))

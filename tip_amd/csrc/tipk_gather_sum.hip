@@ -1,0 +1,238 @@
+// Segmented gather-sum: the sparse aggregation of all three TIP graphs (P-P GCN, P->D mean, D-D
+// R-GCN) and of their backward passes.  See include/tipk.h section 1 for the contract and
+// DESIGN.md "Kernels / gather_sum" for the roofline.
+//
+// Mapping (gfx950, wave = 64 lanes): a *slot* of L lanes owns one work item (<= chunk edges of one
+// output row) and keeps its running sum in registers, 4 floats (one dwordx4) per lane, so one
+// gathered feature row is ONE coalesced L*16-byte read.  A wave holds 64/L slots.  The slot's
+// lanes fetch L edge ids with one coalesced load and hand them round with ds_bpermute (`__shfl`),
+// so per 64 edges a wave issues 1 index load + 64/L... row loads of full width and no atomics at
+// all: rows split over several items are combined in slot order by `gather_sum_finalize`
+// (bitwise reproducible).  Items are pre-sorted by length so the slots of a wave finish together.
+#include "tipk_common.h"
+
+namespace {
+
+struct Epilogue {
+    const float* row_scale;
+    const float* bias;
+    int relu;
+};
+
+template <int V>
+struct Acc;
+template <>
+struct Acc<4> {
+    float4 v;
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void fma_row(const float* p, float w) {
+        float4 t = tipk_ld4(p);
+        v.x = fmaf(w, t.x, v.x); v.y = fmaf(w, t.y, v.y); v.z = fmaf(w, t.z, v.z); v.w = fmaf(w, t.w, v.w);
+    }
+    __device__ __forceinline__ void add_row(const float* p) {
+        float4 t = tipk_ld4(p);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+    __device__ __forceinline__ void epilogue(const Epilogue& ep, int row, int col) {
+        if (ep.row_scale) { float s = ep.row_scale[row]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+        if (ep.bias) { float4 b = tipk_ld4(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    __device__ __forceinline__ void store(float* p) const { tipk_st4(p, v); }
+};
+template <>
+struct Acc<1> {
+    float v;
+    __device__ __forceinline__ void zero() { v = 0.f; }
+    __device__ __forceinline__ void fma_row(const float* p, float w) { v = fmaf(w, *p, v); }
+    __device__ __forceinline__ void add_row(const float* p) { v += *p; }
+    __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
+    __device__ __forceinline__ void epilogue(const Epilogue& ep, int row, int col) {
+        if (ep.row_scale) v *= ep.row_scale[row];
+        if (ep.bias) v += ep.bias[col];
+        if (ep.relu) v = fmaxf(v, 0.f);
+    }
+    __device__ __forceinline__ void store(float* p) const { *p = v; }
+};
+
+template <int V, int L, bool HAS_W>
+__global__ __launch_bounds__(256) void gather_sum_kernel(
+    const float* __restrict__ table, int64_t ld_table, const int32_t* __restrict__ row_id,
+    const float* __restrict__ edge_w, const int4* __restrict__ items, int64_t n_items,
+    float* __restrict__ out, int64_t ld_out, float* __restrict__ partial, Epilogue ep, int d) {
+    constexpr int SLOTS = TIPK_WAVE / L;
+    constexpr int U = L < 8 ? L : 8;                       // row loads kept in flight per lane
+    const int lane = tipk_lane();
+    const int sub = lane & (L - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / TIPK_WAVE;
+    const int64_t w = wave * SLOTS + lane / L;
+    const bool active = w < n_items;
+    int4 it = make_int4(0, 0, 0, 1);
+    if (active) it = items[w];
+    const int col = sub * V;
+    const bool col_ok = col < d;
+    const float* tcol = table + col;
+
+    Acc<V> acc;
+    acc.zero();
+    for (int e0 = it.x; e0 < it.y; e0 += L) {
+        const int mine = e0 + sub;
+        int id = -1;
+        float wgt = 0.f;
+        if (mine < it.y) {
+            id = row_id[mine];
+            if (HAS_W) wgt = edge_w[mine];
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < L; j0 += U) {
+            int ids[U];
+            float ws[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                ids[j] = __shfl(id, j0 + j, L);
+                if (HAS_W) ws[j] = __shfl(wgt, j0 + j, L);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (ids[j] >= 0 && col_ok) {
+                    const float* p = tcol + (int64_t)ids[j] * ld_table;
+                    if (HAS_W) acc.fma_row(p, ws[j]); else acc.add_row(p);
+                }
+            }
+        }
+    }
+    if (!active || !col_ok) return;
+    if (it.w & 1) {
+        acc.epilogue(ep, it.z, col);
+        acc.store(out + (int64_t)it.z * ld_out + col);
+    } else {
+        acc.store(partial + (int64_t)it.z * d + col);
+    }
+}
+
+// One 256-thread workgroup per split row: lanes tile [sub-row][column group]; slots are added in
+// increasing order per sub-row, then the sub-rows are combined in a fixed tree through LDS.
+template <int V>
+__global__ __launch_bounds__(256) void gather_sum_finalize_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ rows, float* __restrict__ out,
+    int64_t ld_out, Epilogue ep, int d, int lanes_per_row) {
+    __shared__ __attribute__((aligned(16))) float red[256 * V];
+    const int t = threadIdx.x;
+    const int sub = t % lanes_per_row;
+    const int part = t / lanes_per_row;
+    const int n_part = 256 / lanes_per_row;
+    const int col = sub * V;
+    const int row = rows[3 * blockIdx.x + 0];
+    const int s0 = rows[3 * blockIdx.x + 1];
+    const int s1 = rows[3 * blockIdx.x + 2];
+    Acc<V> acc;
+    acc.zero();
+    const bool ok = col < d && part < n_part;
+    if (ok) {
+        for (int s = s0 + part; s < s1; s += n_part) acc.add_row(partial + (int64_t)s * d + col);
+    }
+    acc.store(red + t * V);
+    __syncthreads();
+    if (part == 0 && ok) {
+        Acc<V> tot;
+        tot.zero();
+        for (int p = 0; p < n_part; ++p) {
+            Acc<V> o;
+            o.zero();
+            o.add_row(red + (p * lanes_per_row + sub) * V);
+            tot.add(o);
+        }
+        tot.epilogue(ep, row, col);
+        tot.store(out + (int64_t)row * ld_out + col);
+    }
+}
+
+template <int V, int L>
+int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, const float* edge_w,
+                  const int32_t* items, int64_t n_items, float* out, int64_t ld_out, float* partial,
+                  Epilogue ep, int d, hipStream_t st) {
+    constexpr int SLOTS = TIPK_WAVE / L;
+    const int64_t waves = tipk_ceil_div(n_items, SLOTS);
+    const int64_t blocks = tipk_ceil_div(waves, 4);
+    if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    const int4* it4 = reinterpret_cast<const int4*>(items);
+    if (edge_w)
+        hipLaunchKernelGGL((gather_sum_kernel<V, L, true>), dim3((unsigned)blocks), dim3(256), 0, st, table,
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
+    else
+        hipLaunchKernelGGL((gather_sum_kernel<V, L, false>), dim3((unsigned)blocks), dim3(256), 0, st, table,
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
+    TIPK_RETURN_LAUNCH();
+}
+
+inline int pow2_at_least(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, const int32_t* row_id,
+                               const float* edge_w, const int32_t* items, int64_t n_items, float* out,
+                               int64_t ld_out, float* partial, const float* row_scale, const float* bias,
+                               int relu, int d, tipk_stream_t stream) {
+    if (n_items < 0 || d <= 0 || !items || !out || (n_items > 0 && (!table || !row_id))) return TIPK_EINVAL;
+    if (n_items == 0) return TIPK_OK;
+    if (!aligned16(items)) return TIPK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Epilogue ep{row_scale, bias, relu};
+    const bool vec = d % 4 == 0 && ld_table % 4 == 0 && ld_out % 4 == 0 && aligned16(table) && aligned16(out) &&
+                     (!partial || aligned16(partial)) && (!bias || aligned16(bias));
+#define TIPK_GS(V, L) \
+    return launch_gather<V, L>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, partial, ep, d, st)
+    if (vec) {
+        if (d > 256) return TIPK_EUNSUPPORTED;
+        switch (pow2_at_least(d / 4)) {
+            case 1: TIPK_GS(4, 1);
+            case 2: TIPK_GS(4, 2);
+            case 4: TIPK_GS(4, 4);
+            case 8: TIPK_GS(4, 8);
+            case 16: TIPK_GS(4, 16);
+            case 32: TIPK_GS(4, 32);
+            default: TIPK_GS(4, 64);
+        }
+    }
+    if (d > 64) return TIPK_EUNSUPPORTED;
+    switch (pow2_at_least(d)) {
+        case 1: TIPK_GS(1, 1);
+        case 2: TIPK_GS(1, 2);
+        case 4: TIPK_GS(1, 4);
+        case 8: TIPK_GS(1, 8);
+        case 16: TIPK_GS(1, 16);
+        case 32: TIPK_GS(1, 32);
+        default: TIPK_GS(1, 64);
+    }
+#undef TIPK_GS
+}
+
+extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t n_rows, float* out,
+                                        int64_t ld_out, const float* row_scale, const float* bias, int relu,
+                                        int d, tipk_stream_t stream) {
+    if (n_rows < 0 || d <= 0) return TIPK_EINVAL;
+    if (n_rows == 0) return TIPK_OK;
+    if (!partial || !rows || !out || n_rows > 0x7fffffffLL) return TIPK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Epilogue ep{row_scale, bias, relu};
+    const bool vec = d % 4 == 0 && ld_out % 4 == 0 && aligned16(partial) && aligned16(out) && (!bias || aligned16(bias));
+    if (vec) {
+        if (d > 256) return TIPK_EUNSUPPORTED;
+        const int lpr = pow2_at_least(d / 4);
+        hipLaunchKernelGGL((gather_sum_finalize_kernel<4>), dim3((unsigned)n_rows), dim3(256), 0, st, partial, rows,
+                           out, ld_out, ep, d, lpr);
+    } else {
+        if (d > 64) return TIPK_EUNSUPPORTED;
+        const int lpr = pow2_at_least(d);
+        hipLaunchKernelGGL((gather_sum_finalize_kernel<1>), dim3((unsigned)n_rows), dim3(256), 0, st, partial, rows,
+                           out, ld_out, ep, d, lpr);
+    }
+    TIPK_RETURN_LAUNCH();
+}

@@ -1,0 +1,78 @@
+// Typed negative sampling on device (include/tipk.h section 5; reference src/neg_sampling.py:5-26).
+// One thread per positive position: counter-based Philox4x32-10 (no state, replayable), candidate
+// pair = mulhi64(random64, n^2), rejected while it is a positive of the SAME relation (binary search
+// in that relation's sorted keys, which stay L2-resident).  Bit-exact specification:
+// oracle/philox_sampler.py.
+#include "tipk_common.h"
+
+namespace {
+
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
+constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+constexpr int MAX_ATTEMPTS = 64;
+
+__device__ __forceinline__ uint64_t philox64(uint64_t ctr, uint32_t attempt, uint32_t k0, uint32_t k1) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = attempt, c3 = 0u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
+        const uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    return (uint64_t)c0 | ((uint64_t)c1 << 32);
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restrict__ keys,
+                                                         const int64_t* __restrict__ rel_ptr, int64_t n_rel,
+                                                         int64_t n_nodes, uint32_t k0, uint32_t k1,
+                                                         OT* __restrict__ out_u, OT* __restrict__ out_v) {
+    const int64_t total = rel_ptr[n_rel];
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    // relation of position e: largest r with rel_ptr[r] <= e
+    int64_t lo = 0, hi = n_rel;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rel_ptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    const int64_t a = rel_ptr[lo], b = rel_ptr[lo + 1];
+    const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
+    uint64_t cand = 0;
+    for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
+        cand = __umul64hi(philox64((uint64_t)e, (uint32_t)attempt, k0, k1), nn);
+        int64_t l = a, h = b;                       // lower_bound(keys[a:b], cand)
+        while (l < h) {
+            const int64_t mid = (l + h) >> 1;
+            if ((uint64_t)keys[mid] < cand) l = mid + 1; else h = mid;
+        }
+        if (l == b || (uint64_t)keys[l] != cand) break;
+    }
+    out_u[e] = (OT)(cand / (uint64_t)n_nodes);
+    out_v[e] = (OT)(cand % (uint64_t)n_nodes);
+}
+
+}  // namespace
+
+extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
+                                            int64_t n_nodes, uint64_t seed, void* out_u, void* out_v,
+                                            int idx_bytes, int64_t n_positions, tipk_stream_t stream) {
+    if (n_rel < 0 || n_nodes <= 0 || n_positions < 0 || n_nodes > 0xffffffffLL) return TIPK_EINVAL;
+    if (n_positions == 0 || n_rel == 0) return TIPK_OK;
+    if (!pos_key_sorted || !rel_ptr || !out_u || !out_v) return TIPK_EINVAL;
+    const int64_t blocks = tipk_ceil_div(n_positions, 256);
+    if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (idx_bytes == 8)
+        hipLaunchKernelGGL(neg_sample_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
+                           rel_ptr, n_rel, n_nodes, k0, k1, (int64_t*)out_u, (int64_t*)out_v);
+    else if (idx_bytes == 4)
+        hipLaunchKernelGGL(neg_sample_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
+                           rel_ptr, n_rel, n_nodes, k0, k1, (int32_t*)out_u, (int32_t*)out_v);
+    else
+        return TIPK_EINVAL;
+    TIPK_RETURN_LAUNCH();
+}

@@ -81,6 +81,7 @@ def build_data_dict(blob_path=BIOSNAP_BLOB, sp_rate=0.9, seed=1111, min_pairs=No
     (d['dd_train_idx'], d['dd_train_et'], d['dd_train_range'],
      d['dd_test_idx'], d['dd_test_et'], d['dd_test_range']) = process_edges(raw, p=sp_rate, rng=rng)
     pp = torch.from_numpy(z['pp_pairs'].astype(np.int64))
+    d['dd_edge_index'] = raw                      # un-split pairs per relation (re-split if sp_rate != 0.9)
     d['pp_train_indices'], d['pp_test_indices'] = process_prot_edge(pp, rng=rng)
     d['dp_edge_index'], d['dp_range_list'] = _dp_tables(z['dp_pairs'], n_drug, n_prot)
     d['d_feat'] = sparse_id(n_drug)                                       # prepare.py:22-23

@@ -1,0 +1,462 @@
+"""MI355X-native TIP modules behind the reference's `nn.Module` surface (`src/layers.py`).
+
+Class names, constructor/forward signatures, parameter names, shapes and init rules follow the
+reference so that its `state_dict`s load and `tip.py`'s loop runs unchanged (SURVEY.md section
+8(b)); the bodies are new: every layer is a `torch.autograd.Function` from `tip_amd.ops` that
+launches the HIP kernels of libtipk through the C ABI.  There is no PyG and no CPU path.
+
+Static-graph caching: the reference's `GCNConv(cached=True)` (`src/layers.py:386-387`) keeps the
+normalised P-P graph after the first call.  Here EVERY layer caches its gather plans, keyed by the
+identity (storage pointer, shape, version counter) of the edge tensors it was given, because all
+three TIP graphs are constant during training.  Pass a new tensor (or modify in place) to rebuild.
+"""
+import math
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import Parameter as Param
+
+from . import ops
+from .data import Data, build_data_dict
+from .neg_sampling import typed_negative_sampling
+from .plan import build_gather_plan, DEFAULT_CHUNK
+from .utils import process_edges, auprc_auroc_ap_by_range
+
+EPS = 1e-13                    # src/layers.py:15
+
+__all__ = ['GCNConv', 'MyRGCNConv', 'MyRGCNConv2', 'MyHierarchyConv', 'PPEncoder', 'FMEncoder',
+           'FMEncoderCat', 'MultiInnerProductDecoder', 'Setting', 'TIP']
+
+
+# ---------------------------------------------------------------------------------------------
+# plan caches
+# ---------------------------------------------------------------------------------------------
+def _ident(*tensors):
+    key = []
+    for t in tensors:
+        if t is None:
+            key.append(None)
+        else:
+            key.append((t.data_ptr(), tuple(t.shape), t._version, str(t.device), t.dtype))
+    return tuple(key)
+
+
+class _PlanCache(object):
+    """One slot per layer (graphs are static; a changed tensor identity rebuilds)."""
+
+    def __init__(self):
+        self.key, self.value, self.pins = None, None, None
+
+    def get(self, key_tensors, builder):
+        key = _ident(*key_tensors)
+        if key != self.key:
+            self.value = builder()
+            self.key, self.pins = key, key_tensors          # keep the tensors alive: pointers stay unique
+        return self.value
+
+
+def _is_identity_features(x):
+    """True for the `sparse_id(n)` features of prepare.py:22-23 (cached on the tensor object)."""
+    if x is None:
+        return True
+    flag = getattr(x, '_tipk_identity', None)
+    if flag is None:
+        flag = False
+        if x.is_sparse and x.shape[0] == x.shape[1]:
+            xc = x.coalesce()
+            idx, val = xc.indices(), xc.values()
+            n = x.shape[0]
+            ar = torch.arange(n, device=idx.device)
+            flag = bool(idx.shape[1] == n and (idx[0] == ar).all() and (idx[1] == ar).all() and (val == 1).all())
+        try:
+            x._tipk_identity = flag
+        except Exception:
+            pass
+    return flag
+
+
+def _sparse_feature_graph(x, chunk):
+    """Plans for y = x_sparse @ table (general sparse features, e.g. mono side-effect columns)."""
+    xc = x.coalesce()
+    r, c, v = xc.indices()[0], xc.indices()[1], xc.values().to(torch.float32)
+    n, m = x.shape
+    return ops.AggGraph(build_gather_plan(r, c, n, m, v, chunk), build_gather_plan(c, r, m, n, v, chunk))
+
+
+class _FeatureInput(nn.Module):
+    """`x @ W` for identity / sparse / dense `x` -- the three feature kinds the reference's
+    `torch.matmul(x_drug, embed)` (:532) and `GCNConv.lin` can meet."""
+
+    def __init__(self):
+        super().__init__()
+        self._cache = _PlanCache()
+
+    def apply_table(self, x, table):
+        """table: [in, out] (already in x @ table orientation)."""
+        if _is_identity_features(x):
+            return table
+        if x.is_sparse:
+            graph = self._cache.get((x,), lambda: _sparse_feature_graph(x, DEFAULT_CHUNK))
+            return ops.aggregate(table, graph)
+        return ops.matmul(x, table)
+
+
+# ---------------------------------------------------------------------------------------------
+# A1  GCNConv / PPEncoder   (src/layers.py:380-395; GCNConv = PyG 2.0.1 semantics)
+# ---------------------------------------------------------------------------------------------
+class _Lin(nn.Module):
+    """bias-free linear map with glorot weight [out, in] (PyG `Linear(weight_initializer='glorot')`)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.weight = Param(torch.empty(out_channels, in_channels))
+        bound = math.sqrt(6.0 / (in_channels + out_channels))
+        self.weight.data.uniform_(-bound, bound)
+
+
+def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK):
+    """Normalised adjacency D^-1/2 (A + I) D^-1/2 as a pair of gather plans: existing self loops
+    are replaced by exactly one unit loop per node, deg = in-degree incl. the loop, inf -> 0."""
+    row, col = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+    keep = row != col
+    loop = torch.arange(num_nodes, device=row.device)
+    row, col = torch.cat([row[keep], loop]), torch.cat([col[keep], loop])
+    deg = torch.bincount(col, minlength=num_nodes).to(torch.float32)
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0
+    w = dis[row] * dis[col]
+    return ops.AggGraph(build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd'),
+                        build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd'))
+
+
+class GCNConv(nn.Module):
+    """out = A_hat (x W^T) + bias.  `cached` is accepted for signature parity; plans are always
+    cached by edge-tensor identity."""
+
+    def __init__(self, in_channels, out_channels, cached=False, bias=True, chunk=DEFAULT_CHUNK):
+        super().__init__()
+        self.in_channels, self.out_channels, self.cached, self.chunk = in_channels, out_channels, cached, chunk
+        self.lin = _Lin(in_channels, out_channels)
+        if bias:
+            self.bias = Param(torch.zeros(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._feat = _FeatureInput()
+        self._cache = _PlanCache()
+
+    def forward(self, x, edge_index, fuse_relu=False):
+        n = x.shape[0]
+        graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk))
+        if _is_identity_features(x):
+            xl = ops.linear_t(None, self.lin.weight)                  # = W^T, one transpose kernel
+        elif x.is_sparse:
+            xl = self._feat.apply_table(x, ops.linear_t(None, self.lin.weight))
+        else:
+            xl = ops.linear_t(x, self.lin.weight)
+        return ops.aggregate(xl, graph, bias=self.bias, relu=fuse_relu)
+
+    def __repr__(self):
+        return 'GCNConv(%d, %d)' % (self.in_channels, self.out_channels)
+
+
+class PPEncoder(nn.Module):
+    def __init__(self, in_dim, hid1=32, hid2=16):
+        super().__init__()
+        self.out_dim = hid2
+        self.conv1 = GCNConv(in_dim, hid1, cached=True)
+        self.conv2 = GCNConv(hid1, hid2, cached=True)
+
+    def forward(self, x, edge_index):
+        x = self.conv1(x, edge_index, fuse_relu=True)                # ReLU fused into the epilogue
+        return self.conv2(x, edge_index)
+
+
+# ---------------------------------------------------------------------------------------------
+# A2  MyHierarchyConv   (src/layers.py:196-247)
+# ---------------------------------------------------------------------------------------------
+def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK):
+    """mean over incoming edges in the concatenated node space, rows [n_source:] only."""
+    src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+    keep = dst >= n_source
+    src, dst = src[keep], dst[keep] - n_source
+    n_t = n_all - n_source
+    cnt = torch.bincount(dst, minlength=n_t).to(torch.float32).clamp_(min=1)
+    return ops.AggGraph(build_gather_plan(dst, src, n_t, n_all, None, chunk, 'pd.fwd'),
+                        build_gather_plan(src, dst, n_all, n_t, None, chunk, 'pd.bwd'), (1.0 / cnt).contiguous())
+
+
+class MyHierarchyConv(nn.Module):
+    """Directed protein -> drug mean aggregation followed by a dense map."""
+
+    def __init__(self, in_dim, out_dim, unigue_source_num, unique_target_num,
+                 is_after_relu=True, is_bias=False, chunk=DEFAULT_CHUNK):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.unique_source_num, self.unique_target_num = unigue_source_num, unique_target_num
+        self.is_after_relu, self.chunk = is_after_relu, chunk
+        self.weight = Param(torch.empty(in_dim, out_dim))
+        if is_bias:
+            # the reference's bias branch cannot run (`if self.bias:` on a tensor, and an
+            # out_dim-sized bias added to in_dim-wide rows, :236-237); every caller passes False
+            raise NotImplementedError('MyHierarchyConv(is_bias=True) is not executable in the reference either')
+        self.register_parameter('bias', None)
+        self._cache = _PlanCache()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        scale = 1.0 if self.is_after_relu else 2.0
+        self.weight.data.normal_(std=scale / np.sqrt(self.in_dim))
+
+    def forward(self, x, edge_index, range_list=None):
+        n_all = x.shape[0]
+        graph = self._cache.get((edge_index,), lambda: hier_graph(edge_index, n_all, self.unique_source_num,
+                                                                  self.chunk))
+        mean = ops.aggregate(x, graph)
+        out = ops.matmul(mean, self.weight)
+        assert out.shape[0] == self.unique_target_num
+        return out
+
+    def __repr__(self):
+        return 'MyHierarchyConv(%d, %d)' % (self.in_dim, self.out_dim)
+
+
+# ---------------------------------------------------------------------------------------------
+# A4/A5  R-GCN layers   (src/layers.py:21-99, :102-193)
+# ---------------------------------------------------------------------------------------------
+def relation_of_edges(range_list, n_edges, device):
+    rg = torch.as_tensor(range_list).to(torch.int64).cpu()
+    sizes = rg[:, 1] - rg[:, 0]
+    if not (int(sizes.sum()) == n_edges and int(rg[0, 0]) == 0 and bool((rg[1:, 0] == rg[:-1, 1]).all())):
+        raise ValueError('range_list must be consecutive blocks covering all %d edges' % n_edges)
+    return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
+
+
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK):
+    """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
+    scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean')."""
+    src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+    rel = rel.to(torch.int64)
+    if rel.numel() and (int(rel.min()) < 0 or int(rel.max()) >= n_rel):
+        raise IndexError('edge_type out of range')
+    yrow = rel * n_nodes + src
+    deg = torch.bincount(dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
+    return ops.AggGraph(build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
+                        build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
+                        (1.0 / deg).contiguous())
+
+
+class _RGCNBase(nn.Module):
+    def __init__(self, in_channels, out_channels, num_relations, num_bases, after_relu, bias=False,
+                 chunk=DEFAULT_CHUNK):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_relations, self.num_bases, self.after_relu, self.chunk = num_relations, num_bases, after_relu, chunk
+        self.basis = Param(torch.empty(num_bases, in_channels, out_channels))
+        self.att = Param(torch.empty(num_relations, num_bases))
+        self.root = Param(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Param(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._cache = _PlanCache()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.att.data.normal_(std=1 / np.sqrt(self.num_bases))
+        std = 2 / self.in_channels if self.after_relu else 1 / np.sqrt(self.in_channels)
+        self.root.data.normal_(std=std)
+        self.basis.data.normal_(std=std)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def _run(self, x, graph):
+        out = ops.rgcn(x, self.basis, self.att, self.root, graph)
+        return out if self.bias is None else out + self.bias
+
+    def __repr__(self):
+        return '%s(%d, %d, num_relations=%d)' % (self.__class__.__name__, self.in_channels, self.out_channels,
+                                                 self.num_relations)
+
+
+class MyRGCNConv2(_RGCNBase):
+    """Range-list variant (:102-193): relation r owns edges `range_list[r] = (start, end)`;
+    `edge_type` is accepted and ignored, as in the reference."""
+
+    def forward(self, x, edge_index, edge_type, range_list):
+        n = x.shape[0]
+
+        def build():
+            rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
+            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk)
+        graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
+        return self._run(x, graph)
+
+
+class MyRGCNConv(_RGCNBase):
+    """Per-edge-type variant (:21-99): same arithmetic, relation id taken from `edge_type`; the
+    reference gathers an E x in x out weight tensor here, this build needs no edge ordering."""
+
+    def forward(self, x, edge_index, edge_type):
+        n = x.shape[0]
+        graph = self._cache.get((edge_index, edge_type),
+                                lambda: rgcn_graph(edge_index, edge_type, n, self.num_relations, self.chunk))
+        return self._run(x, graph)
+
+
+# ---------------------------------------------------------------------------------------------
+# A3 + composition  FMEncoder   (src/layers.py:471-553; FMEncoderCat :401-468 is its cat mode)
+# ---------------------------------------------------------------------------------------------
+class FMEncoder(nn.Module):
+    def __init__(self, device, in_dim_drug, num_dd_et, in_dim_prot, uni_num_prot, uni_num_drug,
+                 prot_drug_dim=64, num_base=32, n_embed=64, n_hid1=32, n_hid2=16, mod='cat'):
+        super().__init__()
+        assert mod in {'add', 'cat'}
+        if mod == 'add':
+            assert n_embed == prot_drug_dim
+        self.num_et, self.out_dim, self.mod = num_dd_et, n_hid2, mod
+        self.uni_num_drug, self.uni_num_prot = uni_num_drug, uni_num_prot
+        self.pp_encoder = PPEncoder(in_dim_prot)
+        self.embed = Param(torch.empty(in_dim_drug, n_embed))
+        self.hgcn = MyHierarchyConv(self.pp_encoder.out_dim, prot_drug_dim, uni_num_prot, uni_num_drug)
+        self.hdrug = torch.zeros((uni_num_drug, self.pp_encoder.out_dim), device=device)
+        d_in = n_embed + self.hgcn.out_dim if mod == 'cat' else n_embed
+        self.rgcn1 = MyRGCNConv2(d_in, n_hid1, num_dd_et, num_base, after_relu=False)
+        self.rgcn2 = MyRGCNConv2(n_hid1, n_hid2, num_dd_et, num_base, after_relu=True)
+        self._drug_feat = _FeatureInput()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embed.data.normal_()
+
+    def forward(self, x_drug, dd_edge_index, dd_edge_type, dd_range_list, d_norm,
+                x_prot, pp_edge_index, dp_edge_index, dp_range_list):
+        h_prot = self.pp_encoder(x_prot, pp_edge_index)                               # P-P GCN x2
+        if self.hdrug.device != h_prot.device:
+            self.hdrug = self.hdrug.to(h_prot.device)
+        h_all = torch.cat((h_prot, self.hdrug))                                       # :526
+        pd = self.hgcn(h_all, dp_edge_index, dp_range_list)                           # P -> D
+        xd = self._drug_feat.apply_table(x_drug, self.embed)                          # x_drug @ embed
+        x0 = ops.drug_mix(xd, pd, d_norm, self.mod == 'cat')                          # /d_norm, cat|add
+        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list)
+        x1 = torch.relu(x1)
+        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list)
+
+
+class FMEncoderCat(FMEncoder):
+    """cat-only constructor signature of `src/layers.py:403-405`."""
+
+    def __init__(self, device, in_dim_drug, num_dd_et, in_dim_prot, uni_num_prot, uni_num_drug,
+                 prot_drug_dim=16, num_base=32, n_embed=48, n_hid1=32, n_hid2=16):
+        super().__init__(device, in_dim_drug, num_dd_et, in_dim_prot, uni_num_prot, uni_num_drug,
+                         prot_drug_dim, num_base, n_embed, n_hid1, n_hid2, mod='cat')
+
+
+# ---------------------------------------------------------------------------------------------
+# A6  DistMult decoder   (src/layers.py:581-595)
+# ---------------------------------------------------------------------------------------------
+class MultiInnerProductDecoder(nn.Module):
+    def __init__(self, in_dim, num_et):
+        super().__init__()
+        self.num_et, self.in_dim = num_et, in_dim
+        self.weight = Param(torch.empty(num_et, in_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.weight.data.normal_(std=1 / np.sqrt(self.in_dim))
+
+    def forward(self, z, edge_index, edge_type, sigmoid=True):
+        return ops.distmult(z, self.weight, edge_index, edge_type, sigmoid)
+
+    def objective(self, z, pos_index, neg_index, edge_type):
+        """-mean log(sigma(pos)+eps) - mean log(1-sigma(neg)+eps), fused (K9+K10)."""
+        return ops.distmult_objective(z, self.weight, pos_index, neg_index, edge_type)
+
+
+# ---------------------------------------------------------------------------------------------
+# A9  training framework   (src/layers.py:260-375)
+# ---------------------------------------------------------------------------------------------
+class Setting(object):
+    def __init__(self, sp_rate=0.9, lr=0.01, prot_drug_dim=16, n_embed=48, n_hid1=32, n_hid2=16, num_base=32):
+        self.sp_rate, self.lr = sp_rate, lr
+        self.prot_drug_dim, self.n_embed = prot_drug_dim, n_embed
+        self.n_hid1, self.n_hid2, self.num_base = n_hid1, n_hid2, num_base
+
+
+class TIP(nn.Module):
+    """`TIP(settings, device, mod='cat', data_path='./data/data_dict.pkl')` as in the reference.
+
+    data_path: a pickle written by the reference's `prepare.py` loads as is; if the default file
+    does not exist, the BioSNAP graph bundled with this package is split with seed 1111.
+    `data` (extension): an already built data dict.  `fused_loss=False` computes the loss with
+    torch ops on the decoder scores exactly as `src/layers.py:335-340` spells it."""
+
+    def __init__(self, settings, device, mod='cat', data_path='./data/data_dict.pkl', data=None, fused_loss=True):
+        super().__init__()
+        assert mod in {'cat', 'add'}
+        self.mod, self.device, self.settings, self.fused_loss = mod, device, settings, fused_loss
+        self.data = self.__prepare_data(data_path, settings.sp_rate, data).to(device)
+        self.__prepare_model()
+
+    def __prepare_data(self, data_path, sp_rate, data_dict):
+        if data_dict is None:
+            if data_path is not None and os.path.exists(data_path):
+                with open(data_path, 'rb') as f:
+                    data_dict = pickle.load(f)
+            else:
+                data_dict = build_data_dict(sp_rate=0.9)
+        data = Data.from_dict(dict(data_dict))
+        if sp_rate != 0.9:                                                   # :290-291
+            (data.dd_train_idx, data.dd_train_et, data.dd_train_range,
+             data.dd_test_idx, data.dd_test_et, data.dd_test_range) = process_edges(data.dd_edge_index, p=sp_rate)
+        self._test_neg_host = None
+        return data
+
+    def __encode(self):
+        d = self.data
+        return self.encoder(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm,
+                            d.p_feat, d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
+
+    def __prepare_model(self):
+        d, s = self.data, self.settings
+        self.test_neg_index = typed_negative_sampling(d.dd_test_idx, d.n_drug, d.dd_test_range)   # :293
+        self.encoder = FMEncoder(self.device, d.n_drug_feat, d.n_dd_et, d.n_prot, d.n_prot, d.n_drug,
+                                 s.prot_drug_dim, s.num_base, s.n_embed, s.n_hid1, s.n_hid2,
+                                 mod=self.mod).to(self.device)
+        self.embeddings = self.__encode()                # initial pass (:319, with self.device)
+        self.decoder = MultiInnerProductDecoder(s.n_hid2, d.n_dd_et).to(self.device)
+
+    def forward(self, neg_index=None):
+        """One full-batch training objective (:328-342).  `neg_index` (extension) injects fixed
+        negatives for parity tests; by default they are drawn on device every call."""
+        d = self.data
+        self.embeddings = self.__encode()
+        pos_index = d.dd_train_idx
+        if neg_index is None:
+            neg_index = typed_negative_sampling(d.dd_train_idx, d.n_drug, d.dd_train_range)
+        neg_index = neg_index.type_as(pos_index)
+        if self.fused_loss:
+            return self.decoder.objective(self.embeddings, pos_index, neg_index, d.dd_train_et)
+        pos_score = self.decoder(self.embeddings, pos_index, d.dd_train_et)
+        neg_score = self.decoder(self.embeddings, neg_index, d.dd_train_et)
+        return -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()
+
+    def pred(self, dd_idx, dd_et):
+        return self.decoder(self.embeddings, dd_idx, dd_et)
+
+    def test(self, print_output=True):
+        self.eval()
+        d = self.data
+        with torch.no_grad():
+            pos_score = self.decoder(self.embeddings, d.dd_test_idx, d.dd_test_et)
+            neg_score = self.decoder(self.embeddings, self.test_neg_index, d.dd_test_et)
+        return self.compute_auprc_auroc_ap_by_et(pos_score, neg_score, d.dd_test_range, print_output)
+
+    def compute_auprc_auroc_ap_by_et(self, pos_score, neg_score, dd_range, print_out):
+        record = auprc_auroc_ap_by_range(pos_score, neg_score, dd_range)      # [3, R]
+        if print_out:
+            auprc, auroc, ap = record.sum(axis=1) / self.data.n_dd_et
+            print('On test set: auprc:{:0.4f}   auroc:{:0.4f}   ap@50:{:0.4f}    '.format(auprc, auroc, ap))
+        return record

@@ -1,0 +1,96 @@
+"""Typed negative sampling on the GPU (mirror of the reference's `src/neg_sampling.py:5-26`).
+
+Same call signature and result contract: for every relation block `[start, end)` of
+`range_list`, as many pairs as the block has positives, drawn uniformly with replacement from
+`num_nodes ** 2` (self pairs and repeats allowed, exactly like `np.random.choice`), none of them
+equal to a positive pair of the SAME relation; result int64 `[2, E]` on the positives' device.
+
+Differences, on purpose:
+  * the reference makes one device->host copy and one numpy sort per relation per epoch
+    (1 097 round trips); here the sorted positive keys are built once per positive tensor and one
+    kernel draws all relations (`tipk_typed_negative_sampling`);
+  * the reference's resample loop re-indexes `rest` into the wrong array (:13-16), so a few
+    sampled pairs ARE positives (879 of 51 546 in the densest relation); this sampler implements
+    the intended rejection, so none is;
+  * randomness is counter-based Philox4x32-10 keyed by `(seed, call counter)` instead of numpy's
+    global Mersenne state: `manual_seed` makes a run reproducible, sample-level equality with
+    numpy is impossible by construction (tests check the distribution instead).
+"""
+import torch
+
+from . import ops
+
+_MASK = (1 << 64) - 1
+_state = {'seed': 1111, 'calls': 0}
+_key_cache = {}
+
+
+def manual_seed(seed):
+    """Reset the sampler stream (the analogue of `np.random.seed`, src/layers.py:14)."""
+    _state['seed'] = int(seed) & _MASK
+    _state['calls'] = 0
+
+
+def _mix(seed, n):
+    """splitmix64 of (seed + n * golden): the 64-bit Philox key of call n."""
+    z = (seed + (n + 1) * 0x9E3779B97F4A7C15) & _MASK
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+    return z ^ (z >> 31)
+
+
+def relation_ptr(range_list, n_edges):
+    """[R+1] int64 offsets from the reference's [R,2] (start,end) table; blocks must tile [0,E)."""
+    rg = torch.as_tensor(range_list).to(torch.int64).cpu()
+    if rg.numel() == 0:
+        return torch.zeros(1, dtype=torch.int64)
+    ok = int(rg[0, 0]) == 0 and bool((rg[1:, 0] == rg[:-1, 1]).all()) and int(rg[-1, 1]) == n_edges
+    if not ok:
+        raise ValueError('range_list must be consecutive blocks covering all %d positions' % n_edges)
+    return torch.cat([rg[:1, 0], rg[:, 1]])
+
+
+def sorted_positive_keys(pos_edge_index, num_nodes, rel_ptr):
+    """key = u * num_nodes + v, sorted ascending inside each relation block (one-off)."""
+    dev = pos_edge_index.device
+    key = pos_edge_index[0].to(torch.int64) * num_nodes + pos_edge_index[1].to(torch.int64)
+    sizes = (rel_ptr[1:] - rel_ptr[:-1]).to(dev)
+    rel = torch.repeat_interleave(torch.arange(sizes.numel(), device=dev), sizes)
+    # one global sort of (relation, key): relation-major order keeps the blocks in place
+    order = torch.sort(rel * (num_nodes * num_nodes) + key).indices
+    return key[order].contiguous()
+
+
+def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
+    if range_ident is None:
+        range_ident = (range_list.data_ptr(), tuple(range_list.shape)) if torch.is_tensor(range_list) \
+            else tuple(map(tuple, range_list))
+    ident = (pos_edge_index.data_ptr(), tuple(pos_edge_index.shape), pos_edge_index._version,
+             str(pos_edge_index.device), int(num_nodes), range_ident)
+    hit = _key_cache.get(ident)
+    if hit is None:
+        rel_ptr = relation_ptr(range_list, pos_edge_index.shape[1])
+        keys = sorted_positive_keys(pos_edge_index, num_nodes, rel_ptr)
+        hit = (keys, rel_ptr.to(pos_edge_index.device), rel_ptr.numel() - 1, pos_edge_index)
+        if len(_key_cache) > 8:
+            _key_cache.clear()
+        _key_cache[ident] = hit
+    return hit
+
+
+def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _range_ident=None):
+    """Drop-in for `src/neg_sampling.py:22-26`.  `seed` (optional) pins the Philox key of this
+    call; by default consecutive calls use consecutive keys of the `manual_seed` stream."""
+    num_nodes = int(num_nodes)
+    keys, rel_ptr, n_rel, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
+    if seed is None:
+        seed = _mix(_state['seed'], _state['calls'])
+        _state['calls'] += 1
+    return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
+                                              pos_edge_index.shape[1], dtype=torch.int64)
+
+
+def negative_sampling(pos_edge_index, num_nodes, seed=None):
+    """Single-relation form (`src/neg_sampling.py:5-19`)."""
+    rg = torch.tensor([[0, pos_edge_index.shape[1]]])
+    return typed_negative_sampling(pos_edge_index, num_nodes, rg, seed=seed, _range_ident='single')

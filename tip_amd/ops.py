@@ -1,0 +1,469 @@
+"""Python face of libtipk: thin launch wrappers + the `torch.autograd.Function`s of the TIP layers.
+
+torch supplies device memory, the current HIP stream and autograd bookkeeping; every FLOP of the
+path is executed by the HIP kernels in `tip_amd/csrc` through the C ABI (`include/tipk.h`).
+Backward passes are explicit (no autograd tracing through E x d tensors): each Function saves
+only N x d activations and the static graph plans.
+"""
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check, lib, ptr, stream_ptr, require_device
+from .plan import GatherPlan
+
+
+def _f32c(t):
+    """fp32, unit column stride (row stride free)."""
+    if t.dtype != torch.float32:
+        raise _lib.TipkError('tip_amd computes in fp32; got %s' % t.dtype)
+    if t.dim() >= 1 and t.stride(-1) != 1 and t.shape[-1] != 1:
+        t = t.contiguous()
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# optional per-kernel timing (bench.py): HIP events recorded on the launch stream around one launch
+# ---------------------------------------------------------------------------------------------
+_TIMING = None          # None (off) or dict: label -> list of (start_event, end_event)
+
+
+def timing_start():
+    global _TIMING
+    _TIMING = {}
+
+
+def timing_stop():
+    """-> {label: (n_launches, mean_ms)}; call after a device synchronize."""
+    global _TIMING
+    rec, _TIMING = _TIMING or {}, None
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in rec.items()}
+
+
+class _timed(object):
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            self.ev[1].record()
+            _TIMING.setdefault(self.label, []).append(self.ev)
+
+
+# ---------------------------------------------------------------------------------------------
+# launch wrappers (one C call each)
+# ---------------------------------------------------------------------------------------------
+def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
+    """out[n_out, d] per `plan` over `table` [n_table, d] (include/tipk.h section 1)."""
+    table = _f32c(table)
+    require_device(table, plan.items)
+    d = table.shape[1]
+    assert table.shape[0] == plan.n_table, (table.shape, plan.n_table)
+    if out is None:
+        out = torch.empty((plan.n_out, d), dtype=torch.float32, device=table.device)
+    partial = None
+    if plan.n_slots:
+        partial = torch.empty((plan.n_slots, d), dtype=torch.float32, device=table.device)
+    st = stream_ptr(table.device)
+    L = lib()
+    with _timed('gather_sum[%s,d=%d]' % (plan.tag, d)):
+        check(L.tipk_gather_sum(ptr(table), table.stride(0), ptr(plan.row_id), ptr(plan.edge_w), ptr(plan.items),
+                                plan.items.shape[0], ptr(out), out.stride(0), ptr(partial), ptr(row_scale),
+                                ptr(bias), int(relu), d, st), 'tipk_gather_sum')
+    if plan.n_slots:
+        check(L.tipk_gather_sum_finalize(ptr(partial), ptr(plan.split_rows), plan.split_rows.shape[0], ptr(out),
+                                         out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, st),
+              'tipk_gather_sum_finalize')
+    return out
+
+
+def _strides3(t):
+    """(batch stride, row stride, col stride) of a 2-D (batch stride 0) or 3-D tensor."""
+    if t.dim() == 2:
+        return 0, t.stride(0), t.stride(1)
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=1):
+    """out = relu?(alpha * a @ b + c_in) on the matrix cores (include/tipk.h section 2).
+
+    a: [M,K] or [Z,M,K]; b: [K,N] or [Z,K,N] -- arbitrary strides (transposed views are free).
+    reduce_batch: sum the Z products into one [M,N] (the basis-sum of the R-GCN backward).
+    ksplit > 1: split-K into slabs + ordered slab sum (skinny outputs with huge K).
+    """
+    require_device(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise _lib.TipkError('gemm: fp32 only')
+    z = max(a.shape[0] if a.dim() == 3 else 1, b.shape[0] if b.dim() == 3 else 1)
+    batched = a.dim() == 3 or b.dim() == 3
+    m, k = a.shape[-2], a.shape[-1]
+    k2, n = b.shape[-2], b.shape[-1]
+    assert k == k2, (a.shape, b.shape)
+    a_sz, a_sm, a_sk = _strides3(a)
+    b_sz, b_sk, b_sn = _strides3(b)
+    if batched and not reduce_batch:
+        oshape = (z, m, n)
+    else:
+        oshape = (m, n)
+    dev = a.device
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=dev)
+    assert tuple(out.shape) == oshape and out.stride(-1) == 1, (out.shape, oshape, out.stride())
+    g = GemmDesc()
+    g.m, g.n, g.k = m, n, k
+    g.ksplit = ksplit
+    g.a, g.b = a.data_ptr(), b.data_ptr()
+    g.a_sm, g.a_sk, g.b_sk, g.b_sn = a_sm, a_sk, b_sk, b_sn
+    if batched and reduce_batch:
+        g.batch, g.kbatch = 1, z
+        g.a_sq, g.b_sq, g.a_sz, g.b_sz = a_sz, b_sz, 0, 0
+    else:
+        g.batch, g.kbatch = (z if batched else 1), 1
+        g.a_sq, g.b_sq, g.a_sz, g.b_sz = 0, 0, a_sz, b_sz
+    slabs = None
+    if ksplit > 1:
+        assert c_in is None and not relu and not (batched and not reduce_batch)
+        slabs = torch.empty((ksplit, m, n), dtype=torch.float32, device=dev)
+        g.c, g.c_sm, g.c_sz, g.c_ss = slabs.data_ptr(), n, 0, m * n
+    else:
+        g.c, g.c_sm = out.data_ptr(), out.stride(-2)
+        g.c_sz = out.stride(0) if out.dim() == 3 else 0
+        g.c_ss = 0
+    if c_in is not None:
+        assert c_in.shape == out.shape and c_in.stride(-1) == 1
+        g.c_in, g.cin_sm = c_in.data_ptr(), c_in.stride(-2)
+        g.cin_sz = c_in.stride(0) if c_in.dim() == 3 else 0
+    else:
+        g.c_in, g.cin_sm, g.cin_sz = None, 0, 0
+    g.alpha, g.relu = alpha, int(relu)
+    st = stream_ptr(dev)
+    with _timed('gemm[%dx%dx%d,z=%d%s]' % (m, n, k, z, ',ksplit=%d' % ksplit if ksplit > 1 else '')):
+        check(lib().tipk_gemm_f32(g, st), 'tipk_gemm_f32')
+        if slabs is not None:
+            assert out.is_contiguous()
+            check(lib().tipk_sum_slabs(ptr(slabs), ksplit, m * n, m * n, 1.0, 0, ptr(out), st), 'tipk_sum_slabs')
+    return out
+
+
+def transpose(x):
+    x = _f32c(x).contiguous()
+    require_device(x)
+    out = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float32, device=x.device)
+    check(lib().tipk_transpose(ptr(x), x.shape[0], x.shape[1], ptr(out), stream_ptr(x.device)), 'tipk_transpose')
+    return out
+
+
+def rows_affine(x, row_mul=None, row_div=None, gate=None, out=None, accumulate=False):
+    """out (+)= x * row_mul / row_div * (gate > 0); x/out/gate may be column-slice views."""
+    x = _f32c(x)
+    require_device(x)
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+        assert not accumulate
+    assert out.shape == x.shape and out.stride(1) == 1
+    if gate is not None:
+        gate = _f32c(gate)
+    check(lib().tipk_rows_affine(ptr(x), x.stride(0), ptr(row_mul), ptr(row_div), ptr(gate),
+                                 gate.stride(0) if gate is not None else 0, ptr(out), out.stride(0), rows, cols,
+                                 int(accumulate), stream_ptr(x.device)), 'tipk_rows_affine')
+    return out
+
+
+def col_sum(x):
+    x = _f32c(x)
+    require_device(x)
+    rows, cols = x.shape
+    scratch = torch.empty((256, cols), dtype=torch.float32, device=x.device)
+    out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    check(lib().tipk_col_sum(ptr(x), x.stride(0), rows, cols, ptr(scratch), ptr(out), stream_ptr(x.device)),
+          'tipk_col_sum')
+    return out
+
+
+def _idx_bytes(t):
+    if t.dtype == torch.int64:
+        return 8
+    if t.dtype == torch.int32:
+        return 4
+    raise _lib.TipkError('index tensors must be int32 or int64, got %s' % t.dtype)
+
+
+def _uv(edge_index):
+    ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+    return ei[0], ei[1]
+
+
+def distmult_fwd(z, weight, edge_index, edge_type, sigmoid=True):
+    z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
+    require_device(z, weight, edge_index, edge_type)
+    u, v = _uv(edge_index)
+    et = edge_type.contiguous()
+    n = u.numel()
+    score = torch.empty((n,), dtype=torch.float32, device=z.device)
+    check(lib().tipk_distmult_fwd(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(u), ptr(v),
+                                  _idx_bytes(u), ptr(et), _idx_bytes(et), n, int(sigmoid), ptr(score),
+                                  stream_ptr(z.device)), 'tipk_distmult_fwd')
+    return score
+
+
+def distmult_bwd(g_score, score, z, weight, edge_index, edge_type, sigmoid=True):
+    z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
+    g_score = _f32c(g_score).contiguous()
+    u, v = _uv(edge_index)
+    et = edge_type.contiguous()
+    g_z, g_w = torch.zeros_like(z), torch.zeros_like(weight)
+    check(lib().tipk_distmult_bwd(ptr(g_score), ptr(score), ptr(z), z.shape[0], z.shape[1], ptr(weight),
+                                  weight.shape[0], ptr(u), ptr(v), _idx_bytes(u), ptr(et), _idx_bytes(et),
+                                  u.numel(), int(sigmoid), ptr(g_z), ptr(g_w), stream_ptr(z.device)),
+          'tipk_distmult_bwd')
+    return g_z, g_w
+
+
+def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
+    """(loss [1], g_z, g_w) of the fused TIP objective (include/tipk.h section 4)."""
+    z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
+    require_device(z, weight, pos_index, neg_index, edge_type)
+    pu, pv = _uv(pos_index)
+    nu, nv = _uv(neg_index)
+    assert pu.dtype == nu.dtype and pu.numel() == nu.numel()
+    et = edge_type.contiguous()
+    loss = torch.zeros((1,), dtype=torch.float32, device=z.device)
+    g_z = torch.zeros_like(z) if need_grad else None
+    g_w = torch.zeros_like(weight) if need_grad else None
+    check(lib().tipk_distmult_loss(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pu), ptr(pv),
+                                   ptr(nu), ptr(nv), _idx_bytes(pu), ptr(et), _idx_bytes(et), pu.numel(),
+                                   ptr(loss), ptr(g_z), ptr(g_w), stream_ptr(z.device)), 'tipk_distmult_loss')
+    return loss, g_z, g_w
+
+
+def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64):
+    require_device(pos_key_sorted, rel_ptr)
+    out = torch.empty((2, n_positions), dtype=dtype, device=pos_key_sorted.device)
+    check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed, ptr(out[0]),
+                                             ptr(out[1]), 8 if dtype == torch.int64 else 4, n_positions,
+                                             stream_ptr(out.device)), 'tipk_typed_negative_sampling')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# static graph containers (plans in both directions + normalisers)
+# ---------------------------------------------------------------------------------------------
+class AggGraph(object):
+    """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
+
+    def __init__(self, fwd, bwd, scale=None):
+        self.fwd, self.bwd, self.scale = fwd, bwd, scale
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------------------------
+class _Aggregate(torch.autograd.Function):
+    """out = scale * (A table) + bias, optional fused ReLU; grad: A^T (scale * g)."""
+
+    @staticmethod
+    def forward(ctx, table, bias, graph, relu):
+        out = gather_sum(graph.fwd, table, row_scale=graph.scale, bias=bias, relu=relu)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
+        ctx.save_for_backward(out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        graph = ctx.graph
+        g = _f32c(g)
+        # pre = scale * agg + bias, out = relu(pre):  g_pre = g (.) [out > 0];  g_agg = scale * g_pre
+        g_pre = rows_affine(g, gate=out) if ctx.relu else g
+        g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
+        g_table = gather_sum(graph.bwd, g_agg) if ctx.needs_input_grad[0] else None
+        g_bias = col_sum(g_pre) if ctx.has_bias else None
+        return g_table, g_bias, None, None
+
+
+def aggregate(table, graph, bias=None, relu=False):
+    return _Aggregate.apply(table, bias, graph, relu)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W^T with W [out, in] (the `lin` of GCNConv); x=None means identity features."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.identity = x is None
+        if x is None:
+            ctx.save_for_backward(weight)
+            return transpose(weight)
+        x = _f32c(x)
+        ctx.save_for_backward(x, weight)
+        return gemm(x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        if ctx.identity:
+            return None, transpose(g)
+        x, weight = ctx.saved_tensors
+        g_x = gemm(g, weight) if ctx.needs_input_grad[0] else None
+        g_w = gemm(g.t(), x)
+        return g_x, g_w
+
+
+def linear_t(x, weight):
+    return _Linear.apply(x, weight)
+
+
+class _MatMul(torch.autograd.Function):
+    """y = x @ w  (plain dense product on the matrix cores)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _f32c(x), _f32c(w)
+        ctx.save_for_backward(x, w)
+        return gemm(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _f32c(g)
+        g_x = gemm(g, w.t()) if ctx.needs_input_grad[0] else None
+        g_w = gemm(x.t(), g) if ctx.needs_input_grad[1] else None
+        return g_x, g_w
+
+
+def matmul(x, w):
+    return _MatMul.apply(x, w)
+
+
+def _att_ksplit(k):
+    """slabs for the skinny dAtt product (M = relations, N = bases, K = nodes*out)."""
+    return int(max(1, min(64, k // 512)))
+
+
+class _RGCN(torch.autograd.Function):
+    """One basis-decomposed R-GCN layer with global-mean aggregation
+    (reference MyRGCNConv2 / MyRGCNConv, src/layers.py:102-193 / :21-99):
+
+        out = D^-1 sum_r A_r X W_r + X root,   W_r = sum_b att[r,b] basis[b]
+
+    evaluated basis-first / transform-then-gather: XB_b = X basis_b, Y = att . XB, then one
+    gather-sum over the rows of Y (no E x d intermediates)."""
+
+    @staticmethod
+    def forward(ctx, x, basis, att, root, graph):
+        x, basis, att, root = _f32c(x), basis.contiguous(), att.contiguous(), root.contiguous()
+        n, d_in = x.shape
+        nb, _, d_out = basis.shape
+        r = att.shape[0]
+        assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
+        xb = gemm(x, basis)                                              # [B, N, out]
+        y = gemm(att, xb.view(nb, n * d_out))                            # [R, N*out]
+        agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
+        del y
+        out = gemm(x, root, out=agg, c_in=agg)                           # + X root
+        ctx.graph = graph
+        ctx.save_for_backward(x, basis, att, root, xb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, basis, att, root, xb = ctx.saved_tensors
+        graph = ctx.graph
+        g = _f32c(g).contiguous()
+        n, d_in = x.shape
+        nb, _, d_out = basis.shape
+        r = att.shape[0]
+        need_x = ctx.needs_input_grad[0]
+        g_root = gemm(x.t(), g)
+        gs = rows_affine(g, row_mul=graph.scale)
+        g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)               # dY_r = A_r^T (D^-1 g)
+        xb2 = xb.view(nb, n * d_out)
+        g_att = gemm(g_y, xb2.t(), ksplit=_att_ksplit(n * d_out))
+        g_xb = gemm(att.t(), g_y).view(nb, n, d_out)
+        del g_y
+        g_basis = gemm(x.t(), g_xb)                                      # [B, in, out]
+        g_x = None
+        if need_x:
+            g_x = gemm(g, root.t())
+            g_x = gemm(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
+        return g_x, g_basis, g_att, g_root, None
+
+
+def rgcn(x, basis, att, root, graph):
+    return _RGCN.apply(x, basis, att, root, graph)
+
+
+class _DrugMix(torch.autograd.Function):
+    """x0 = cat(embed / d_norm, pd) or embed / d_norm + pd  (src/layers.py:532-539)."""
+
+    @staticmethod
+    def forward(ctx, xd, pd, d_norm, cat):
+        xd, pd = _f32c(xd), _f32c(pd)
+        n, ne = xd.shape
+        if cat:
+            out = torch.empty((n, ne + pd.shape[1]), dtype=torch.float32, device=xd.device)
+            rows_affine(xd, row_div=d_norm, out=out[:, :ne])
+            rows_affine(pd, out=out[:, ne:])
+        else:
+            out = rows_affine(xd, row_div=d_norm)
+            rows_affine(pd, out=out, accumulate=True)
+        ctx.cat, ctx.ne = cat, ne
+        ctx.save_for_backward(d_norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_norm,) = ctx.saved_tensors
+        g = _f32c(g)
+        ne = ctx.ne
+        if ctx.cat:
+            return rows_affine(g[:, :ne], row_div=d_norm), rows_affine(g[:, ne:]), None, None
+        return rows_affine(g, row_div=d_norm), g, None, None
+
+
+def drug_mix(xd, pd, d_norm, cat):
+    return _DrugMix.apply(xd, pd, d_norm, cat)
+
+
+class _DistMult(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, weight, edge_index, edge_type, sigmoid):
+        score = distmult_fwd(z, weight, edge_index, edge_type, sigmoid)
+        ctx.sigmoid = sigmoid
+        ctx.save_for_backward(z, weight, edge_index, edge_type, score)
+        return score
+
+    @staticmethod
+    def backward(ctx, g):
+        z, weight, edge_index, edge_type, score = ctx.saved_tensors
+        g_z, g_w = distmult_bwd(g, score, z, weight, edge_index, edge_type, ctx.sigmoid)
+        return g_z, g_w, None, None, None
+
+
+def distmult(z, weight, edge_index, edge_type, sigmoid=True):
+    return _DistMult.apply(z, weight, edge_index, edge_type, sigmoid)
+
+
+class _DistMultLoss(torch.autograd.Function):
+    """loss of TIP.forward (src/layers.py:335-340) with gradients produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, z, weight, pos_index, neg_index, edge_type):
+        need = z.requires_grad or weight.requires_grad
+        loss, g_z, g_w = distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=need)
+        ctx.save_for_backward(g_z, g_w)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g_z, g_w = ctx.saved_tensors
+        return g_z * g, g_w * g, None, None, None
+
+
+def distmult_objective(z, weight, pos_index, neg_index, edge_type):
+    return _DistMultLoss.apply(z, weight, pos_index, neg_index, edge_type)

@@ -1,0 +1,123 @@
+"""Gather-sum plans: the static preprocessing of a graph for `tipk_gather_sum`.
+
+The reference re-derives everything from COO `edge_index` on every call (PyG `propagate`:
+`index_select` + `scatter`).  The graphs of the TIP path never change during training, so -- like
+`GCNConv(cached=True)` at `src/layers.py:386-387` -- the work is done once:
+
+  * edges are stably sorted by OUTPUT row (destination for a forward pass, source row for the
+    transposed/backward pass), int64 ids are narrowed to int32;
+  * every row's edge list is cut into work items of <= `chunk` edges (skewed rows -- a drug has
+    up to 70 715 in-edges, SURVEY.md section 0 -- become many equal items; short rows one item);
+  * items are ordered by decreasing length so the slots of one wavefront finish together;
+  * rows that were split get consecutive slots in a `partial` buffer, summed in slot order by
+    `tipk_gather_sum_finalize` -> results do not depend on scheduling (no float atomics).
+
+Everything here is index arithmetic in torch (runs on CPU or GPU; unit-tested on CPU).  The layout
+of `items` / `split_rows` is the contract of include/tipk.h section 1.
+"""
+import torch
+
+DEFAULT_CHUNK = 128
+
+
+class GatherPlan(object):
+    """Device-resident plan.  Fields (all int32 unless noted):
+    row_id [E]        source-table row per edge, in plan (sorted) order
+    edge_w [E] fp32   optional per-edge weight in plan order
+    items [n_items,4] (begin, end, target, flags)
+    split_rows [m,3]  (out_row, first_slot, end_slot)
+    perm [E] int64    plan order -> caller's edge order (for re-weighting)
+    """
+
+    def __init__(self, n_out, n_table, row_id, edge_w, items, split_rows, n_slots, perm, chunk, tag=''):
+        self.tag = tag
+        self.n_out, self.n_table = int(n_out), int(n_table)
+        self.row_id, self.edge_w = row_id, edge_w
+        self.items, self.split_rows = items, split_rows
+        self.n_slots, self.perm, self.chunk = int(n_slots), perm, int(chunk)
+        self.n_edges = int(row_id.numel())
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return GatherPlan(self.n_out, self.n_table, mv(self.row_id), mv(self.edge_w), mv(self.items),
+                          mv(self.split_rows), self.n_slots, mv(self.perm), self.chunk, self.tag)
+
+    @property
+    def device(self):
+        return self.items.device
+
+
+def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEFAULT_CHUNK, tag=''):
+    """Plan for  out[o] = sum_{e: out_row[e]=o} edge_w[e] * table[table_row[e]].
+
+    out_row, table_row: int64 [E] (any device); n_out / n_table: row counts of `out` / `table`.
+    Every output row gets at least one (possibly empty) item, so the kernel also writes the zeros.
+    """
+    dev = out_row.device
+    E = int(out_row.numel())
+    if E >= 2 ** 31 - 1 or n_out >= 2 ** 31 - 1 or n_table >= 2 ** 31 - 1:
+        raise ValueError('graph too large for int32 plans')
+    if E:
+        lo, hi = int(out_row.min()), int(out_row.max())
+        tlo, thi = int(table_row.min()), int(table_row.max())
+        if lo < 0 or hi >= n_out or tlo < 0 or thi >= n_table:
+            raise IndexError('edge index out of range: out rows [%d,%d] of %d, table rows [%d,%d] of %d'
+                             % (lo, hi, n_out, tlo, thi, n_table))
+    order = torch.sort(out_row, stable=True).indices
+    counts = torch.bincount(out_row, minlength=n_out) if E else torch.zeros(n_out, dtype=torch.long, device=dev)
+    row_ptr = torch.zeros(n_out + 1, dtype=torch.long, device=dev)
+    row_ptr[1:] = torch.cumsum(counts, 0)
+
+    n_chunks = torch.clamp((counts + chunk - 1) // chunk, min=1)            # items per row
+    item_ptr = torch.zeros(n_out + 1, dtype=torch.long, device=dev)
+    item_ptr[1:] = torch.cumsum(n_chunks, 0)
+    n_items = int(item_ptr[-1])
+    item_row = torch.repeat_interleave(torch.arange(n_out, device=dev), n_chunks)
+    local = torch.arange(n_items, device=dev) - item_ptr[item_row]
+    begin = row_ptr[item_row] + local * chunk
+    end = torch.minimum(begin + chunk, row_ptr[item_row + 1])
+
+    direct = n_chunks[item_row] == 1
+    slot = torch.cumsum((~direct).long(), 0) - 1                             # slot id of split items
+    target = torch.where(direct, item_row, slot)
+    n_slots = int((~direct).sum())
+
+    by_len = torch.sort(end - begin, descending=True, stable=True).indices
+    items = torch.stack([begin, end, target, direct.long()], dim=1)[by_len].to(torch.int32).contiguous()
+
+    split = torch.nonzero(n_chunks > 1).view(-1)
+    if split.numel():
+        first = slot[item_ptr[split]]
+        split_rows = torch.stack([split, first, first + n_chunks[split]], dim=1).to(torch.int32).contiguous()
+    else:
+        split_rows = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+
+    row_id = table_row[order].to(torch.int32).contiguous()
+    w = None if edge_w is None else edge_w[order].to(torch.float32).contiguous()
+    return GatherPlan(n_out, n_table, row_id, w, items, split_rows, n_slots, order, chunk, tag)
+
+
+def execute_plan_reference(plan, table, row_scale=None):
+    """Pure-torch interpretation of a plan (item by item semantics, vectorised).  Used by the CPU
+    unit tests of the plan builder and of the host logic; NOT used by the product path."""
+    d = table.shape[1]
+    it = plan.items.long()
+    lens = it[:, 1] - it[:, 0]
+    item_of_edge = torch.repeat_interleave(torch.arange(it.shape[0], device=table.device), lens)
+    starts = torch.cumsum(lens, 0) - lens
+    edge_pos = it[item_of_edge, 0] + (torch.arange(int(lens.sum()), device=table.device) - starts[item_of_edge])
+    rows = table[plan.row_id.long()[edge_pos]]
+    if plan.edge_w is not None:
+        rows = rows * plan.edge_w[edge_pos].unsqueeze(1)
+    per_item = torch.zeros((it.shape[0], d), dtype=table.dtype, device=table.device).index_add_(0, item_of_edge, rows)
+    out = torch.zeros((plan.n_out, d), dtype=table.dtype, device=table.device)
+    direct = it[:, 3] == 1
+    out[it[direct, 2]] = per_item[direct]
+    if plan.n_slots:
+        partial = torch.zeros((plan.n_slots, d), dtype=table.dtype, device=table.device)
+        partial[it[~direct, 2]] = per_item[~direct]
+        for r, a, b in plan.split_rows.tolist():
+            out[r] = partial[a:b].sum(0)
+    if row_scale is not None:
+        out = out * row_scale.unsqueeze(1)
+    return out
