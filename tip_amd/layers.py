@@ -39,6 +39,8 @@ def _ident(*tensors):
     for t in tensors:
         if t is None:
             key.append(None)
+        elif t.is_sparse:                        # no storage pointer: the (pinned) object itself
+            key.append((id(t), tuple(t.shape), str(t.device), t.dtype))
         else:
             key.append((t.data_ptr(), tuple(t.shape), t._version, str(t.device), t.dtype))
     return tuple(key)
