@@ -76,7 +76,9 @@ def cpu_baseline(dd, dims, mod, budget_s):
                       n_embed=dims['n_embed'], n_hid1=dims['n_hid1'], n_hid2=dims['n_hid2'],
                       num_base=dims['num_base'])
     up = torch.randn(dd['n_drug'], dims['n_hid2'], generator=torch.Generator().manual_seed(0))
-    threads = torch.get_num_threads()
+    # torch's default (= all hardware threads) oversubscribes these small ops on big hosts
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
 
     def step():
         z, saved = O.fm_encoder_fwd(p, dd, mod)

@@ -113,6 +113,12 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device=dev)
     assert tuple(out.shape) == oshape and out.stride(-1) == 1, (out.shape, oshape, out.stride())
+    if ksplit == 1 and c_in is None and not relu and not batched and k >= 2048 and out.is_contiguous():
+        # few output tiles but a long reduction (e.g. dW = g^T h over 19 081 proteins): split K
+        # so the launch fills the chip; slabs are then added in order (deterministic)
+        tiles = -(-m // 64) * -(-n // 64)
+        if tiles <= 64:
+            ksplit = int(min(128, k // 256))
     g = GemmDesc()
     g.m, g.n, g.k = m, n, k
     g.ksplit = ksplit
