@@ -41,6 +41,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--chunk', type=int, default=None, help='gather plan chunk (edges per work item)')
+    ap.add_argument('--launch', default=None, choices=['graph', 'eager'],
+                    help='graph: the step is captured once into a hipGraph and replayed (default on 1 GPU); '
+                         'eager: one ctypes launch per kernel (default with collectives in the step)')
     return ap.parse_args()
 
 
@@ -138,11 +141,9 @@ def main():
     from tip_amd import ops
     from tip_amd.data import Data
     from tip_amd.layers import FMEncoder
-    from tip_amd import plan as plan_mod
     if args.chunk:
-        plan_mod.DEFAULT_CHUNK = args.chunk
-        import tip_amd.layers as layers_mod
-        layers_mod.DEFAULT_CHUNK = args.chunk
+        os.environ['TIPK_CHUNK'] = str(args.chunk)
+    launch = args.launch or ('graph' if world == 1 else 'eager')
 
     dd, dims, wl_name = make_workload(args)
     E = int(dd['dd_train_idx'].shape[1])
@@ -163,9 +164,6 @@ def main():
         z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat,
                 d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
         z.backward(g_up)
-        if world > 1:
-            from tip_amd.dist import finish_grads
-            finish_grads(enc)
 
     def fence():
         torch.cuda.synchronize()
@@ -177,15 +175,33 @@ def main():
     step()                                                     # builds + caches all gather plans
     torch.cuda.synchronize()
     preprocess_s = time.perf_counter() - t0
+    run = step
+    if launch == 'graph':
+        # the whole step (about 70 kernels) becomes one hipGraph: replay removes the per-launch host
+        # cost, which is larger than the kernels themselves at BioSNAP scale
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
-    ops.timing_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     fence()
     elapsed = time.perf_counter() - t0
+    # per-kernel durations: HIP events on the launch stream around every launch of an eager pass of
+    # the same steps, same process (events cannot be read back from inside a replayed graph)
+    ops.timing_start()
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+    fence()
     kern = ops.timing_stop()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -214,11 +230,12 @@ def main():
             if args.workload.startswith('biosnap') else 'synthetic',
             'config': {'workload': wl_name, 'mod': args.mod, 'directed_dd_edges': E, 'relations': R,
                        'parallelism': 'relation-sharded x%d' % world if world > 1 else 'single GPU',
-                       'launch': 'eager (one ctypes call per kernel)'},
+                       'launch': 'hipGraph replay of the captured step' if launch == 'graph'
+                       else 'eager (one ctypes call per kernel)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'launch_ms': gs[dom][1], 'algorithmic_bytes_per_launch': alg_bytes},
-            'kernels_ms': {k: {'launches_per_step': v[0] / args.steps, 'mean_ms': round(v[1], 5)}
+            'kernels_ms': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
                            for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])},
             'preprocess_s': preprocess_s,
             'whole_step_algorithmic_GBps': E * sum(2 * (4 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2')) / (ms * 1e-3) / 1e9,

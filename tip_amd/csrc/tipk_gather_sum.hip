@@ -76,13 +76,21 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
 
     Acc<V> acc;
     acc.zero();
+    // software-pipelined ids: the slot's next L edge ids are requested before the current L rows
+    int id_next = -1;
+    float w_next = 0.f;
+    if (it.x + sub < it.y) {
+        id_next = row_id[it.x + sub];
+        if (HAS_W) w_next = edge_w[it.x + sub];
+    }
     for (int e0 = it.x; e0 < it.y; e0 += L) {
-        const int mine = e0 + sub;
-        int id = -1;
-        float wgt = 0.f;
-        if (mine < it.y) {
-            id = row_id[mine];
-            if (HAS_W) wgt = edge_w[mine];
+        const int id = id_next;
+        const float wgt = w_next;
+        const int nxt = e0 + L + sub;
+        id_next = -1;
+        if (nxt < it.y) {
+            id_next = row_id[nxt];
+            if (HAS_W) w_next = edge_w[nxt];
         }
 #pragma unroll
         for (int j0 = 0; j0 < L; j0 += U) {

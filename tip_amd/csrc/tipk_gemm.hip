@@ -4,16 +4,17 @@
 // or N = out channels <= 128), so the kernel is a plain LDS-tiled loop with register prefetch of
 // the next K tile; generic element strides make every transpose / basis reshape copy-free.
 //
-// Tile: WM x WN waves of 32x32 (one MFMA accumulator each), BK = 16.  LDS tiles are k-major
-// (As[k][m], Bs[k][n]) so the MFMA operand fetch (lane l: row l&31 of k = 2*kk + (l>>5)) is a
-// conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+// Tile: WM x WN waves of 32x32 (one MFMA accumulator each), BK = 32, LDS double-buffered (one
+// barrier per K step; the next tile's global loads are in flight during the MFMAs).  LDS tiles
+// are k-major (As[k][m], Bs[k][n]) so the MFMA operand fetch (lane l: row l&31 of
+// k = 2*kk + (l>>5)) is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
 #include "tipk_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int PAD = 4;
 
 struct GemmArgs {
@@ -60,8 +61,8 @@ template <int WM, int WN, bool A_KFAST, bool B_KFAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WM * 32, BN = WN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ float As[BK][BM + PAD];
-    __shared__ float Bs[BK][BN + PAD];
+    __shared__ float As[2][BK][BM + PAD];
+    __shared__ float Bs[2][BK][BN + PAD];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
@@ -91,18 +92,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     if (n_tiles > 0) fetch(0);
     for (int64_t tile = 0; tile < n_tiles; ++tile) {
-        la.store(As, t);
-        lb.store(Bs, t);
+        const int buf = (int)(tile & 1);
+        // buffer `buf` was last read two steps ago; the barrier of the previous step fences it
+        la.store(As[buf], t);
+        lb.store(Bs[buf], t);
         __syncthreads();
         if (tile + 1 < n_tiles) fetch(tile + 1);
         const int row = lane & 31, kh = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const float av = As[2 * kk + kh][wm * 32 + row];
-            const float bv = Bs[2 * kk + kh][wn * 32 + row];
+            const float av = As[buf][2 * kk + kh][wm * 32 + row];
+            const float bv = Bs[buf][2 * kk + kh][wn * 32 + row];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
-        __syncthreads();
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -166,6 +168,7 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
     g.alpha = d->alpha; g.relu = d->relu;
     hipStream_t st = (hipStream_t)stream;
     if (d->n <= 32) return launch<4, 1>(g, d->batch, st);
+    if (d->m <= 32) return launch<1, 4>(g, d->batch, st);
     return launch<2, 2>(g, d->batch, st);
 }
 

@@ -236,15 +236,17 @@ def relation_of_edges(range_list, n_edges, device):
     return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
 
 
-def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK):
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
-    scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean')."""
+    scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `degree_from`:
+    destination ids of the FULL edge list when `edge_index` is only one rank's shard."""
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = rel.to(torch.int64)
     if rel.numel() and (int(rel.min()) < 0 or int(rel.max()) >= n_rel):
         raise IndexError('edge_type out of range')
     yrow = rel * n_nodes + src
-    deg = torch.bincount(dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
+    all_dst = dst if degree_from is None else degree_from.to(torch.int64)
+    deg = torch.bincount(all_dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
     return ops.AggGraph(build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
                         build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous())
@@ -264,6 +266,7 @@ class _RGCNBase(nn.Module):
         else:
             self.register_parameter('bias', None)
         self._cache = _PlanCache()
+        self.shard = None                       # tip_amd.dist.RelationShard for multi-GPU runs
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -275,7 +278,7 @@ class _RGCNBase(nn.Module):
             self.bias.data.zero_()
 
     def _run(self, x, graph):
-        out = ops.rgcn(x, self.basis, self.att, self.root, graph)
+        out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard)
         return out if self.bias is None else out + self.bias
 
     def __repr__(self):
@@ -291,6 +294,10 @@ class MyRGCNConv2(_RGCNBase):
         n = x.shape[0]
 
         def build():
+            if self.shard is not None:                       # this rank's relations only
+                from .dist import shard_edges
+                ei, rel = shard_edges(edge_index, range_list, self.shard.rel_ids)
+                return rgcn_graph(ei, rel, n, int(self.shard.rel_ids.numel()), self.chunk, degree_from=edge_index[1])
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
             return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk)
         graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
@@ -303,6 +310,8 @@ class MyRGCNConv(_RGCNBase):
 
     def forward(self, x, edge_index, edge_type):
         n = x.shape[0]
+        if self.shard is not None:
+            raise NotImplementedError('relation sharding needs the range-list variant MyRGCNConv2')
         graph = self._cache.get((edge_index, edge_type),
                                 lambda: rgcn_graph(edge_index, edge_type, n, self.num_relations, self.chunk))
         return self._run(x, graph)

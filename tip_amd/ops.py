@@ -88,12 +88,24 @@ def _strides3(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=1):
+def _tile_shape(m, n):
+    """(BM, BN) the kernel picks (tip_amd/csrc/tipk_gemm.hip: 4x1, 1x4 or 2x2 waves of 32x32)."""
+    if n <= 32:
+        return 128, 32
+    if m <= 32:
+        return 32, 128
+    return 64, 64
+
+
+def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
     """out = relu?(alpha * a @ b + c_in) on the matrix cores (include/tipk.h section 2).
 
     a: [M,K] or [Z,M,K]; b: [K,N] or [Z,K,N] -- arbitrary strides (transposed views are free).
     reduce_batch: sum the Z products into one [M,N] (the basis-sum of the R-GCN backward).
-    ksplit > 1: split-K into slabs + ordered slab sum (skinny outputs with huge K).
+    ksplit: K slabs (None = automatic).  Products with few output tiles but a long reduction
+    (dW = g^T h over 19 081 proteins, X^T g over 645 drugs, att^T dY over 1 097 relations) would
+    run as a handful of serial workgroups; they are cut into slabs that fill the chip and the
+    slabs are added in order by `tipk_sum_slabs` (deterministic, no atomics).
     """
     require_device(a, b)
     if a.dtype != torch.float32 or b.dtype != torch.float32:
@@ -105,53 +117,64 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     assert k == k2, (a.shape, b.shape)
     a_sz, a_sm, a_sk = _strides3(a)
     b_sz, b_sk, b_sn = _strides3(b)
-    if batched and not reduce_batch:
-        oshape = (z, m, n)
-    else:
-        oshape = (m, n)
+    reduce_batch = bool(reduce_batch and batched)
+    oshape = (z, m, n) if (batched and not reduce_batch) else (m, n)
     dev = a.device
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device=dev)
     assert tuple(out.shape) == oshape and out.stride(-1) == 1, (out.shape, oshape, out.stride())
-    if ksplit == 1 and c_in is None and not relu and not batched and k >= 2048 and out.is_contiguous():
-        # few output tiles but a long reduction (e.g. dW = g^T h over 19 081 proteins): split K
-        # so the launch fills the chip; slabs are then added in order (deterministic)
-        tiles = -(-m // 64) * -(-n // 64)
-        if tiles <= 64:
-            ksplit = int(min(128, k // 256))
+    if c_in is not None:
+        assert c_in.shape == out.shape and c_in.stride(-1) == 1
+
+    bm, bn = _tile_shape(m, n)
+    tiles = -(-m // bm) * -(-n // bn) * (1 if reduce_batch else z)
+    plain = relu is False and (c_in is None or c_in.data_ptr() == out.data_ptr()) and out.is_contiguous()
+    slab_mode = None                       # None | 'k' (split the k range) | 'q' (one slab per batch term)
+    if reduce_batch and plain and tiles * 2 <= 256 and z > 1:
+        slab_mode, n_slabs = 'q', z
+    elif ksplit is None:
+        want = min(k // 64, -(-512 // tiles))
+        if plain and not reduce_batch and want >= 2 and tiles < 256:
+            slab_mode, n_slabs = 'k', int(min(128, want))
+    elif ksplit > 1:
+        assert plain and not reduce_batch
+        slab_mode, n_slabs = 'k', int(ksplit)
+
     g = GemmDesc()
     g.m, g.n, g.k = m, n, k
-    g.ksplit = ksplit
     g.a, g.b = a.data_ptr(), b.data_ptr()
     g.a_sm, g.a_sk, g.b_sk, g.b_sn = a_sm, a_sk, b_sk, b_sn
-    if batched and reduce_batch:
+    g.ksplit = n_slabs if slab_mode == 'k' else 1
+    if reduce_batch and slab_mode != 'q':
         g.batch, g.kbatch = 1, z
         g.a_sq, g.b_sq, g.a_sz, g.b_sz = a_sz, b_sz, 0, 0
     else:
         g.batch, g.kbatch = (z if batched else 1), 1
         g.a_sq, g.b_sq, g.a_sz, g.b_sz = 0, 0, a_sz, b_sz
     slabs = None
-    if ksplit > 1:
-        assert c_in is None and not relu and not (batched and not reduce_batch)
-        slabs = torch.empty((ksplit, m, n), dtype=torch.float32, device=dev)
-        g.c, g.c_sm, g.c_sz, g.c_ss = slabs.data_ptr(), n, 0, m * n
+    per = m * n * (z if (batched and not reduce_batch) else 1)       # floats of the final result
+    if slab_mode == 'k':
+        slabs = torch.empty((n_slabs,) + oshape, dtype=torch.float32, device=dev)
+        g.c, g.c_sm, g.c_sz, g.c_ss = slabs.data_ptr(), n, m * n, per
+    elif slab_mode == 'q':
+        slabs = torch.empty((z, m, n), dtype=torch.float32, device=dev)
+        g.c, g.c_sm, g.c_sz, g.c_ss = slabs.data_ptr(), n, m * n, 0
     else:
         g.c, g.c_sm = out.data_ptr(), out.stride(-2)
         g.c_sz = out.stride(0) if out.dim() == 3 else 0
         g.c_ss = 0
-    if c_in is not None:
-        assert c_in.shape == out.shape and c_in.stride(-1) == 1
+    if c_in is not None and slab_mode is None:
         g.c_in, g.cin_sm = c_in.data_ptr(), c_in.stride(-2)
         g.cin_sz = c_in.stride(0) if c_in.dim() == 3 else 0
     else:
         g.c_in, g.cin_sm, g.cin_sz = None, 0, 0
-    g.alpha, g.relu = alpha, int(relu)
+    g.alpha, g.relu = (1.0 if slab_mode else alpha), int(relu)
     st = stream_ptr(dev)
-    with _timed('gemm[%dx%dx%d,z=%d%s]' % (m, n, k, z, ',ksplit=%d' % ksplit if ksplit > 1 else '')):
+    with _timed('gemm[%dx%dx%d,z=%d%s]' % (m, n, k, z, ',slabs=%s%d' % (slab_mode, n_slabs) if slab_mode else '')):
         check(lib().tipk_gemm_f32(g, st), 'tipk_gemm_f32')
-        if slabs is not None:
-            assert out.is_contiguous()
-            check(lib().tipk_sum_slabs(ptr(slabs), ksplit, m * n, m * n, 1.0, 0, ptr(out), st), 'tipk_sum_slabs')
+        if slab_mode:
+            check(lib().tipk_sum_slabs(ptr(slabs), n_slabs, per, per, alpha, int(c_in is not None), ptr(out), st),
+                  'tipk_sum_slabs')
     return out
 
 
@@ -346,11 +369,6 @@ def matmul(x, w):
     return _MatMul.apply(x, w)
 
 
-def _att_ksplit(k):
-    """slabs for the skinny dAtt product (M = relations, N = bases, K = nodes*out)."""
-    return int(max(1, min(64, k // 512)))
-
-
 class _RGCN(torch.autograd.Function):
     """One basis-decomposed R-GCN layer with global-mean aggregation
     (reference MyRGCNConv2 / MyRGCNConv, src/layers.py:102-193 / :21-99):
@@ -358,50 +376,74 @@ class _RGCN(torch.autograd.Function):
         out = D^-1 sum_r A_r X W_r + X root,   W_r = sum_b att[r,b] basis[b]
 
     evaluated basis-first / transform-then-gather: XB_b = X basis_b, Y = att . XB, then one
-    gather-sum over the rows of Y (no E x d intermediates)."""
+    gather-sum over the rows of Y (no E x d intermediates).
+
+    With a `shard` (tip_amd/dist.py) the graph holds only this rank's relations: the partial
+    aggregate is all-reduced before the 1/deg scaling, and the partial dX / d basis / d att rows
+    are all-reduced in one packed collective on the way back."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, graph):
+    def forward(ctx, x, basis, att, root, graph, shard):
         x, basis, att, root = _f32c(x), basis.contiguous(), att.contiguous(), root.contiguous()
         n, d_in = x.shape
         nb, _, d_out = basis.shape
-        r = att.shape[0]
+        att_l = att if shard is None else att.index_select(0, shard.rel_ids_on(att.device))
+        r = att_l.shape[0]
         assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         xb = gemm(x, basis)                                              # [B, N, out]
-        y = gemm(att, xb.view(nb, n * d_out))                            # [R, N*out]
-        agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
+        if r > 0:
+            y = gemm(att_l, xb.view(nb, n * d_out))                      # [R, N*out]
+        else:
+            y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
+        if shard is None:
+            agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
+        else:
+            from .dist import all_reduce_packed
+            agg = gather_sum(graph.fwd, y.view(r * n, d_out))
+            all_reduce_packed([agg], shard.group)
+            rows_affine(agg, row_mul=graph.scale, out=agg)
         del y
         out = gemm(x, root, out=agg, c_in=agg)                           # + X root
-        ctx.graph = graph
-        ctx.save_for_backward(x, basis, att, root, xb)
+        ctx.graph, ctx.shard = graph, shard
+        ctx.save_for_backward(x, basis, att, att_l, root, xb)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, basis, att, root, xb = ctx.saved_tensors
-        graph = ctx.graph
+        x, basis, att, att_l, root, xb = ctx.saved_tensors
+        graph, shard = ctx.graph, ctx.shard
         g = _f32c(g).contiguous()
         n, d_in = x.shape
         nb, _, d_out = basis.shape
-        r = att.shape[0]
-        need_x = ctx.needs_input_grad[0]
+        r = att_l.shape[0]
         g_root = gemm(x.t(), g)
         gs = rows_affine(g, row_mul=graph.scale)
-        g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)               # dY_r = A_r^T (D^-1 g)
         xb2 = xb.view(nb, n * d_out)
-        g_att = gemm(g_y, xb2.t(), ksplit=_att_ksplit(n * d_out))
-        g_xb = gemm(att.t(), g_y).view(nb, n, d_out)
-        del g_y
+        if r > 0:
+            g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)           # dY_r = A_r^T (D^-1 g)
+            g_att_l = gemm(g_y, xb2.t())                                 # split-K (automatic)
+            g_xb = gemm(att_l.t(), g_y).view(nb, n, d_out)
+            del g_y
+        else:
+            g_att_l = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
+            g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
         g_basis = gemm(x.t(), g_xb)                                      # [B, in, out]
-        g_x = None
-        if need_x:
+        if shard is None:
+            g_att = g_att_l
             g_x = gemm(g, root.t())
             g_x = gemm(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
-        return g_x, g_basis, g_att, g_root, None
+        else:
+            from .dist import all_reduce_packed
+            g_x = gemm(g_xb, basis.transpose(1, 2), reduce_batch=True)   # partial over this shard
+            g_att = torch.zeros_like(att)
+            g_att.index_copy_(0, shard.rel_ids_on(att.device), g_att_l)
+            all_reduce_packed([g_x, g_basis, g_att], shard.group)
+            g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
+        return g_x, g_basis, g_att, g_root, None, None
 
 
-def rgcn(x, basis, att, root, graph):
-    return _RGCN.apply(x, basis, att, root, graph)
+def rgcn(x, basis, att, root, graph, shard=None):
+    return _RGCN.apply(x, basis, att, root, graph, shard)
 
 
 class _DrugMix(torch.autograd.Function):

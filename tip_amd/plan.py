@@ -15,9 +15,21 @@ The reference re-derives everything from COO `edge_index` on every call (PyG `pr
 Everything here is index arithmetic in torch (runs on CPU or GPU; unit-tested on CPU).  The layout
 of `items` / `split_rows` is the contract of include/tipk.h section 1.
 """
+import os
+
 import torch
 
-DEFAULT_CHUNK = 128
+DEFAULT_CHUNK = None          # None = `auto_chunk` (edges per work item chosen from the edge count)
+TARGET_ITEMS = 65536          # ~ 256 CUs x 32 waves x 8 slots: one item per slot fills the chip
+
+
+def auto_chunk(n_edges):
+    """Power-of-two chunk in [16, 128] that yields about TARGET_ITEMS work items: short chains
+    (few dependent index->row round trips per slot) while every CU still has a full set of waves."""
+    c = 16
+    while c < 128 and n_edges // c > TARGET_ITEMS:
+        c *= 2
+    return c
 
 
 class GatherPlan(object):
@@ -55,6 +67,8 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     """
     dev = out_row.device
     E = int(out_row.numel())
+    if chunk is None:
+        chunk = int(os.environ.get('TIPK_CHUNK', '0')) or auto_chunk(E)      # env override for sweeps
     if E >= 2 ** 31 - 1 or n_out >= 2 ** 31 - 1 or n_table >= 2 ** 31 - 1:
         raise ValueError('graph too large for int32 plans')
     if E:
