@@ -139,15 +139,25 @@ int launch(const GemmArgs& g, int64_t batch, hipStream_t st) {
     TIPK_RETURN_LAUNCH();
 }
 
+// 64 consecutive elements x 4 slab lanes per workgroup: lane j adds slabs j, j+4, ... in order,
+// then the four lanes are combined in a fixed order through LDS (deterministic, and a
+// 128-slab x 512-element reduction is no longer two serial workgroups).
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ in, int64_t n_slabs,
                                                         int64_t slab_stride, int64_t count, float alpha,
                                                         int accumulate, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int64_t k = 0; k < n_slabs; ++k) s += in[k * slab_stride + i];
-    s *= alpha;
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < count)
+        for (int64_t k = j; k < n_slabs; k += 4) s += in[k * slab_stride + i];
+    red[j][e] = s;
+    __syncthreads();
+    if (j == 0 && i < count) {
+        s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        s *= alpha;
+        out[i] = accumulate ? out[i] + s : s;
+    }
 }
 
 }  // namespace
@@ -177,7 +187,7 @@ extern "C" int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_str
     if (n_slabs < 0 || count < 0) return TIPK_EINVAL;
     if (count == 0) return TIPK_OK;
     if (!out || (n_slabs > 0 && !in)) return TIPK_EINVAL;
-    const int64_t blocks = tipk_ceil_div(count, 256);
+    const int64_t blocks = tipk_ceil_div(count, 64);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, n_slabs,
                        slab_stride, count, alpha, accumulate, out);

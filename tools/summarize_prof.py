@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (tools/profile_gpu.sh) into the small summaries kept under profiles/.
+
+  profiles/<tag>_kernel_stats.csv   per-kernel calls / total / average / min / max (ns), the
+                                    rocprofv3 --kernel-trace --stats table for libtipk kernels and the
+                                    largest torch kernels, names shortened
+  profiles/<tag>_pmc_traffic.json   per kernel: average FETCH_SIZE / WRITE_SIZE per launch and the
+                                    HBM bytes derived as the MI355X guide prescribes
+                                    (bytes = KB * 1024; gfx950 reads: FETCH_SIZE doubled)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+os.makedirs('profiles', exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([A-Za-z0-9_:]+(<[^(]*>)?)\(', name)
+    if m:
+        name = m.group(1)
+    return name[:110]
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats = find('trace/**/*kernel_stats.csv')
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open('profiles/%s_kernel_stats.csv' % tag, 'w') as f:
+        f.write('# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`\n')
+        f.write('kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n')
+        for r in rows[:45]:
+            f.write('"%s",%s,%s,%.0f,%s,%s,%s\n' % (short(r['Name']), r['Calls'], r['TotalDurationNs'],
+                                                  float(r['AverageNs']), r['Percentage'], r['MinNs'], r['MaxNs']))
+
+# per-dispatch trace: split the gather_sum launches by grid size so that dd.fwd / dd.bwd / pp are separate
+trace = find('trace/**/*kernel_trace.csv')
+if trace:
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        n = short(r['Kernel_Name'])
+        if 'gather_sum_kernel' in n or 'gemm_f32' in n:
+            key = '%s grid=%s' % (n, r.get('Grid_Size', r.get('Grid_Size_X', '?')))
+            agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    with open('profiles/%s_kernel_by_grid.csv' % tag, 'w') as f:
+        f.write('# libtipk launches of the same command, split by grid size (one line per distinct launch shape)\n')
+        f.write('kernel_and_grid,calls,avg_ns,min_ns,max_ns\n')
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            f.write('"%s",%d,%.0f,%d,%d\n' % (k, len(v), sum(v) / len(v), min(v), max(v)))
+
+pmc = {}
+for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    fn = find(sub + '/**/*counter_collection.csv')
+    if not fn:
+        continue
+    per = defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        if r.get('Counter_Name') != counter:
+            continue
+        n = short(r['Kernel_Name'])
+        if 'gather_sum_kernel' in n or 'gemm_f32' in n or 'finalize' in n:
+            n = '%s grid=%s' % (n, r.get('Grid_Size', '?'))
+        per[n].append(float(r['Counter_Value']))
+    for n, v in per.items():
+        pmc.setdefault(n, {})[counter + '_KB_avg'] = sum(v) / len(v)
+        pmc[n]['launches_' + counter] = len(v)
+for n, d in pmc.items():
+    f_kb, w_kb = d.get('FETCH_SIZE_KB_avg', 0.0), d.get('WRITE_SIZE_KB_avg', 0.0)
+    d['hbm_bytes_per_launch'] = (2.0 * f_kb + w_kb) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 of wide reads
+    d['hbm_bytes_per_launch_uncorrected'] = (f_kb + w_kb) * 1024.0
+if pmc:
+    top = dict(sorted(pmc.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:40])
+    json.dump({'note': 'FETCH_SIZE/WRITE_SIZE in KB per launch (separate rocprofv3 --pmc passes of bench.py --launch eager); '
+                       'hbm_bytes = (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md HBM section', 'kernels': top},
+              open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
+print('summaries written for', tag)
