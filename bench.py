@@ -120,6 +120,32 @@ def cpu_baseline(dd, dims, mod, budget_s):
     return out
 
 
+def pmc_traffic(enc, label, d_row):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    command, corrected as MI355X_MICROARCH.md prescribes); None if no summary matches the launch."""
+    import glob
+    try:
+        graph = {'dd': enc.rgcn1 if d_row == enc.rgcn1.out_channels else enc.rgcn2}['dd']._cache.value \
+            if '[dd.' in label else None
+        if graph is None:
+            return None
+        plan = graph.fwd if '.fwd' in label else graph.bwd
+        lanes = 1
+        while lanes < d_row // 4:
+            lanes *= 2
+        waves = -(-plan.items.shape[0] // (64 // lanes))
+        grid = -(-waves // 4) * 256
+        key = 'gather_sum_kernel<4, %d, false> grid=%d' % (lanes, grid)
+        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+            k = json.load(open(fn))['kernels'].get(key)
+            if k:
+                return k['hbm_bytes_per_launch']
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -221,6 +247,7 @@ def main():
             n_launch_edges = n_launch_edges // world           # rank 0's share (balanced by edges)
         alg_bytes = n_launch_edges * (4 + 4 * d_row)           # int32 row id + one d-wide fp32 row per edge
         achieved = alg_bytes / (gs[dom][1] * 1e-3) / 1e9
+        traffic = pmc_traffic(enc, dom, d_row)
         out = {
             'metric': 'D-D edges aggregated/sec (encoder fwd+bwd)',
             'value': E * args.steps / elapsed, 'unit': 'edges/s',
@@ -233,7 +260,7 @@ def main():
                        'launch': 'hipGraph replay of the captured step' if launch == 'graph'
                        else 'eager (one ctypes call per kernel)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'launch_ms': gs[dom][1], 'algorithmic_bytes_per_launch': alg_bytes},
             'kernels_ms': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
                            for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])},

@@ -71,11 +71,13 @@ int tipk_gather_sum(const float* table, int64_t ld_table,
                     const float* bias /* nullable, [d] */, int relu,
                     int d, tipk_stream_t stream);
 
-/* rows[m] = { out_row, first_slot, end_slot } int32 x 3: out[out_row] = epi(sum partial[slots]) */
+/* rows[m] = { out_row, first_slot, end_slot } int32 x 3: out[out_row] = epi(sum partial[slots]).
+ * max_slots: largest slot count of any row (host knows it from the plan; 0 = unknown) -- picks
+ * a slot-per-row kernel for lightly split rows, a workgroup-per-row kernel otherwise. */
 int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t n_rows,
                              float* out, int64_t ld_out,
                              const float* row_scale, const float* bias, int relu,
-                             int d, tipk_stream_t stream);
+                             int d, int max_slots, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).

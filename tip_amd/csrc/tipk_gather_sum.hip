@@ -156,6 +156,35 @@ __global__ __launch_bounds__(256) void gather_sum_finalize_kernel(
     }
 }
 
+// Rows cut into only a few slots (P-P: 2-4): one L-lane slot per row, 64/L rows per wave.
+template <int V, int L>
+__global__ __launch_bounds__(256) void gather_sum_finalize_small_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ rows, int64_t n_rows, float* __restrict__ out,
+    int64_t ld_out, Epilogue ep, int d) {
+    const int lane = tipk_lane();
+    const int sub = lane & (L - 1);
+    const int64_t m = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / TIPK_WAVE) * (TIPK_WAVE / L) + lane / L;
+    const int col = sub * V;
+    if (m >= n_rows || col >= d) return;
+    const int row = rows[3 * m + 0], s0 = rows[3 * m + 1], s1 = rows[3 * m + 2];
+    Acc<V> acc;
+    acc.zero();
+    for (int s = s0; s < s1; ++s) acc.add_row(partial + (int64_t)s * d + col);
+    acc.epilogue(ep, row, col);
+    acc.store(out + (int64_t)row * ld_out + col);
+}
+
+template <int V, int L>
+int launch_finalize_small(const float* partial, const int32_t* rows, int64_t n_rows, float* out, int64_t ld_out,
+                          Epilogue ep, int d, hipStream_t st) {
+    const int64_t waves = tipk_ceil_div(n_rows, TIPK_WAVE / L);
+    const int64_t blocks = tipk_ceil_div(waves, 4);
+    if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    hipLaunchKernelGGL((gather_sum_finalize_small_kernel<V, L>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
+                       rows, n_rows, out, ld_out, ep, d);
+    TIPK_RETURN_LAUNCH();
+}
+
 template <int V, int L>
 int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, const float* edge_w,
                   const int32_t* items, int64_t n_items, float* out, int64_t ld_out, float* partial,
@@ -224,13 +253,23 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, const int32
 
 extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t n_rows, float* out,
                                         int64_t ld_out, const float* row_scale, const float* bias, int relu,
-                                        int d, tipk_stream_t stream) {
+                                        int d, int max_slots, tipk_stream_t stream) {
     if (n_rows < 0 || d <= 0) return TIPK_EINVAL;
     if (n_rows == 0) return TIPK_OK;
     if (!partial || !rows || !out || n_rows > 0x7fffffffLL) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Epilogue ep{row_scale, bias, relu};
     const bool vec = d % 4 == 0 && ld_out % 4 == 0 && aligned16(partial) && aligned16(out) && (!bias || aligned16(bias));
+    if (vec && max_slots > 0 && max_slots <= 8 && d <= 128) {
+        switch (pow2_at_least(d / 4)) {
+            case 1: return launch_finalize_small<4, 1>(partial, rows, n_rows, out, ld_out, ep, d, st);
+            case 2: return launch_finalize_small<4, 2>(partial, rows, n_rows, out, ld_out, ep, d, st);
+            case 4: return launch_finalize_small<4, 4>(partial, rows, n_rows, out, ld_out, ep, d, st);
+            case 8: return launch_finalize_small<4, 8>(partial, rows, n_rows, out, ld_out, ep, d, st);
+            case 16: return launch_finalize_small<4, 16>(partial, rows, n_rows, out, ld_out, ep, d, st);
+            default: return launch_finalize_small<4, 32>(partial, rows, n_rows, out, ld_out, ep, d, st);
+        }
+    }
     if (vec) {
         if (d > 256) return TIPK_EUNSUPPORTED;
         const int lpr = pow2_at_least(d / 4);

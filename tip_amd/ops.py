@@ -76,7 +76,7 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
                                 ptr(bias), int(relu), d, st), 'tipk_gather_sum')
     if plan.n_slots:
         check(L.tipk_gather_sum_finalize(ptr(partial), ptr(plan.split_rows), plan.split_rows.shape[0], ptr(out),
-                                         out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, st),
+                                         out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, plan.max_slots, st),
               'tipk_gather_sum_finalize')
     return out
 

@@ -48,6 +48,7 @@ class GatherPlan(object):
         self.items, self.split_rows = items, split_rows
         self.n_slots, self.perm, self.chunk = int(n_slots), perm, int(chunk)
         self.n_edges = int(row_id.numel())
+        self.max_slots = int((split_rows[:, 2] - split_rows[:, 1]).max()) if split_rows.shape[0] else 0
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
