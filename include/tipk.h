@@ -145,12 +145,17 @@ int tipk_distmult_fwd(const float* z, int64_t n_nodes, int k, const float* rel_w
                       int sigmoid, float* score, tipk_stream_t stream);
 
 /* g_z [n_nodes x k] and g_w [n_rel x k] are ACCUMULATED into (caller zeroes them);
- * `score` is the forward output when sigmoid != 0 (unused otherwise). */
+ * `score` is the forward output when sigmoid != 0 (unused otherwise).
+ * tasks (nullable): int32 [n_tasks, 3] = (relation, begin, end) -- ranges of positions that share
+ * one relation, covering [0, n_triples), largest first.  TIP's triples are grouped by relation
+ * (src/utils.py:57-63), so the host builds this once; with it (and k a power of two in 4..64,
+ * 2*n_nodes*(k+4)*4 B <= 150 KB) the LDS-resident fast kernel runs, otherwise the generic one. */
 int tipk_distmult_bwd(const float* g_score, const float* score,
                       const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                       const void* idx_u, const void* idx_v, int idx_bytes,
                       const void* edge_type, int et_bytes, int64_t n_triples,
-                      int sigmoid, float* g_z, float* g_w, tipk_stream_t stream);
+                      int sigmoid, const int32_t* tasks, int64_t n_tasks,
+                      float* g_z, float* g_w, tipk_stream_t stream);
 
 /* Fused training objective of TIP.forward (src/layers.py:335-340, K9+K10): one pass over the
  * positive triples and their negatives (same relation per position):
@@ -160,6 +165,7 @@ int tipk_distmult_bwd(const float* g_score, const float* score,
 int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                        const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
                        int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
+                       const int32_t* tasks, int64_t n_tasks,
                        float* loss_out, float* g_z, float* g_w, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

@@ -47,8 +47,8 @@ SIGNATURES = {
     'tipk_rows_affine': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _L, _L, _I, _P]),
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),
     'tipk_distmult_fwd': (_I, [_P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
-    'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P]),
-    'tipk_distmult_loss': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _P, _P, _P]),
+    'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P, _P, _P]),
+    'tipk_distmult_loss': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P]),
     'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _P, _I, _L, _P]),
 }
 

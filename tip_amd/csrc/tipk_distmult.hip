@@ -145,6 +145,168 @@ __global__ __launch_bounds__(256) void distmult_grad_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Task kernel: the fast path when triples are grouped by relation (TIP's layout).
+//
+// A *task* = (relation, begin, end) with at most a few thousand positions of ONE relation, so the
+// relation row w[r] lives in registers and d w[r] is reduced inside the workgroup (one set of k
+// global atomics per task).  z is staged once per workgroup into LDS next to a zeroed d z image
+// (row stride k+4 floats: 16-byte aligned float4 reads that spread over the banks; the dense
+// stride k=16 puts every lane of a column access on two banks).  KL = k/4 lanes share one position:
+// each reads one float4 of every row, the dot product is finished with KL-wide shuffles.
+// Persistent grid (one 1024-thread workgroup per CU), tasks dealt round-robin, largest first.
+template <typename IT, int MODE>
+__global__ __launch_bounds__(1024) void distmult_task_kernel(
+    const float* __restrict__ z, int n_nodes, int k, const float* __restrict__ w,
+    const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
+    const IT* __restrict__ nu, const IT* __restrict__ nv, const float* __restrict__ g_score, int sig,
+    int64_t n_total, float* __restrict__ loss_out, float* __restrict__ g_z, float* __restrict__ g_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    const int ld = k + 4;
+    float* zl = lds;
+    float* gzl = lds + (int64_t)n_nodes * ld;
+    float* red = gzl + (int64_t)n_nodes * ld;                 // [16 waves][k] + [16]
+    const bool want_grad = g_z != nullptr;
+    for (int i = t; i < n_nodes * k; i += 1024) {
+        const int r = i / k, c = i - r * k;
+        zl[r * ld + c] = z[i];
+        gzl[r * ld + c] = 0.f;
+    }
+    __syncthreads();
+    const int KL = k >> 2;                                    // lanes per position (power of two <= 16)
+    const int sub = t & (KL - 1);
+    const int slot = t / KL;
+    const int n_slots = 1024 / KL;
+    const int c0 = sub * 4;
+    const float inv_n = 1.f / (float)n_total;
+    float loss = 0.f;
+
+    for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int rel = tasks[3 * task], tb = tasks[3 * task + 1], te = tasks[3 * task + 2];
+        const float4 wr = tipk_ld4(w + (int64_t)rel * k + c0);
+        float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
+        // software-pipelined indices
+        int64_t p = (int64_t)tb + slot;
+        int u0 = 0, v0 = 0, u1 = 0, v1 = 0;
+        if (p < te) {
+            u0 = (int)pu[p]; v0 = (int)pv[p];
+            if (MODE == 1) { u1 = (int)nu[p]; v1 = (int)nv[p]; }
+        }
+        for (int64_t base = tb; base < te; base += n_slots) {
+            const int64_t pos = base + slot;
+            const bool valid = pos < te;
+            const int cu0 = u0, cv0 = v0, cu1 = u1, cv1 = v1;
+            const int64_t pn = pos + n_slots;
+            if (pn < te) {
+                u0 = (int)pu[pn]; v0 = (int)pv[pn];
+                if (MODE == 1) { u1 = (int)nu[pn]; v1 = (int)nv[pn]; }
+            }
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0, a1 = a0, b1 = a0;
+            float d0 = 0.f, d1 = 0.f;
+            if (valid) {
+                a0 = tipk_ld4(zl + cu0 * ld + c0);
+                b0 = tipk_ld4(zl + cv0 * ld + c0);
+                d0 = a0.x * b0.x * wr.x + a0.y * b0.y * wr.y + a0.z * b0.z * wr.z + a0.w * b0.w * wr.w;
+                if (MODE == 1) {
+                    a1 = tipk_ld4(zl + cu1 * ld + c0);
+                    b1 = tipk_ld4(zl + cv1 * ld + c0);
+                    d1 = a1.x * b1.x * wr.x + a1.y * b1.y * wr.y + a1.z * b1.z * wr.z + a1.w * b1.w * wr.w;
+                }
+            }
+            for (int o = 1; o < KL; o <<= 1) {
+                d0 += __shfl_xor(d0, o);
+                if (MODE == 1) d1 += __shfl_xor(d1, o);
+            }
+            float q0 = 0.f, q1 = 0.f;
+            if (valid) {
+                if (MODE == 1) {
+                    const float sp = sigmoidf(d0), sn = sigmoidf(d1);
+                    if (sub == 0) loss -= logf(sp + TIP_EPS) + logf(1.f - sn + TIP_EPS);
+                    q0 = -inv_n * sp * (1.f - sp) / (sp + TIP_EPS);
+                    q1 = inv_n * sn * (1.f - sn) / (1.f - sn + TIP_EPS);
+                } else {
+                    q0 = g_score[pos];
+                    if (sig) { const float sg = sigmoidf(d0); q0 *= sg * (1.f - sg); }
+                }
+            }
+            if (want_grad && valid) {
+                float* gu = gzl + cu0 * ld + c0;
+                float* gv = gzl + cv0 * ld + c0;
+                atomicAdd(gu + 0, q0 * b0.x * wr.x); atomicAdd(gu + 1, q0 * b0.y * wr.y);
+                atomicAdd(gu + 2, q0 * b0.z * wr.z); atomicAdd(gu + 3, q0 * b0.w * wr.w);
+                atomicAdd(gv + 0, q0 * a0.x * wr.x); atomicAdd(gv + 1, q0 * a0.y * wr.y);
+                atomicAdd(gv + 2, q0 * a0.z * wr.z); atomicAdd(gv + 3, q0 * a0.w * wr.w);
+                gw.x = fmaf(q0, a0.x * b0.x, gw.x); gw.y = fmaf(q0, a0.y * b0.y, gw.y);
+                gw.z = fmaf(q0, a0.z * b0.z, gw.z); gw.w = fmaf(q0, a0.w * b0.w, gw.w);
+                if (MODE == 1) {
+                    float* hu = gzl + cu1 * ld + c0;
+                    float* hv = gzl + cv1 * ld + c0;
+                    atomicAdd(hu + 0, q1 * b1.x * wr.x); atomicAdd(hu + 1, q1 * b1.y * wr.y);
+                    atomicAdd(hu + 2, q1 * b1.z * wr.z); atomicAdd(hu + 3, q1 * b1.w * wr.w);
+                    atomicAdd(hv + 0, q1 * a1.x * wr.x); atomicAdd(hv + 1, q1 * a1.y * wr.y);
+                    atomicAdd(hv + 2, q1 * a1.z * wr.z); atomicAdd(hv + 3, q1 * a1.w * wr.w);
+                    gw.x = fmaf(q1, a1.x * b1.x, gw.x); gw.y = fmaf(q1, a1.y * b1.y, gw.y);
+                    gw.z = fmaf(q1, a1.z * b1.z, gw.z); gw.w = fmaf(q1, a1.w * b1.w, gw.w);
+                }
+            }
+        }
+        if (want_grad) {                                       // d w[rel]: wave shuffle, then 16 waves via LDS
+            for (int o = KL; o < TIPK_WAVE; o <<= 1) {
+                gw.x += __shfl_xor(gw.x, o); gw.y += __shfl_xor(gw.y, o);
+                gw.z += __shfl_xor(gw.z, o); gw.w += __shfl_xor(gw.w, o);
+            }
+            if (tipk_lane() < KL) tipk_st4(red + (t >> 6) * k + c0, gw);
+            __syncthreads();
+            if (t < k) {
+                float tot = 0.f;
+                for (int wv = 0; wv < 16; ++wv) tot += red[wv * k + t];
+                atomicAdd(g_w + (int64_t)rel * k + t, tot);
+            }
+            __syncthreads();
+        }
+    }
+    if (MODE == 1) {
+        loss = wave_sum(loss);
+        if (tipk_lane() == 0) red[16 * k + (t >> 6)] = loss;
+        __syncthreads();
+        if (t == 0) {
+            float tot = 0.f;
+            for (int wv = 0; wv < 16; ++wv) tot += red[16 * k + wv];
+            atomicAdd(loss_out, tot * inv_n);
+        }
+    }
+    if (want_grad) {
+        __syncthreads();
+        for (int i = t; i < n_nodes * k; i += 1024) {
+            const int r = i / k, c = i - r * k;
+            const float a = gzl[r * ld + c];
+            if (a != 0.f) atomicAdd(g_z + i, a);
+        }
+    }
+}
+
+inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
+    if (k % 4 != 0 || k < 4 || k > 64 || (k & (k - 1)) != 0) return false;
+    *lds_bytes = (2 * n_nodes * (k + 4) + 16 * k + 16) * (int64_t)sizeof(float);
+    return *lds_bytes <= 150 * 1024;
+}
+
+template <typename IT, int MODE>
+int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, const int32_t* tasks, int64_t n_tasks,
+                 const void* pu, const void* pv, const void* nu, const void* nv, const float* g_score, int sig,
+                 int64_t n_total, float* loss_out, float* g_z, float* g_w, int64_t lds_bytes, hipStream_t st) {
+    auto kern = distmult_task_kernel<IT, MODE>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return tipk_hip_status(e);
+    int64_t grid = n_tasks < 256 ? n_tasks : 256;              // one persistent workgroup per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), (size_t)lds_bytes, st, z, (int)n_nodes, k, w, tasks,
+                       (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, g_score, sig,
+                       n_total, loss_out, g_z, g_w);
+    TIPK_RETURN_LAUNCH();
+}
+
 constexpr int64_t LDS_GZ_LIMIT = 96 * 1024;
 
 template <typename IT, typename ET, int V, int MODE>
@@ -216,13 +378,24 @@ extern "C" int tipk_distmult_fwd(const float* z, int64_t n_nodes, int k, const f
 extern "C" int tipk_distmult_bwd(const float* g_score, const float* score, const float* z, int64_t n_nodes, int k,
                                  const float* rel_w, int64_t n_rel, const void* idx_u, const void* idx_v,
                                  int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples, int sigmoid,
-                                 float* g_z, float* g_w, tipk_stream_t stream) {
-    if (n_triples < 0 || k <= 0 || n_nodes < 0 || n_rel < 0) return TIPK_EINVAL;
+                                 const int32_t* tasks, int64_t n_tasks, float* g_z, float* g_w,
+                                 tipk_stream_t stream) {
+    if (n_triples < 0 || k <= 0 || n_nodes < 0 || n_rel < 0 || n_tasks < 0) return TIPK_EINVAL;
     if (n_triples == 0) return TIPK_OK;
     if (!g_score || !z || !rel_w || !idx_u || !idx_v || !edge_type || !g_z || !g_w || (sigmoid && !score))
         return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = vec_ok(z, rel_w, k);
+    int64_t lds_bytes = 0;
+    if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
+        if (idx_bytes == 8)
+            return launch_tasks<int64_t, 0>(z, n_nodes, k, rel_w, tasks, n_tasks, idx_u, idx_v, nullptr, nullptr,
+                                            g_score, sigmoid, n_triples, nullptr, g_z, g_w, lds_bytes, st);
+        if (idx_bytes == 4)
+            return launch_tasks<int32_t, 0>(z, n_nodes, k, rel_w, tasks, n_tasks, idx_u, idx_v, nullptr, nullptr,
+                                            g_score, sigmoid, n_triples, nullptr, g_z, g_w, lds_bytes, st);
+        return TIPK_EINVAL;
+    }
 #define CALL(IT, ET)                                                                                          \
     {                                                                                                         \
         if (vec) return launch_grad<IT, ET, 4, 0>(g_score, score, z, n_nodes, k, rel_w, idx_u, idx_v, nullptr, \
@@ -237,12 +410,23 @@ extern "C" int tipk_distmult_bwd(const float* g_score, const float* score, const
 extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                                   const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
                                   int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
-                                  float* loss_out, float* g_z, float* g_w, tipk_stream_t stream) {
-    if (n_triples <= 0 || k <= 0 || n_nodes < 0 || n_rel < 0) return TIPK_EINVAL;
+                                  const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
+                                  tipk_stream_t stream) {
+    if (n_triples <= 0 || k <= 0 || n_nodes < 0 || n_rel < 0 || n_tasks < 0) return TIPK_EINVAL;
     if (!z || !rel_w || !pos_u || !pos_v || !neg_u || !neg_v || !edge_type || !loss_out) return TIPK_EINVAL;
     if ((g_z == nullptr) != (g_w == nullptr)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = vec_ok(z, rel_w, k);
+    int64_t lds_bytes = 0;
+    if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
+        if (idx_bytes == 8)
+            return launch_tasks<int64_t, 1>(z, n_nodes, k, rel_w, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
+                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st);
+        if (idx_bytes == 4)
+            return launch_tasks<int32_t, 1>(z, n_nodes, k, rel_w, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
+                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st);
+        return TIPK_EINVAL;
+    }
 #define CALL(IT, ET)                                                                                             \
     {                                                                                                            \
         if (vec) return launch_grad<IT, ET, 4, 1>(nullptr, nullptr, z, n_nodes, k, rel_w, pos_u, pos_v, neg_u, neg_v, \

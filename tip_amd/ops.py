@@ -227,6 +227,36 @@ def _uv(edge_index):
     return ei[0], ei[1]
 
 
+_TASK_CACHE = {}
+TASK_POSITIONS = 4096
+
+
+def relation_tasks(edge_type):
+    """int32 [T,3] (relation, begin, end) tasks for the LDS-resident decoder kernels, or None when
+    the triples are not grouped by relation (include/tipk.h section 4).  Built once per tensor."""
+    key = (edge_type.data_ptr(), tuple(edge_type.shape), edge_type._version, str(edge_type.device))
+    hit = _TASK_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    tasks = None
+    if edge_type.numel():
+        rels, counts = torch.unique_consecutive(edge_type, return_counts=True)
+        if torch.unique(rels).numel() == rels.numel():                      # each relation is one run
+            start = torch.cumsum(counts, 0) - counts
+            n_chunks = (counts + TASK_POSITIONS - 1) // TASK_POSITIONS
+            run = torch.repeat_interleave(torch.arange(rels.numel(), device=rels.device), n_chunks)
+            first = torch.cumsum(n_chunks, 0) - n_chunks
+            local = torch.arange(run.numel(), device=rels.device) - first[run]
+            begin = start[run] + local * TASK_POSITIONS
+            end = torch.minimum(begin + TASK_POSITIONS, start[run] + counts[run])
+            order = torch.sort(end - begin, descending=True, stable=True).indices
+            tasks = torch.stack([rels[run], begin, end], dim=1)[order].to(torch.int32).contiguous()
+    if len(_TASK_CACHE) > 16:
+        _TASK_CACHE.clear()
+    _TASK_CACHE[key] = (tasks, edge_type)                                    # pin the tensor: pointer stays unique
+    return tasks
+
+
 def distmult_fwd(z, weight, edge_index, edge_type, sigmoid=True):
     z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
     require_device(z, weight, edge_index, edge_type)
@@ -246,9 +276,11 @@ def distmult_bwd(g_score, score, z, weight, edge_index, edge_type, sigmoid=True)
     u, v = _uv(edge_index)
     et = edge_type.contiguous()
     g_z, g_w = torch.zeros_like(z), torch.zeros_like(weight)
+    tasks = relation_tasks(et)
     check(lib().tipk_distmult_bwd(ptr(g_score), ptr(score), ptr(z), z.shape[0], z.shape[1], ptr(weight),
                                   weight.shape[0], ptr(u), ptr(v), _idx_bytes(u), ptr(et), _idx_bytes(et),
-                                  u.numel(), int(sigmoid), ptr(g_z), ptr(g_w), stream_ptr(z.device)),
+                                  u.numel(), int(sigmoid), ptr(tasks), 0 if tasks is None else tasks.shape[0],
+                                  ptr(g_z), ptr(g_w), stream_ptr(z.device)),
           'tipk_distmult_bwd')
     return g_z, g_w
 
@@ -264,8 +296,10 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     loss = torch.zeros((1,), dtype=torch.float32, device=z.device)
     g_z = torch.zeros_like(z) if need_grad else None
     g_w = torch.zeros_like(weight) if need_grad else None
+    tasks = relation_tasks(et)
     check(lib().tipk_distmult_loss(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pu), ptr(pv),
                                    ptr(nu), ptr(nv), _idx_bytes(pu), ptr(et), _idx_bytes(et), pu.numel(),
+                                   ptr(tasks), 0 if tasks is None else tasks.shape[0],
                                    ptr(loss), ptr(g_z), ptr(g_w), stream_ptr(z.device)), 'tipk_distmult_loss')
     return loss, g_z, g_w
 
