@@ -164,15 +164,16 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     int64_t n_total, float* __restrict__ loss_out, float* __restrict__ g_z, float* __restrict__ g_w) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
-    const int ld = k + 4;
+    const int ld = k + 4;                                     // z image: float4 reads, 16-byte aligned rows
+    const int lg = k + 1;                                     // d z image: scalar ds_add_f32, odd stride = all banks
     float* zl = lds;
     float* gzl = lds + (int64_t)n_nodes * ld;
-    float* red = gzl + (int64_t)n_nodes * ld;                 // [16 waves][k] + [16]
+    float* red = gzl + (((int64_t)n_nodes * lg + 3) & ~3LL);  // [16 waves][k] + [16]
     const bool want_grad = g_z != nullptr;
     for (int i = t; i < n_nodes * k; i += 1024) {
         const int r = i / k, c = i - r * k;
         zl[r * ld + c] = z[i];
-        gzl[r * ld + c] = 0.f;
+        gzl[r * lg + c] = 0.f;
     }
     __syncthreads();
     const int KL = k >> 2;                                    // lanes per position (power of two <= 16)
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 }
             }
             if (want_grad && valid) {
-                float* gu = gzl + cu0 * ld + c0;
-                float* gv = gzl + cv0 * ld + c0;
+                float* gu = gzl + cu0 * lg + c0;
+                float* gv = gzl + cv0 * lg + c0;
                 atomicAdd(gu + 0, q0 * b0.x * wr.x); atomicAdd(gu + 1, q0 * b0.y * wr.y);
                 atomicAdd(gu + 2, q0 * b0.z * wr.z); atomicAdd(gu + 3, q0 * b0.w * wr.w);
                 atomicAdd(gv + 0, q0 * a0.x * wr.x); atomicAdd(gv + 1, q0 * a0.y * wr.y);
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 gw.x = fmaf(q0, a0.x * b0.x, gw.x); gw.y = fmaf(q0, a0.y * b0.y, gw.y);
                 gw.z = fmaf(q0, a0.z * b0.z, gw.z); gw.w = fmaf(q0, a0.w * b0.w, gw.w);
                 if (MODE == 1) {
-                    float* hu = gzl + cu1 * ld + c0;
-                    float* hv = gzl + cv1 * ld + c0;
+                    float* hu = gzl + cu1 * lg + c0;
+                    float* hv = gzl + cv1 * lg + c0;
                     atomicAdd(hu + 0, q1 * b1.x * wr.x); atomicAdd(hu + 1, q1 * b1.y * wr.y);
                     atomicAdd(hu + 2, q1 * b1.z * wr.z); atomicAdd(hu + 3, q1 * b1.w * wr.w);
                     atomicAdd(hv + 0, q1 * a1.x * wr.x); atomicAdd(hv + 1, q1 * a1.y * wr.y);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         __syncthreads();
         for (int i = t; i < n_nodes * k; i += 1024) {
             const int r = i / k, c = i - r * k;
-            const float a = gzl[r * ld + c];
+            const float a = gzl[r * lg + c];
             if (a != 0.f) atomicAdd(g_z + i, a);
         }
     }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
 
 inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
     if (k % 4 != 0 || k < 4 || k > 64 || (k & (k - 1)) != 0) return false;
-    *lds_bytes = (2 * n_nodes * (k + 4) + 16 * k + 16) * (int64_t)sizeof(float);
+    *lds_bytes = (n_nodes * (k + 4) + ((n_nodes * (k + 1) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float);
     return *lds_bytes <= 150 * 1024;
 }
 
