@@ -1,0 +1,21 @@
+import sys, time, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tip_amd import ops
+from tip_amd.data import build_data_dict
+from tip_amd.neg_sampling import typed_negative_sampling
+dd = build_data_dict()
+dev = 'cuda:0'
+pos = dd['dd_train_idx'].to(dev); et = dd['dd_train_et'].to(dev); rg = dd['dd_train_range'].to(dev)
+z = torch.randn(645, 16, device=dev) * 0.5; w = torch.randn(dd['n_dd_et'], 16, device=dev) * 0.3
+neg = typed_negative_sampling(pos, 645, rg)
+def t(f, n=10):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print('loss+grad ms', t(lambda: ops.distmult_loss(z, w, pos, neg, et)))
+print('loss only ms', t(lambda: ops.distmult_loss(z, w, pos, neg, et, need_grad=False)))
+print('sampler   ms', t(lambda: typed_negative_sampling(pos, 645, rg)))
+print('fwd score ms', t(lambda: ops.distmult_fwd(z, w, pos, et)))
+pos32, neg32, et32 = pos.int(), neg.int(), et.int()
+ops.relation_tasks(et32)
+print('loss+grad int32 ms', t(lambda: ops.distmult_loss(z, w, pos32, neg32, et32)))
