@@ -151,29 +151,85 @@ __global__ __launch_bounds__(256) void distmult_grad_kernel(
 //
 // A *task* = (relation, begin, end) with at most a few thousand positions of ONE relation, so the
 // relation row w[r] lives in registers and d w[r] is reduced inside the workgroup (one set of k
-// global atomics per task).  z is staged once per workgroup into LDS next to a zeroed d z image
-// (row stride k+4 floats: 16-byte aligned float4 reads that spread over the banks; the dense
-// stride k=16 puts every lane of a column access on two banks).  KL = k/4 lanes share one position:
+// global atomics per task).  z is staged once per workgroup into LDS (row stride k+4 floats:
+// 16-byte aligned float4 reads that spread over the banks).  KL = k/4 lanes share one position:
 // each reads one float4 of every row, the dot product is finished with KL-wide shuffles.
+//
+// d z is scattered over N rows that every position hits.  Measured on gfx950
+// (tools/microbench/lds_atomics.hip): ds_add_f32 sustains 0.33 lane-ops/clk/CU, ds_add_u64 5.0 --
+// 15x more.  The d z image is therefore a 64-bit FIXED-POINT accumulator in LDS: every fp32
+// contribution is scaled by a power of two chosen from a bound on the sum of |contributions|
+// (exact conversion, 60 bits of headroom), integer-added (associative: the result does not depend on
+// scheduling), and converted back once per workgroup.
 // Persistent grid (one 1024-thread workgroup per CU), tasks dealt round-robin, largest first.
+__device__ __forceinline__ float block_max_1024(float v, float* red, int t) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    return m;
+}
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red, int t) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    float m = 0.f;
+    for (int i = 0; i < 16; ++i) m += red[i];
+    __syncthreads();
+    return m;
+}
+
+__device__ __forceinline__ void fx_add(unsigned long long* p, float c, double scale) {
+    atomicAdd(p, (unsigned long long)(long long)((double)c * scale));      // ds_add_u64
+}
+
 template <typename IT, int MODE>
 __global__ __launch_bounds__(1024) void distmult_task_kernel(
-    const float* __restrict__ z, int n_nodes, int k, const float* __restrict__ w,
+    const float* __restrict__ z, int n_nodes, int k, const float* __restrict__ w, int n_rel,
     const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
     const IT* __restrict__ nu, const IT* __restrict__ nv, const float* __restrict__ g_score, int sig,
     int64_t n_total, float* __restrict__ loss_out, float* __restrict__ g_z, float* __restrict__ g_w) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
     const int t = threadIdx.x;
     const int ld = k + 4;                                     // z image: float4 reads, 16-byte aligned rows
-    const int lg = k + 1;                                     // d z image: scalar ds_add_f32, odd stride = all banks
-    float* zl = lds;
-    float* gzl = lds + (int64_t)n_nodes * ld;
-    float* red = gzl + (((int64_t)n_nodes * lg + 3) & ~3LL);  // [16 waves][k] + [16]
+    const int lg = k + 1;                                     // d z image: odd stride = all banks
+    unsigned long long* gzl = lds64;                          // [n_nodes][k+1] fixed point
+    float* zl = (float*)(gzl + (int64_t)n_nodes * lg);        // [n_nodes][k+4]
+    float* red = zl + (((int64_t)n_nodes * ld + 3) & ~3LL);   // [16 waves][k] + [16]
     const bool want_grad = g_z != nullptr;
+    float zmax = 0.f;
     for (int i = t; i < n_nodes * k; i += 1024) {
         const int r = i / k, c = i - r * k;
-        zl[r * ld + c] = z[i];
-        gzl[r * lg + c] = 0.f;
+        const float v = z[i];
+        zl[r * ld + c] = v;
+        zmax = fmaxf(zmax, fabsf(v));
+    }
+    for (int i = t; i < n_nodes * lg; i += 1024) gzl[i] = 0ull;
+    double scale = 1.0;
+    if (want_grad) {
+        float wmax = 0.f;
+        for (int i = t; i < n_rel * k; i += 1024) wmax = fmaxf(wmax, fabsf(w[i]));
+        zmax = block_max_1024(zmax, red, t);
+        wmax = block_max_1024(wmax, red, t);
+        // bound on sum |contribution| into any element: every position adds <= 4 |q| zmax wmax with
+        // sum |q| <= 1 (fused objective: |q| <= 1/n each) or <= sum |g| over this workgroup's positions
+        float bound = 4.f * zmax * wmax;
+        if (MODE == 0) {
+            float sg = 0.f;
+            for (int task = blockIdx.x; task < n_tasks; task += gridDim.x)
+                for (int p = tasks[3 * task + 1] + t; p < tasks[3 * task + 2]; p += 1024) sg += fabsf(g_score[p]);
+            bound *= block_sum_1024(sg, red, t);
+        }
+        int ex = 60;
+        if (bound > 0.f && bound < 3.0e38f) ex = 60 - (ilogbf(bound) + 1);
+        ex = ex > 180 ? 180 : ex;
+        scale = ldexp(1.0, ex);
     }
     __syncthreads();
     const int KL = k >> 2;                                    // lanes per position (power of two <= 16)
@@ -233,21 +289,21 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 }
             }
             if (want_grad && valid) {
-                float* gu = gzl + cu0 * lg + c0;
-                float* gv = gzl + cv0 * lg + c0;
-                atomicAdd(gu + 0, q0 * b0.x * wr.x); atomicAdd(gu + 1, q0 * b0.y * wr.y);
-                atomicAdd(gu + 2, q0 * b0.z * wr.z); atomicAdd(gu + 3, q0 * b0.w * wr.w);
-                atomicAdd(gv + 0, q0 * a0.x * wr.x); atomicAdd(gv + 1, q0 * a0.y * wr.y);
-                atomicAdd(gv + 2, q0 * a0.z * wr.z); atomicAdd(gv + 3, q0 * a0.w * wr.w);
+                unsigned long long* gu = gzl + cu0 * lg + c0;
+                unsigned long long* gv = gzl + cv0 * lg + c0;
+                fx_add(gu + 0, q0 * b0.x * wr.x, scale); fx_add(gu + 1, q0 * b0.y * wr.y, scale);
+                fx_add(gu + 2, q0 * b0.z * wr.z, scale); fx_add(gu + 3, q0 * b0.w * wr.w, scale);
+                fx_add(gv + 0, q0 * a0.x * wr.x, scale); fx_add(gv + 1, q0 * a0.y * wr.y, scale);
+                fx_add(gv + 2, q0 * a0.z * wr.z, scale); fx_add(gv + 3, q0 * a0.w * wr.w, scale);
                 gw.x = fmaf(q0, a0.x * b0.x, gw.x); gw.y = fmaf(q0, a0.y * b0.y, gw.y);
                 gw.z = fmaf(q0, a0.z * b0.z, gw.z); gw.w = fmaf(q0, a0.w * b0.w, gw.w);
                 if (MODE == 1) {
-                    float* hu = gzl + cu1 * lg + c0;
-                    float* hv = gzl + cv1 * lg + c0;
-                    atomicAdd(hu + 0, q1 * b1.x * wr.x); atomicAdd(hu + 1, q1 * b1.y * wr.y);
-                    atomicAdd(hu + 2, q1 * b1.z * wr.z); atomicAdd(hu + 3, q1 * b1.w * wr.w);
-                    atomicAdd(hv + 0, q1 * a1.x * wr.x); atomicAdd(hv + 1, q1 * a1.y * wr.y);
-                    atomicAdd(hv + 2, q1 * a1.z * wr.z); atomicAdd(hv + 3, q1 * a1.w * wr.w);
+                    unsigned long long* hu = gzl + cu1 * lg + c0;
+                    unsigned long long* hv = gzl + cv1 * lg + c0;
+                    fx_add(hu + 0, q1 * b1.x * wr.x, scale); fx_add(hu + 1, q1 * b1.y * wr.y, scale);
+                    fx_add(hu + 2, q1 * b1.z * wr.z, scale); fx_add(hu + 3, q1 * b1.w * wr.w, scale);
+                    fx_add(hv + 0, q1 * a1.x * wr.x, scale); fx_add(hv + 1, q1 * a1.y * wr.y, scale);
+                    fx_add(hv + 2, q1 * a1.z * wr.z, scale); fx_add(hv + 3, q1 * a1.w * wr.w, scale);
                     gw.x = fmaf(q1, a1.x * b1.x, gw.x); gw.y = fmaf(q1, a1.y * b1.y, gw.y);
                     gw.z = fmaf(q1, a1.z * b1.z, gw.z); gw.w = fmaf(q1, a1.w * b1.w, gw.w);
                 }
@@ -280,30 +336,32 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     }
     if (want_grad) {
         __syncthreads();
+        const double inv_scale = 1.0 / scale;
         for (int i = t; i < n_nodes * k; i += 1024) {
             const int r = i / k, c = i - r * k;
-            const float a = gzl[r * lg + c];
-            if (a != 0.f) atomicAdd(g_z + i, a);
+            const long long a = (long long)gzl[r * lg + c];
+            if (a != 0) atomicAdd(g_z + i, (float)((double)a * inv_scale));
         }
     }
 }
 
 inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
     if (k % 4 != 0 || k < 4 || k > 64 || (k & (k - 1)) != 0) return false;
-    *lds_bytes = (n_nodes * (k + 4) + ((n_nodes * (k + 1) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float);
-    return *lds_bytes <= 150 * 1024;
+    *lds_bytes = n_nodes * (k + 1) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float);
+    return *lds_bytes <= 156 * 1024;
 }
 
 template <typename IT, int MODE>
-int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, const int32_t* tasks, int64_t n_tasks,
-                 const void* pu, const void* pv, const void* nu, const void* nv, const float* g_score, int sig,
-                 int64_t n_total, float* loss_out, float* g_z, float* g_w, int64_t lds_bytes, hipStream_t st) {
+int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, int64_t n_rel, const int32_t* tasks,
+                 int64_t n_tasks, const void* pu, const void* pv, const void* nu, const void* nv,
+                 const float* g_score, int sig, int64_t n_total, float* loss_out, float* g_z, float* g_w,
+                 int64_t lds_bytes, hipStream_t st) {
     auto kern = distmult_task_kernel<IT, MODE>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return tipk_hip_status(e);
     int64_t grid = n_tasks < 256 ? n_tasks : 256;              // one persistent workgroup per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), (size_t)lds_bytes, st, z, (int)n_nodes, k, w, tasks,
-                       (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, g_score, sig,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), (size_t)lds_bytes, st, z, (int)n_nodes, k, w, (int)n_rel,
+                       tasks, (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, g_score, sig,
                        n_total, loss_out, g_z, g_w);
     TIPK_RETURN_LAUNCH();
 }
@@ -390,10 +448,10 @@ extern "C" int tipk_distmult_bwd(const float* g_score, const float* score, const
     int64_t lds_bytes = 0;
     if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
         if (idx_bytes == 8)
-            return launch_tasks<int64_t, 0>(z, n_nodes, k, rel_w, tasks, n_tasks, idx_u, idx_v, nullptr, nullptr,
+            return launch_tasks<int64_t, 0>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, idx_u, idx_v, nullptr, nullptr,
                                             g_score, sigmoid, n_triples, nullptr, g_z, g_w, lds_bytes, st);
         if (idx_bytes == 4)
-            return launch_tasks<int32_t, 0>(z, n_nodes, k, rel_w, tasks, n_tasks, idx_u, idx_v, nullptr, nullptr,
+            return launch_tasks<int32_t, 0>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, idx_u, idx_v, nullptr, nullptr,
                                             g_score, sigmoid, n_triples, nullptr, g_z, g_w, lds_bytes, st);
         return TIPK_EINVAL;
     }
@@ -421,10 +479,10 @@ extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const 
     int64_t lds_bytes = 0;
     if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
         if (idx_bytes == 8)
-            return launch_tasks<int64_t, 1>(z, n_nodes, k, rel_w, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
+            return launch_tasks<int64_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
                                             1, n_triples, loss_out, g_z, g_w, lds_bytes, st);
         if (idx_bytes == 4)
-            return launch_tasks<int32_t, 1>(z, n_nodes, k, rel_w, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
+            return launch_tasks<int32_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
                                             1, n_triples, loss_out, g_z, g_w, lds_bytes, st);
         return TIPK_EINVAL;
     }
