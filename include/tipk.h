@@ -80,6 +80,34 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
                              int d, int max_slots, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 1b. Relation-local gather -- the D-D aggregation (K5/K6, src/layers.py:159-180) when one
+ *     relation's node table fits in LDS (n_nodes * (d+4) * 4 B + 40 KB <= 158 KB; d a power of two
+ *     in 4..64; n_nodes <= 65535 and <= 8 * 4096/d).  Same sums as `tipk_gather_sum` over the plan
+ *     of the same graph, evaluated with every gathered row coming from LDS:
+ *
+ *       backward = 0:  table = Y [n_rel * n_nodes, d];  out = partial [n_wg, n_nodes, d] with
+ *                      sum_wg partial[wg, o] = sum_r sum_{e in r: out(e)=o} Y[r * n_nodes + tab(e)]
+ *                      (combine with tipk_sum_slabs);
+ *       backward = 1:  table = g' [n_nodes, d];  out = dY [n_rel * n_nodes, d],
+ *                      dY[r * n_nodes + o] = sum_{e in r: out(e)=o} g'[tab(e)]   (every row written).
+ *
+ *     Relation-local plan (tip_amd/plan.py `build_rel_plan`), all device arrays:
+ *       node_at[p]              node id at owner position p (nodes sorted by decreasing degree)
+ *       rel_edge_ptr[n_rel+1]   int64 edge offsets per relation
+ *       idx[E]                  uint16 table node of each edge; inside a relation the edges are
+ *                               sorted by the owner position of their OUTPUT node
+ *       runs[n_rel][n_nodes][2] (begin relative to the relation's first edge, length) of the edges
+ *                               whose output node sits at position p
+ *       wg_rel_ptr[n_wg+1], wg_rels[n_rel]   relations handled by each of the n_wg workgroups
+ *                               (edge-balanced; n_wg = number of CUs)
+ */
+int tipk_rel_gather_supported(int64_t n_nodes, int d);       /* host predicate, 1 = usable */
+int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
+                    int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
+                    const int64_t* rel_edge_ptr, const uint16_t* idx, const int32_t* runs,
+                    const int32_t* node_at, float* out, int64_t ld_out, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
  *
  *   C[z] = relu?( alpha * sum_{q<kbatch} A[z,q] (m x k) . B[z,q] (k x n) + C_in[z] ),  z < batch

@@ -244,3 +244,42 @@ def test_negative_sampler_uniformity_vs_reference_distribution():
     # the reference leaks a few positives (its resample quirk); on the free cells it is flat too
     chi2_ref = float(((rhist - rhist.sum() / free.size) ** 2 / (rhist.sum() / free.size)).sum())
     assert chi2_ref < free.size + 6 * np.sqrt(2 * free.size)
+
+
+# ------------------------------------------------------------------ relation-local (LDS) gather
+@pytest.mark.parametrize('d', [4, 16, 32])
+def test_rel_gather_fwd_bwd(ops, d):
+    from tip_amd.plan import build_rel_plan
+    from tip_amd import _lib
+    g = torch.Generator().manual_seed(d)
+    N, R = 645, 9
+    sizes = torch.tensor([40000, 1, 0, 3000, 17000, 250, 5, 9000, 700])          # > 16384: several id chunks
+    E = int(sizes.sum())
+    rel = torch.repeat_interleave(torch.arange(R), sizes)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N - 7, (E,), generator=g)
+    dst[:9000] = 11                                                            # hub (longest run 9000 edges)
+    assert _lib.lib().tipk_rel_gather_supported(N, d) == 1
+    y = torch.randn(R * N, d, generator=g)
+    plan = build_rel_plan(dst, src, rel, N, R, n_wg=256).to(DEV)
+    got = ops.rel_gather(plan, y.to(DEV), backward=False)
+    close(got, O.gather_sum(y.double(), rel * N + src, dst, N))
+    assert torch.equal(got, ops.rel_gather(plan, y.to(DEV), backward=False))    # bitwise reproducible
+    gp = torch.randn(N, d, generator=g)
+    planb = build_rel_plan(src, dst, rel, N, R, n_wg=256).to(DEV)
+    gotb = ops.rel_gather(planb, gp.to(DEV), backward=True)
+    close(gotb, O.gather_sum(gp.double(), dst, rel * N + src, R * N))
+    # few workgroups (several relations each) and strided table
+    plan3 = build_rel_plan(dst, src, rel, N, R, n_wg=2).to(DEV)
+    wide = torch.randn(R * N, d + 8, generator=g).to(DEV)
+    close(ops.rel_gather(plan3, wide[:, 4:4 + d], backward=False),
+          O.gather_sum(wide[:, 4:4 + d].cpu().double(), rel * N + src, dst, N))
+
+
+def test_rel_gather_unsupported_shapes():
+    from tip_amd import _lib
+    L = _lib.lib()
+    assert L.tipk_rel_gather_supported(645, 64) == 0        # 645 x 68 floats do not fit in LDS
+    assert L.tipk_rel_gather_supported(645, 24) == 0        # not a power of two
+    assert L.tipk_rel_gather_supported(10000, 32) == 0
+    assert L.tipk_rel_gather_supported(645, 32) == 1 and L.tipk_rel_gather_supported(645, 16) == 1

@@ -191,9 +191,13 @@ def biosnap_full():
     return build_data_dict()
 
 
-@pytest.mark.parametrize('mod', ['cat', 'add'])
-def test_full_biosnap_encoder_vs_oracle(biosnap_full, mod):
-    """BASELINE configs 2 and 3 at full size: z and all parameter gradients vs the CPU oracle."""
+@pytest.mark.parametrize('mod,generic', [('cat', False), ('add', False), ('cat', True)])
+def test_full_biosnap_encoder_vs_oracle(biosnap_full, mod, generic, monkeypatch):
+    """BASELINE configs 2 and 3 at full size: z and all parameter gradients vs the CPU oracle.
+    `generic` forces the fabric-gather kernels (the path large graphs take) instead of the
+    LDS-resident relation-local ones."""
+    if generic:
+        monkeypatch.setenv('TIPK_NO_RELLOCAL', '1')
     from tip_amd.data import Data
     from tip_amd.layers import FMEncoder
     dd = biosnap_full

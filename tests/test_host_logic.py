@@ -172,3 +172,28 @@ def test_ops_refuse_cpu_tensors():
     plan = build_gather_plan(torch.tensor([0, 1]), torch.tensor([1, 0]), 2, 2)
     with pytest.raises(_lib.TipkError):
         ops.gather_sum(plan, torch.ones(2, 4))
+
+
+# ------------------------------------------------------------------ relation-local plans (LDS kernels)
+def test_rel_plan_semantics():
+    from tip_amd.plan import build_rel_plan, execute_rel_plan_reference, assign_relations
+    g = torch.Generator().manual_seed(4)
+    N, R, E, d = 29, 7, 900, 4
+    rel = torch.sort(torch.randint(0, R - 1, (E,), generator=g)).values          # last relation empty
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N - 3, (E,), generator=g)
+    dst[:300] = 2                                                              # a hub node
+    y = torch.randn(R * N, d, generator=g, dtype=torch.float64)
+    plan = build_rel_plan(dst, src, rel, N, R, n_wg=4)
+    want = torch.zeros(N, d, dtype=torch.float64).index_add_(0, dst, y[rel * N + src])
+    torch.testing.assert_close(execute_rel_plan_reference(plan, y, False), want)
+    gp = torch.randn(N, d, generator=g, dtype=torch.float64)
+    planb = build_rel_plan(src, dst, rel, N, R, n_wg=4)
+    wantb = torch.zeros(R * N, d, dtype=torch.float64).index_add_(0, rel * N + src, gp[dst])
+    torch.testing.assert_close(execute_rel_plan_reference(planb, gp, True), wantb)
+    assert plan.idx.dtype == torch.uint16 and plan.runs.shape == (R, N, 2)
+    assert int(plan.node_at[0]) == 2                                            # hub first in owner order
+    assert sorted(plan.wg_rels.tolist()) == list(range(R)) and plan.wg_rel_ptr.tolist()[-1] == R
+    ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
+    loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]
+    assert sorted(loads) == [14, 14]

@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import build_gather_plan, DEFAULT_CHUNK
+from .plan import build_gather_plan, build_rel_plan, DEFAULT_CHUNK
 from .utils import process_edges, auprc_auroc_ap_by_range
 
 EPS = 1e-13                    # src/layers.py:15
@@ -247,9 +247,15 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from
     yrow = rel * n_nodes + src
     all_dst = dst if degree_from is None else degree_from.to(torch.int64)
     deg = torch.bincount(all_dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
+    rl_fwd = rl_bwd = None
+    if n_nodes <= 65535 and n_rel > 0:
+        # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
+        n_wg = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
+        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, n_wg)
+        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, n_wg)
     return ops.AggGraph(build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
                         build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
-                        (1.0 / deg).contiguous())
+                        (1.0 / deg).contiguous(), rl_fwd, rl_bwd)
 
 
 class _RGCNBase(nn.Module):

@@ -5,6 +5,8 @@ path is executed by the HIP kernels in `tip_amd/csrc` through the C ABI (`includ
 Backward passes are explicit (no autograd tracing through E x d tensors): each Function saves
 only N x d activations and the static graph plans.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -79,6 +81,42 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
                                          out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, plan.max_slots, st),
               'tipk_gather_sum_finalize')
     return out
+
+
+def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False):
+    """out = alpha * sum_s slabs[s] (+ out): ordered, deterministic (include/tipk.h section 2)."""
+    assert slabs.is_contiguous()
+    n = slabs.shape[0]
+    per = slabs[0].numel()
+    if out is None:
+        out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    assert out.is_contiguous() and out.numel() == per
+    check(lib().tipk_sum_slabs(ptr(slabs), n, per, per, alpha, int(accumulate), ptr(out), stream_ptr(slabs.device)),
+          'tipk_sum_slabs')
+    return out
+
+
+def rel_gather_usable(rp, n_nodes, d):
+    return (rp is not None and not os.environ.get('TIPK_NO_RELLOCAL')
+            and bool(lib().tipk_rel_gather_supported(n_nodes, d)))
+
+
+def rel_gather(rp, table, backward):
+    """LDS-resident D-D aggregation (include/tipk.h section 1b).  forward: table = Y [R*N, d] ->
+    [N, d] (sum over relations); backward: table = g' [N, d] -> dY [R*N, d]."""
+    table = _f32c(table)
+    require_device(table, rp.idx)
+    d = table.shape[1]
+    n, r = rp.n_nodes, rp.n_rel
+    if backward:
+        out = torch.empty((r * n, d), dtype=torch.float32, device=table.device)
+    else:
+        out = torch.empty((rp.n_wg, n, d), dtype=torch.float32, device=table.device)
+    with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
+        check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
+                                    ptr(rp.wg_rels), ptr(rp.rel_edge_ptr), ptr(rp.idx), ptr(rp.runs), ptr(rp.node_at),
+                                    ptr(out), d, stream_ptr(table.device)), 'tipk_rel_gather')
+    return out if backward else sum_slabs(out)
 
 
 def _strides3(t):
@@ -319,8 +357,9 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
-    def __init__(self, fwd, bwd, scale=None):
+    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None):
         self.fwd, self.bwd, self.scale = fwd, bwd, scale
+        self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
 
 
 # ---------------------------------------------------------------------------------------------
@@ -429,12 +468,17 @@ class _RGCN(torch.autograd.Function):
             y = gemm(att_l, xb.view(nb, n * d_out))                      # [R, N*out]
         else:
             y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
-        if shard is None:
+        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out)
+        if use_rl:
+            agg = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False)
+        elif shard is None:
             agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
         else:
-            from .dist import all_reduce_packed
             agg = gather_sum(graph.fwd, y.view(r * n, d_out))
+        if shard is not None:
+            from .dist import all_reduce_packed
             all_reduce_packed([agg], shard.group)
+        if use_rl or shard is not None:
             rows_affine(agg, row_mul=graph.scale, out=agg)
         del y
         out = gemm(x, root, out=agg, c_in=agg)                           # + X root
@@ -454,7 +498,10 @@ class _RGCN(torch.autograd.Function):
         gs = rows_affine(g, row_mul=graph.scale)
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
-            g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)           # dY_r = A_r^T (D^-1 g)
+            if rel_gather_usable(graph.rl_bwd, n, d_out):                # dY_r = A_r^T (D^-1 g)
+                g_y = rel_gather(graph.rl_bwd, gs, backward=True).view(r, n * d_out)
+            else:
+                g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
             g_att_l = gemm(g_y, xb2.t())                                 # split-K (automatic)
             g_xb = gemm(att_l.t(), g_y).view(nb, n, d_out)
             del g_y

@@ -136,3 +136,86 @@ def execute_plan_reference(plan, table, row_scale=None):
     if row_scale is not None:
         out = out * row_scale.unsqueeze(1)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# relation-local plans (include/tipk.h section 1b): LDS-resident D-D aggregation
+# ---------------------------------------------------------------------------------------------
+class RelPlan(object):
+    """Device arrays of `tipk_rel_gather` for one direction of a multi-relational graph."""
+
+    def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_edge_ptr, idx, runs, wg_rel_ptr, wg_rels):
+        self.n_nodes, self.n_rel, self.n_wg = int(n_nodes), int(n_rel), int(n_wg)
+        self.node_at, self.rel_edge_ptr, self.idx, self.runs = node_at, rel_edge_ptr, idx, runs
+        self.wg_rel_ptr, self.wg_rels = wg_rel_ptr, wg_rels
+
+    def to(self, device):
+        return RelPlan(self.n_nodes, self.n_rel, self.n_wg, *[t.to(device) for t in (
+            self.node_at, self.rel_edge_ptr, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels)])
+
+
+def assign_relations(sizes, n_wg, fixed_cost=0):
+    """Greedy longest-processing-time deal of relations to workgroups (cost = edges + fixed_cost).
+    -> (wg_rel_ptr [n_wg+1], wg_rels [R]) int32 CPU tensors; deterministic."""
+    sizes = [int(s) for s in sizes]
+    order = sorted(range(len(sizes)), key=lambda r: (-sizes[r], r))
+    import heapq
+    heap = [(0, w) for w in range(n_wg)]
+    heapq.heapify(heap)
+    parts = [[] for _ in range(n_wg)]
+    for r in order:
+        load, w = heapq.heappop(heap)
+        parts[w].append(r)
+        heapq.heappush(heap, (load + sizes[r] + fixed_cost, w))
+    ptr = [0]
+    flat = []
+    for p in parts:
+        flat.extend(p)
+        ptr.append(len(flat))
+    return torch.tensor(ptr, dtype=torch.int32), torch.tensor(flat, dtype=torch.int32)
+
+
+def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost=2048):
+    """Relation-local plan for  result[r, o] = sum_{e in r: out_node[e]=o} table_r[tab_node[e]].
+
+    out_node / tab_node / rel: int64 [E]; nodes < 65536.  Nodes are ordered by decreasing
+    out-degree ("owner positions"); inside a relation edges are sorted by the owner position of
+    their output node, so the edges of one (relation, node) pair form one contiguous run."""
+    dev = out_node.device
+    assert n_nodes <= 65535
+    E = int(out_node.numel())
+    deg = torch.bincount(out_node, minlength=n_nodes) if E else torch.zeros(n_nodes, dtype=torch.long, device=dev)
+    node_at = torch.sort(deg, descending=True, stable=True).indices                  # position -> node
+    pos_of = torch.empty(n_nodes, dtype=torch.long, device=dev)
+    pos_of[node_at] = torch.arange(n_nodes, device=dev)
+    key = rel * n_nodes + pos_of[out_node]
+    order = torch.sort(key, stable=True).indices
+    idx = tab_node[order].to(torch.int32).to(torch.uint16) if hasattr(torch, 'uint16') else None
+    cnt = torch.bincount(key, minlength=n_rel * n_nodes).view(n_rel, n_nodes)
+    begin = torch.cumsum(cnt, 1) - cnt                                               # relative to the relation
+    runs = torch.stack([begin, cnt], dim=2).to(torch.int32).contiguous()
+    rel_sizes = cnt.sum(1)
+    rel_edge_ptr = torch.zeros(n_rel + 1, dtype=torch.int64, device=dev)
+    rel_edge_ptr[1:] = torch.cumsum(rel_sizes, 0)
+    wg_ptr, wg_rels = assign_relations(rel_sizes.tolist(), n_wg, fixed_cost)
+    return RelPlan(n_nodes, n_rel, n_wg, node_at.to(torch.int32).contiguous(), rel_edge_ptr, idx.contiguous(), runs,
+                   wg_ptr.to(dev), wg_rels.to(dev))
+
+
+def execute_rel_plan_reference(plan, table, backward):
+    """Pure-torch interpretation of a relation-local plan (CPU unit tests only)."""
+    n, R = plan.n_nodes, plan.n_rel
+    d = table.shape[1]
+    idx = plan.idx.to(torch.int64)
+    runs = plan.runs.to(torch.int64)
+    node_at = plan.node_at.to(torch.int64)
+    res = torch.zeros((R, n, d), dtype=table.dtype)
+    for r in range(R):
+        e0 = int(plan.rel_edge_ptr[r])
+        for p in range(n):
+            b, ln = int(runs[r, p, 0]), int(runs[r, p, 1])
+            if ln:
+                rows = idx[e0 + b:e0 + b + ln]
+                src = table[rows] if backward else table[r * n + rows]
+                res[r, node_at[p]] = src.sum(0)
+    return res.view(R * n, d) if backward else res.sum(0)
