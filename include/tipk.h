@@ -93,9 +93,12 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *
  *     Relation-local plan (tip_amd/plan.py `build_rel_plan`), all device arrays:
  *       node_at[p]              node id at owner position p (nodes sorted by decreasing degree)
- *       rel_edge_ptr[n_rel+1]   int64 edge offsets per relation
- *       idx[E]                  uint16 table node of each edge; inside a relation the edges are
- *                               sorted by the owner position of their OUTPUT node
+ *       rel_idx_off[n_rel]      int64 offset of the relation's ids in idx (multiple of 8: segments
+ *                               are padded so they can be staged with 16-byte loads)
+ *       rel_len[n_rel]          int32 edges of the relation
+ *       idx[..]                 uint16 table node of each edge (16-byte aligned array); inside a
+ *                               relation the edges are sorted by the owner position of their OUTPUT
+ *                               node; a slot owns positions j*S + slot (j even) / j*S + S-1-slot (j odd)
  *       runs[n_rel][n_nodes][2] (begin relative to the relation's first edge, length) of the edges
  *                               whose output node sits at position p
  *       wg_rel_ptr[n_wg+1], wg_rels[n_rel]   relations handled by each of the n_wg workgroups
@@ -104,8 +107,9 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
 int tipk_rel_gather_supported(int64_t n_nodes, int d);       /* host predicate, 1 = usable */
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                     int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
-                    const int64_t* rel_edge_ptr, const uint16_t* idx, const int32_t* runs,
-                    const int32_t* node_at, float* out, int64_t ld_out, tipk_stream_t stream);
+                    const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
+                    const int32_t* runs, const int32_t* node_at, float* out, int64_t ld_out,
+                    tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).

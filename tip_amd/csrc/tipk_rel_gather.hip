@@ -21,7 +21,7 @@ constexpr int RG_CHUNK = 16384;        // edge ids staged per pass (uint16: 32 K
 template <int L, int J, bool BWD>
 __global__ __launch_bounds__(1024) void rel_gather_kernel(
     const float* __restrict__ table, int64_t ld_t, int n_nodes, int d, const int32_t* __restrict__ wg_rel_ptr,
-    const int32_t* __restrict__ wg_rels, const int64_t* __restrict__ rel_edge_ptr,
+    const int32_t* __restrict__ wg_rels, const int64_t* __restrict__ rel_idx_off, const int32_t* __restrict__ rel_len,
     const uint16_t* __restrict__ idx, const int32_t* __restrict__ runs, const int32_t* __restrict__ node_at,
     float* __restrict__ out, int64_t ld_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
     const int t = threadIdx.x;
     const int ldt = d + 4;                             // odd multiple of 16 B: ds_read_b128 spreads over banks
     float* tab = lds;                                  // [n_nodes][d+4]
-    int32_t* run_l = reinterpret_cast<int32_t*>(tab + (int64_t)n_nodes * ldt);      // [n_nodes][2]
-    uint16_t* idx_l = reinterpret_cast<uint16_t*>(run_l + 2 * n_nodes);             // [RG_CHUNK]
+    int32_t* run_l = reinterpret_cast<int32_t*>(tab + (int64_t)n_nodes * ldt);      // [n_nodes][2] (+pad to 16 B)
+    uint16_t* idx_l = reinterpret_cast<uint16_t*>(run_l + ((2 * n_nodes + 3) & ~3)); // [RG_CHUNK], 16-byte aligned
     const int slot = t / L, sub = t & (L - 1), c0 = sub * 4;
     const int q4 = d >> 2;                             // float4 per row
     const bool col_ok = c0 < d;
@@ -39,35 +39,60 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    if (BWD) {                                         // g' stays resident for the whole launch
-        for (int i = t; i < n_nodes * q4; i += 1024) {
-            const int r = i / q4, c = (i - r * q4) * 4;
-            tipk_st4(tab + r * ldt + c, tipk_ld4(table + (int64_t)r * ld_t + c));
+    // Staging loops issue a whole batch of global loads before the first LDS write: a plain
+    // load->ds_write loop waits for every load in turn (one HBM latency per iteration).
+    auto stage_table = [&](const float* src) {
+        constexpr int U = 8;
+        const int total = n_nodes * q4;
+        for (int base = 0; base < total; base += 1024 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 1024 + t;
+                if (i < total) { const int r = i / q4, c = (i - r * q4) * 4; v[u] = tipk_ld4(src + (int64_t)r * ld_t + c); }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * 1024 + t;
+                if (i < total) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, v[u]); }
+            }
         }
-    }
+    };
+    if (BWD) stage_table(table);                       // g' stays resident for the whole launch
     const int wg = blockIdx.x;
     for (int ri = wg_rel_ptr[wg]; ri < wg_rel_ptr[wg + 1]; ++ri) {
         const int rel = wg_rels[ri];
-        const int64_t e0 = rel_edge_ptr[rel];
-        const int ne = (int)(rel_edge_ptr[rel + 1] - e0);
+        const int64_t e0 = rel_idx_off[rel];           // multiple of 8 ids: 16-byte aligned segment
+        const int ne = rel_len[rel];
         __syncthreads();                               // readers of the previous relation are done
-        if (!BWD) {
-            const float* src = table + (int64_t)rel * n_nodes * ld_t;
-            for (int i = t; i < n_nodes * q4; i += 1024) {
-                const int r = i / q4, c = (i - r * q4) * 4;
-                tipk_st4(tab + r * ldt + c, tipk_ld4(src + (int64_t)r * ld_t + c));
-            }
+        {   // run table (2*n_nodes ints) and the first chunk of ids are requested together with Y_r
+            const int32_t* rsrc = runs + (int64_t)rel * n_nodes * 2;
+            int rv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; rv[u] = i < 2 * n_nodes ? rsrc[i] : 0; }
+            if (!BWD) stage_table(table + (int64_t)rel * n_nodes * ld_t);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < 2 * n_nodes) run_l[i] = rv[u]; }
+            for (int i = 2048 + t; i < 2 * n_nodes; i += 1024) run_l[i] = rsrc[i];
         }
-        const int32_t* rsrc = runs + (int64_t)rel * n_nodes * 2;
-        for (int i = t; i < 2 * n_nodes; i += 1024) run_l[i] = rsrc[i];
         for (int cb = 0; cb < ne; cb += RG_CHUNK) {
             const int cn = ne - cb < RG_CHUNK ? ne - cb : RG_CHUNK;
             if (cb > 0) __syncthreads();               // readers of the previous chunk are done
-            for (int i = t; i < cn; i += 1024) idx_l[i] = idx[e0 + cb + i];
+            {   // 8 ids (16 B) per lane per load; the segment is padded to a multiple of 8 ids
+                const uint4* isrc = reinterpret_cast<const uint4*>(idx + e0 + cb);
+                uint4* idst = reinterpret_cast<uint4*>(idx_l);
+                const int n8 = (cn + 7) >> 3;
+                uint4 iv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) iv[u] = isrc[i]; }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = iv[u]; }
+            }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const int p = slot + NS * j;
+                // snake deal of the degree-sorted positions: even bands ascending, odd bands descending
+                const int p = NS * j + ((j & 1) ? NS - 1 - slot : slot);
                 if (p < n_nodes) {
                     const int b = run_l[2 * p], len = run_l[2 * p + 1];
                     int lo = b > cb ? b : cb;
@@ -92,7 +117,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
         if (BWD) {
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const int p = slot + NS * j;
+                const int p = NS * j + ((j & 1) ? NS - 1 - slot : slot);
                 if (p < n_nodes && col_ok)
                     tipk_st4(out + ((int64_t)rel * n_nodes + node_at[p]) * ld_out + c0, acc[j]);
                 acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -102,20 +127,20 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
     if (!BWD) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const int p = slot + NS * j;
+            const int p = NS * j + ((j & 1) ? NS - 1 - slot : slot);
             if (p < n_nodes && col_ok) tipk_st4(out + ((int64_t)wg * n_nodes + node_at[p]) * ld_out + c0, acc[j]);
         }
     }
 }
 
 inline int64_t rel_gather_lds(int64_t n_nodes, int d) {
-    return n_nodes * (d + 4) * 4 + n_nodes * 8 + RG_CHUNK * 2;
+    return n_nodes * (d + 4) * 4 + ((2 * n_nodes + 3) & ~3LL) * 4 + RG_CHUNK * 2;
 }
 
 template <int L, int J>
 int launch_rg(bool bwd, const float* table, int64_t ld_t, int n_nodes, int d, int n_wg, const int32_t* wg_rel_ptr,
-              const int32_t* wg_rels, const int64_t* rel_edge_ptr, const uint16_t* idx, const int32_t* runs,
-              const int32_t* node_at, float* out, int64_t ld_out, hipStream_t st) {
+              const int32_t* wg_rels, const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
+              const int32_t* runs, const int32_t* node_at, float* out, int64_t ld_out, hipStream_t st) {
     const size_t lds = (size_t)rel_gather_lds(n_nodes, d);
     hipError_t e;
     if (bwd) {
@@ -123,13 +148,13 @@ int launch_rg(bool bwd, const float* table, int64_t ld_t, int n_nodes, int d, in
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return tipk_hip_status(e);
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), lds, st, table, ld_t, n_nodes, d, wg_rel_ptr,
-                           wg_rels, rel_edge_ptr, idx, runs, node_at, out, ld_out);
+                           wg_rels, rel_idx_off, rel_len, idx, runs, node_at, out, ld_out);
     } else {
         auto kern = rel_gather_kernel<L, J, false>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return tipk_hip_status(e);
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), lds, st, table, ld_t, n_nodes, d, wg_rel_ptr,
-                           wg_rels, rel_edge_ptr, idx, runs, node_at, out, ld_out);
+                           wg_rels, rel_idx_off, rel_len, idx, runs, node_at, out, ld_out);
     }
     TIPK_RETURN_LAUNCH();
 }
@@ -146,10 +171,11 @@ extern "C" int tipk_rel_gather_supported(int64_t n_nodes, int d) {
 
 extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                                int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
-                               const int64_t* rel_edge_ptr, const uint16_t* idx, const int32_t* runs,
-                               const int32_t* node_at, float* out, int64_t ld_out, tipk_stream_t stream) {
-    if (n_wg <= 0 || n_wg > 65535 || !table || !wg_rel_ptr || !wg_rels || !rel_edge_ptr || !idx || !runs ||
-        !node_at || !out)
+                               const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
+                               const int32_t* runs, const int32_t* node_at, float* out, int64_t ld_out,
+                               tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table || !wg_rel_ptr || !wg_rels || !rel_idx_off || !rel_len || !idx || !runs ||
+        !node_at || !out || (reinterpret_cast<uintptr_t>(idx) & 15))
         return TIPK_EINVAL;
     if (!tipk_rel_gather_supported(n_nodes, d)) return TIPK_EUNSUPPORTED;
     if (ld_table % 4 != 0 || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(table) & 15) ||
@@ -161,7 +187,7 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     const int j = (int)((n_nodes + slots - 1) / slots);          // nodes owned per slot
 #define TIPK_RG(LL, JJ)                                                                                         \
     return launch_rg<LL, JJ>(backward != 0, table, ld_table, (int)n_nodes, d, (int)n_wg, wg_rel_ptr, wg_rels,      \
-                             rel_edge_ptr, idx, runs, node_at, out, ld_out, st)
+                             rel_idx_off, rel_len, idx, runs, node_at, out, ld_out, st)
 #define TIPK_RG_J(LL)                    \
     do {                                 \
         if (j <= 1) { TIPK_RG(LL, 1); }  \

@@ -114,7 +114,8 @@ def rel_gather(rp, table, backward):
         out = torch.empty((rp.n_wg, n, d), dtype=torch.float32, device=table.device)
     with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
         check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
-                                    ptr(rp.wg_rels), ptr(rp.rel_edge_ptr), ptr(rp.idx), ptr(rp.runs), ptr(rp.node_at),
+                                    ptr(rp.wg_rels), ptr(rp.rel_idx_off), ptr(rp.rel_len), ptr(rp.idx), ptr(rp.runs),
+                                    ptr(rp.node_at),
                                     ptr(out), d, stream_ptr(table.device)), 'tipk_rel_gather')
     return out if backward else sum_slabs(out)
 

@@ -144,14 +144,14 @@ def execute_plan_reference(plan, table, row_scale=None):
 class RelPlan(object):
     """Device arrays of `tipk_rel_gather` for one direction of a multi-relational graph."""
 
-    def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_edge_ptr, idx, runs, wg_rel_ptr, wg_rels):
+    def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_idx_off, rel_len, idx, runs, wg_rel_ptr, wg_rels):
         self.n_nodes, self.n_rel, self.n_wg = int(n_nodes), int(n_rel), int(n_wg)
-        self.node_at, self.rel_edge_ptr, self.idx, self.runs = node_at, rel_edge_ptr, idx, runs
+        self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs = node_at, rel_idx_off, rel_len, idx, runs
         self.wg_rel_ptr, self.wg_rels = wg_rel_ptr, wg_rels
 
     def to(self, device):
         return RelPlan(self.n_nodes, self.n_rel, self.n_wg, *[t.to(device) for t in (
-            self.node_at, self.rel_edge_ptr, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels)])
+            self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels)])
 
 
 def assign_relations(sizes, n_wg, fixed_cost=0):
@@ -190,16 +190,23 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
     pos_of[node_at] = torch.arange(n_nodes, device=dev)
     key = rel * n_nodes + pos_of[out_node]
     order = torch.sort(key, stable=True).indices
-    idx = tab_node[order].to(torch.int32).to(torch.uint16) if hasattr(torch, 'uint16') else None
     cnt = torch.bincount(key, minlength=n_rel * n_nodes).view(n_rel, n_nodes)
     begin = torch.cumsum(cnt, 1) - cnt                                               # relative to the relation
     runs = torch.stack([begin, cnt], dim=2).to(torch.int32).contiguous()
     rel_sizes = cnt.sum(1)
-    rel_edge_ptr = torch.zeros(n_rel + 1, dtype=torch.int64, device=dev)
-    rel_edge_ptr[1:] = torch.cumsum(rel_sizes, 0)
+    # every relation's id segment starts at a multiple of 8 ids (16 B) and is padded to one
+    padded = (rel_sizes + 7) // 8 * 8
+    off = torch.cumsum(padded, 0) - padded
+    total = int(padded.sum()) + 8
+    start = torch.cumsum(rel_sizes, 0) - rel_sizes
+    srel = rel[order]
+    dest = off[srel] + (torch.arange(E, device=dev) - start[srel])
+    idx32 = torch.zeros(total, dtype=torch.int32, device=dev)
+    idx32[dest] = tab_node[order].to(torch.int32)
+    idx = idx32.to(torch.uint16).contiguous()
     wg_ptr, wg_rels = assign_relations(rel_sizes.tolist(), n_wg, fixed_cost)
-    return RelPlan(n_nodes, n_rel, n_wg, node_at.to(torch.int32).contiguous(), rel_edge_ptr, idx.contiguous(), runs,
-                   wg_ptr.to(dev), wg_rels.to(dev))
+    return RelPlan(n_nodes, n_rel, n_wg, node_at.to(torch.int32).contiguous(), off.to(torch.int64).contiguous(),
+                   rel_sizes.to(torch.int32).contiguous(), idx, runs, wg_ptr.to(dev), wg_rels.to(dev))
 
 
 def execute_rel_plan_reference(plan, table, backward):
@@ -211,7 +218,8 @@ def execute_rel_plan_reference(plan, table, backward):
     node_at = plan.node_at.to(torch.int64)
     res = torch.zeros((R, n, d), dtype=table.dtype)
     for r in range(R):
-        e0 = int(plan.rel_edge_ptr[r])
+        e0 = int(plan.rel_idx_off[r])
+        assert e0 % 8 == 0
         for p in range(n):
             b, ln = int(runs[r, p, 0]), int(runs[r, p, 1])
             if ln:
