@@ -102,13 +102,19 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
                     for (int e = lo; e < hi; e += L) {
                         const int mine = e + sub;
                         const int id = mine < hi ? (int)idx_l[mine] : -1;
+                        // branch-free batch: all L row reads are issued before the first add (a
+                        // predicated read-then-add per row pays one LDS latency per edge, which is
+                        // what the longest run of a relation -- one slot -- is bound by)
+                        float4 v[L];
 #pragma unroll
                         for (int jj = 0; jj < L; ++jj) {
                             const int idj = __shfl(id, jj, L);
-                            if (idj >= 0 && col_ok) {
-                                const float4 v = tipk_ld4(tab + idj * ldt + c0);
-                                acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
-                            }
+                            v[jj] = tipk_ld4(tab + (idj < 0 ? 0 : idj) * ldt + c0);
+                            if (idj < 0) v[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < L; ++jj) {
+                            acc[j].x += v[jj].x; acc[j].y += v[jj].y; acc[j].z += v[jj].z; acc[j].w += v[jj].w;
                         }
                     }
                 }
