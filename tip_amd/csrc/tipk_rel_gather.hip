@@ -12,6 +12,7 @@
 //   FWD: sums persist across the workgroup's relations -> one partial [N x d] slab per workgroup,
 //        combined in order by tipk_sum_slabs.
 //   BWD: one output row per (relation, node) written straight to dY; sums reset per relation.
+#include <stdlib.h>
 #include "tipk_common.h"
 
 namespace {
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
     const float* __restrict__ table, int64_t ld_t, int n_nodes, int d, const int32_t* __restrict__ wg_rel_ptr,
     const int32_t* __restrict__ wg_rels, const int64_t* __restrict__ rel_idx_off, const int32_t* __restrict__ rel_len,
     const uint16_t* __restrict__ idx, const int32_t* __restrict__ runs, const int32_t* __restrict__ node_at,
-    float* __restrict__ out, int64_t ld_out) {
+    float* __restrict__ out, int64_t ld_out, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NS = 1024 / L;                       // slots per workgroup
     const int t = threadIdx.x;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
             int rv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; rv[u] = i < 2 * n_nodes ? rsrc[i] : 0; }
-            if (!BWD) stage_table(table + (int64_t)rel * n_nodes * ld_t);
+            if (!BWD && !(dbg & 2)) stage_table(table + (int64_t)rel * n_nodes * ld_t);
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < 2 * n_nodes) run_l[i] = rv[u]; }
             for (int i = 2048 + t; i < 2 * n_nodes; i += 1024) run_l[i] = rsrc[i];
@@ -84,11 +85,12 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
                 const int n8 = (cn + 7) >> 3;
                 uint4 iv[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) iv[u] = isrc[i]; }
+                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8 && !(dbg & 4)) iv[u] = isrc[i]; }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = iv[u]; }
             }
             __syncthreads();
+            if (dbg & 1) continue;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 // snake deal of the degree-sorted positions: even bands ascending, odd bands descending
@@ -147,6 +149,8 @@ template <int L, int J>
 int launch_rg(bool bwd, const float* table, int64_t ld_t, int n_nodes, int d, int n_wg, const int32_t* wg_rel_ptr,
               const int32_t* wg_rels, const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
               const int32_t* runs, const int32_t* node_at, float* out, int64_t ld_out, hipStream_t st) {
+    const char* dbg_env = getenv("TIPK_RG_DEBUG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     const size_t lds = (size_t)rel_gather_lds(n_nodes, d);
     hipError_t e;
     if (bwd) {
@@ -154,13 +158,13 @@ int launch_rg(bool bwd, const float* table, int64_t ld_t, int n_nodes, int d, in
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return tipk_hip_status(e);
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), lds, st, table, ld_t, n_nodes, d, wg_rel_ptr,
-                           wg_rels, rel_idx_off, rel_len, idx, runs, node_at, out, ld_out);
+                           wg_rels, rel_idx_off, rel_len, idx, runs, node_at, out, ld_out, dbg);
     } else {
         auto kern = rel_gather_kernel<L, J, false>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return tipk_hip_status(e);
         hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), lds, st, table, ld_t, n_nodes, d, wg_rel_ptr,
-                           wg_rels, rel_idx_off, rel_len, idx, runs, node_at, out, ld_out);
+                           wg_rels, rel_idx_off, rel_len, idx, runs, node_at, out, ld_out, dbg);
     }
     TIPK_RETURN_LAUNCH();
 }
