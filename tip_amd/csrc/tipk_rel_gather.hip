@@ -101,21 +101,23 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(
                     int hi = b + len < cb + cn ? b + len : cb + cn;
                     lo -= cb;
                     hi -= cb;
-                    for (int e = lo; e < hi; e += L) {
-                        const int mine = e + sub;
-                        const int id = mine < hi ? (int)idx_l[mine] : -1;
-                        // branch-free batch: all L row reads are issued before the first add (a
-                        // predicated read-then-add per row pays one LDS latency per edge, which is
-                        // what the longest run of a relation -- one slot -- is bound by)
-                        float4 v[L];
+                    // 8 edges per step: the 8 ids come as ONE 16-byte LDS read (same address for the
+                    // slot's lanes = broadcast), so a step costs 1 + 8 LDS reads and no ds_bpermute;
+                    // all row reads are issued before the first add (no per-row latency).
+                    for (int eb = lo & ~7; eb < hi; eb += 8) {
+                        const uint4 pk = *reinterpret_cast<const uint4*>(idx_l + eb);
+                        const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+                        float4 v[8];
 #pragma unroll
-                        for (int jj = 0; jj < L; ++jj) {
-                            const int idj = __shfl(id, jj, L);
-                            v[jj] = tipk_ld4(tab + (idj < 0 ? 0 : idj) * ldt + c0);
-                            if (idj < 0) v[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int e = eb + jj;
+                            const int idj = (int)((w4[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
+                            const bool ok = e >= lo && e < hi;
+                            v[jj] = tipk_ld4(tab + (ok ? idj : 0) * ldt + c0);
+                            if (!ok) v[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
 #pragma unroll
-                        for (int jj = 0; jj < L; ++jj) {
+                        for (int jj = 0; jj < 8; ++jj) {
                             acc[j].x += v[jj].x; acc[j].y += v[jj].y; acc[j].z += v[jj].z; acc[j].w += v[jj].w;
                         }
                     }
