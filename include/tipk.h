@@ -81,9 +81,8 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
 
 /* --------------------------------------------------------------------------------------------
  * 1b. Relation-local gather -- the D-D aggregation (K5/K6, src/layers.py:159-180) when one
- *     relation's node table fits in LDS (n_nodes * (d+4) * 4 B + 40 KB <= 158 KB; d a power of two
- *     in 4..64; n_nodes <= 65535 and <= 8 * 4096/d).  Same sums as `tipk_gather_sum` over the plan
- *     of the same graph, evaluated with every gathered row coming from LDS:
+ *     relation's node table fits in LDS (BioSNAP: 645 drugs x 32 floats).  Same sums as
+ *     `tipk_gather_sum` over the plan of the same graph, with every gathered row read from LDS:
  *
  *       backward = 0:  table = Y [n_rel * n_nodes, d];  out = partial [n_wg, n_nodes, d] with
  *                      sum_wg partial[wg, o] = sum_r sum_{e in r: out(e)=o} Y[r * n_nodes + tab(e)]
@@ -91,24 +90,26 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *       backward = 1:  table = g' [n_nodes, d];  out = dY [n_rel * n_nodes, d],
  *                      dY[r * n_nodes + o] = sum_{e in r: out(e)=o} g'[tab(e)]   (every row written).
  *
+ *     d: power of two >= 4; n_nodes <= 65535; the columns are cut into blocks until a block's table
+ *     (+ accumulators when backward = 0) fits in 158 KB of LDS -- `tipk_rel_gather_supported`.
+ *
  *     Relation-local plan (tip_amd/plan.py `build_rel_plan`), all device arrays:
- *       node_at[p]              node id at owner position p (nodes sorted by decreasing degree)
+ *       node_at[n_rel][n_nodes] uint16: output node at position p of relation r; positions are
+ *                               ordered by decreasing run length inside the relation
  *       rel_idx_off[n_rel]      int64 offset of the relation's ids in idx (multiple of 8: segments
  *                               are padded so they can be staged with 16-byte loads)
  *       rel_len[n_rel]          int32 edges of the relation
  *       idx[..]                 uint16 table node of each edge (16-byte aligned array); inside a
- *                               relation the edges are sorted by the owner position of their OUTPUT
- *                               node; a slot owns positions j*S + slot (j even) / j*S + S-1-slot (j odd)
- *       runs[n_rel][n_nodes][2] (begin relative to the relation's first edge, length) of the edges
- *                               whose output node sits at position p
+ *                               relation the edges are sorted by the position of their OUTPUT node
+ *       runs[n_rel][n_nodes][2] (begin relative to the relation's first edge, length) per position
  *       wg_rel_ptr[n_wg+1], wg_rels[n_rel]   relations handled by each of the n_wg workgroups
  *                               (edge-balanced; n_wg = number of CUs)
  */
-int tipk_rel_gather_supported(int64_t n_nodes, int d);       /* host predicate, 1 = usable */
+int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);   /* host predicate, 1 = usable */
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                     int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
                     const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
-                    const int32_t* runs, const int32_t* node_at, float* out, int64_t ld_out,
+                    const int32_t* runs, const uint16_t* node_at, float* out, int64_t ld_out,
                     tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

@@ -247,7 +247,7 @@ def test_negative_sampler_uniformity_vs_reference_distribution():
 
 
 # ------------------------------------------------------------------ relation-local (LDS) gather
-@pytest.mark.parametrize('d', [4, 16, 32])
+@pytest.mark.parametrize('d', [4, 16, 32, 128])
 def test_rel_gather_fwd_bwd(ops, d):
     from tip_amd.plan import build_rel_plan
     from tip_amd import _lib
@@ -259,7 +259,7 @@ def test_rel_gather_fwd_bwd(ops, d):
     src = torch.randint(0, N, (E,), generator=g)
     dst = torch.randint(0, N - 7, (E,), generator=g)
     dst[:9000] = 11                                                            # hub (longest run 9000 edges)
-    assert _lib.lib().tipk_rel_gather_supported(N, d) == 1
+    assert _lib.lib().tipk_rel_gather_supported(N, d, 0) == 1 and _lib.lib().tipk_rel_gather_supported(N, d, 1) == 1
     y = torch.randn(R * N, d, generator=g)
     plan = build_rel_plan(dst, src, rel, N, R, n_wg=256).to(DEV)
     got = ops.rel_gather(plan, y.to(DEV), backward=False)
@@ -279,7 +279,8 @@ def test_rel_gather_fwd_bwd(ops, d):
 def test_rel_gather_unsupported_shapes():
     from tip_amd import _lib
     L = _lib.lib()
-    assert L.tipk_rel_gather_supported(645, 64) == 0        # 645 x 68 floats do not fit in LDS
-    assert L.tipk_rel_gather_supported(645, 24) == 0        # not a power of two
-    assert L.tipk_rel_gather_supported(10000, 32) == 0
-    assert L.tipk_rel_gather_supported(645, 32) == 1 and L.tipk_rel_gather_supported(645, 16) == 1
+    assert L.tipk_rel_gather_supported(645, 24, 0) == 0     # not a power of two
+    assert L.tipk_rel_gather_supported(10000, 32, 0) == 0 and L.tipk_rel_gather_supported(10000, 32, 1) == 0
+    assert L.tipk_rel_gather_supported(70000, 16, 1) == 0   # ids are 16 bit
+    for d in (16, 32, 64, 128):                             # wide rows run as several column blocks
+        assert L.tipk_rel_gather_supported(645, d, 0) == 1 and L.tipk_rel_gather_supported(645, d, 1) == 1

@@ -192,7 +192,7 @@ def test_rel_plan_semantics():
     wantb = torch.zeros(R * N, d, dtype=torch.float64).index_add_(0, rel * N + src, gp[dst])
     torch.testing.assert_close(execute_rel_plan_reference(planb, gp, True), wantb)
     assert plan.idx.dtype == torch.uint16 and plan.runs.shape == (R, N, 2)
-    assert int(plan.node_at[0]) == 2                                            # hub first in owner order
+    assert plan.node_at.shape == (R, N) and int(plan.node_at[0, 0]) == 2            # hub first in relation 0
     assert sorted(plan.wg_rels.tolist()) == list(range(R)) and plan.wg_rel_ptr.tolist()[-1] == R
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
     loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]

@@ -96,9 +96,9 @@ def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False):
     return out
 
 
-def rel_gather_usable(rp, n_nodes, d):
+def rel_gather_usable(rp, n_nodes, d, backward):
     return (rp is not None and not os.environ.get('TIPK_NO_RELLOCAL')
-            and bool(lib().tipk_rel_gather_supported(n_nodes, d)))
+            and bool(lib().tipk_rel_gather_supported(n_nodes, d, int(backward))))
 
 
 def rel_gather(rp, table, backward):
@@ -469,7 +469,7 @@ class _RGCN(torch.autograd.Function):
             y = gemm(att_l, xb.view(nb, n * d_out))                      # [R, N*out]
         else:
             y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
-        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out)
+        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
         if use_rl:
             agg = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False)
         elif shard is None:
@@ -499,7 +499,7 @@ class _RGCN(torch.autograd.Function):
         gs = rows_affine(g, row_mul=graph.scale)
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
-            if rel_gather_usable(graph.rl_bwd, n, d_out):                # dY_r = A_r^T (D^-1 g)
+            if rel_gather_usable(graph.rl_bwd, n, d_out, True):                # dY_r = A_r^T (D^-1 g)
                 g_y = rel_gather(graph.rl_bwd, gs, backward=True).view(r, n * d_out)
             else:
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)

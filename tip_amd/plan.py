@@ -178,20 +178,21 @@ def assign_relations(sizes, n_wg, fixed_cost=0):
 def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost=2048):
     """Relation-local plan for  result[r, o] = sum_{e in r: out_node[e]=o} table_r[tab_node[e]].
 
-    out_node / tab_node / rel: int64 [E]; nodes < 65536.  Nodes are ordered by decreasing
-    out-degree ("owner positions"); inside a relation edges are sorted by the owner position of
-    their output node, so the edges of one (relation, node) pair form one contiguous run."""
+    out_node / tab_node / rel: int64 [E]; nodes < 65536.  Inside every relation the output nodes
+    are ordered by decreasing run length (`node_at[r, p]` = node at position p) and the edges are
+    sorted by the position of their output node, so the edges of one (relation, node) pair form one
+    contiguous run and neighbouring positions have runs of similar length."""
     dev = out_node.device
     assert n_nodes <= 65535
     E = int(out_node.numel())
-    deg = torch.bincount(out_node, minlength=n_nodes) if E else torch.zeros(n_nodes, dtype=torch.long, device=dev)
-    node_at = torch.sort(deg, descending=True, stable=True).indices                  # position -> node
-    pos_of = torch.empty(n_nodes, dtype=torch.long, device=dev)
-    pos_of[node_at] = torch.arange(n_nodes, device=dev)
-    key = rel * n_nodes + pos_of[out_node]
+    cnt_nodes = torch.bincount(rel * n_nodes + out_node, minlength=n_rel * n_nodes).view(n_rel, n_nodes)
+    node_at = torch.sort(cnt_nodes, dim=1, descending=True, stable=True).indices          # [R, N] position -> node
+    pos_of = torch.empty_like(node_at)
+    pos_of.scatter_(1, node_at, torch.arange(n_nodes, device=dev).expand(n_rel, n_nodes).contiguous())
+    key = rel * n_nodes + pos_of.view(-1)[rel * n_nodes + out_node]
     order = torch.sort(key, stable=True).indices
-    cnt = torch.bincount(key, minlength=n_rel * n_nodes).view(n_rel, n_nodes)
-    begin = torch.cumsum(cnt, 1) - cnt                                               # relative to the relation
+    cnt = torch.gather(cnt_nodes, 1, node_at)                                             # run length per position
+    begin = torch.cumsum(cnt, 1) - cnt                                                    # relative to the relation
     runs = torch.stack([begin, cnt], dim=2).to(torch.int32).contiguous()
     rel_sizes = cnt.sum(1)
     # every relation's id segment starts at a multiple of 8 ids (16 B) and is padded to one
@@ -205,8 +206,9 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
     idx32[dest] = tab_node[order].to(torch.int32)
     idx = idx32.to(torch.uint16).contiguous()
     wg_ptr, wg_rels = assign_relations(rel_sizes.tolist(), n_wg, fixed_cost)
-    return RelPlan(n_nodes, n_rel, n_wg, node_at.to(torch.int32).contiguous(), off.to(torch.int64).contiguous(),
-                   rel_sizes.to(torch.int32).contiguous(), idx, runs, wg_ptr.to(dev), wg_rels.to(dev))
+    return RelPlan(n_nodes, n_rel, n_wg, node_at.to(torch.int32).to(torch.uint16).contiguous(),
+                   off.to(torch.int64).contiguous(), rel_sizes.to(torch.int32).contiguous(), idx, runs,
+                   wg_ptr.to(dev), wg_rels.to(dev))
 
 
 def execute_rel_plan_reference(plan, table, backward):
@@ -215,7 +217,7 @@ def execute_rel_plan_reference(plan, table, backward):
     d = table.shape[1]
     idx = plan.idx.to(torch.int64)
     runs = plan.runs.to(torch.int64)
-    node_at = plan.node_at.to(torch.int64)
+    node_at = plan.node_at.to(torch.int64)                 # [R, N]
     res = torch.zeros((R, n, d), dtype=table.dtype)
     for r in range(R):
         e0 = int(plan.rel_idx_off[r])
@@ -225,5 +227,5 @@ def execute_rel_plan_reference(plan, table, backward):
             if ln:
                 rows = idx[e0 + b:e0 + b + ln]
                 src = table[rows] if backward else table[r * n + rows]
-                res[r, node_at[p]] = src.sum(0)
+                res[r, node_at[r, p]] = src.sum(0)
     return res.view(R * n, d) if backward else res.sum(0)
