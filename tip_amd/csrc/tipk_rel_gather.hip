@@ -43,8 +43,8 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     const int n_nodes = a.n_nodes, dc = a.dc;
     const int ldt = dc + 4;                            // odd multiple of 16 B: ds_read_b128 spreads over banks
     const int q4 = dc >> 2;                            // float4 per row (== L)
-    float* tab = lds;                                                                  // [n_nodes][dc+4]
-    float* accl = tab + (int64_t)n_nodes * ldt;                                        // FWD: [n_nodes][dc]
+    float* tab = lds;                                                   // [n_nodes + 1][dc+4], last row = 0
+    float* accl = tab + (int64_t)(n_nodes + 1) * ldt;                                  // FWD: [n_nodes][dc]
     int32_t* run_l = reinterpret_cast<int32_t*>(accl + (BWD ? 0 : (int64_t)n_nodes * dc));     // [n_nodes][2]
     uint16_t* node_l = reinterpret_cast<uint16_t*>(run_l + ((2 * n_nodes + 3) & ~3));  // [n_nodes] (+pad)
     uint16_t* idx_l = node_l + ((n_nodes + 7) & ~7);                                   // [RG_CHUNK], 16-B aligned
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
             }
         }
     };
+    if (t < ldt) tab[(int64_t)n_nodes * ldt + t] = 0.f;                    // the sentinel's row
     if (BWD) {
         stage_table(table);                            // g' stays resident for the whole launch
     } else {
@@ -116,24 +117,22 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
             for (int p = slot; p < n_nodes; p += NS) {
                 const int b = run_l[2 * p], len = run_l[2 * p + 1];
                 if (!BWD && len == 0) break;           // rows are sorted by length: the rest is empty
-                int lo = b > cb ? b : cb;
+                int lo = b > cb ? b : cb;                // b, len, cb, cn are multiples of 8
                 int hi = b + len < cb + cn ? b + len : cb + cn;
                 lo -= cb;
                 hi -= cb;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                // 8 edges per step: the ids come as ONE 16-byte LDS read (same address for the slot's
-                // lanes = broadcast); all row reads are issued before the first add.
-                for (int eb = lo & ~7; eb < hi; eb += 8) {
+                // 8 edges per step.  Runs are padded to multiples of 8 ids with the sentinel id
+                // n_nodes, whose table row is all zeros: no masks, no tails -- a step is one 16-byte id
+                // read (same address for the slot's lanes = broadcast) + 8 row reads + 8 adds.
+                for (int eb = lo; eb < hi; eb += 8) {
                     const uint4 pk = *reinterpret_cast<const uint4*>(idx_l + eb);
                     const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
                     float4 v[8];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
-                        const int e = eb + jj;
-                        const int idj = (int)((w4[jj >> 1] >> (16 * (jj & 1))) & 0xffffu);
-                        const bool ok = e >= lo && e < hi;
-                        v[jj] = tipk_ld4(tab + (ok ? idj : 0) * ldt + c0);
-                        if (!ok) v[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const unsigned idj = (w4[jj >> 1] >> (16 * (jj & 1))) & 0xffffu;
+                        v[jj] = tipk_ld4(tab + idj * ldt + c0);
                     }
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
 }
 
 inline int64_t rel_gather_lds(int64_t n_nodes, int dc, bool bwd) {
-    return n_nodes * (dc + 4) * 4 + (bwd ? 0 : n_nodes * dc * 4) + ((2 * n_nodes + 3) & ~3LL) * 4 +
+    return (n_nodes + 1) * (dc + 4) * 4 + (bwd ? 0 : n_nodes * dc * 4) + ((2 * n_nodes + 3) & ~3LL) * 4 +
            ((n_nodes + 7) & ~7LL) * 2 + RG_CHUNK * 2;
 }
 
@@ -176,7 +175,7 @@ constexpr int64_t RG_LDS_LIMIT = 158 * 1024;
 
 // column blocks needed so that one block's table (+ accumulators) fits in LDS; 0 = impossible
 inline int rel_gather_split(int64_t n_nodes, int d, bool bwd) {
-    if (n_nodes <= 0 || n_nodes > 65535 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
+    if (n_nodes <= 0 || n_nodes > 65534 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
     for (int split = 1; d / split >= 4; split *= 2) {
         const int dc = d / split;
         if (dc > 64) continue;                          // L = dc/4 <= 16 lanes per slot

@@ -192,17 +192,20 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
     key = rel * n_nodes + pos_of.view(-1)[rel * n_nodes + out_node]
     order = torch.sort(key, stable=True).indices
     cnt = torch.gather(cnt_nodes, 1, node_at)                                             # run length per position
-    begin = torch.cumsum(cnt, 1) - cnt                                                    # relative to the relation
-    runs = torch.stack([begin, cnt], dim=2).to(torch.int32).contiguous()
-    rel_sizes = cnt.sum(1)
-    # every relation's id segment starts at a multiple of 8 ids (16 B) and is padded to one
-    padded = (rel_sizes + 7) // 8 * 8
-    off = torch.cumsum(padded, 0) - padded
-    total = int(padded.sum()) + 8
-    start = torch.cumsum(rel_sizes, 0) - rel_sizes
-    srel = rel[order]
-    dest = off[srel] + (torch.arange(E, device=dev) - start[srel])
-    idx32 = torch.zeros(total, dtype=torch.int32, device=dev)
+    # every run is padded to a multiple of 8 ids with the sentinel id n_nodes (its table row is
+    # zero in the kernel), so runs and relation segments start 16-byte aligned and need no masks
+    cnt8 = (cnt + 7) // 8 * 8
+    begin8 = torch.cumsum(cnt8, 1) - cnt8                                                 # relative to the relation
+    runs = torch.stack([begin8, cnt8], dim=2).to(torch.int32).contiguous()
+    rel_sizes = cnt8.sum(1)                                                               # padded ids per relation
+    off = torch.cumsum(rel_sizes, 0) - rel_sizes
+    total = int(rel_sizes.sum()) + 8
+    # destination of every (sorted) edge: relation offset + run begin + rank inside the run
+    skey = key[order]
+    run_first = torch.cumsum(cnt.view(-1), 0) - cnt.view(-1)                              # first sorted edge of a run
+    rank = torch.arange(E, device=dev) - run_first[skey]
+    dest = off[skey // n_nodes] + begin8.view(-1)[skey] + rank
+    idx32 = torch.full((total,), n_nodes, dtype=torch.int32, device=dev)
     idx32[dest] = tab_node[order].to(torch.int32)
     idx = idx32.to(torch.uint16).contiguous()
     wg_ptr, wg_rels = assign_relations(rel_sizes.tolist(), n_wg, fixed_cost)
@@ -225,7 +228,9 @@ def execute_rel_plan_reference(plan, table, backward):
         for p in range(n):
             b, ln = int(runs[r, p, 0]), int(runs[r, p, 1])
             if ln:
+                assert b % 8 == 0 and ln % 8 == 0
                 rows = idx[e0 + b:e0 + b + ln]
+                rows = rows[rows < n]                                  # drop the padding sentinel
                 src = table[rows] if backward else table[r * n + rows]
                 res[r, node_at[r, p]] = src.sum(0)
     return res.view(R * n, d) if backward else res.sum(0)
