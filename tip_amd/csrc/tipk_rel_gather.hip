@@ -53,66 +53,80 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     const float* table = a.table + col0;
     float* out = a.out + col0;
 
-    // Staging issues a whole batch of global loads before the first LDS write: a plain
-    // load->ds_write loop waits for every load in turn (one HBM latency per iteration).
-    auto stage_table = [&](const float* src) {
-        constexpr int U = 8;
-        const int total = n_nodes * q4;
-        for (int base = 0; base < total; base += 1024 * U) {
-            float4 v[U];
+    // Staging is software-pipelined across relations: the NEXT relation's table rows, run table,
+    // node order and first id chunk are requested into registers before the current relation is
+    // processed and written to LDS afterwards, so HBM latency hides behind the LDS-bound compute
+    // (one workgroup per CU: there is no other wave to hide it).
+    constexpr int TU = 8;                              // float4 of table per thread (n_nodes*q4 <= 8192)
+    float4 tv[TU];
+    int rv[2];
+    uint16_t nv = 0;
+    uint4 iv[2];
+    const int total4 = n_nodes * q4;
+    auto prefetch = [&](int rel, bool with_table) {
+        const int32_t* rsrc = a.runs + (int64_t)rel * n_nodes * 2;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = base + u * 1024 + t;
-                if (i < total) { const int r = i / q4, c = (i - r * q4) * 4; v[u] = tipk_ld4(src + (int64_t)r * a.ld_t + c); }
+        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; rv[u] = i < 2 * n_nodes ? rsrc[i] : 0; }
+        nv = t < n_nodes ? a.node_at[(int64_t)rel * n_nodes + t] : (uint16_t)0;
+        const int ne = a.rel_len[rel];
+        const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
+        const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + a.rel_idx_off[rel]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) iv[u] = isrc[i]; }
+        if (with_table) {
+            const float* src = table + (BWD ? 0 : (int64_t)rel * n_nodes * a.ld_t);
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int i = u * 1024 + t;
+                if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tv[u] = tipk_ld4(src + (int64_t)r * a.ld_t + c); }
             }
+        }
+    };
+    auto commit = [&](int rel, bool with_table) {      // registers -> LDS
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = base + u * 1024 + t;
-                if (i < total) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, v[u]); }
+        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < 2 * n_nodes) run_l[i] = rv[u]; }
+        if (t < n_nodes) node_l[t] = nv;
+        const int ne = a.rel_len[rel];
+        const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
+        uint4* idst = reinterpret_cast<uint4*>(idx_l);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = iv[u]; }
+        if (with_table) {
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int i = u * 1024 + t;
+                if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, tv[u]); }
             }
         }
     };
     if (t < ldt) tab[(int64_t)n_nodes * ldt + t] = 0.f;                    // the sentinel's row
-    if (BWD) {
-        stage_table(table);                            // g' stays resident for the whole launch
-    } else {
+    if (!BWD)
         for (int i = t; i < n_nodes * q4; i += 1024) tipk_st4(accl + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
     const int wg = blockIdx.x;
-    for (int ri = a.wg_rel_ptr[wg]; ri < a.wg_rel_ptr[wg + 1]; ++ri) {
+    const int ri0 = a.wg_rel_ptr[wg], ri1 = a.wg_rel_ptr[wg + 1];
+    if (ri0 < ri1) prefetch(a.wg_rels[ri0], true);     // BWD: g' is staged once, with the first relation
+    for (int ri = ri0; ri < ri1; ++ri) {
         const int rel = a.wg_rels[ri];
         const int64_t e0 = a.rel_idx_off[rel];         // multiple of 8 ids: 16-byte aligned segment
         const int ne = a.rel_len[rel];
         __syncthreads();                               // readers of the previous relation are done
-        {   // run table, node order and Y_r are requested together
-            const int32_t* rsrc = a.runs + (int64_t)rel * n_nodes * 2;
-            const uint16_t* nsrc = a.node_at + (int64_t)rel * n_nodes;
-            int rv[2];
-            uint16_t nv = 0;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; rv[u] = i < 2 * n_nodes ? rsrc[i] : 0; }
-            if (t < n_nodes) nv = nsrc[t];
-            if (!BWD && !(a.dbg & 2)) stage_table(table + (int64_t)rel * n_nodes * a.ld_t);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < 2 * n_nodes) run_l[i] = rv[u]; }
-            if (t < n_nodes) node_l[t] = nv;
-            for (int i = 2048 + t; i < 2 * n_nodes; i += 1024) run_l[i] = rsrc[i];
-            for (int i = 1024 + t; i < n_nodes; i += 1024) node_l[i] = nsrc[i];
-        }
+        commit(rel, !BWD || ri == ri0);
+        __syncthreads();
+        if (ri + 1 < ri1) prefetch(a.wg_rels[ri + 1], !BWD);      // in flight during the compute below
         for (int cb = 0; cb == 0 || cb < ne; cb += RG_CHUNK) {
             const int cn = ne - cb < RG_CHUNK ? ne - cb : RG_CHUNK;
-            if (cb > 0) __syncthreads();               // readers of the previous chunk are done
-            {   // 8 ids (16 B) per lane per load; the segment is padded to a multiple of 8 ids
+            if (cb > 0) {                              // rare: a relation with more than RG_CHUNK ids
+                __syncthreads();
                 const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + e0 + cb);
                 uint4* idst = reinterpret_cast<uint4*>(idx_l);
                 const int n8 = (cn + 7) >> 3;
-                uint4 iv[2];
+                uint4 jv[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8 && !(a.dbg & 4)) iv[u] = isrc[i]; }
+                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) jv[u] = isrc[i]; }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = iv[u]; }
+                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = jv[u]; }
+                __syncthreads();
             }
-            __syncthreads();
             if (a.dbg & 1) continue;
             for (int p = slot; p < n_nodes; p += NS) {
                 const int b = run_l[2 * p], len = run_l[2 * p + 1];
@@ -179,6 +193,7 @@ inline int rel_gather_split(int64_t n_nodes, int d, bool bwd) {
     for (int split = 1; d / split >= 4; split *= 2) {
         const int dc = d / split;
         if (dc > 64) continue;                          // L = dc/4 <= 16 lanes per slot
+        if (n_nodes * (dc / 4) > 8192) continue;       // table rows are prefetched in 8 float4 per thread
         if (rel_gather_lds(n_nodes, dc, bwd) <= RG_LDS_LIMIT) return split;
     }
     return 0;
