@@ -281,6 +281,6 @@ def test_rel_gather_unsupported_shapes():
     L = _lib.lib()
     assert L.tipk_rel_gather_supported(645, 24, 0) == 0     # not a power of two
     assert L.tipk_rel_gather_supported(10000, 32, 0) == 0 and L.tipk_rel_gather_supported(10000, 32, 1) == 0
-    assert L.tipk_rel_gather_supported(70000, 16, 1) == 0   # ids are 16 bit
+    assert L.tipk_rel_gather_supported(2000, 16, 1) == 0    # node tables are prefetched by 1024 threads
     for d in (16, 32, 64, 128):                             # wide rows run as several column blocks
         assert L.tipk_rel_gather_supported(645, d, 0) == 1 and L.tipk_rel_gather_supported(645, d, 1) == 1

@@ -35,7 +35,9 @@ struct RgArgs {
     int dbg;
 };
 
-template <int L, bool BWD>
+// TU = float4 of one relation's table per thread (ceil(n_nodes*dc/4 / 1024)); it sizes the register
+// prefetch buffer, so it is a template parameter (a fixed 8 spills at 128 VGPRs).
+template <int L, bool BWD, int TU>
 __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NS = 1024 / L;                       // slots per workgroup
@@ -57,62 +59,92 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     // node order and first id chunk are requested into registers before the current relation is
     // processed and written to LDS afterwards, so HBM latency hides behind the LDS-bound compute
     // (one workgroup per CU: there is no other wave to hide it).
-    constexpr int TU = 8;                              // float4 of table per thread (n_nodes*q4 <= 8192)
-    float4 tv[TU];
-    int rv[2];
+    // (named scalars, not arrays: hipcc keeps small arrays that are written in one lambda and read in
+    // another in scratch memory, which puts a vmcnt(0) wait right behind every prefetch load)
+    float4 tv0, tv1, tv2, tv3, tv4, tv5, tv6, tv7;
+    int rv0 = 0, rv1 = 0;
     uint16_t nv = 0;
-    uint4 iv[2];
+    uint4 iv0, iv1;
     const int total4 = n_nodes * q4;
-    auto prefetch = [&](int rel, bool with_table) {
+    // All prefetch loads are UNCONDITIONAL (indices clamped into the valid range): a load inside an
+    // exec-masked branch makes hipcc wait vmcnt(0) at the end of the branch, which would serialise the
+    // pipeline again.  Out-of-range lanes simply re-read the last valid element and drop it in commit.
+#define RG_TLOAD(U, V)                                                         \
+    if (TU > U) {                                                              \
+        int i = U * 1024 + t;                                                  \
+        i = i < total4 ? i : total4 - 1;                                       \
+        const int r = i / q4, c = (i - r * q4) * 4;                            \
+        V = tipk_ld4(src + (int64_t)r * a.ld_t + c);                           \
+    }
+#define RG_TSTORE(U, V)                                                        \
+    if (TU > U) {                                                              \
+        const int i = U * 1024 + t;                                            \
+        if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, V); } \
+    }
+    auto prefetch = [&](int rel) {
         const int32_t* rsrc = a.runs + (int64_t)rel * n_nodes * 2;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; rv[u] = i < 2 * n_nodes ? rsrc[i] : 0; }
-        nv = t < n_nodes ? a.node_at[(int64_t)rel * n_nodes + t] : (uint16_t)0;
+        rv0 = rsrc[t < 2 * n_nodes ? t : 2 * n_nodes - 1];
+        rv1 = rsrc[1024 + t < 2 * n_nodes ? 1024 + t : 2 * n_nodes - 1];
+        nv = a.node_at[(int64_t)rel * n_nodes + (t < n_nodes ? t : n_nodes - 1)];
         const int ne = a.rel_len[rel];
         const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
+        const int last = n8 > 0 ? n8 - 1 : 0;
         const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + a.rel_idx_off[rel]);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) iv[u] = isrc[i]; }
-        if (with_table) {
-            const float* src = table + (BWD ? 0 : (int64_t)rel * n_nodes * a.ld_t);
-#pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int i = u * 1024 + t;
-                if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tv[u] = tipk_ld4(src + (int64_t)r * a.ld_t + c); }
-            }
+        iv0 = isrc[t < n8 ? t : last];
+        iv1 = isrc[1024 + t < n8 ? 1024 + t : last];
+        if (!BWD) {
+            const float* src = table + (int64_t)rel * n_nodes * a.ld_t;
+            RG_TLOAD(0, tv0) RG_TLOAD(1, tv1) RG_TLOAD(2, tv2) RG_TLOAD(3, tv3)
+            RG_TLOAD(4, tv4) RG_TLOAD(5, tv5) RG_TLOAD(6, tv6) RG_TLOAD(7, tv7)
         }
     };
-    auto commit = [&](int rel, bool with_table) {      // registers -> LDS
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < 2 * n_nodes) run_l[i] = rv[u]; }
+    auto commit = [&](int rel) {                       // registers -> LDS
+        if (t < 2 * n_nodes) run_l[t] = rv0;
+        if (1024 + t < 2 * n_nodes) run_l[1024 + t] = rv1;
         if (t < n_nodes) node_l[t] = nv;
         const int ne = a.rel_len[rel];
         const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
         uint4* idst = reinterpret_cast<uint4*>(idx_l);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = iv[u]; }
-        if (with_table) {
-#pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int i = u * 1024 + t;
-                if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, tv[u]); }
-            }
+        if (t < n8) idst[t] = iv0;
+        if (1024 + t < n8) idst[1024 + t] = iv1;
+        if (!BWD) {
+            RG_TSTORE(0, tv0) RG_TSTORE(1, tv1) RG_TSTORE(2, tv2) RG_TSTORE(3, tv3)
+            RG_TSTORE(4, tv4) RG_TSTORE(5, tv5) RG_TSTORE(6, tv6) RG_TSTORE(7, tv7)
         }
     };
+#undef RG_TLOAD
+#undef RG_TSTORE
     if (t < ldt) tab[(int64_t)n_nodes * ldt + t] = 0.f;                    // the sentinel's row
-    if (!BWD)
+    if (!BWD) {
         for (int i = t; i < n_nodes * q4; i += 1024) tipk_st4(accl + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    } else {                                           // g' is staged once and stays for the whole launch
+        for (int base = 0; base < total4; base += 4096) {
+            float4 gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int i = base + u * 1024 + t;
+                i = i < total4 ? i : total4 - 1;
+                const int r = i / q4, c = (i - r * q4) * 4;
+                gv[u] = tipk_ld4(table + (int64_t)r * a.ld_t + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 1024 + t;
+                if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, gv[u]); }
+            }
+        }
+    }
     const int wg = blockIdx.x;
     const int ri0 = a.wg_rel_ptr[wg], ri1 = a.wg_rel_ptr[wg + 1];
-    if (ri0 < ri1) prefetch(a.wg_rels[ri0], true);     // BWD: g' is staged once, with the first relation
+    if (ri0 < ri1) prefetch(a.wg_rels[ri0]);
     for (int ri = ri0; ri < ri1; ++ri) {
         const int rel = a.wg_rels[ri];
         const int64_t e0 = a.rel_idx_off[rel];         // multiple of 8 ids: 16-byte aligned segment
         const int ne = a.rel_len[rel];
         __syncthreads();                               // readers of the previous relation are done
-        commit(rel, !BWD || ri == ri0);
+        commit(rel);
         __syncthreads();
-        if (ri + 1 < ri1) prefetch(a.wg_rels[ri + 1], !BWD);      // in flight during the compute below
+        if (ri + 1 < ri1) prefetch(a.wg_rels[ri + 1]);             // in flight during the compute below
         for (int cb = 0; cb == 0 || cb < ne; cb += RG_CHUNK) {
             const int cn = ne - cb < RG_CHUNK ? ne - cb : RG_CHUNK;
             if (cb > 0) {                              // rare: a relation with more than RG_CHUNK ids
@@ -120,11 +152,11 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + e0 + cb);
                 uint4* idst = reinterpret_cast<uint4*>(idx_l);
                 const int n8 = (cn + 7) >> 3;
-                uint4 jv[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) jv[u] = isrc[i]; }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { const int i = u * 1024 + t; if (i < n8) idst[i] = jv[u]; }
+                const int last = n8 > 0 ? n8 - 1 : 0;
+                const uint4 j0 = isrc[t < n8 ? t : last];
+                const uint4 j1 = isrc[1024 + t < n8 ? 1024 + t : last];
+                if (t < n8) idst[t] = j0;
+                if (1024 + t < n8) idst[1024 + t] = j1;
                 __syncthreads();
             }
             if (a.dbg & 1) continue;
@@ -189,7 +221,7 @@ constexpr int64_t RG_LDS_LIMIT = 158 * 1024;
 
 // column blocks needed so that one block's table (+ accumulators) fits in LDS; 0 = impossible
 inline int rel_gather_split(int64_t n_nodes, int d, bool bwd) {
-    if (n_nodes <= 0 || n_nodes > 65534 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
+    if (n_nodes <= 0 || n_nodes > 1024 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
     for (int split = 1; d / split >= 4; split *= 2) {
         const int dc = d / split;
         if (dc > 64) continue;                          // L = dc/4 <= 16 lanes per slot
@@ -199,23 +231,23 @@ inline int rel_gather_split(int64_t n_nodes, int d, bool bwd) {
     return 0;
 }
 
+template <int L, bool BWD, int TU>
+int launch_rg3(const RgArgs& a, int n_wg, int split, hipStream_t st) {
+    const size_t lds = (size_t)rel_gather_lds(a.n_nodes, a.dc, BWD);
+    auto kern = rel_gather_kernel<L, BWD, TU>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return tipk_hip_status(e);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)split), dim3(1024), lds, st, a);
+    TIPK_RETURN_LAUNCH();
+}
+
 template <int L>
 int launch_rg(bool bwd, const RgArgs& a, int n_wg, int split, hipStream_t st) {
-    const size_t lds = (size_t)rel_gather_lds(a.n_nodes, a.dc, bwd);
-    hipError_t e;
-    dim3 grid((unsigned)n_wg, (unsigned)split);
-    if (bwd) {
-        auto kern = rel_gather_kernel<L, true>;
-        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return tipk_hip_status(e);
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, a);
-    } else {
-        auto kern = rel_gather_kernel<L, false>;
-        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return tipk_hip_status(e);
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, st, a);
-    }
-    TIPK_RETURN_LAUNCH();
+    if (bwd) return launch_rg3<L, true, 1>(a, n_wg, split, st);
+    const int64_t per_thread = ((int64_t)a.n_nodes * (a.dc / 4) + 1023) / 1024;
+    if (per_thread <= 2) return launch_rg3<L, false, 2>(a, n_wg, split, st);
+    if (per_thread <= 4) return launch_rg3<L, false, 4>(a, n_wg, split, st);
+    return launch_rg3<L, false, 8>(a, n_wg, split, st);
 }
 
 }  // namespace
