@@ -50,7 +50,7 @@ if trace:
     agg = defaultdict(list)
     for r in csv.DictReader(open(trace)):
         n = short(r['Kernel_Name'])
-        if 'gather_sum_kernel' in n or 'gemm_f32' in n:
+        if 'gather_sum_kernel' in n or 'gemm_f32' in n or 'rel_gather' in n:
             key = '%s grid=%sx%sx%s' % (n, r.get('Grid_Size_X', '?'), r.get('Grid_Size_Y', '?'), r.get('Grid_Size_Z', '?'))
             agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     with open('profiles/%s_kernel_by_grid.csv' % tag, 'w') as f:
@@ -69,7 +69,7 @@ for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
         if r.get('Counter_Name') != counter:
             continue
         n = short(r['Kernel_Name'])
-        if 'gather_sum_kernel' in n or 'gemm_f32' in n or 'finalize' in n:
+        if 'gather_sum_kernel' in n or 'gemm_f32' in n or 'finalize' in n or 'rel_gather' in n:
             n = '%s grid=%s' % (n, r.get('Grid_Size', r.get('Grid_Size_X', '?')))
         per[n].append(float(r['Counter_Value']))
     for n, v in per.items():
