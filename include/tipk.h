@@ -105,12 +105,15 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *       wg_rel_ptr[n_wg+1], wg_rels[n_rel]   relations handled by each of the n_wg workgroups
  *                               (edge-balanced; n_wg = number of CUs)
  */
-int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);   /* host predicate, 1 = usable */
+/* host predicate: number of column blocks the launch will use (grid = n_wg x blocks), 0 = the
+ * shape is not supported (use tipk_gather_sum).  row_scale (backward only, nullable): the table
+ * rows are multiplied by row_scale[node] while they are staged (g' = g / deg fused). */
+int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                     int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
                     const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
-                    const int32_t* runs, const uint16_t* node_at, float* out, int64_t ld_out,
-                    tipk_stream_t stream);
+                    const int32_t* runs, const uint16_t* node_at, const float* row_scale,
+                    float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
@@ -145,6 +148,12 @@ int tipk_gemm_f32(const tipk_gemm_desc* desc /* host */, tipk_stream_t stream);
  * Ordered (deterministic) reduction of split-K slabs / per-workgroup partials. */
 int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count,
                    float alpha, int accumulate, float* out, tipk_stream_t stream);
+/* same with a fused epilogue: out[i] = relu?( alpha * row_scale[i / cols] * sum_s in[s][i] + addend[i]
+ * (+ out[i]) ); row_scale / addend nullable.  Finishes an R-GCN layer in one pass:
+ * relu( D^-1 sum_partials + X root )  (src/layers.py:184, :547). */
+int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count,
+                      float alpha, int accumulate, const float* row_scale, int64_t cols,
+                      const float* addend, int relu, float* out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).

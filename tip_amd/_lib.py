@@ -42,9 +42,10 @@ SIGNATURES = {
     'tipk_gather_sum': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
-    'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
+    'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),
     'tipk_rows_affine': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _L, _L, _I, _P]),
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),

@@ -34,6 +34,9 @@ struct Acc<4> {
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+    __device__ __forceinline__ void add_shfl_xor(int o) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+    }
     __device__ __forceinline__ void epilogue(const Epilogue& ep, int row, int col) {
         if (ep.row_scale) { float s = ep.row_scale[row]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
         if (ep.bias) { float4 b = tipk_ld4(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
@@ -48,6 +51,7 @@ struct Acc<1> {
     __device__ __forceinline__ void fma_row(const float* p, float w) { v = fmaf(w, *p, v); }
     __device__ __forceinline__ void add_row(const float* p) { v += *p; }
     __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
+    __device__ __forceinline__ void add_shfl_xor(int o) { v += __shfl_xor(v, o); }
     __device__ __forceinline__ void epilogue(const Epilogue& ep, int row, int col) {
         if (ep.row_scale) v *= ep.row_scale[row];
         if (ep.bias) v += ep.bias[col];
@@ -119,40 +123,30 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
     }
 }
 
-// One 256-thread workgroup per split row: lanes tile [sub-row][column group]; slots are added in
-// increasing order per sub-row, then the sub-rows are combined in a fixed tree through LDS.
+// One WAVE per split row (4 rows per workgroup): the wave's 64/LPR lane groups add the row's slots
+// g, g+G, g+2G, ... in order, then the groups are combined with a fixed xor-shuffle tree, so the result
+// does not depend on scheduling.  (A workgroup per row cost 9 000 tiny workgroups on the P-P graph.)
 template <int V>
 __global__ __launch_bounds__(256) void gather_sum_finalize_kernel(
-    const float* __restrict__ partial, const int32_t* __restrict__ rows, float* __restrict__ out,
+    const float* __restrict__ partial, const int32_t* __restrict__ rows, int64_t n_rows, float* __restrict__ out,
     int64_t ld_out, Epilogue ep, int d, int lanes_per_row) {
-    __shared__ __attribute__((aligned(16))) float red[256 * V];
-    const int t = threadIdx.x;
-    const int sub = t % lanes_per_row;
-    const int part = t / lanes_per_row;
-    const int n_part = 256 / lanes_per_row;
+    const int lane = tipk_lane();
+    const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / TIPK_WAVE;
+    if (m >= n_rows) return;
+    const int sub = lane % lanes_per_row;
+    const int part = lane / lanes_per_row;
+    const int n_part = TIPK_WAVE / lanes_per_row;
     const int col = sub * V;
-    const int row = rows[3 * blockIdx.x + 0];
-    const int s0 = rows[3 * blockIdx.x + 1];
-    const int s1 = rows[3 * blockIdx.x + 2];
+    const int row = rows[3 * m + 0], s0 = rows[3 * m + 1], s1 = rows[3 * m + 2];
     Acc<V> acc;
     acc.zero();
-    const bool ok = col < d && part < n_part;
-    if (ok) {
+    const bool ok = col < d;
+    if (ok)
         for (int s = s0 + part; s < s1; s += n_part) acc.add_row(partial + (int64_t)s * d + col);
-    }
-    acc.store(red + t * V);
-    __syncthreads();
+    for (int o = lanes_per_row; o < TIPK_WAVE; o <<= 1) acc.add_shfl_xor(o);
     if (part == 0 && ok) {
-        Acc<V> tot;
-        tot.zero();
-        for (int p = 0; p < n_part; ++p) {
-            Acc<V> o;
-            o.zero();
-            o.add_row(red + (p * lanes_per_row + sub) * V);
-            tot.add(o);
-        }
-        tot.epilogue(ep, row, col);
-        tot.store(out + (int64_t)row * ld_out + col);
+        acc.epilogue(ep, row, col);
+        acc.store(out + (int64_t)row * ld_out + col);
     }
 }
 
@@ -273,13 +267,13 @@ extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* row
     if (vec) {
         if (d > 256) return TIPK_EUNSUPPORTED;
         const int lpr = pow2_at_least(d / 4);
-        hipLaunchKernelGGL((gather_sum_finalize_kernel<4>), dim3((unsigned)n_rows), dim3(256), 0, st, partial, rows,
-                           out, ld_out, ep, d, lpr);
+        hipLaunchKernelGGL((gather_sum_finalize_kernel<4>), dim3((unsigned)tipk_ceil_div(n_rows, 4)), dim3(256), 0, st,
+                           partial, rows, n_rows, out, ld_out, ep, d, lpr);
     } else {
         if (d > 64) return TIPK_EUNSUPPORTED;
         const int lpr = pow2_at_least(d);
-        hipLaunchKernelGGL((gather_sum_finalize_kernel<1>), dim3((unsigned)n_rows), dim3(256), 0, st, partial, rows,
-                           out, ld_out, ep, d, lpr);
+        hipLaunchKernelGGL((gather_sum_finalize_kernel<1>), dim3((unsigned)tipk_ceil_div(n_rows, 4)), dim3(256), 0, st,
+                           partial, rows, n_rows, out, ld_out, ep, d, lpr);
     }
     TIPK_RETURN_LAUNCH();
 }

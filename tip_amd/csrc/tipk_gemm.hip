@@ -140,11 +140,13 @@ int launch(const GemmArgs& g, int64_t batch, hipStream_t st) {
 }
 
 // 64 consecutive elements x 4 slab lanes per workgroup: lane j adds slabs j, j+4, ... in order,
-// then the four lanes are combined in a fixed order through LDS (deterministic, and a
-// 128-slab x 512-element reduction is no longer two serial workgroups).
+// then the four lanes are combined in a fixed order through LDS (deterministic).  Optional fused
+// epilogue: out = relu?( alpha * row_scale[i / cols] * sum + addend[i] (+ out[i]) ).
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ in, int64_t n_slabs,
                                                         int64_t slab_stride, int64_t count, float alpha,
-                                                        int accumulate, float* __restrict__ out) {
+                                                        int accumulate, const float* __restrict__ row_scale,
+                                                        int64_t cols, const float* __restrict__ addend, int relu,
+                                                        float* __restrict__ out) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, j = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
@@ -156,7 +158,11 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     if (j == 0 && i < count) {
         s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
         s *= alpha;
-        out[i] = accumulate ? out[i] + s : s;
+        if (row_scale) s *= row_scale[i / cols];
+        if (addend) s += addend[i];
+        if (accumulate) s += out[i];
+        if (relu) s = fmaxf(s, 0.f);
+        out[i] = s;
     }
 }
 
@@ -182,14 +188,20 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
     return launch<2, 2>(g, d->batch, st);
 }
 
-extern "C" int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count, float alpha,
-                              int accumulate, float* out, tipk_stream_t stream) {
-    if (n_slabs < 0 || count < 0) return TIPK_EINVAL;
+extern "C" int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count, float alpha,
+                                 int accumulate, const float* row_scale, int64_t cols, const float* addend, int relu,
+                                 float* out, tipk_stream_t stream) {
+    if (n_slabs < 0 || count < 0 || (row_scale && cols <= 0)) return TIPK_EINVAL;
     if (count == 0) return TIPK_OK;
     if (!out || (n_slabs > 0 && !in)) return TIPK_EINVAL;
     const int64_t blocks = tipk_ceil_div(count, 64);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, n_slabs,
-                       slab_stride, count, alpha, accumulate, out);
+                       slab_stride, count, alpha, accumulate, row_scale, cols, addend, relu, out);
     TIPK_RETURN_LAUNCH();
+}
+
+extern "C" int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count, float alpha,
+                              int accumulate, float* out, tipk_stream_t stream) {
+    return tipk_sum_slabs_ex(in, n_slabs, slab_stride, count, alpha, accumulate, nullptr, 0, nullptr, 0, out, stream);
 }

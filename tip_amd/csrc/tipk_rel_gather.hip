@@ -32,6 +32,7 @@ struct RgArgs {
     const int64_t* rel_idx_off; const int32_t* rel_len;
     const uint16_t* idx; const int32_t* runs; const uint16_t* node_at;
     float* out; int64_t ld_out;
+    const float* row_scale;            // BWD: g' = row_scale[node] * table[node] applied while staging (nullable)
     int dbg;
 };
 
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 i = i < total4 ? i : total4 - 1;
                 const int r = i / q4, c = (i - r * q4) * 4;
                 gv[u] = tipk_ld4(table + (int64_t)r * a.ld_t + c);
+                if (a.row_scale) { const float sc = a.row_scale[r]; gv[u].x *= sc; gv[u].y *= sc; gv[u].z *= sc; gv[u].w *= sc; }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -253,14 +255,14 @@ int launch_rg(bool bwd, const RgArgs& a, int n_wg, int split, hipStream_t st) {
 }  // namespace
 
 extern "C" int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward) {
-    return rel_gather_split(n_nodes, d, backward != 0) > 0 ? 1 : 0;
+    return rel_gather_split(n_nodes, d, backward != 0);
 }
 
 extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                                int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
                                const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
-                               const int32_t* runs, const uint16_t* node_at, float* out, int64_t ld_out,
-                               tipk_stream_t stream) {
+                               const int32_t* runs, const uint16_t* node_at, const float* row_scale, float* out,
+                               int64_t ld_out, tipk_stream_t stream) {
     if (n_wg <= 0 || n_wg > 65535 || !table || !wg_rel_ptr || !wg_rels || !rel_idx_off || !rel_len || !idx || !runs ||
         !node_at || !out || (reinterpret_cast<uintptr_t>(idx) & 15))
         return TIPK_EINVAL;
@@ -274,6 +276,7 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     a.table = table; a.ld_t = ld_table; a.n_nodes = (int)n_nodes; a.dc = d / split;
     a.wg_rel_ptr = wg_rel_ptr; a.wg_rels = wg_rels; a.rel_idx_off = rel_idx_off; a.rel_len = rel_len;
     a.idx = idx; a.runs = runs; a.node_at = node_at; a.out = out; a.ld_out = ld_out;
+    a.row_scale = backward ? row_scale : nullptr;
     a.dbg = dbg_env ? atoi(dbg_env) : 0;
     hipStream_t st = (hipStream_t)stream;
     switch (a.dc / 4) {

@@ -179,15 +179,18 @@ class PPEncoder(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # A2  MyHierarchyConv   (src/layers.py:196-247)
 # ---------------------------------------------------------------------------------------------
-def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK):
-    """mean over incoming edges in the concatenated node space, rows [n_source:] only."""
+def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None):
+    """mean over incoming edges in the concatenated node space, rows [n_source:] only.
+    table_rows: rows of the table actually handed to the kernel (n_all for the concatenated
+    tensor, n_source when only the source block is passed and no edge starts beyond it)."""
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     keep = dst >= n_source
     src, dst = src[keep], dst[keep] - n_source
     n_t = n_all - n_source
+    n_tab = n_all if table_rows is None else table_rows
     cnt = torch.bincount(dst, minlength=n_t).to(torch.float32).clamp_(min=1)
-    return ops.AggGraph(build_gather_plan(dst, src, n_t, n_all, None, chunk, 'pd.fwd'),
-                        build_gather_plan(src, dst, n_all, n_t, None, chunk, 'pd.bwd'), (1.0 / cnt).contiguous())
+    return ops.AggGraph(build_gather_plan(dst, src, n_t, n_tab, None, chunk, 'pd.fwd'),
+                        build_gather_plan(src, dst, n_tab, n_t, None, chunk, 'pd.bwd'), (1.0 / cnt).contiguous())
 
 
 class MyHierarchyConv(nn.Module):
@@ -206,6 +209,7 @@ class MyHierarchyConv(nn.Module):
             raise NotImplementedError('MyHierarchyConv(is_bias=True) is not executable in the reference either')
         self.register_parameter('bias', None)
         self._cache = _PlanCache()
+        self._cache_src = _PlanCache()
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -220,6 +224,22 @@ class MyHierarchyConv(nn.Module):
         out = ops.matmul(mean, self.weight)
         assert out.shape[0] == self.unique_target_num
         return out
+
+    def forward_sources(self, x_src, edge_index):
+        """Same result as `forward(cat(x_src, zeros[n_target]), edge_index, ...)` without building
+        the concatenation (the reference's zero rows `hdrug`, :526, are never read when every edge
+        starts at a source node).  Returns None if some edge starts beyond the source block."""
+        n_src = self.unique_source_num
+        n_all = n_src + self.unique_target_num
+
+        def build():
+            if edge_index.numel() and int(edge_index[0].max()) >= n_src:
+                return None
+            return hier_graph(edge_index, n_all, n_src, self.chunk, table_rows=n_src)
+        graph = self._cache_src.get((edge_index,), build)
+        if graph is None:
+            return None
+        return ops.matmul(ops.aggregate(x_src, graph), self.weight)
 
     def __repr__(self):
         return 'MyHierarchyConv(%d, %d)' % (self.in_dim, self.out_dim)
@@ -236,7 +256,7 @@ def relation_of_edges(range_list, n_edges, device):
     return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
 
 
-def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from=None):
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from=None, d_out=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
     scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `degree_from`:
     destination ids of the FULL edge list when `edge_index` is only one rank's shard."""
@@ -248,10 +268,12 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from
     all_dst = dst if degree_from is None else degree_from.to(torch.int64)
     deg = torch.bincount(all_dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
     rl_fwd = rl_bwd = None
-    if n_nodes <= 65535 and n_rel > 0:
+    if n_nodes <= 1024 and n_rel > 0:
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_wg = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
-        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, n_wg)
+        split = ops.rel_gather_split(n_nodes, d_out, False) if (d_out and src.is_cuda) else 1
+        # the forward launch is (workgroups x column blocks): keep it at one workgroup per CU
+        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, max(1, n_wg // max(1, split)))
         rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, n_wg)
     return ops.AggGraph(build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
                         build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
@@ -283,9 +305,11 @@ class _RGCNBase(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def _run(self, x, graph):
-        out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard)
-        return out if self.bias is None else out + self.bias
+    def _run(self, x, graph, fuse_relu=False):
+        if self.bias is not None:
+            out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard) + self.bias
+            return torch.relu(out) if fuse_relu else out
+        return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu)
 
     def __repr__(self):
         return '%s(%d, %d, num_relations=%d)' % (self.__class__.__name__, self.in_channels, self.out_channels,
@@ -296,18 +320,21 @@ class MyRGCNConv2(_RGCNBase):
     """Range-list variant (:102-193): relation r owns edges `range_list[r] = (start, end)`;
     `edge_type` is accepted and ignored, as in the reference."""
 
-    def forward(self, x, edge_index, edge_type, range_list):
+    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False):
+        """`fuse_relu` (extension): apply the ReLU that follows the layer in FMEncoder
+        (src/layers.py:547) inside the layer's last kernel."""
         n = x.shape[0]
 
         def build():
             if self.shard is not None:                       # this rank's relations only
                 from .dist import shard_edges
                 ei, rel = shard_edges(edge_index, range_list, self.shard.rel_ids)
-                return rgcn_graph(ei, rel, n, int(self.shard.rel_ids.numel()), self.chunk, degree_from=edge_index[1])
+                return rgcn_graph(ei, rel, n, int(self.shard.rel_ids.numel()), self.chunk, degree_from=edge_index[1],
+                                  d_out=self.out_channels)
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
-            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk)
+            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, d_out=self.out_channels)
         graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
-        return self._run(x, graph)
+        return self._run(x, graph, fuse_relu)
 
 
 class MyRGCNConv(_RGCNBase):
@@ -319,7 +346,8 @@ class MyRGCNConv(_RGCNBase):
         if self.shard is not None:
             raise NotImplementedError('relation sharding needs the range-list variant MyRGCNConv2')
         graph = self._cache.get((edge_index, edge_type),
-                                lambda: rgcn_graph(edge_index, edge_type, n, self.num_relations, self.chunk))
+                                lambda: rgcn_graph(edge_index, edge_type, n, self.num_relations, self.chunk,
+                                                   d_out=self.out_channels))
         return self._run(x, graph)
 
 
@@ -351,14 +379,14 @@ class FMEncoder(nn.Module):
     def forward(self, x_drug, dd_edge_index, dd_edge_type, dd_range_list, d_norm,
                 x_prot, pp_edge_index, dp_edge_index, dp_range_list):
         h_prot = self.pp_encoder(x_prot, pp_edge_index)                               # P-P GCN x2
-        if self.hdrug.device != h_prot.device:
-            self.hdrug = self.hdrug.to(h_prot.device)
-        h_all = torch.cat((h_prot, self.hdrug))                                       # :526
-        pd = self.hgcn(h_all, dp_edge_index, dp_range_list)                           # P -> D
+        pd = self.hgcn.forward_sources(h_prot, dp_edge_index)                         # P -> D, no cat (:526-528)
+        if pd is None:                                                                # an edge starts at a drug row
+            if self.hdrug.device != h_prot.device:
+                self.hdrug = self.hdrug.to(h_prot.device)
+            pd = self.hgcn(torch.cat((h_prot, self.hdrug)), dp_edge_index, dp_range_list)
         xd = self._drug_feat.apply_table(x_drug, self.embed)                          # x_drug @ embed
         x0 = ops.drug_mix(xd, pd, d_norm, self.mod == 'cat')                          # /d_norm, cat|add
-        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list)
-        x1 = torch.relu(x1)
+        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu=True)   # ReLU (:547) fused
         return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list)
 
 

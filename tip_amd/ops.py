@@ -83,16 +83,20 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
     return out
 
 
-def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False):
-    """out = alpha * sum_s slabs[s] (+ out): ordered, deterministic (include/tipk.h section 2)."""
+def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, addend=None, relu=False):
+    """out = relu?(alpha * row_scale (.) sum_s slabs[s] + addend (+ out)): ordered, deterministic
+    (include/tipk.h section 2).  slabs: [S, rows, cols]."""
     assert slabs.is_contiguous()
     n = slabs.shape[0]
     per = slabs[0].numel()
     if out is None:
         out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
     assert out.is_contiguous() and out.numel() == per
-    check(lib().tipk_sum_slabs(ptr(slabs), n, per, per, alpha, int(accumulate), ptr(out), stream_ptr(slabs.device)),
-          'tipk_sum_slabs')
+    if addend is not None:
+        assert addend.is_contiguous() and addend.numel() == per
+    with _timed('sum_slabs[%dx%d]' % (n, per)):
+        check(lib().tipk_sum_slabs_ex(ptr(slabs), n, per, per, alpha, int(accumulate), ptr(row_scale), slabs.shape[-1],
+                                      ptr(addend), int(relu), ptr(out), stream_ptr(slabs.device)), 'tipk_sum_slabs_ex')
     return out
 
 
@@ -457,7 +461,7 @@ class _RGCN(torch.autograd.Function):
     are all-reduced in one packed collective on the way back."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, graph, shard):
+    def forward(ctx, x, basis, att, root, graph, shard, relu):
         x, basis, att, root = _f32c(x), basis.contiguous(), att.contiguous(), root.contiguous()
         n, d_in = x.shape
         nb, _, d_out = basis.shape
@@ -470,38 +474,46 @@ class _RGCN(torch.autograd.Function):
         else:
             y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
-        if use_rl:
-            agg = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False)
-        elif shard is None:
-            agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
+        if use_rl and shard is None:
+            # LDS-resident gather -> per-workgroup partial slabs; the ordered slab sum also applies
+            # 1/deg, adds X root and the ReLU: the layer is finished in one pass
+            part = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False, reduce=False)
+            xroot = gemm(x, root)
+            out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=relu)
         else:
-            agg = gather_sum(graph.fwd, y.view(r * n, d_out))
-        if shard is not None:
-            from .dist import all_reduce_packed
-            all_reduce_packed([agg], shard.group)
-        if use_rl or shard is not None:
-            rows_affine(agg, row_mul=graph.scale, out=agg)
+            if use_rl:
+                agg = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False)
+            elif shard is None:
+                agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
+            else:
+                agg = gather_sum(graph.fwd, y.view(r * n, d_out))
+            if shard is not None:
+                from .dist import all_reduce_packed
+                all_reduce_packed([agg], shard.group)
+                rows_affine(agg, row_mul=graph.scale, out=agg)
+            out = gemm(x, root, out=agg, c_in=agg, relu=relu)            # + X root (, ReLU)
         del y
-        out = gemm(x, root, out=agg, c_in=agg)                           # + X root
-        ctx.graph, ctx.shard = graph, shard
-        ctx.save_for_backward(x, basis, att, att_l, root, xb)
+        ctx.graph, ctx.shard, ctx.relu = graph, shard, relu
+        ctx.save_for_backward(x, basis, att, att_l, root, xb, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, basis, att, att_l, root, xb = ctx.saved_tensors
+        x, basis, att, att_l, root, xb, out = ctx.saved_tensors
         graph, shard = ctx.graph, ctx.shard
         g = _f32c(g).contiguous()
+        if ctx.relu:
+            g = rows_affine(g, gate=out)                                 # ReLU gate of the fused epilogue
         n, d_in = x.shape
         nb, _, d_out = basis.shape
         r = att_l.shape[0]
         g_root = gemm(x.t(), g)
-        gs = rows_affine(g, row_mul=graph.scale)
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
-            if rel_gather_usable(graph.rl_bwd, n, d_out, True):                # dY_r = A_r^T (D^-1 g)
-                g_y = rel_gather(graph.rl_bwd, gs, backward=True).view(r, n * d_out)
+            if rel_gather_usable(graph.rl_bwd, n, d_out, True):          # dY_r = A_r^T (D^-1 g), 1/deg fused
+                g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
             else:
+                gs = rows_affine(g, row_mul=graph.scale)
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
             g_att_l = gemm(g_y, xb2.t())                                 # split-K (automatic)
             g_xb = gemm(att_l.t(), g_y).view(nb, n, d_out)
@@ -521,11 +533,11 @@ class _RGCN(torch.autograd.Function):
             g_att.index_copy_(0, shard.rel_ids_on(att.device), g_att_l)
             all_reduce_packed([g_x, g_basis, g_att], shard.group)
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
-        return g_x, g_basis, g_att, g_root, None, None
+        return g_x, g_basis, g_att, g_root, None, None, None
 
 
-def rgcn(x, basis, att, root, graph, shard=None):
-    return _RGCN.apply(x, basis, att, root, graph, shard)
+def rgcn(x, basis, att, root, graph, shard=None, relu=False):
+    return _RGCN.apply(x, basis, att, root, graph, shard, relu)
 
 
 class _DrugMix(torch.autograd.Function):
