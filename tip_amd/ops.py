@@ -100,14 +100,21 @@ def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, adde
     return out
 
 
+def rel_gather_split(n_nodes, d, backward):
+    """column blocks `tipk_rel_gather` would use for this shape; 0 = use the generic gather_sum."""
+    if os.environ.get('TIPK_NO_RELLOCAL'):
+        return 0
+    return int(lib().tipk_rel_gather_supported(n_nodes, d, int(backward)))
+
+
 def rel_gather_usable(rp, n_nodes, d, backward):
-    return (rp is not None and not os.environ.get('TIPK_NO_RELLOCAL')
-            and bool(lib().tipk_rel_gather_supported(n_nodes, d, int(backward))))
+    return rp is not None and rel_gather_split(n_nodes, d, backward) > 0
 
 
-def rel_gather(rp, table, backward):
+def rel_gather(rp, table, backward, row_scale=None, reduce=True):
     """LDS-resident D-D aggregation (include/tipk.h section 1b).  forward: table = Y [R*N, d] ->
-    [N, d] (sum over relations); backward: table = g' [N, d] -> dY [R*N, d]."""
+    partial slabs [n_wg, N, d] (summed here unless reduce=False); backward: table = g [N, d]
+    (optionally scaled per row while staged) -> dY [R*N, d]."""
     table = _f32c(table)
     require_device(table, rp.idx)
     d = table.shape[1]
@@ -119,9 +126,11 @@ def rel_gather(rp, table, backward):
     with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
         check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
                                     ptr(rp.wg_rels), ptr(rp.rel_idx_off), ptr(rp.rel_len), ptr(rp.idx), ptr(rp.runs),
-                                    ptr(rp.node_at),
-                                    ptr(out), d, stream_ptr(table.device)), 'tipk_rel_gather')
-    return out if backward else sum_slabs(out)
+                                    ptr(rp.node_at), ptr(row_scale) if backward else None, ptr(out), d,
+                                    stream_ptr(table.device)), 'tipk_rel_gather')
+    if backward or not reduce:
+        return out
+    return sum_slabs(out)
 
 
 def _strides3(t):
