@@ -259,7 +259,7 @@ def test_rel_gather_fwd_bwd(ops, d):
     src = torch.randint(0, N, (E,), generator=g)
     dst = torch.randint(0, N - 7, (E,), generator=g)
     dst[:9000] = 11                                                            # hub (longest run 9000 edges)
-    assert _lib.lib().tipk_rel_gather_supported(N, d, 0) == 1 and _lib.lib().tipk_rel_gather_supported(N, d, 1) == 1
+    assert _lib.lib().tipk_rel_gather_supported(N, d, 0) >= 1 and _lib.lib().tipk_rel_gather_supported(N, d, 1) >= 1
     y = torch.randn(R * N, d, generator=g)
     plan = build_rel_plan(dst, src, rel, N, R, n_wg=256).to(DEV)
     got = ops.rel_gather(plan, y.to(DEV), backward=False)
@@ -283,4 +283,5 @@ def test_rel_gather_unsupported_shapes():
     assert L.tipk_rel_gather_supported(10000, 32, 0) == 0 and L.tipk_rel_gather_supported(10000, 32, 1) == 0
     assert L.tipk_rel_gather_supported(2000, 16, 1) == 0    # node tables are prefetched by 1024 threads
     for d in (16, 32, 64, 128):                             # wide rows run as several column blocks
-        assert L.tipk_rel_gather_supported(645, d, 0) == 1 and L.tipk_rel_gather_supported(645, d, 1) == 1
+        assert L.tipk_rel_gather_supported(645, d, 0) >= 1 and L.tipk_rel_gather_supported(645, d, 1) >= 1
+    assert L.tipk_rel_gather_supported(645, 32, 0) == 2 and L.tipk_rel_gather_supported(645, 32, 1) == 1   # column blocks
