@@ -57,12 +57,14 @@ struct TileLoader {
     }
 };
 
-template <int WM, int WN, bool A_KFAST, bool B_KFAST>
+// NBUF = LDS buffers: 2 overlaps the next tile's staging with the MFMAs of a K loop; 1 for products
+// whose K fits one tile (Y = att . XB, K = 32): half the LDS, twice the resident workgroups.
+template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WM * 32, BN = WN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ float As[2][BK][BM + PAD];
-    __shared__ float Bs[2][BK][BN + PAD];
+    __shared__ float As[NBUF][BK][BM + PAD];
+    __shared__ float Bs[NBUF][BK][BN + PAD];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
@@ -92,8 +94,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     if (n_tiles > 0) fetch(0);
     for (int64_t tile = 0; tile < n_tiles; ++tile) {
-        const int buf = (int)(tile & 1);
+        const int buf = NBUF == 2 ? (int)(tile & 1) : 0;
         // buffer `buf` was last read two steps ago; the barrier of the previous step fences it
+        if (NBUF == 1 && tile > 0) __syncthreads();
         la.store(As[buf], t);
         lb.store(Bs[buf], t);
         __syncthreads();
@@ -132,31 +135,41 @@ int launch(const GemmArgs& g, int64_t batch, hipStream_t st) {
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz), block(256);
     const bool akf = g.a_sk == 1 || g.a_sm != 1;      // k-contiguous (or generic) -> walk k
     const bool bkf = g.b_sk == 1 && g.b_sn != 1;      // only when B is truly k-contiguous
-    if (akf && bkf) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, true, true>), grid, block, 0, st, g);
-    else if (akf) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, true, false>), grid, block, 0, st, g);
-    else if (bkf) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, false, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, false, false>), grid, block, 0, st, g);
+    const bool one_tile = g.kbatch == 1 && g.kchunk <= BK;
+#define TIPK_GEMM_GO(A, B)                                                                              \
+    do {                                                                                                \
+        if (one_tile) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A, B, 1>), grid, block, 0, st, g);    \
+        else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A, B, 2>), grid, block, 0, st, g);             \
+    } while (0)
+    if (akf && bkf) TIPK_GEMM_GO(true, true);
+    else if (akf) TIPK_GEMM_GO(true, false);
+    else if (bkf) TIPK_GEMM_GO(false, true);
+    else TIPK_GEMM_GO(false, false);
+#undef TIPK_GEMM_GO
     TIPK_RETURN_LAUNCH();
 }
 
 // 64 consecutive elements x 4 slab lanes per workgroup: lane j adds slabs j, j+4, ... in order,
 // then the four lanes are combined in a fixed order through LDS (deterministic).  Optional fused
 // epilogue: out = relu?( alpha * row_scale[i / cols] * sum + addend[i] (+ out[i]) ).
-__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ in, int64_t n_slabs,
-                                                        int64_t slab_stride, int64_t count, float alpha,
-                                                        int accumulate, const float* __restrict__ row_scale,
-                                                        int64_t cols, const float* __restrict__ addend, int relu,
-                                                        float* __restrict__ out) {
-    __shared__ float red[4][64];
+template <int LANES>   // slab lanes per element: 4 (few slabs, many elements) or 16 (many slabs, few elements)
+__global__ __launch_bounds__(64 * LANES) void sum_slabs_kernel(const float* __restrict__ in, int64_t n_slabs,
+                                                               int64_t slab_stride, int64_t count, float alpha,
+                                                               int accumulate, const float* __restrict__ row_scale,
+                                                               int64_t cols, const float* __restrict__ addend,
+                                                               int relu, float* __restrict__ out) {
+    __shared__ float red[LANES][64];
     const int e = threadIdx.x & 63, j = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float s = 0.f;
     if (i < count)
-        for (int64_t k = j; k < n_slabs; k += 4) s += in[k * slab_stride + i];
+        for (int64_t k = j; k < n_slabs; k += LANES) s += in[k * slab_stride + i];
     red[j][e] = s;
     __syncthreads();
     if (j == 0 && i < count) {
-        s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        s = red[0][e];
+#pragma unroll
+        for (int q = 1; q < LANES; ++q) s += red[q][e];
         s *= alpha;
         if (row_scale) s *= row_scale[i / cols];
         if (addend) s += addend[i];
@@ -196,8 +209,12 @@ extern "C" int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_
     if (!out || (n_slabs > 0 && !in)) return TIPK_EINVAL;
     const int64_t blocks = tipk_ceil_div(count, 64);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, n_slabs,
-                       slab_stride, count, alpha, accumulate, row_scale, cols, addend, relu, out);
+    if (n_slabs >= 32 && blocks < 2048)
+        hipLaunchKernelGGL(sum_slabs_kernel<16>, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, in, n_slabs,
+                           slab_stride, count, alpha, accumulate, row_scale, cols, addend, relu, out);
+    else
+        hipLaunchKernelGGL(sum_slabs_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, n_slabs,
+                           slab_stride, count, alpha, accumulate, row_scale, cols, addend, relu, out);
     TIPK_RETURN_LAUNCH();
 }
 
