@@ -24,6 +24,50 @@ def _f32c(t):
 
 
 # ---------------------------------------------------------------------------------------------
+# fork / join: independent launches of one layer run on a second HIP stream
+# ---------------------------------------------------------------------------------------------
+# At BioSNAP scale most kernels are a few microseconds long, so a step is bound by the dependent
+# chain of ~60 launches (about 5 us each even inside a hipGraph), not by throughput.  Products that
+# nothing downstream waits for (parameter gradients d root, d att, d basis, d W; X root in the
+# forward pass) are therefore issued on a side stream: `fork()` makes the side stream wait for the
+# current one and switches to it, `join()` makes the current stream wait for the side stream.  Under
+# `torch.cuda.graph` capture this becomes a graph with parallel branches.  TIPK_NO_OVERLAP=1 disables it.
+_SIDE = {}
+
+
+class fork(object):
+    def __init__(self, device):
+        self.device = device
+        self.on = not os.environ.get('TIPK_NO_OVERLAP') and _TIMING is None
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        main = torch.cuda.current_stream(self.device)
+        key = (self.device.index, main.cuda_stream)
+        side = _SIDE.get(key)
+        if side is None:
+            side = _SIDE[key] = torch.cuda.Stream(self.device)
+        side.wait_stream(main)
+        self.side = side
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+
+
+def join(device):
+    """The current stream waits for everything forked from it (call before results are consumed)."""
+    main = torch.cuda.current_stream(device)
+    side = _SIDE.get((device.index, main.cuda_stream))
+    if side is not None and not os.environ.get('TIPK_NO_OVERLAP'):
+        main.wait_stream(side)
+
+
+# ---------------------------------------------------------------------------------------------
 # optional per-kernel timing (bench.py): HIP events recorded on the launch stream around one launch
 # ---------------------------------------------------------------------------------------------
 _TIMING = None          # None (off) or dict: label -> list of (start_event, end_event)
@@ -396,9 +440,13 @@ class _Aggregate(torch.autograd.Function):
         g = _f32c(g)
         # pre = scale * agg + bias, out = relu(pre):  g_pre = g (.) [out > 0];  g_agg = scale * g_pre
         g_pre = rows_affine(g, gate=out) if ctx.relu else g
+        g_bias = None
+        if ctx.has_bias:
+            with fork(g.device):
+                g_bias = col_sum(g_pre)
         g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
         g_table = gather_sum(graph.bwd, g_agg) if ctx.needs_input_grad[0] else None
-        g_bias = col_sum(g_pre) if ctx.has_bias else None
+        join(g.device)
         return g_table, g_bias, None, None
 
 
@@ -425,8 +473,10 @@ class _Linear(torch.autograd.Function):
         if ctx.identity:
             return None, transpose(g)
         x, weight = ctx.saved_tensors
+        with fork(g.device):
+            g_w = gemm(g.t(), x)
         g_x = gemm(g, weight) if ctx.needs_input_grad[0] else None
-        g_w = gemm(g.t(), x)
+        join(g.device)
         return g_x, g_w
 
 
@@ -447,8 +497,12 @@ class _MatMul(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g = _f32c(g)
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            with fork(g.device):
+                g_w = gemm(x.t(), g)
         g_x = gemm(g, w.t()) if ctx.needs_input_grad[0] else None
-        g_w = gemm(x.t(), g) if ctx.needs_input_grad[1] else None
+        join(g.device)
         return g_x, g_w
 
 
@@ -486,8 +540,10 @@ class _RGCN(torch.autograd.Function):
         if use_rl and shard is None:
             # LDS-resident gather -> per-workgroup partial slabs; the ordered slab sum also applies
             # 1/deg, adds X root and the ReLU: the layer is finished in one pass
+            with fork(x.device):
+                xroot = gemm(x, root)                                    # independent of the aggregation
             part = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False, reduce=False)
-            xroot = gemm(x, root)
+            join(x.device)
             out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=relu)
         else:
             if use_rl:
@@ -516,7 +572,9 @@ class _RGCN(torch.autograd.Function):
         n, d_in = x.shape
         nb, _, d_out = basis.shape
         r = att_l.shape[0]
-        g_root = gemm(x.t(), g)
+        dev = x.device
+        with fork(dev):                                                  # parameter gradients: off the
+            g_root = gemm(x.t(), g)                                      # dependent chain -> side stream
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
             if rel_gather_usable(graph.rl_bwd, n, d_out, True):          # dY_r = A_r^T (D^-1 g), 1/deg fused
@@ -524,18 +582,21 @@ class _RGCN(torch.autograd.Function):
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
-            g_att_l = gemm(g_y, xb2.t())                                 # split-K (automatic)
+            with fork(dev):
+                g_att_l = gemm(g_y, xb2.t())                             # split-K (automatic)
             g_xb = gemm(att_l.t(), g_y).view(nb, n, d_out)
-            del g_y
         else:
             g_att_l = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
             g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
-        g_basis = gemm(x.t(), g_xb)                                      # [B, in, out]
+        with fork(dev):
+            g_basis = gemm(x.t(), g_xb)                                  # [B, in, out]
         if shard is None:
             g_att = g_att_l
             g_x = gemm(g, root.t())
             g_x = gemm(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
+            join(dev)
         else:
+            join(dev)
             from .dist import all_reduce_packed
             g_x = gemm(g_xb, basis.transpose(1, 2), reduce_batch=True)   # partial over this shard
             g_att = torch.zeros_like(att)
