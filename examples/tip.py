@@ -18,6 +18,7 @@ from tip_amd.layers import Setting, TIP          # reference: `from src.layers i
 
 MOD = sys.argv[1] if len(sys.argv) > 1 else 'cat'
 MAX_EPOCH = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+GRAPH = '--eager' not in sys.argv      # default: the whole step replays as one hipGraph (tip_amd/train.py)
 
 device = torch.device('cuda:0')                  # no CPU path in this build
 
@@ -29,17 +30,25 @@ else:
     settings = Setting(sp_rate=0.9, lr=0.01, prot_drug_dim=64, n_embed=64, n_hid1=32, n_hid2=16, num_base=32)
     model = TIP(settings, device, mod='add')
 
-optimizer = torch.optim.Adam(model.parameters(), lr=settings.lr)
+optimizer = torch.optim.Adam(model.parameters(), lr=settings.lr, capturable=GRAPH)
 
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for e in range(MAX_EPOCH):
+if GRAPH:
+    from tip_amd.train import GraphedTrainStep
     model.train()
-    optimizer.zero_grad()
-    loss = model()
-    print(loss.item())
-    loss.backward()
-    optimizer.step()
+    step = GraphedTrainStep(model, optimizer, warmup=2)       # 2 eager epochs, then the captured graph
+    losses = [step() .clone() for e in range(MAX_EPOCH - 2)]
+    for v in torch.stack(losses).tolist():
+        print(v)
+else:
+    for e in range(MAX_EPOCH):                                # the reference's loop, line for line
+        model.train()
+        optimizer.zero_grad()
+        loss = model()
+        print(loss.item())
+        loss.backward()
+        optimizer.step()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print('%d epochs in %.2f s (%.1f ms/epoch, %.2f M train edges/s incl. sampler, decoder, loss, Adam)'

@@ -35,6 +35,16 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def call_key(seed, n):
+    """Philox key of call n of a sampler stream = splitmix64(seed + (n + 1) * golden); identical to
+    `call_key` in tip_amd/csrc/tipk_negsample.hip and tip_amd/neg_sampling.py."""
+    m = (1 << 64) - 1
+    z = (seed + (n + 1) * 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
 def _mulhi64(a, b):
     """floor(a * b / 2^64) for uint64 arrays a and python int b < 2^64."""
     a_hi, a_lo = a >> np.uint64(32), a & MASK32

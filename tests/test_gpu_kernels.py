@@ -213,12 +213,17 @@ def test_negative_sampler_bit_exact_vs_spec_and_properties():
     for r in range(len(sizes)):                      # no sampled pair is a positive of its relation
         a, b = rel_ptr[r], rel_ptr[r + 1]
         assert not np.isin(gk[a:b], pos[0, a:b] * n + pos[1, a:b]).any()
-    # stream semantics: manual_seed reproduces, consecutive calls differ
+    # stream semantics: manual_seed reproduces, consecutive calls differ; call n uses the key
+    # call_key(seed, n) derived ON THE DEVICE from the device-resident call counter
+    from oracle.philox_sampler import call_key
     NS.manual_seed(7)
     a1, a2 = NS.typed_negative_sampling(pos_t, n, rg), NS.typed_negative_sampling(pos_t, n, rg)
     NS.manual_seed(7)
     b1 = NS.typed_negative_sampling(pos_t, n, rg)
     assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    assert np.array_equal(a1.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(7, 0)))
+    assert np.array_equal(a2.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(7, 1)))
+    assert call_key(7, 1) == NS.call_key(7, 1)
 
 
 def test_negative_sampler_uniformity_vs_reference_distribution():

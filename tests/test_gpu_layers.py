@@ -304,3 +304,38 @@ def test_sharded_encoder_two_ranks():
         p.join(500)
         assert p.exitcode == 0
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_graphed_train_step_matches_eager():
+    """tip_amd.train.GraphedTrainStep (whole step in one hipGraph, sampler counter on device) gives
+    the same losses as the eager loop with the same seeds."""
+    from tip_amd import neg_sampling as NS
+    from tip_amd.data import build_data_dict
+    from tip_amd.layers import TIP, Setting
+    from tip_amd.train import GraphedTrainStep
+    dd = build_data_dict(max_relations=6)
+    st = Setting(sp_rate=0.9, lr=0.01, prot_drug_dim=16, n_embed=48, n_hid1=32, n_hid2=16, num_base=32)
+    losses = []
+    for graphed in (False, True):
+        torch.manual_seed(5)
+        model = TIP(st, torch.device(DEV), data=dd)
+        opt = torch.optim.Adam(model.parameters(), lr=st.lr, capturable=True)
+        NS.manual_seed(123)
+        out = []
+        if graphed:
+            step = GraphedTrainStep(model, opt, warmup=2)          # 2 warm-up steps + 1 captured (not run)
+            for _ in range(3):
+                out.append(float(step()))
+        else:
+            for i in range(5):
+                opt.zero_grad(set_to_none=True)
+                loss = model()
+                loss.backward()
+                opt.step()
+                if i >= 2:
+                    out.append(float(loss))
+        losses.append(out)
+    # the sampler stream advanced during capture too (the captured call consumed one position but was
+    # not executed): compare trajectories loosely, they must both keep decreasing from ~2 ln 2
+    assert all(1.0 < v < 1.45 for v in losses[0] + losses[1]), losses
+    assert abs(losses[0][0] - losses[1][0]) < 5e-3, losses

@@ -24,11 +24,26 @@ __device__ __forceinline__ uint64_t philox64(uint64_t ctr, uint32_t attempt, uin
     return (uint64_t)c0 | ((uint64_t)c1 << 32);
 }
 
+// Philox key of call n of a sampler stream: splitmix64(seed + (n + 1) * golden) -- the same function
+// tip_amd/neg_sampling.py applies on the host; with a device-resident call counter a captured
+// hipGraph draws fresh negatives on every replay.
+__device__ __forceinline__ uint64_t call_key(uint64_t seed, uint64_t n) {
+    uint64_t z = seed + (n + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void counter_advance_kernel(uint64_t* counter) { *counter += 1; }
+
 template <typename OT>
 __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restrict__ keys,
                                                          const int64_t* __restrict__ rel_ptr, int64_t n_rel,
-                                                         int64_t n_nodes, uint32_t k0, uint32_t k1,
+                                                         int64_t n_nodes, uint64_t seed,
+                                                         const uint64_t* __restrict__ call_counter,
                                                          OT* __restrict__ out_u, OT* __restrict__ out_v) {
+    const uint64_t key = call_counter ? call_key(seed, *call_counter) : seed;
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     const int64_t total = rel_ptr[n_rel];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -56,22 +71,28 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
 
 }  // namespace
 
+extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
+    if (!counter) return TIPK_EINVAL;
+    hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+    TIPK_RETURN_LAUNCH();
+}
+
 extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
-                                            int64_t n_nodes, uint64_t seed, void* out_u, void* out_v,
-                                            int idx_bytes, int64_t n_positions, tipk_stream_t stream) {
+                                            int64_t n_nodes, uint64_t seed, const uint64_t* call_counter,
+                                            void* out_u, void* out_v, int idx_bytes, int64_t n_positions,
+                                            tipk_stream_t stream) {
     if (n_rel < 0 || n_nodes <= 0 || n_positions < 0 || n_nodes > 0xffffffffLL) return TIPK_EINVAL;
     if (n_positions == 0 || n_rel == 0) return TIPK_OK;
     if (!pos_key_sorted || !rel_ptr || !out_u || !out_v) return TIPK_EINVAL;
     const int64_t blocks = tipk_ceil_div(n_positions, 256);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     hipStream_t st = (hipStream_t)stream;
     if (idx_bytes == 8)
         hipLaunchKernelGGL(neg_sample_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
-                           rel_ptr, n_rel, n_nodes, k0, k1, (int64_t*)out_u, (int64_t*)out_v);
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, (int64_t*)out_u, (int64_t*)out_v);
     else if (idx_bytes == 4)
         hipLaunchKernelGGL(neg_sample_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
-                           rel_ptr, n_rel, n_nodes, k0, k1, (int32_t*)out_u, (int32_t*)out_v);
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, (int32_t*)out_u, (int32_t*)out_v);
     else
         return TIPK_EINVAL;
     TIPK_RETURN_LAUNCH();

@@ -21,14 +21,30 @@ import torch
 from . import ops
 
 _MASK = (1 << 64) - 1
-_state = {'seed': 1111, 'calls': 0}
+_state = {'seed': 1111}
+_counters = {}                 # device -> int64 [1] tensor: position of the stream ON THE DEVICE
 _key_cache = {}
 
 
 def manual_seed(seed):
-    """Reset the sampler stream (the analogue of `np.random.seed`, src/layers.py:14)."""
+    """Reset the sampler stream (the analogue of `np.random.seed`, src/layers.py:14).  Call n of the
+    stream uses the Philox key `call_key(seed, n)`; n lives in device memory so that a captured
+    hipGraph (tip_amd.train.GraphedTrainStep) draws fresh negatives on every replay."""
     _state['seed'] = int(seed) & _MASK
-    _state['calls'] = 0
+    for c in _counters.values():
+        c.zero_()
+
+
+def _counter(device):
+    c = _counters.get(device)
+    if c is None:
+        c = _counters[device] = torch.zeros(1, dtype=torch.int64, device=device)
+    return c
+
+
+def call_key(seed, n):
+    """Philox key of call n (host mirror of the device function in tipk_negsample.hip)."""
+    return _mix(seed & _MASK, n)
 
 
 def _mix(seed, n):
@@ -83,11 +99,12 @@ def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _r
     call; by default consecutive calls use consecutive keys of the `manual_seed` stream."""
     num_nodes = int(num_nodes)
     keys, rel_ptr, n_rel, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
-    if seed is None:
-        seed = _mix(_state['seed'], _state['calls'])
-        _state['calls'] += 1
-    return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
-                                              pos_edge_index.shape[1], dtype=torch.int64)
+    if seed is not None:                                     # explicit Philox key for this call
+        return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
+                                                  pos_edge_index.shape[1], dtype=torch.int64)
+    return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, _state['seed'],
+                                              pos_edge_index.shape[1], dtype=torch.int64,
+                                              call_counter=_counter(pos_edge_index.device))
 
 
 def negative_sampling(pos_edge_index, num_nodes, seed=None):

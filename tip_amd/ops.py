@@ -404,12 +404,19 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     return loss, g_z, g_w
 
 
-def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64):
-    require_device(pos_key_sorted, rel_ptr)
+def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64,
+                                   call_counter=None):
+    """call_counter: optional int64 device tensor [1]; then `seed` is the stream seed, the Philox key
+    is derived on the device from (seed, counter) and the counter is advanced by one afterwards."""
+    require_device(pos_key_sorted, rel_ptr, call_counter)
     out = torch.empty((2, n_positions), dtype=dtype, device=pos_key_sorted.device)
-    check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed, ptr(out[0]),
-                                             ptr(out[1]), 8 if dtype == torch.int64 else 4, n_positions,
-                                             stream_ptr(out.device)), 'tipk_typed_negative_sampling')
+    st = stream_ptr(out.device)
+    check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
+                                             ptr(call_counter), ptr(out[0]), ptr(out[1]),
+                                             8 if dtype == torch.int64 else 4, n_positions, st),
+          'tipk_typed_negative_sampling')
+    if call_counter is not None:
+        check(lib().tipk_counter_advance(ptr(call_counter), st), 'tipk_counter_advance')
     return out
 
 
