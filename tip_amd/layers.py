@@ -470,7 +470,8 @@ class TIP(nn.Module):
         self.encoder = FMEncoder(self.device, d.n_drug_feat, d.n_dd_et, d.n_prot, d.n_prot, d.n_drug,
                                  s.prot_drug_dim, s.num_base, s.n_embed, s.n_hid1, s.n_hid2,
                                  mod=self.mod).to(self.device)
-        self.embeddings = self.__encode()                # initial pass (:319, with self.device)
+        with torch.no_grad():                            # initial pass (:319, with self.device); it only
+            self.embeddings = self.__encode()            # fills .embeddings and the plan caches
         self.decoder = MultiInnerProductDecoder(s.n_hid2, d.n_dd_et).to(self.device)
 
     def forward(self, neg_index=None):

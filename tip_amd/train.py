@@ -26,6 +26,10 @@ class GraphedTrainStep(object):
             for _ in range(warmup):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
+        # nothing may keep the warm-up autograd graph alive: its AccumulateGrad nodes are bound to the
+        # warm-up stream and would be reused (and synchronised with) inside the capture
+        if hasattr(model, 'embeddings') and torch.is_tensor(model.embeddings):
+            model.embeddings = model.embeddings.detach()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._step()
