@@ -176,15 +176,20 @@ def main():
     from tip_amd.layers import FMEncoder
     if args.chunk:
         os.environ['TIPK_CHUNK'] = str(args.chunk)
-    launch = args.launch or ('graph' if world == 1 else 'eager')
+    launch = args.launch or ('graph' if (world == 1 and not os.environ.get('TIPK_FORCE_SHARD')) else 'eager')
 
     dd, dims, wl_name = make_workload(args)
     E = int(dd['dd_train_idx'].shape[1])
     R = dd['n_dd_et']
     torch.manual_seed(1111)
     enc = FMEncoder(dev, dd['n_drug_feat'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], mod=args.mod, **dims).to(dev)
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get('TIPK_FORCE_SHARD'))       # (the env switch exercises the
+    if sharded:                                                            # collective path on one rank)
         from tip_amd.dist import shard_encoder
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         for prm in enc.parameters():                           # identical replicas
             dist.broadcast(prm.data, 0)
         shard_encoder(enc, dd['dd_train_range'], rank, world)
@@ -283,7 +288,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dd, dims, args.mod, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
