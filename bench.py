@@ -176,7 +176,7 @@ def main():
     from tip_amd.layers import FMEncoder
     if args.chunk:
         os.environ['TIPK_CHUNK'] = str(args.chunk)
-    launch = args.launch or ('graph' if (world == 1 and not os.environ.get('TIPK_FORCE_SHARD')) else 'eager')
+    launch = args.launch or 'graph'
 
     dd, dims, wl_name = make_workload(args)
     E = int(dd['dd_train_idx'].shape[1])
@@ -215,17 +215,31 @@ def main():
     preprocess_s = time.perf_counter() - t0
     run = step
     if launch == 'graph':
-        # the whole step (about 70 kernels) becomes one hipGraph: replay removes the per-launch host
-        # cost, which is larger than the kernels themselves at BioSNAP scale
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        run = graph.replay
+        # the whole step (about 55 kernels, plus the RCCL all-reduces when sharded) becomes one
+        # hipGraph: replay removes the per-launch host cost, which is larger than the kernels
+        # themselves at BioSNAP scale.  If capture fails (e.g. a collective that cannot be captured on
+        # this RCCL build) every rank falls back to eager launches together.
+        ok = torch.ones(1, device=dev)
+        graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as exc:                               # noqa: BLE001
+            sys.stderr.write('graph capture failed on rank %d (%r): eager launches\n' % (rank, exc))
+            ok.zero_()
+            torch.cuda.synchronize()
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            run = graph.replay
+        else:
+            launch = 'eager'
     for _ in range(args.warmup):
         run()
     fence()
