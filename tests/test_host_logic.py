@@ -197,3 +197,25 @@ def test_rel_plan_semantics():
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
     loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]
     assert sorted(loads) == [14, 14]
+
+
+def test_relation_tasks_and_sampler_keys_host_side():
+    """Decoder task table (tip_amd/ops.py) and the host mirror of the device sampler-key function."""
+    from tip_amd import ops, neg_sampling as NS
+    from oracle.philox_sampler import call_key
+    et = torch.repeat_interleave(torch.arange(5), torch.tensor([10000, 0, 3, 4097, 1]))
+    tasks = ops.relation_tasks(et)
+    assert tasks.dtype == torch.int32 and tasks.shape[1] == 3
+    t = tasks.long()
+    assert int((t[:, 2] - t[:, 1]).sum()) == et.numel() and int((t[:, 2] - t[:, 1]).max()) <= ops.TASK_POSITIONS
+    assert bool(((t[:-1, 2] - t[:-1, 1]) >= (t[1:, 2] - t[1:, 1])).all())        # largest first
+    for r, a, b in t.tolist():
+        assert bool((et[a:b] == r).all())
+    covered = torch.zeros(et.numel(), dtype=torch.int32)
+    for r, a, b in t.tolist():
+        covered[a:b] += 1
+    assert bool((covered == 1).all())
+    assert ops.relation_tasks(torch.tensor([0, 1, 0, 1])) is None                 # not grouped by relation
+    for seed, n in ((0, 0), (1111, 7), ((1 << 64) - 1, 123456)):
+        assert NS.call_key(seed, n) == call_key(seed, n)
+    assert len({call_key(5, n) for n in range(100)}) == 100
