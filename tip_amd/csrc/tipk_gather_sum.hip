@@ -34,6 +34,10 @@ struct Acc<4> {
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+    __device__ __forceinline__ void load(const float* p) { v = tipk_ld4(p); }
+    __device__ __forceinline__ void fma_acc(const Acc& o, float w) {
+        v.x = fmaf(w, o.v.x, v.x); v.y = fmaf(w, o.v.y, v.y); v.z = fmaf(w, o.v.z, v.z); v.w = fmaf(w, o.v.w, v.w);
+    }
     __device__ __forceinline__ void add_shfl_xor(int o) {
         v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
     }
@@ -51,6 +55,8 @@ struct Acc<1> {
     __device__ __forceinline__ void fma_row(const float* p, float w) { v = fmaf(w, *p, v); }
     __device__ __forceinline__ void add_row(const float* p) { v += *p; }
     __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
+    __device__ __forceinline__ void load(const float* p) { v = *p; }
+    __device__ __forceinline__ void fma_acc(const Acc& o, float w) { v = fmaf(w, o.v, v); }
     __device__ __forceinline__ void add_shfl_xor(int o) { v += __shfl_xor(v, o); }
     __device__ __forceinline__ void epilogue(const Epilogue& ep, int row, int col) {
         if (ep.row_scale) v *= ep.row_scale[row];
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
     if (active) it = items[w];
     const int col = sub * V;
     const bool col_ok = col < d;
-    const float* tcol = table + col;
+    const float* tsafe = table + (col_ok ? col : 0);     // out-of-range column lanes read column 0 (discarded)
 
     Acc<V> acc;
     acc.zero();
@@ -105,12 +111,16 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
                 ids[j] = __shfl(id, j0 + j, L);
                 if (HAS_W) ws[j] = __shfl(wgt, j0 + j, L);
             }
+            // branch-free batch: every row load is issued before the first use (a load inside an
+            // exec-masked branch is waited for on the spot: U dependent memory round trips per batch);
+            // padding lanes re-read row 0 / column 0 and are zeroed afterwards
+            Acc<V> rows[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) rows[j].load(tsafe + (int64_t)(ids[j] < 0 ? 0 : ids[j]) * ld_table);
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                if (ids[j] >= 0 && col_ok) {
-                    const float* p = tcol + (int64_t)ids[j] * ld_table;
-                    if (HAS_W) acc.fma_row(p, ws[j]); else acc.add_row(p);
-                }
+                if (ids[j] < 0) rows[j].zero();
+                if (HAS_W) acc.fma_acc(rows[j], ws[j]); else acc.add(rows[j]);
             }
         }
     }
