@@ -156,20 +156,6 @@ int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_stride, int
                       const float* addend, int relu, float* out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
- * 2b. The two large products of the basis decomposition W_r = sum_b att[r,b] basis_b
- *     (src/layers.py:163-164 and its backward) as HBM-streaming kernels, for n_base == 32:
- *       expand:  y[r, j]   = sum_b att[r, b] * xb[b, j]     att [n_rel x 32], xb [32 x n_cols] -> y [n_rel x n_cols]
- *       reduce:  slabs[s][b, j] = sum_{r in slab s} att[r, b] * dy[r, j];  dXB = sum_s slabs[s]
- *                (tipk_sum_slabs); `tipk_basis_reduce_slabs` tells the caller how many slabs to provide.
- *     Other n_base -> TIPK_EUNSUPPORTED (use tipk_gemm_f32).  All matrices row-major and dense.
- */
-int tipk_basis_expand(const float* att, int64_t n_rel, int n_base, const float* xb, int64_t n_cols,
-                      float* y, tipk_stream_t stream);
-int tipk_basis_reduce_slabs(int64_t n_rel, int64_t n_cols);           /* host: slab count */
-int tipk_basis_reduce(const float* att, int64_t n_rel, int n_base, const float* dy, int64_t n_cols,
-                      float* slabs /* [n_slabs][32][n_cols] */, tipk_stream_t stream);
-
-/* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).
  */
 /* out[c, r] = in[r, c]  -- `lin(x)` for identity features is W^T (src/layers.py:392 with

@@ -290,22 +290,3 @@ def test_rel_gather_unsupported_shapes():
     for d in (16, 32, 64, 128):                             # wide rows run as several column blocks
         assert L.tipk_rel_gather_supported(645, d, 0) >= 1 and L.tipk_rel_gather_supported(645, d, 1) >= 1
     assert L.tipk_rel_gather_supported(645, 32, 0) == 2 and L.tipk_rel_gather_supported(645, 32, 1) == 1   # column blocks
-
-
-# ------------------------------------------------------------------ basis expand / reduce streaming kernels
-@pytest.mark.parametrize('r,j', [(1097, 20640), (1097, 10320), (37, 100), (700, 65), (1, 32), (513, 33)])
-def test_basis_expand_reduce(ops, r, j):
-    g = torch.Generator().manual_seed(r + j)
-    att = torch.randn(r, 32, generator=g)
-    xb = torch.randn(32, j, generator=g)
-    dy = torch.randn(r, j, generator=g)
-    close(ops.basis_expand(att.to(DEV), xb.to(DEV)), att.double() @ xb.double(), rtol=1e-5)
-    close(ops.basis_reduce(att.to(DEV), dy.to(DEV)), att.double().t() @ dy.double(), rtol=1e-5,
-          atol=2e-5 * float((att.double().t().abs() @ dy.double().abs()).max()))
-    # exact on integer data (k-ordered fp32 fma chain)
-    ai = torch.randint(-4, 5, (r, 32), generator=g).float()
-    xi = torch.randint(-4, 5, (32, j), generator=g).float()
-    assert torch.equal(ops.basis_expand(ai.to(DEV), xi.to(DEV)).cpu(), ai @ xi)
-    # non-32 basis count falls back to the generic GEMM
-    a5 = torch.randn(r, 5, generator=g)
-    close(ops.basis_expand(a5.to(DEV), xb[:5].contiguous().to(DEV)), a5.double() @ xb[:5].double(), rtol=1e-5)

@@ -44,9 +44,6 @@ SIGNATURES = {
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
-    'tipk_basis_expand': (_I, [_P, _L, _I, _P, _L, _P, _P]),
-    'tipk_basis_reduce_slabs': (_I, [_L, _L]),
-    'tipk_basis_reduce': (_I, [_P, _L, _I, _P, _L, _P, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

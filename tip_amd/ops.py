@@ -278,32 +278,6 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     return out
 
 
-def basis_expand(att, xb2):
-    """Y = att @ xb2  ([R,32] @ [32,J]) with the streaming kernel (include/tipk.h section 2b);
-    falls back to the generic GEMM for other basis counts."""
-    if att.shape[1] != 32 or os.environ.get('TIPK_NO_BASIS_KERNELS'):
-        return gemm(att, xb2)
-    att, xb2 = att.contiguous(), xb2.contiguous()
-    r, j = att.shape[0], xb2.shape[1]
-    y = torch.empty((r, j), dtype=torch.float32, device=att.device)
-    with _timed('basis_expand[%dx%d]' % (r, j)):
-        check(lib().tipk_basis_expand(ptr(att), r, 32, ptr(xb2), j, ptr(y), stream_ptr(att.device)), 'tipk_basis_expand')
-    return y
-
-
-def basis_reduce(att, g_y):
-    """dXB = att^T @ g_y  ([32,R] @ [R,J]) with the streaming kernel + ordered slab sum."""
-    if att.shape[1] != 32 or os.environ.get('TIPK_NO_BASIS_KERNELS'):
-        return gemm(att.t(), g_y)
-    att, g_y = att.contiguous(), g_y.contiguous()
-    r, j = g_y.shape
-    n_slabs = int(lib().tipk_basis_reduce_slabs(r, j))
-    slabs = torch.empty((n_slabs, 32, j), dtype=torch.float32, device=att.device)
-    with _timed('basis_reduce[%dx%d,slabs=%d]' % (r, j, n_slabs)):
-        check(lib().tipk_basis_reduce(ptr(att), r, 32, ptr(g_y), j, ptr(slabs), stream_ptr(att.device)), 'tipk_basis_reduce')
-    return slabs[0] if n_slabs == 1 else sum_slabs(slabs)
-
-
 def transpose(x):
     x = _f32c(x).contiguous()
     require_device(x)
@@ -570,7 +544,7 @@ class _RGCN(torch.autograd.Function):
         assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         xb = gemm(x, basis)                                              # [B, N, out]
         if r > 0:
-            y = basis_expand(att_l, xb.view(nb, n * d_out))              # [R, N*out]
+            y = gemm(att_l, xb.view(nb, n * d_out))                      # [R, N*out]
         else:
             y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
@@ -621,7 +595,7 @@ class _RGCN(torch.autograd.Function):
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
             with fork(dev):
                 g_att_l = gemm(g_y, xb2.t())                             # split-K (automatic)
-            g_xb = basis_reduce(att_l, g_y).view(nb, n, d_out)
+            g_xb = gemm(att_l.t(), g_y).view(nb, n, d_out)
         else:
             g_att_l = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
             g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
