@@ -234,6 +234,20 @@ int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* r
 
 int tipk_counter_advance(uint64_t* call_counter /* device */, tipk_stream_t stream);   /* *counter += 1 */
 
+/* --------------------------------------------------------------------------------------------
+ * 6. Per-relation ranking metrics on device -- replaces the loop of
+ *    TIP.compute_auprc_auroc_ap_by_et (src/layers.py:355-375) over sklearn's roc_auc_score,
+ *    average_precision_score and auc(precision_recall_curve) (src/utils.py:86-93): 1 097 D2H copies
+ *    and sorts on the host.
+ *
+ * Relation r scores pos_score[range_ptr[r] : range_ptr[r+1]] against the same slice of neg_score
+ * (labels 1 / 0).  out is fp64 [3][n_rel] = (AUPRC, AUROC, AP) rows.  Ties share one operating
+ * point, exactly as sklearn's curves do.  max_pairs (host) = largest slice; 2*max_pairs <= 16384
+ * (one workgroup sorts a relation in LDS), else TIPK_EUNSUPPORTED and the caller evaluates on the host.
+ */
+int tipk_rank_metrics(const float* pos_score, const float* neg_score, const int64_t* range_ptr /* [n_rel+1] */,
+                      int64_t n_rel, int64_t max_pairs, double* out, tipk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,3 +290,34 @@ def test_rel_gather_unsupported_shapes():
     for d in (16, 32, 64, 128):                             # wide rows run as several column blocks
         assert L.tipk_rel_gather_supported(645, d, 0) >= 1 and L.tipk_rel_gather_supported(645, d, 1) >= 1
     assert L.tipk_rel_gather_supported(645, 32, 0) == 2 and L.tipk_rel_gather_supported(645, 32, 1) == 1   # column blocks
+
+
+# ------------------------------------------------------------------ ranking metrics on device
+def test_rank_metrics_vs_sklearn():
+    from tip_amd import ops as O2
+    from tip_amd.utils import auprc_auroc_ap_by_range
+    rng = np.random.RandomState(2)
+    sizes = [1, 3, 700, 40, 8192, 5000, 2]
+    ptr = np.r_[0, np.cumsum(sizes)]
+    tot = int(ptr[-1])
+    pos = (rng.rand(tot) * 0.6 + 0.3).astype(np.float32)
+    neg = (rng.rand(tot) * 0.7).astype(np.float32)
+    a, b = ptr[2], ptr[3]                              # heavy ties in one relation
+    pos[a:b] = np.round(pos[a:b], 1)
+    neg[a:b] = np.round(neg[a:b], 1)
+    neg[ptr[3]:ptr[4]] = pos[ptr[3]:ptr[4]]            # identical score lists: AUROC 0.5 by ties
+    rg = torch.tensor(np.stack([ptr[:-1], ptr[1:]], 1))
+    got = auprc_auroc_ap_by_range(torch.from_numpy(pos).to(DEV), torch.from_numpy(neg).to(DEV), rg)
+    assert got.shape == (3, len(sizes))
+    for r in range(len(sizes)):
+        y = np.r_[np.ones(sizes[r]), np.zeros(sizes[r])]
+        s = np.r_[pos[ptr[r]:ptr[r + 1]], neg[ptr[r]:ptr[r + 1]]]
+        np.testing.assert_allclose(got[:, r], O.auprc_auroc_ap(y, s), rtol=1e-9, atol=1e-12)
+    assert abs(got[1, 3] - 0.5) < 1e-12
+    # a relation beyond the single-workgroup sort falls back to the host path with the same numbers
+    big = 9000
+    p2, n2 = rng.rand(big).astype(np.float32), rng.rand(big).astype(np.float32)
+    assert O2.rank_metrics(torch.from_numpy(p2).to(DEV), torch.from_numpy(n2).to(DEV),
+                           torch.tensor([0, big], device=DEV), big) is None
+    got2 = auprc_auroc_ap_by_range(torch.from_numpy(p2).to(DEV), torch.from_numpy(n2).to(DEV), torch.tensor([[0, big]]))
+    np.testing.assert_allclose(got2[:, 0], O.auprc_auroc_ap(np.r_[np.ones(big), np.zeros(big)], np.r_[p2, n2]), rtol=1e-9)

@@ -690,3 +690,18 @@ class _DistMultLoss(torch.autograd.Function):
 
 def distmult_objective(z, weight, pos_index, neg_index, edge_type):
     return _DistMultLoss.apply(z, weight, pos_index, neg_index, edge_type)
+
+
+def rank_metrics(pos_score, neg_score, range_ptr, max_pairs):
+    """fp64 [3, R] (AUPRC, AUROC, AP) per relation on device (include/tipk.h section 6), or None if a
+    relation is too large for the single-workgroup sort."""
+    pos_score, neg_score = _f32c(pos_score).contiguous(), _f32c(neg_score).contiguous()
+    require_device(pos_score, neg_score, range_ptr)
+    n_rel = range_ptr.numel() - 1
+    out = torch.empty((3, n_rel), dtype=torch.float64, device=pos_score.device)
+    st = lib().tipk_rank_metrics(ptr(pos_score), ptr(neg_score), ptr(range_ptr), n_rel, int(max_pairs), ptr(out),
+                                 stream_ptr(pos_score.device))
+    if st == -2:                                   # TIPK_EUNSUPPORTED
+        return None
+    check(st, 'tipk_rank_metrics')
+    return out

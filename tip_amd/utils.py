@@ -124,7 +124,18 @@ def auprc_auroc_ap(target_tensor, score_tensor):
 
 
 def auprc_auroc_ap_by_range(pos_score, neg_score, range_list):
-    """[3, R] record of (AUPRC, AUROC, AP) per relation block (`src/layers.py:355-368`)."""
+    """[3, R] record of (AUPRC, AUROC, AP) per relation block (`src/layers.py:355-368`).
+    Device tensors are evaluated by `tipk_rank_metrics` (one launch for all relations); host tensors,
+    non-consecutive ranges or oversized relations take the numpy path below."""
+    if torch.is_tensor(pos_score) and pos_score.is_cuda:
+        rg = torch.as_tensor(range_list).to(torch.int64).cpu()
+        consecutive = rg.numel() > 0 and int(rg[0, 0]) == 0 and bool((rg[1:, 0] == rg[:-1, 1]).all())
+        if consecutive and int(rg[-1, 1]) == pos_score.numel() == neg_score.numel():
+            from . import ops
+            ptr = torch.cat([rg[:1, 0], rg[:, 1]]).to(pos_score.device)
+            rec = ops.rank_metrics(pos_score.detach(), neg_score.detach(), ptr, int((rg[:, 1] - rg[:, 0]).max()))
+            if rec is not None:
+                return rec.cpu().numpy()
     pos = torch.as_tensor(pos_score).detach().cpu().numpy()
     neg = torch.as_tensor(neg_score).detach().cpu().numpy()
     rg = torch.as_tensor(range_list).cpu().numpy().astype(np.int64)
