@@ -5,7 +5,7 @@ from tip_amd.layers import TIP, Setting
 from tip_amd.train import GraphedTrainStep
 torch.manual_seed(1111)
 m = TIP(Setting(), torch.device('cuda:0'))
-opt = torch.optim.Adam(m.parameters(), lr=0.01, capturable=True)
+opt = torch.optim.Adam(m.parameters(), lr=0.01, capturable=True, fused=True)
 step = GraphedTrainStep(m, opt)
 for _ in range(3): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
