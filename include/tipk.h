@@ -221,6 +221,9 @@ int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_
  * -- specified bit-exactly in oracle/philox_sampler.py.  `pos_key_sorted` holds u*n+v of each
  * relation's positives sorted ascending within the relation (int64).  After 64 rejected attempts
  * the 64th candidate is kept (probability < density^64).
+ * wg_rel_ptr / wg_rels (nullable): edge-balanced deal of the relations to n_wg workgroups; with it and
+ * n_nodes^2 bits <= 150 KB each workgroup tests candidates against an LDS bitmap of its relation's
+ * positives instead of searching the sorted keys (same output bit for bit, ~6x faster on BioSNAP).
  * call_counter != NULL: the Philox key is splitmix64(seed + (*call_counter + 1) * 0x9E3779B97F4A7C15)
  * instead of `seed` itself -- a sampler STREAM whose position lives on the device, so that a captured
  * hipGraph draws new negatives on every replay (`tipk_counter_advance` is the next node).
@@ -228,6 +231,7 @@ int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_
 int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
                                  const uint64_t* call_counter /* nullable device word, see below */,
+                                 const int32_t* wg_rel_ptr /* nullable */, const int32_t* wg_rels, int64_t n_wg,
                                  void* out_u, void* out_v, int idx_bytes,
                                  int64_t n_positions /* = rel_ptr[n_rel], host copy */,
                                  tipk_stream_t stream);

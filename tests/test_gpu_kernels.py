@@ -207,7 +207,14 @@ def test_negative_sampler_bit_exact_vs_spec_and_properties():
     got = NS.typed_negative_sampling(pos_t, n, rg, seed=0x1234567887654321)
     assert got.dtype == torch.int64 and got.shape == pos_t.shape and got.device == pos_t.device
     want = typed_negative_sampling_spec(pos, n, rel_ptr, 0x1234567887654321)
-    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(got.cpu().numpy(), want)                  # LDS-bitmap kernel (n^2 bits fit)
+    import os
+    os.environ['TIPK_NO_BITMAP'] = '1'                              # binary-search kernel: same bits
+    try:
+        got_bs = NS.typed_negative_sampling(pos_t, n, rg, seed=0x1234567887654321)
+    finally:
+        del os.environ['TIPK_NO_BITMAP']
+    assert torch.equal(got, got_bs)
     gk = (got[0] * n + got[1]).cpu().numpy()
     assert gk.min() >= 0 and gk.max() < n * n
     for r in range(len(sizes)):                      # no sampled pair is a positive of its relation

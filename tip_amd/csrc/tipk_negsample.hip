@@ -69,6 +69,45 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
     out_v[e] = (OT)(cand % (uint64_t)n_nodes);
 }
 
+// Bitmap variant (n_nodes^2 bits fit in LDS: BioSNAP 645^2 bits = 52 KB): a persistent 1024-thread
+// workgroup per CU walks its relations (edge-balanced deal, as in tipk_rel_gather); per relation it
+// sets one bit per positive pair (ds_or_b32: integer LDS atomics run at 5 lane-ops/clk/CU) and every
+// candidate is then tested with ONE LDS read instead of a 16-step binary search through L2.
+// Same candidates, same acceptance rule, same output as `neg_sample_kernel` (bit-exact).
+template <typename OT>
+__global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
+    const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_rel_ptr,
+    const int32_t* __restrict__ wg_rels, int64_t n_nodes, uint64_t seed, const uint64_t* __restrict__ call_counter,
+    OT* __restrict__ out_u, OT* __restrict__ out_v) {
+    extern __shared__ unsigned bm[];
+    const uint64_t key = call_counter ? call_key(seed, *call_counter) : seed;
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
+    const int words = (int)((nn + 31) >> 5);
+    const int t = threadIdx.x;
+    for (int ri = wg_rel_ptr[blockIdx.x]; ri < wg_rel_ptr[blockIdx.x + 1]; ++ri) {
+        const int rel = wg_rels[ri];
+        const int64_t a = rel_ptr[rel], b = rel_ptr[rel + 1];
+        __syncthreads();                                   // the previous relation's tests are done
+        for (int i = t; i < words; i += 1024) bm[i] = 0u;
+        __syncthreads();
+        for (int64_t e = a + t; e < b; e += 1024) {
+            const uint64_t k = (uint64_t)keys[e];
+            atomicOr(&bm[k >> 5], 1u << (k & 31));
+        }
+        __syncthreads();
+        for (int64_t e = a + t; e < b; e += 1024) {
+            uint64_t cand = 0;
+            for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
+                cand = __umul64hi(philox64((uint64_t)e, (uint32_t)attempt, k0, k1), nn);
+                if (!((bm[cand >> 5] >> (cand & 31)) & 1u)) break;
+            }
+            out_u[e] = (OT)(cand / (uint64_t)n_nodes);
+            out_v[e] = (OT)(cand % (uint64_t)n_nodes);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
@@ -79,6 +118,7 @@ extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
 
 extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
                                             int64_t n_nodes, uint64_t seed, const uint64_t* call_counter,
+                                            const int32_t* wg_rel_ptr, const int32_t* wg_rels, int64_t n_wg,
                                             void* out_u, void* out_v, int idx_bytes, int64_t n_positions,
                                             tipk_stream_t stream) {
     if (n_rel < 0 || n_nodes <= 0 || n_positions < 0 || n_nodes > 0xffffffffLL) return TIPK_EINVAL;
@@ -87,6 +127,25 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
     const int64_t blocks = tipk_ceil_div(n_positions, 256);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    const int64_t bm_bytes = (((int64_t)n_nodes * n_nodes + 31) / 32) * 4;
+    if (wg_rel_ptr && wg_rels && n_wg > 0 && n_wg <= 65535 && bm_bytes <= 150 * 1024) {
+        if (idx_bytes == 8) {
+            auto kern = neg_sample_bitmap_kernel<int64_t>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
+            if (e != hipSuccess) return tipk_hip_status(e);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, (int64_t*)out_u, (int64_t*)out_v);
+        } else if (idx_bytes == 4) {
+            auto kern = neg_sample_bitmap_kernel<int32_t>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
+            if (e != hipSuccess) return tipk_hip_status(e);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, (int32_t*)out_u, (int32_t*)out_v);
+        } else {
+            return TIPK_EINVAL;
+        }
+        TIPK_RETURN_LAUNCH();
+    }
     if (idx_bytes == 8)
         hipLaunchKernelGGL(neg_sample_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
                            rel_ptr, n_rel, n_nodes, seed, call_counter, (int64_t*)out_u, (int64_t*)out_v);

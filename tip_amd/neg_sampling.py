@@ -87,7 +87,11 @@ def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
     if hit is None:
         rel_ptr = relation_ptr(range_list, pos_edge_index.shape[1])
         keys = sorted_positive_keys(pos_edge_index, num_nodes, rel_ptr)
-        hit = (keys, rel_ptr.to(pos_edge_index.device), rel_ptr.numel() - 1, pos_edge_index)
+        dev = pos_edge_index.device
+        n_wg = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
+        from .plan import assign_relations
+        wg_ptr, wg_rels = assign_relations((rel_ptr[1:] - rel_ptr[:-1]).tolist(), n_wg, fixed_cost=4096)
+        hit = (keys, rel_ptr.to(dev), rel_ptr.numel() - 1, (wg_ptr.to(dev), wg_rels.to(dev)), pos_edge_index)
         if len(_key_cache) > 8:
             _key_cache.clear()
         _key_cache[ident] = hit
@@ -98,13 +102,13 @@ def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _r
     """Drop-in for `src/neg_sampling.py:22-26`.  `seed` (optional) pins the Philox key of this
     call; by default consecutive calls use consecutive keys of the `manual_seed` stream."""
     num_nodes = int(num_nodes)
-    keys, rel_ptr, n_rel, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
+    keys, rel_ptr, n_rel, wg, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
     if seed is not None:                                     # explicit Philox key for this call
         return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
-                                                  pos_edge_index.shape[1], dtype=torch.int64)
+                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg)
     return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, _state['seed'],
                                               pos_edge_index.shape[1], dtype=torch.int64,
-                                              call_counter=_counter(pos_edge_index.device))
+                                              call_counter=_counter(pos_edge_index.device), wg=wg)
 
 
 def negative_sampling(pos_edge_index, num_nodes, seed=None):

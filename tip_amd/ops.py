@@ -405,14 +405,16 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
 
 
 def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64,
-                                   call_counter=None):
+                                   call_counter=None, wg=None):
     """call_counter: optional int64 device tensor [1]; then `seed` is the stream seed, the Philox key
     is derived on the device from (seed, counter) and the counter is advanced by one afterwards."""
     require_device(pos_key_sorted, rel_ptr, call_counter)
     out = torch.empty((2, n_positions), dtype=dtype, device=pos_key_sorted.device)
     st = stream_ptr(out.device)
+    wg_ptr, wg_rels = wg if (wg is not None and not os.environ.get('TIPK_NO_BITMAP')) else (None, None)
     check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
-                                             ptr(call_counter), ptr(out[0]), ptr(out[1]),
+                                             ptr(call_counter), ptr(wg_ptr), ptr(wg_rels),
+                                             0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(out[0]), ptr(out[1]),
                                              8 if dtype == torch.int64 else 4, n_positions, st),
           'tipk_typed_negative_sampling')
     if call_counter is not None:
