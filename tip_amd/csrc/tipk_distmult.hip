@@ -189,6 +189,8 @@ __device__ __forceinline__ void fx_add(unsigned long long* p, float c, double sc
     atomicAdd(p, (unsigned long long)(long long)((double)c * scale));      // ds_add_u64
 }
 
+constexpr int TASK_MAX = 2048;          // positions per task (ids staged in LDS: 4 x 2048 x 2 B)
+
 template <typename IT, int MODE>
 __global__ __launch_bounds__(1024) void distmult_task_kernel(
     const float* __restrict__ z, int n_nodes, int k, const float* __restrict__ w, int n_rel,
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     unsigned long long* gzl = lds64;                          // [n_nodes][k+1] fixed point
     float* zl = (float*)(gzl + (int64_t)n_nodes * lg);        // [n_nodes][k+4]
     float* red = zl + (((int64_t)n_nodes * ld + 3) & ~3LL);   // [16 waves][k] + [16]
+    uint16_t* ixl = reinterpret_cast<uint16_t*>(red + 16 * k + 16);   // [4][TASK_MAX] ids of the current task
     const bool want_grad = g_z != nullptr;
     float zmax = 0.f;
     for (int i = t; i < n_nodes * k; i += 1024) {
@@ -244,22 +247,38 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         const int rel = tasks[3 * task], tb = tasks[3 * task + 1], te = tasks[3 * task + 2];
         const float4 wr = tipk_ld4(w + (int64_t)rel * k + c0);
         float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
-        // software-pipelined indices
-        int64_t p = (int64_t)tb + slot;
-        int u0 = 0, v0 = 0, u1 = 0, v1 = 0;
-        if (p < te) {
-            u0 = (int)pu[p]; v0 = (int)pv[p];
-            if (MODE == 1) { u1 = (int)nu[p]; v1 = (int)nv[p]; }
+        // The task's ids are staged into LDS as 16-bit values with ONE batch of coalesced loads per
+        // thread (a per-iteration prefetch left the loop bound by one HBM latency per 256 positions).
+        {
+            const int cnt = te - tb;
+            int64_t g[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = h * 1024 + t;
+                const int64_t q = (int64_t)tb + (i < cnt ? i : cnt - 1);
+                g[h * 4 + 0] = (int64_t)pu[q];
+                g[h * 4 + 1] = (int64_t)pv[q];
+                g[h * 4 + 2] = MODE == 1 ? (int64_t)nu[q] : 0;
+                g[h * 4 + 3] = MODE == 1 ? (int64_t)nv[q] : 0;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = h * 1024 + t;
+                if (i < cnt) {
+                    ixl[0 * TASK_MAX + i] = (uint16_t)g[h * 4 + 0];
+                    ixl[1 * TASK_MAX + i] = (uint16_t)g[h * 4 + 1];
+                    ixl[2 * TASK_MAX + i] = (uint16_t)g[h * 4 + 2];
+                    ixl[3 * TASK_MAX + i] = (uint16_t)g[h * 4 + 3];
+                }
+            }
         }
+        __syncthreads();
         for (int64_t base = tb; base < te; base += n_slots) {
             const int64_t pos = base + slot;
             const bool valid = pos < te;
-            const int cu0 = u0, cv0 = v0, cu1 = u1, cv1 = v1;
-            const int64_t pn = pos + n_slots;
-            if (pn < te) {
-                u0 = (int)pu[pn]; v0 = (int)pv[pn];
-                if (MODE == 1) { u1 = (int)nu[pn]; v1 = (int)nv[pn]; }
-            }
+            const int li = valid ? (int)(pos - tb) : 0;
+            const int cu0 = ixl[li], cv0 = ixl[TASK_MAX + li];
+            const int cu1 = MODE == 1 ? ixl[2 * TASK_MAX + li] : 0, cv1 = MODE == 1 ? ixl[3 * TASK_MAX + li] : 0;
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0, a1 = a0, b1 = a0;
             float d0 = 0.f, d1 = 0.f;
             if (valid) {
@@ -309,6 +328,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 }
             }
         }
+        if (!want_grad) __syncthreads();                       // ids of this task are no longer needed
         if (want_grad) {                                       // d w[rel]: wave shuffle, then 16 waves via LDS
             for (int o = KL; o < TIPK_WAVE; o <<= 1) {
                 gw.x += __shfl_xor(gw.x, o); gw.y += __shfl_xor(gw.y, o);
@@ -347,8 +367,10 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
 
 inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
     if (k % 4 != 0 || k < 4 || k > 64 || (k & (k - 1)) != 0) return false;
-    *lds_bytes = n_nodes * (k + 1) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float);
-    return *lds_bytes <= 156 * 1024;
+    if (n_nodes > 65535) return false;                    // ids are staged as 16-bit values
+    *lds_bytes = n_nodes * (k + 1) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float) +
+                 4 * TASK_MAX * 2;
+    return *lds_bytes <= 158 * 1024;
 }
 
 template <typename IT, int MODE>

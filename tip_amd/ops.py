@@ -328,7 +328,7 @@ def _uv(edge_index):
 
 
 _TASK_CACHE = {}
-TASK_POSITIONS = 4096
+TASK_POSITIONS = 2048          # = TASK_MAX in tipk_distmult.hip (a task's ids are staged in LDS)
 
 
 def relation_tasks(edge_type):
