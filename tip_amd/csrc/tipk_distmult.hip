@@ -296,16 +296,30 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 if (MODE == 1) d1 += __shfl_xor(d1, o);
             }
             float q0 = 0.f, q1 = 0.f;
-            if (valid) {
-                if (MODE == 1) {
-                    const float sp = sigmoidf(d0), sn = sigmoidf(d1);
-                    if (sub == 0) loss -= logf(sp + TIP_EPS) + logf(1.f - sn + TIP_EPS);
-                    q0 = -inv_n * sp * (1.f - sp) / (sp + TIP_EPS);
+            if (MODE == 1) {
+                // the positive's and the negative's sigmoid / log / divide are evaluated by DIFFERENT
+                // lanes of the position (sub 0 and sub 1) and exchanged with two shuffles: the SIMD
+                // executes one transcendental sequence per step instead of two
+                const bool neg_lane = KL > 1 && sub == 1;
+                const float x = neg_lane ? d1 : d0;
+                const float sg = sigmoidf(x);
+                const float val = neg_lane ? 1.f - sg : sg;
+                const float lg = logf(val + TIP_EPS);
+                const float qq = inv_n * sg * (1.f - sg) / (val + TIP_EPS);
+                if (KL > 1) {
+                    if (valid && sub < 2) loss -= lg;
+                    q0 = -__shfl(qq, 0, KL);
+                    q1 = __shfl(qq, 1, KL);
+                } else {                                   // k = 4: one lane per position does both
+                    const float sn = sigmoidf(d1);
+                    if (valid) loss -= lg + logf(1.f - sn + TIP_EPS);
+                    q0 = -qq;
                     q1 = inv_n * sn * (1.f - sn) / (1.f - sn + TIP_EPS);
-                } else {
-                    q0 = g_score[pos];
-                    if (sig) { const float sg = sigmoidf(d0); q0 *= sg * (1.f - sg); }
                 }
+                if (!valid) { q0 = 0.f; q1 = 0.f; }
+            } else if (valid) {
+                q0 = g_score[pos];
+                if (sig) { const float sg = sigmoidf(d0); q0 *= sg * (1.f - sg); }
             }
             if (want_grad && valid) {
                 unsigned long long* gu = gzl + cu0 * lg + c0;
