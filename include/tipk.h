@@ -211,6 +211,21 @@ int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_
                        float* loss_out, float* g_z, float* g_w, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 4b. NNDecoder triple scoring (reference src/layers.py:598-637, the paper's DR-NN ablation; SURVEY
+ *     section 8(f) item 1):  score[e] = sigma( s1[u_e, r_e] + s2[v_e, r_e] )  with the dense tables
+ *     s1 = relu(z w1_l1) w1_l2^T and s2 = relu(z w2_l1) w2_l2^T ([n_nodes x n_rel], row stride ld)
+ *     produced by tipk_gemm_f32.  bwd ACCUMULATES d s1 / d s2 (caller zeroes) with float atomics.
+ */
+int tipk_pair_table_fwd(const float* s1, const float* s2, int64_t ld,
+                        const void* idx_u, const void* idx_v, int idx_bytes,
+                        const void* edge_type, int et_bytes, int64_t n_triples,
+                        int sigmoid, float* score, tipk_stream_t stream);
+int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
+                        const void* idx_u, const void* idx_v, int idx_bytes,
+                        const void* edge_type, int et_bytes, int64_t n_triples,
+                        int sigmoid, float* g_s1, float* g_s2, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 5. Typed negative sampling on device -- replaces typed_negative_sampling / negative_sampling,
  *    src/neg_sampling.py:5-26 (K11: host numpy + one D2H copy per relation).
  *

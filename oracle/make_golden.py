@@ -170,6 +170,19 @@ def golden_decoder(seed):
         loss=loss, loss_grad_z=z.grad, loss_grad_weight=m.weight.grad, **rec)
 
 
+def golden_nn_decoder(seed):
+    g = small_graph(seed)
+    torch.manual_seed(seed)
+    m = ref.NNDecoder(6, g['n_rel'], l1_dim=5)
+    randomize_(m, seed)
+    z = torch.randn(g['n_drug'], 6, requires_grad=True)
+    s = m(z, g['dd_idx'], g['dd_et'])
+    up = torch.linspace(-1, 1, s.numel())
+    (s * up).sum().backward()
+    npz('nn_decoder', z=z, dd_idx=g['dd_idx'], dd_et=g['dd_et'], upstream=up, score=s, grad_z=z.grad,
+        **params_of(m), **grads_of(m))
+
+
 def golden_encoder(seed, mod, name):
     g = small_graph(seed)
     torch.manual_seed(seed)
@@ -262,6 +275,7 @@ if __name__ == '__main__':
     golden_hier(13)
     golden_pp(14)
     golden_decoder(15)
+    golden_nn_decoder(19)
     golden_encoder(16, 'cat', 'encoder_cat_small')
     golden_encoder(17, 'add', 'encoder_add_small')
     golden_tip(18)

@@ -267,6 +267,13 @@ def distmult_bwd(g_score, z, edge_index, edge_type, weight, sigmoid=True):
     return g_z, g_w
 
 
+def nn_decoder_fwd(z, edge_index, edge_type, w1_l1, w1_l2, w2_l1, w2_l2):
+    """NNDecoder.forward (src/layers.py:620-631), literal op order."""
+    d1 = torch.relu(z[edge_index[0]] @ w1_l1)
+    d2 = torch.relu(z[edge_index[1]] @ w2_l1)
+    return torch.sigmoid((d1 * w1_l2[edge_type]).sum(dim=1) + (d2 * w2_l2[edge_type]).sum(dim=1))
+
+
 def tip_loss(pos_score, neg_score):
     """-mean log(pos + eps) - mean log(1 - neg + eps)   (src/layers.py:338-340)."""
     return -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()

@@ -339,3 +339,17 @@ def test_graphed_train_step_matches_eager():
     # not executed): compare trajectories loosely, they must both keep decreasing from ~2 ln 2
     assert all(1.0 < v < 1.45 for v in losses[0] + losses[1]), losses
     assert abs(losses[0][0] - losses[1][0]) < 5e-3, losses
+
+
+def test_nn_decoder_golden():
+    """NNDecoder against the reference's own forward and autograd gradients."""
+    from tip_amd.layers import NNDecoder
+    g = load_golden('nn_decoder')
+    m = load_params(NNDecoder(6, g['w1_l2'].shape[0], l1_dim=5), g)
+    z = g['z'].to(DEV).requires_grad_(True)
+    s = m(z, g['dd_idx'].to(DEV), g['dd_et'].to(DEV))
+    close(s, g['score'])
+    (s * g['upstream'].to(DEV)).sum().backward()
+    close(z.grad, g['grad_z'], atol=1e-5)
+    for k in ('w1_l1', 'w1_l2', 'w2_l1', 'w2_l2'):
+        close(getattr(m, k).grad, g['grad.' + k], atol=1e-5)

@@ -167,3 +167,9 @@ def test_negative_sampling_restatement_distribution():
     neg = O.typed_negative_sampling(g['dd_train_idx'], n, g['dd_train_range'], rng)
     assert neg.shape == g['dd_train_idx'].shape and neg.dtype == torch.int64
     assert int(neg.min()) >= 0 and int(neg.max()) < n
+
+
+def test_nn_decoder_restatement():
+    g = load_golden('nn_decoder')
+    s = O.nn_decoder_fwd(g['z'], g['dd_idx'], g['dd_et'], g['w1_l1'], g['w1_l2'], g['w2_l1'], g['w2_l2'])
+    close(s, g['score'])

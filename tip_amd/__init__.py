@@ -5,7 +5,7 @@ DistMult decoder, typed negative sampling -- hand-written gfx950 HIP kernels (`t
 C ABI in `include/tipk.h`) behind the reference's `nn.Module` surface (`tip_amd.layers`).
 """
 from .layers import (GCNConv, MyRGCNConv, MyRGCNConv2, MyHierarchyConv, PPEncoder, FMEncoder,  # noqa: F401
-                     FMEncoderCat, MultiInnerProductDecoder, Setting, TIP)
+                     FMEncoderCat, MultiInnerProductDecoder, NNDecoder, Setting, TIP)
 from .neg_sampling import typed_negative_sampling, negative_sampling, manual_seed          # noqa: F401
 
 __version__ = '0.1.0'

@@ -28,7 +28,7 @@ from .utils import process_edges, auprc_auroc_ap_by_range
 EPS = 1e-13                    # src/layers.py:15
 
 __all__ = ['GCNConv', 'MyRGCNConv', 'MyRGCNConv2', 'MyHierarchyConv', 'PPEncoder', 'FMEncoder',
-           'FMEncoderCat', 'MultiInnerProductDecoder', 'Setting', 'TIP']
+           'FMEncoderCat', 'MultiInnerProductDecoder', 'NNDecoder', 'Setting', 'TIP']
 
 
 # ---------------------------------------------------------------------------------------------
@@ -418,6 +418,38 @@ class MultiInnerProductDecoder(nn.Module):
     def objective(self, z, pos_index, neg_index, edge_type):
         """-mean log(sigma(pos)+eps) - mean log(1-sigma(neg)+eps), fused (K9+K10)."""
         return ops.distmult_objective(z, self.weight, pos_index, neg_index, edge_type)
+
+
+class NNDecoder(nn.Module):
+    """The paper's DR-NN decoder (reference `src/layers.py:598-637`):
+    score = sigma( relu(z[u] w1_l1) . w1_l2[r] + relu(z[v] w2_l1) . w2_l2[r] ).
+
+    The reference gathers z[u], z[v] (E x in), multiplies E x in by in x l1 twice and gathers two
+    E x l1 relation rows.  Here the node-level part is done once per node (two GEMMs with fused ReLU),
+    the relation-specific dot products of ALL (node, relation) pairs are two small dense GEMMs
+    (N x R tables, 2.8 MB), and a triple costs two scalar reads (`tipk_pair_table_fwd`)."""
+
+    def __init__(self, in_dim, num_uni_edge_type, l1_dim=16):
+        super().__init__()
+        self.l1_dim = l1_dim
+        self.w1_l1 = Param(torch.empty(in_dim, l1_dim))
+        self.w1_l2 = Param(torch.empty(num_uni_edge_type, l1_dim))
+        self.w2_l1 = Param(torch.empty(in_dim, l1_dim))
+        self.w2_l2 = Param(torch.empty(num_uni_edge_type, l1_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.w1_l1.data.normal_()
+        self.w2_l1.data.normal_()
+        self.w1_l2.data.normal_(std=1 / np.sqrt(self.l1_dim))
+        self.w2_l2.data.normal_(std=1 / np.sqrt(self.l1_dim))
+
+    def forward(self, z, edge_index, edge_type):
+        p = torch.relu(ops.matmul(z, self.w1_l1))
+        q = torch.relu(ops.matmul(z, self.w2_l1))
+        s1 = ops.matmul(p, self.w1_l2.t())                       # [N, R]: every (node, relation) dot product
+        s2 = ops.matmul(q, self.w2_l2.t())
+        return ops.pair_table_score(s1, s2, edge_index, edge_type, sigmoid=True)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -707,3 +707,39 @@ def rank_metrics(pos_score, neg_score, range_ptr, max_pairs):
         return None
     check(st, 'tipk_rank_metrics')
     return out
+
+
+class _PairTable(torch.autograd.Function):
+    """score[e] = sigma(s1[u_e, r_e] + s2[v_e, r_e])  (include/tipk.h section 4b)."""
+
+    @staticmethod
+    def forward(ctx, s1, s2, edge_index, edge_type, sigmoid):
+        s1, s2 = _f32c(s1).contiguous(), _f32c(s2).contiguous()
+        require_device(s1, s2, edge_index, edge_type)
+        assert s1.shape == s2.shape
+        u, v = _uv(edge_index)
+        et = edge_type.contiguous()
+        n = u.numel()
+        score = torch.empty((n,), dtype=torch.float32, device=s1.device)
+        check(lib().tipk_pair_table_fwd(ptr(s1), ptr(s2), s1.shape[1], ptr(u), ptr(v), _idx_bytes(u), ptr(et),
+                                        _idx_bytes(et), n, int(sigmoid), ptr(score), stream_ptr(s1.device)),
+              'tipk_pair_table_fwd')
+        ctx.sigmoid, ctx.shape = sigmoid, s1.shape
+        ctx.save_for_backward(edge_index, et, score)
+        return score
+
+    @staticmethod
+    def backward(ctx, g):
+        edge_index, et, score = ctx.saved_tensors
+        g = _f32c(g).contiguous()
+        u, v = _uv(edge_index)
+        g1 = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        g2 = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib().tipk_pair_table_bwd(ptr(g), ptr(score), ctx.shape[1], ptr(u), ptr(v), _idx_bytes(u), ptr(et),
+                                        _idx_bytes(et), u.numel(), int(ctx.sigmoid), ptr(g1), ptr(g2),
+                                        stream_ptr(g.device)), 'tipk_pair_table_bwd')
+        return g1, g2, None, None, None
+
+
+def pair_table_score(s1, s2, edge_index, edge_type, sigmoid=True):
+    return _PairTable.apply(s1, s2, edge_index, edge_type, sigmoid)
