@@ -162,9 +162,13 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 __syncthreads();
             }
             if (a.dbg & 1) continue;
-            for (int p = slot; p < n_nodes; p += NS) {
+            for (int pb = 0, band = 0; pb < n_nodes; pb += NS, ++band) {
+                // snake deal of the length-sorted rows: band 0 ascending, band 1 descending, ... so the
+                // slot that got the longest row of one band gets the shortest of the next
+                const int p = pb + ((band & 1) ? NS - 1 - slot : slot);
+                if (p >= n_nodes) continue;
                 const int b = run_l[2 * p], len = run_l[2 * p + 1];
-                if (!BWD && len == 0) break;           // rows are sorted by length: the rest is empty
+                if (!BWD && len == 0) continue;
                 int lo = b > cb ? b : cb;                // b, len, cb, cn are multiples of 8
                 int hi = b + len < cb + cn ? b + len : cb + cn;
                 lo -= cb;
