@@ -59,9 +59,11 @@ struct TileLoader {
 
 // NBUF = LDS buffers: 2 overlaps the next tile's staging with the MFMAs of a K loop; 1 for products
 // whose K fits one tile (Y = att . XB, K = 32): half the LDS, twice the resident workgroups.
-template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF>
+// R = register tile per wave: R x R accumulators of 32x32 (R = 2: a 128x128 workgroup tile, each LDS
+// operand read feeds two MFMAs -- used for the large square-ish products such as Y = att . XB).
+template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF, int R = 1>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = WM * 32, BN = WN * 32;
+    constexpr int BM = WM * 32 * R, BN = WN * 32 * R;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     __shared__ float As[NBUF][BK][BM + PAD];
     __shared__ float Bs[NBUF][BK][BN + PAD];
@@ -81,9 +83,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     TileLoader<BM, A_KFAST> la;
     TileLoader<BN, B_KFAST> lb;
-    f32x16 acc;
+    f32x16 acc[R][R];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
     auto fetch = [&](int64_t tile) {
         const int64_t q = tile / tiles_per_q;
@@ -104,32 +110,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const int row = lane & 31, kh = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const float av = As[buf][2 * kk + kh][wm * 32 + row];
-            const float bv = Bs[buf][2 * kk + kh][wn * 32 + row];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            float av[R], bv[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) av[a] = As[buf][2 * kk + kh][(wm * R + a) * 32 + row];
+#pragma unroll
+            for (int b = 0; b < R; ++b) bv[b] = Bs[buf][2 * kk + kh][(wn * R + b) * 32 + row];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int b = 0; b < R; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    const int64_t col = n0 + wn * 32 + (lane & 31);
-    if (col >= g.n) return;
     float* c_z = g.c + z * g.c_sz + slab * g.c_ss;
     const float* cin_z = g.c_in ? g.c_in + z * g.cin_sz : nullptr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t rowi = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (rowi < g.m) {
-            float v = g.alpha * acc[r];
-            if (cin_z) v += cin_z[rowi * g.cin_sm + col];
-            if (g.relu) v = fmaxf(v, 0.f);
-            c_z[rowi * g.c_sm + col] = v;
+    for (int a = 0; a < R; ++a) {
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            const int64_t col = n0 + (wn * R + b) * 32 + (lane & 31);
+            if (col >= g.n) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t rowi = m0 + (wm * R + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (rowi < g.m) {
+                    float v = g.alpha * acc[a][b][r];
+                    if (cin_z) v += cin_z[rowi * g.cin_sm + col];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    c_z[rowi * g.c_sm + col] = v;
+                }
+            }
         }
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int R = 1>
 int launch(const GemmArgs& g, int64_t batch, hipStream_t st) {
-    constexpr int BM = WM * 32, BN = WN * 32;
+    constexpr int BM = WM * 32 * R, BN = WN * 32 * R;
     const int64_t gx = tipk_ceil_div(g.n, BN), gy = tipk_ceil_div(g.m, BM), gz = batch * g.ksplit;
     if (gx > 0x7fffffffLL || gy > 65535 || gz > 65535) return TIPK_EUNSUPPORTED;
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz), block(256);
@@ -138,8 +157,8 @@ int launch(const GemmArgs& g, int64_t batch, hipStream_t st) {
     const bool one_tile = g.kbatch == 1 && g.kchunk <= BK;
 #define TIPK_GEMM_GO(A, B)                                                                              \
     do {                                                                                                \
-        if (one_tile) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A, B, 1>), grid, block, 0, st, g);    \
-        else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A, B, 2>), grid, block, 0, st, g);             \
+        if (one_tile) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A, B, 1, R>), grid, block, 0, st, g); \
+        else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, A, B, (R > 1 ? 1 : 2), R>), grid, block, 0, st, g); \
     } while (0)
     if (akf && bkf) TIPK_GEMM_GO(true, true);
     else if (akf) TIPK_GEMM_GO(true, false);
@@ -198,6 +217,7 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d->n <= 32) return launch<4, 1>(g, d->batch, st);
     if (d->m <= 32) return launch<1, 4>(g, d->batch, st);
+    if (d->m >= 512 && d->n >= 512 && d->ksplit == 1) return launch<2, 2, 2>(g, d->batch, st);   // 128 x 128 tiles
     return launch<2, 2>(g, d->batch, st);
 }
 
