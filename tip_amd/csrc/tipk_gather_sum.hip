@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
     if (active) it = items[w];
     const int col = sub * V;
     const bool col_ok = col < d;
-    const float* tsafe = table + (col_ok ? col : 0);     // out-of-range column lanes read column 0 (discarded)
 
     Acc<V> acc;
     acc.zero();
@@ -111,15 +110,18 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
                 ids[j] = __shfl(id, j0 + j, L);
                 if (HAS_W) ws[j] = __shfl(wgt, j0 + j, L);
             }
-            // branch-free batch: every row load is issued before the first use (a load inside an
-            // exec-masked branch is waited for on the spot: U dependent memory round trips per batch);
-            // padding lanes re-read row 0 / column 0 and are zeroed afterwards
+            // all row loads of the batch are issued before the first use: a load whose result is
+            // consumed inside its own exec-masked branch is waited for on the spot (U dependent memory
+            // round trips per batch).  Lanes without an edge skip the load (short rows -- the backward
+            // plans average 2.5 edges per row -- must not pay for 8).
             Acc<V> rows[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) rows[j].load(tsafe + (int64_t)(ids[j] < 0 ? 0 : ids[j]) * ld_table);
+            for (int j = 0; j < U; ++j) {
+                rows[j].zero();
+                if (ids[j] >= 0 && col_ok) rows[j].load(table + col + (int64_t)ids[j] * ld_table);
+            }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                if (ids[j] < 0) rows[j].zero();
                 if (HAS_W) acc.fma_acc(rows[j], ws[j]); else acc.add(rows[j]);
             }
         }
