@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
             id_next = row_id[nxt];
             if (HAS_W) w_next = edge_w[nxt];
         }
-#pragma unroll
+#pragma unroll 1                          // one batch of U rows in flight: unrolling L/U batches cost 167 VGPRs at L = 32
         for (int j0 = 0; j0 < L; j0 += U) {
             int ids[U];
             float ws[U];
