@@ -144,6 +144,14 @@ typedef struct tipk_gemm_desc {
 
 int tipk_gemm_f32(const tipk_gemm_desc* desc /* host */, tipk_stream_t stream);
 
+/* Up to TIPK_GROUP_MAX independent products in ONE launch (no ordering between them; outputs must
+ * not overlap any input of the group).  Each product is computed exactly as tipk_gemm_f32 would
+ * (same tile shape and k order -> bit-identical).  Used where the path needs several small
+ * products at the same point of the dependent chain: XB and X root going forward
+ * (src/layers.py:163-172 and :184), d basis / d root / both halves of dX going back. */
+#define TIPK_GROUP_MAX 6
+int tipk_gemm_f32_group(const tipk_gemm_desc* descs /* host, [count] */, int32_t count, tipk_stream_t stream);
+
 /* out[i] = alpha * sum_{s<n_slabs} in[s*slab_stride + i] (+ out[i] if accumulate), i < count.
  * Ordered (deterministic) reduction of split-K slabs / per-workgroup partials. */
 int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count,
@@ -154,6 +162,15 @@ int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_
 int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count,
                       float alpha, int accumulate, const float* row_scale, int64_t cols,
                       const float* addend, int relu, float* out, tipk_stream_t stream);
+/* the same for up to TIPK_GROUP_MAX independent slab sets in one launch (arguments as above) */
+typedef struct tipk_slab_sum_desc {
+    const float* in; int64_t n_slabs, slab_stride, count;
+    float alpha; int accumulate;
+    const float* row_scale; int64_t cols;
+    const float* addend; int relu;
+    float* out;
+} tipk_slab_sum_desc;
+int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, int32_t count, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).

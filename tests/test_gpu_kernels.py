@@ -123,6 +123,46 @@ def test_gemm_is_exact_fp32_fma_chain(ops):
     assert torch.equal(ops.gemm(eye.to(DEV), b[:45].contiguous().to(DEV)).cpu(), b[:45])
 
 
+def test_gemm_group_bit_identical_to_single_launches(ops):
+    """tipk_gemm_f32_group / tipk_sum_slabs_group: the R-GCN backward's mix of shapes (batched, split-K,
+    batch-reduced on top of another member's output, transposed views) in one launch == one by one."""
+    g = torch.Generator().manual_seed(77)
+    n, d_in, d_out, nb = 645, 64, 32, 8
+    x = torch.randn(n, d_in, generator=g).to(DEV)
+    gr = torch.randn(n, d_out, generator=g).to(DEV)
+    g_xb = torch.randn(nb, n, d_out, generator=g).to(DEV)
+    basis = torch.randn(nb, d_in, d_out, generator=g).to(DEV)
+    root = torch.randn(d_in, d_out, generator=g).to(DEV)
+
+    def build(gx_buf):
+        j_basis = ops.gemm_job(x.t(), g_xb)
+        j_root = ops.gemm_job(x.t(), gr)
+        j_xr = ops.gemm_job(gr, root.t(), out=gx_buf)
+        j_xq = ops.gemm_job(g_xb, basis.transpose(1, 2), out=gx_buf, c_in=gx_buf, reduce_batch=True)
+        return [j_basis, j_root, j_xr, j_xq]
+
+    jobs = build(torch.empty(n, d_in, device=DEV))
+    assert jobs[0].slabs is not None and jobs[1].slabs is not None and jobs[3].slabs is not None
+    got = [o.clone() for o in ops.gemm_group(jobs)]
+    want_basis = ops.gemm(x.t(), g_xb)
+    want_root = ops.gemm(x.t(), gr)
+    want_x = ops.gemm(gr, root.t())
+    want_x = ops.gemm(g_xb, basis.transpose(1, 2), out=want_x, c_in=want_x, reduce_batch=True)
+    assert torch.equal(got[0], want_basis) and torch.equal(got[1], want_root)
+    assert torch.equal(got[2], want_x) and jobs[3].out.data_ptr() == jobs[2].out.data_ptr()
+    close(got[0], torch.einsum('nk,bno->bko', x.double().cpu(), g_xb.double().cpu()), rtol=1e-5, atol=1e-4)
+    close(got[2], gr.double().cpu() @ root.double().cpu().t()
+          + torch.einsum('bno,bko->nk', g_xb.double().cpu(), basis.double().cpu()), rtol=1e-5, atol=1e-4)
+    # more members than TIPK_GROUP_MAX are chunked; empty group is a no-op; extra slab jobs ride along
+    many = [ops.gemm_job(x.t(), gr) for _ in range(8)]
+    part = torch.randn(5, 40, 16, generator=g).to(DEV)
+    sj = ops.slab_job(part, alpha=0.5, relu=True)
+    outs = ops.gemm_group(many, [sj])
+    assert all(torch.equal(o, want_root) for o in outs)
+    assert torch.equal(sj.out, ops.sum_slabs(part, alpha=0.5, relu=True))
+    assert ops.gemm_group([]) == []
+
+
 # ------------------------------------------------------------------ row-wise glue
 def test_rowwise_ops(ops):
     g = torch.Generator().manual_seed(2)

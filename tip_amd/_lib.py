@@ -32,6 +32,17 @@ class GemmDesc(C.Structure):
                 ('alpha', C.c_float), ('relu', C.c_int)]
 
 
+class SlabSumDesc(C.Structure):
+    """struct tipk_slab_sum_desc (include/tipk.h)."""
+    _fields_ = [('in_', C.c_void_p), ('n_slabs', C.c_int64), ('slab_stride', C.c_int64), ('count', C.c_int64),
+                ('alpha', C.c_float), ('accumulate', C.c_int),
+                ('row_scale', C.c_void_p), ('cols', C.c_int64),
+                ('addend', C.c_void_p), ('relu', C.c_int),
+                ('out', C.c_void_p)]
+
+
+GROUP_MAX = 6                                  # TIPK_GROUP_MAX
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list exactly the functions of include/tipk.h
@@ -44,6 +55,8 @@ SIGNATURES = {
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
+    'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),
+    'tipk_sum_slabs_group': (_I, [C.POINTER(SlabSumDesc), C.c_int32, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

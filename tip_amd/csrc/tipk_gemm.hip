@@ -62,17 +62,17 @@ struct TileLoader {
 // R = register tile per wave: R x R accumulators of 32x32 (R = 2: a 128x128 workgroup tile, each LDS
 // operand read feeds two MFMAs -- used for the large square-ish products such as Y = att . XB).
 template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF, int R = 1>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int64_t bx, int64_t by, int64_t bz, float* smem) {
     constexpr int BM = WM * 32 * R, BN = WN * 32 * R;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ float As[NBUF][BK][BM + PAD];
-    __shared__ float Bs[NBUF][BK][BN + PAD];
+    float (*As)[BK][BM + PAD] = reinterpret_cast<float (*)[BK][BM + PAD]>(smem);
+    float (*Bs)[BK][BN + PAD] = reinterpret_cast<float (*)[BK][BN + PAD]>(smem + NBUF * BK * (BM + PAD));
 
     const int t = threadIdx.x;
     const int lane = t & 63, wid = t >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    const int64_t z = blockIdx.z / g.ksplit, slab = blockIdx.z % g.ksplit;
+    const int64_t m0 = by * BM, n0 = bx * BN;
+    const int64_t z = bz / g.ksplit, slab = bz % g.ksplit;
     const int64_t k_lo = slab * g.kchunk;
     const int64_t k_hi = (k_lo + g.kchunk < g.k) ? k_lo + g.kchunk : g.k;
     const int64_t tiles_per_q = (k_hi > k_lo) ? (k_hi - k_lo + BK - 1) / BK : 0;
@@ -146,6 +146,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF, int R = 1>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * BK * (WM * 32 * R + WN * 32 * R + 2 * PAD)];
+    gemm_body<WM, WN, A_KFAST, B_KFAST, NBUF, R>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Several independent products in ONE launch (tipk_gemm_f32_group): the backward of an R-GCN layer
+// needs d basis, d root and the two halves of dX at the same moment, each far too small to fill
+// 256 CUs; as separate launches they cost ~5 us apiece on the dependent chain of the step.
+// Workgroup -> (problem, tile) through a prefix of block counts; every problem keeps the tile shape
+// tipk_gemm_f32 would have picked for it, so the results are bit-identical to separate launches.
+constexpr int GROUP_MAX = TIPK_GROUP_MAX;
+
+struct GemmGroupArgs {
+    int count;
+    int first_block[GROUP_MAX + 1];
+    int cfg[GROUP_MAX];                    // shape * 4 + a_kfast * 2 + b_kfast
+    int gx[GROUP_MAX], gy[GROUP_MAX];
+    GemmArgs g[GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (160 + 2 * PAD)];
+    // constant indices only: a dynamic index into the by-value argument would copy it to scratch
+    GemmArgs g = ga.g[0];
+    int first = 0, gx = ga.gx[0], gy = ga.gy[0], cfg = ga.cfg[0];
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+        if (q < ga.count && (int)blockIdx.x >= ga.first_block[q]) {
+            g = ga.g[q]; first = ga.first_block[q]; gx = ga.gx[q]; gy = ga.gy[q]; cfg = ga.cfg[q];
+        }
+    const int local = (int)blockIdx.x - first;
+    const int64_t bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+    switch (cfg) {
+#define TIPK_CASE(S, WM, WN)                                                  \
+    case S * 4 + 0: gemm_body<WM, WN, false, false, 2>(g, bx, by, bz, smem); break; \
+    case S * 4 + 1: gemm_body<WM, WN, false, true, 2>(g, bx, by, bz, smem); break;  \
+    case S * 4 + 2: gemm_body<WM, WN, true, false, 2>(g, bx, by, bz, smem); break;  \
+    case S * 4 + 3: gemm_body<WM, WN, true, true, 2>(g, bx, by, bz, smem); break;
+        TIPK_CASE(0, 4, 1)
+        TIPK_CASE(1, 1, 4)
+        TIPK_CASE(2, 2, 2)
+#undef TIPK_CASE
+    }
+}
+
 template <int WM, int WN, int R = 1>
 int launch(const GemmArgs& g, int64_t batch, hipStream_t st) {
     constexpr int BM = WM * 32 * R, BN = WN * 32 * R;
@@ -198,14 +244,55 @@ __global__ __launch_bounds__(64 * LANES) void sum_slabs_kernel(const float* __re
     }
 }
 
+struct SlabArgs {
+    const float* in; int64_t n_slabs, slab_stride, count; float alpha; int accumulate;
+    const float* row_scale; int64_t cols; const float* addend; int relu; float* out; int lanes;
+};
+struct SlabGroupArgs {
+    int count;
+    int first_block[GROUP_MAX + 1];
+    SlabArgs s[GROUP_MAX];
+};
+
+// tipk_sum_slabs_group: several ordered slab sums in one launch.  1024 threads = `lanes` slab lanes
+// x (1024 / lanes) elements; per element the additions happen in exactly the order of
+// sum_slabs_kernel<lanes>.
+__global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa) {
+    __shared__ float red[1024];
+    SlabArgs a = sa.s[0];
+    int first = 0;
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+        if (q < sa.count && (int)blockIdx.x >= sa.first_block[q]) { a = sa.s[q]; first = sa.first_block[q]; }
+    const int lanes = a.lanes, epb = 1024 / lanes;
+    const int e = threadIdx.x % epb, j = threadIdx.x / epb;
+    const int64_t i = (int64_t)((int)blockIdx.x - first) * epb + e;
+    const float* __restrict__ in = a.in;
+    float s = 0.f;
+    if (i < a.count)
+        for (int64_t k = j; k < a.n_slabs; k += lanes) s += in[k * a.slab_stride + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && i < a.count) {
+        s = red[e];
+        for (int q = 1; q < lanes; ++q) s += red[q * epb + e];
+        s *= a.alpha;
+        if (a.row_scale) s *= a.row_scale[i / a.cols];
+        if (a.addend) s += a.addend[i];
+        if (a.accumulate) s += a.out[i];
+        if (a.relu) s = fmaxf(s, 0.f);
+        a.out[i] = s;
+    }
+}
+
 }  // namespace
 
-extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
+// validates a descriptor and converts it; returns 1 when there is nothing to compute
+static int fill_args(const tipk_gemm_desc* d, GemmArgs& g) {
     if (!d || d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0 || d->kbatch < 1 || d->ksplit < 1) return TIPK_EINVAL;
-    if (d->m == 0 || d->n == 0 || d->batch == 0) return TIPK_OK;
+    if (d->m == 0 || d->n == 0 || d->batch == 0) return 1;
     if (!d->a || !d->b || !d->c) return TIPK_EINVAL;
     if (d->ksplit > 1 && (d->c_in || d->relu)) return TIPK_EINVAL;
-    GemmArgs g;
     g.m = d->m; g.n = d->n; g.k = d->k; g.kbatch = d->kbatch; g.ksplit = d->ksplit;
     g.kchunk = tipk_ceil_div(tipk_ceil_div(d->k, d->ksplit), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
@@ -214,11 +301,75 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
     g.c = d->c; g.c_sm = d->c_sm; g.c_sz = d->c_sz; g.c_ss = d->c_ss;
     g.c_in = d->c_in; g.cin_sm = d->cin_sm; g.cin_sz = d->cin_sz;
     g.alpha = d->alpha; g.relu = d->relu;
+    return TIPK_OK;
+}
+
+extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
+    GemmArgs g;
+    const int rc = fill_args(d, g);
+    if (rc != TIPK_OK) return rc > 0 ? TIPK_OK : rc;
     hipStream_t st = (hipStream_t)stream;
     if (d->n <= 32) return launch<4, 1>(g, d->batch, st);
     if (d->m <= 32) return launch<1, 4>(g, d->batch, st);
     if (d->m >= 512 && d->n >= 512 && d->ksplit == 1) return launch<2, 2, 2>(g, d->batch, st);   // 128 x 128 tiles
     return launch<2, 2>(g, d->batch, st);
+}
+
+extern "C" int tipk_gemm_f32_group(const tipk_gemm_desc* descs, int32_t count, tipk_stream_t stream) {
+    if (count < 0 || count > GROUP_MAX || (count > 0 && !descs)) return TIPK_EINVAL;
+    GemmGroupArgs ga;
+    ga.count = 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        GemmArgs& g = ga.g[ga.count];
+        const int rc = fill_args(descs + i, g);
+        if (rc < 0) return rc;
+        if (rc > 0) continue;
+        const int shape = g.n <= 32 ? 0 : (g.m <= 32 ? 1 : 2);
+        const int bm = shape == 0 ? 128 : (shape == 1 ? 32 : 64), bn = shape == 0 ? 32 : (shape == 1 ? 128 : 64);
+        const bool akf = g.a_sk == 1 || g.a_sm != 1;
+        const bool bkf = g.b_sk == 1 && g.b_sn != 1;
+        const int64_t gx = tipk_ceil_div(g.n, bn), gy = tipk_ceil_div(g.m, bm), gz = descs[i].batch * g.ksplit;
+        if (gx > 0x7fffffLL || gy > 65535 || gz > 65535 || gx * gy * gz > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+        ga.cfg[ga.count] = shape * 4 + (akf ? 2 : 0) + (bkf ? 1 : 0);
+        ga.gx[ga.count] = (int)gx;
+        ga.gy[ga.count] = (int)gy;
+        ga.first_block[ga.count] = (int)blocks;
+        blocks += gx * gy * gz;
+        if (blocks > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+        ++ga.count;
+    }
+    if (ga.count == 0) return TIPK_OK;
+    ga.first_block[ga.count] = (int)blocks;
+    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ga);
+    TIPK_RETURN_LAUNCH();
+}
+
+extern "C" int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs, int32_t count, tipk_stream_t stream) {
+    if (count < 0 || count > GROUP_MAX || (count > 0 && !descs)) return TIPK_EINVAL;
+    SlabGroupArgs sa;
+    sa.count = 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const tipk_slab_sum_desc& d = descs[i];
+        if (d.n_slabs < 0 || d.count < 0 || (d.row_scale && d.cols <= 0)) return TIPK_EINVAL;
+        if (d.count == 0) continue;
+        if (!d.out || (d.n_slabs > 0 && !d.in)) return TIPK_EINVAL;
+        SlabArgs& a = sa.s[sa.count];
+        a.in = d.in; a.n_slabs = d.n_slabs; a.slab_stride = d.slab_stride; a.count = d.count; a.alpha = d.alpha;
+        a.accumulate = d.accumulate; a.row_scale = d.row_scale; a.cols = d.cols; a.addend = d.addend; a.relu = d.relu;
+        a.out = d.out;
+        // same slab-lane rule as tipk_sum_slabs_ex, so grouped and single launches add in the same order
+        a.lanes = (d.n_slabs >= 32 && tipk_ceil_div(d.count, 64) < 2048) ? 16 : 4;
+        sa.first_block[sa.count] = (int)blocks;
+        blocks += tipk_ceil_div(d.count, 1024 / a.lanes);
+        if (blocks > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+        ++sa.count;
+    }
+    if (sa.count == 0) return TIPK_OK;
+    sa.first_block[sa.count] = (int)blocks;
+    hipLaunchKernelGGL(sum_slabs_group_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, sa);
+    TIPK_RETURN_LAUNCH();
 }
 
 extern "C" int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count, float alpha,

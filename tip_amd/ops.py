@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, check, lib, ptr, stream_ptr, require_device
+from ._lib import SlabSumDesc, GemmDesc, check, lib, ptr, stream_ptr, require_device
 from .plan import GatherPlan
 
 
@@ -197,8 +197,15 @@ def _tile_shape(m, n):
     return 64, 64
 
 
-def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
-    """out = relu?(alpha * a @ b + c_in) on the matrix cores (include/tipk.h section 2).
+class GemmJob(object):
+    """One product prepared for launch: the descriptor, the slab buffer of a split reduction and
+    the ordered slab sum that finishes it.  `gemm` runs one job; `gemm_group` runs several
+    independent jobs in one grouped launch (+ one grouped slab sum)."""
+    __slots__ = ('desc', 'label', 'slabs', 'n_slabs', 'per', 'alpha', 'accumulate', 'out', 'keep')
+
+
+def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
+    """Prepare out = relu?(alpha * a @ b + c_in) on the matrix cores (include/tipk.h section 2).
 
     a: [M,K] or [Z,M,K]; b: [K,N] or [Z,K,N] -- arbitrary strides (transposed views are free).
     reduce_batch: sum the Z products into one [M,N] (the basis-sum of the R-GCN backward).
@@ -230,6 +237,7 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     tiles = -(-m // bm) * -(-n // bn) * (1 if reduce_batch else z)
     plain = relu is False and (c_in is None or c_in.data_ptr() == out.data_ptr()) and out.is_contiguous()
     slab_mode = None                       # None | 'k' (split the k range) | 'q' (one slab per batch term)
+    n_slabs = 0
     if reduce_batch and plain and tiles * 2 <= 256 and z > 1:
         slab_mode, n_slabs = 'q', z
     elif ksplit is None:
@@ -269,13 +277,82 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     else:
         g.c_in, g.cin_sm, g.cin_sz = None, 0, 0
     g.alpha, g.relu = (1.0 if slab_mode else alpha), int(relu)
+
+    job = GemmJob()
+    job.desc, job.slabs, job.n_slabs, job.per, job.alpha, job.out = g, slabs, n_slabs, per, alpha, out
+    job.accumulate = c_in is not None
+    job.keep = (a, b, c_in)                                          # operands stay alive until launched
+    job.label = '%dx%dx%d,z=%d%s' % (m, n, k, z, ',slabs=%s%d' % (slab_mode, n_slabs) if slab_mode else '')
+    return job
+
+
+def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
+    """out = relu?(alpha * a @ b + c_in): one product, launched now (see `gemm_job`)."""
+    job = gemm_job(a, b, out, c_in, relu, alpha, reduce_batch, ksplit)
+    st = stream_ptr(a.device)
+    with _timed('gemm[%s]' % job.label):
+        check(lib().tipk_gemm_f32(job.desc, st), 'tipk_gemm_f32')
+        if job.slabs is not None:
+            check(lib().tipk_sum_slabs(ptr(job.slabs), job.n_slabs, job.per, job.per, job.alpha,
+                                       int(job.accumulate), ptr(job.out), st), 'tipk_sum_slabs')
+    return job.out
+
+
+class SlabJob(object):
+    """An ordered slab sum with the fused epilogue of `sum_slabs`, prepared for a grouped launch."""
+    __slots__ = ('desc', 'out', 'keep')
+
+
+def slab_job(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, addend=None, relu=False):
+    assert slabs.is_contiguous()
+    per = slabs[0].numel()
+    if out is None:
+        out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    assert out.is_contiguous() and out.numel() == per
+    if addend is not None:
+        assert addend.is_contiguous() and addend.numel() == per
+    d = SlabSumDesc()
+    d.in_, d.n_slabs, d.slab_stride, d.count = slabs.data_ptr(), slabs.shape[0], per, per
+    d.alpha, d.accumulate = alpha, int(accumulate)
+    d.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    d.cols = slabs.shape[-1]
+    d.addend = addend.data_ptr() if addend is not None else None
+    d.relu, d.out = int(relu), out.data_ptr()
+    job = SlabJob()
+    job.desc, job.out, job.keep = d, out, (slabs, row_scale, addend)
+    return job
+
+
+def _slab_desc_of(job):
+    d = SlabSumDesc()
+    d.in_, d.n_slabs, d.slab_stride, d.count = job.slabs.data_ptr(), job.n_slabs, job.per, job.per
+    d.alpha, d.accumulate = job.alpha, int(job.accumulate)
+    d.row_scale, d.cols, d.addend, d.relu, d.out = None, 0, None, 0, job.out.data_ptr()
+    return d
+
+
+def gemm_group(jobs, slab_jobs=()):
+    """Run independent products in ONE grouped launch, then ONE grouped ordered slab sum for those
+    that were split (plus any extra `slab_jobs` that are ready at the same point).  Results are
+    bit-identical to running the jobs one by one.  Returns the jobs' outputs."""
+    jobs = list(jobs)
+    slab_jobs = list(slab_jobs)
+    if not jobs and not slab_jobs:
+        return []
+    dev = (jobs[0].out if jobs else slab_jobs[0].out).device
     st = stream_ptr(dev)
-    with _timed('gemm[%dx%dx%d,z=%d%s]' % (m, n, k, z, ',slabs=%s%d' % (slab_mode, n_slabs) if slab_mode else '')):
-        check(lib().tipk_gemm_f32(g, st), 'tipk_gemm_f32')
-        if slab_mode:
-            check(lib().tipk_sum_slabs(ptr(slabs), n_slabs, per, per, alpha, int(c_in is not None), ptr(out), st),
-                  'tipk_sum_slabs')
-    return out
+    for i in range(0, len(jobs), _lib.GROUP_MAX):
+        part = jobs[i:i + _lib.GROUP_MAX]
+        arr = (GemmDesc * len(part))(*[j.desc for j in part])
+        with _timed('gemm_group[%s]' % ' | '.join(j.label for j in part)):
+            check(lib().tipk_gemm_f32_group(arr, len(part), st), 'tipk_gemm_f32_group')
+    sums = [_slab_desc_of(j) for j in jobs if j.slabs is not None] + [s.desc for s in slab_jobs]
+    for i in range(0, len(sums), _lib.GROUP_MAX):
+        part = sums[i:i + _lib.GROUP_MAX]
+        arr = (SlabSumDesc * len(part))(*part)
+        with _timed('sum_slabs_group[%s]' % ' | '.join('%dx%d' % (d.n_slabs, d.count) for d in part)):
+            check(lib().tipk_sum_slabs_group(arr, len(part), st), 'tipk_sum_slabs_group')
+    return [j.out for j in jobs]
 
 
 def transpose(x):
@@ -486,11 +563,11 @@ class _Linear(torch.autograd.Function):
         if ctx.identity:
             return None, transpose(g)
         x, weight = ctx.saved_tensors
-        with fork(g.device):
-            g_w = gemm(g.t(), x)
-        g_x = gemm(g, weight) if ctx.needs_input_grad[0] else None
-        join(g.device)
-        return g_x, g_w
+        jobs = [gemm_job(g.t(), x)]
+        if ctx.needs_input_grad[0]:
+            jobs.append(gemm_job(g, weight))
+        outs = gemm_group(jobs)                                          # d W and d x: one grouped launch
+        return (outs[1] if len(outs) > 1 else None), outs[0]
 
 
 def linear_t(x, weight):
@@ -510,13 +587,10 @@ class _MatMul(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g = _f32c(g)
-        g_w = None
-        if ctx.needs_input_grad[1]:
-            with fork(g.device):
-                g_w = gemm(x.t(), g)
-        g_x = gemm(g, w.t()) if ctx.needs_input_grad[0] else None
-        join(g.device)
-        return g_x, g_w
+        j_w = gemm_job(x.t(), g) if ctx.needs_input_grad[1] else None
+        j_x = gemm_job(g, w.t()) if ctx.needs_input_grad[0] else None
+        gemm_group([j for j in (j_w, j_x) if j is not None])
+        return (j_x.out if j_x else None), (j_w.out if j_w else None)
 
 
 def matmul(x, w):
@@ -544,19 +618,20 @@ class _RGCN(torch.autograd.Function):
         att_l = att if shard is None else att.index_select(0, shard.rel_ids_on(att.device))
         r = att_l.shape[0]
         assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
-        xb = gemm(x, basis)                                              # [B, N, out]
+        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
+        fused = use_rl and shard is None
+        if fused:                                                        # XB and X root: one grouped launch
+            xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])
+        else:
+            xb = gemm(x, basis)                                          # [B, N, out]
         if r > 0:
             y = gemm(att_l, xb.view(nb, n * d_out))                      # [R, N*out]
         else:
             y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
-        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
-        if use_rl and shard is None:
+        if fused:
             # LDS-resident gather -> per-workgroup partial slabs; the ordered slab sum also applies
             # 1/deg, adds X root and the ReLU: the layer is finished in one pass
-            with fork(x.device):
-                xroot = gemm(x, root)                                    # independent of the aggregation
             part = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False, reduce=False)
-            join(x.device)
             out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=relu)
         else:
             if use_rl:
@@ -586,8 +661,6 @@ class _RGCN(torch.autograd.Function):
         nb, _, d_out = basis.shape
         r = att_l.shape[0]
         dev = x.device
-        with fork(dev):                                                  # parameter gradients: off the
-            g_root = gemm(x.t(), g)                                      # dependent chain -> side stream
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
             if rel_gather_usable(graph.rl_bwd, n, d_out, True):          # dY_r = A_r^T (D^-1 g), 1/deg fused
@@ -595,23 +668,30 @@ class _RGCN(torch.autograd.Function):
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
-            with fork(dev):
-                g_att_l = gemm(g_y, xb2.t())                             # split-K (automatic)
-            g_xb = gemm(att_l.t(), g_y).view(nb, n, d_out)
+            # both consumers of dY in one grouped launch (+ one grouped slab sum)
+            g_att_l, g_xb = gemm_group([gemm_job(g_y, xb2.t()), gemm_job(att_l.t(), g_y)])
+            g_xb = g_xb.view(nb, n, d_out)
         else:
             g_att_l = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
             g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
-        with fork(dev):
-            g_basis = gemm(x.t(), g_xb)                                  # [B, in, out]
+        # d basis, d root and both halves of dX are independent given dXB and g: one grouped launch
+        j_basis = gemm_job(x.t(), g_xb)                                  # [B, in, out]
+        j_root = gemm_job(x.t(), g)
         if shard is None:
             g_att = g_att_l
-            g_x = gemm(g, root.t())
-            g_x = gemm(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
-            join(dev)
+            j_xr = gemm_job(g, root.t())
+            g_x = j_xr.out
+            j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
+            if j_xq.slabs is not None:                                   # summed on top of g root^T afterwards
+                gemm_group([j_basis, j_root, j_xr, j_xq])
+            else:                                                        # reads g_x while accumulating
+                gemm_group([j_basis, j_root, j_xr])
+                gemm_group([j_xq])
+            g_basis, g_root = j_basis.out, j_root.out
         else:
-            join(dev)
             from .dist import all_reduce_packed
-            g_x = gemm(g_xb, basis.transpose(1, 2), reduce_batch=True)   # partial over this shard
+            j_xq = gemm_job(g_xb, basis.transpose(1, 2), reduce_batch=True)   # partial over this shard
+            g_basis, g_root, g_x = gemm_group([j_basis, j_root, j_xq])
             g_att = torch.zeros_like(att)
             g_att.index_copy_(0, shard.rel_ids_on(att.device), g_att_l)
             all_reduce_packed([g_x, g_basis, g_att], shard.group)
