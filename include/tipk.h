@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 1
+#define TIPK_ABI_VERSION 2
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -57,8 +57,15 @@ int         tipk_device_info(int device, int* n_cu, int* lds_bytes_per_cu, int* 
  *   items[w] = { begin, end, target, flags }     int32 x 4, items ordered by decreasing length
  *     flags bit0 = 1: the row has one item; `target` is the output row and the epilogue
  *                     (row_scale, bias, relu) is applied here;
- *     flags bit0 = 0: the row is split; `target` is a slot of `partial` ([n_slots x d], dense);
+ *     flags = 0:      the row is split; `target` is a slot of `partial` ([n_slots x d], dense);
  *                     `tipk_gather_sum_finalize` adds the row's slots in order (deterministic).
+ *   Plans built with group_slots = G > 0 never use `partial`: the pieces of a split row occupy
+ *   consecutive items inside one aligned block of G items, padded with null items, and are added
+ *   in item order through LDS by the kernel itself:
+ *     flags bit1 (2): piece; flags bit2 (4): first piece of its row, (flags >> 8) pieces in all,
+ *                     `target` = output row, epilogue applied; flags bit3 (8): null item.
+ *   One workgroup runs one block: G * lanes-per-item threads (lanes per item = next pow2 of d/4,
+ *   or of d when d % 4 != 0) must be a multiple of 64 and <= 1024 (G = 128: d <= 32).
  * d = floats per row (d % 4 == 0: 4..256, or any d <= 64); ld_* = row strides in floats
  * (multiples of 4 when d % 4 == 0; table/out/partial 16-byte aligned in that case).
  */
@@ -69,7 +76,7 @@ int tipk_gather_sum(const float* table, int64_t ld_table,
                     float* partial /* nullable when no item is split */,
                     const float* row_scale /* nullable, per out row */,
                     const float* bias /* nullable, [d] */, int relu,
-                    int d, tipk_stream_t stream);
+                    int d, int group_slots /* G of the plan, 0 = none */, tipk_stream_t stream);
 
 /* rows[m] = { out_row, first_slot, end_slot } int32 x 3: out[out_row] = epi(sum partial[slots]).
  * max_slots: largest slot count of any row (host knows it from the plan; 0 = unknown) -- picks
@@ -93,25 +100,33 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *     d: power of two >= 4; n_nodes <= 65535; the columns are cut into blocks until a block's table
  *     (+ accumulators when backward = 0) fits in 158 KB of LDS -- `tipk_rel_gather_supported`.
  *
- *     Relation-local plan (tip_amd/plan.py `build_rel_plan`), all device arrays:
- *       node_at[n_rel][n_nodes] uint16: output node at position p of relation r; positions are
- *                               ordered by decreasing run length inside the relation
- *       rel_idx_off[n_rel]      int64 offset of the relation's ids in idx (multiple of 8: segments
+ *     Relation-local plan (tip_amd/plan.py `build_rel_plan`), all device arrays.  The plan is a
+ *     list of n_units WORK UNITS: a unit is one relation, or -- for relations much larger than the
+ *     per-workgroup average, which would otherwise set the length of the launch -- every k-th output
+ *     position of one relation:
+ *       unit_rel[n_units]       int32 relation of the unit (selects the Y_r block / the dY rows)
+ *       unit_npos[n_units]      int32 positions the unit walks (backward: all its positions, so every
+ *                               dY row is written exactly once; forward: those with edges)
+ *       node_at[n_units][n_nodes] uint16: output node at position p of the unit; positions are
+ *                               ordered by decreasing run length
+ *       unit_idx_off[n_units]   int64 offset of the unit's ids in idx (multiple of 8: segments
  *                               are padded so they can be staged with 16-byte loads)
- *       rel_len[n_rel]          int32 edges of the relation
+ *       unit_len[n_units]       int32 ids of the unit (runs padded to multiples of 8 with the
+ *                               sentinel id n_nodes, whose table row is zero)
  *       idx[..]                 uint16 table node of each edge (16-byte aligned array); inside a
- *                               relation the edges are sorted by the position of their OUTPUT node
- *       runs[n_rel][n_nodes][2] (begin relative to the relation's first edge, length) per position
- *       wg_rel_ptr[n_wg+1], wg_rels[n_rel]   relations handled by each of the n_wg workgroups
- *                               (edge-balanced; n_wg = number of CUs)
+ *                               unit the edges are sorted by the position of their OUTPUT node
+ *       runs[n_units][n_nodes][2] (begin relative to the unit's first id, padded length) per position
+ *       wg_unit_ptr[n_wg+1], wg_units[n_units]   units handled by each of the n_wg workgroups
+ *                               (longest-processing-time deal; n_wg = number of CUs)
  */
 /* host predicate: number of column blocks the launch will use (grid = n_wg x blocks), 0 = the
  * shape is not supported (use tipk_gather_sum).  row_scale (backward only, nullable): the table
  * rows are multiplied by row_scale[node] while they are staged (g' = g / deg fused). */
 int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
-                    int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
-                    const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
+                    int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* wg_units,
+                    const int32_t* unit_rel, const int32_t* unit_npos,
+                    const int64_t* unit_idx_off, const int32_t* unit_len, const uint16_t* idx,
                     const int32_t* runs, const uint16_t* node_at, const float* row_scale,
                     float* out, int64_t ld_out, tipk_stream_t stream);
 

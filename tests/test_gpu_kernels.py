@@ -55,6 +55,38 @@ def test_gather_sum(ops, d, chunk, weighted):
     assert float(out[-5:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('d', [4, 16, 32, 64, 128, 6])
+@pytest.mark.parametrize('chunk,weighted', [(16, True), (2, False)])
+def test_gather_sum_grouped_plan(ops, d, chunk, weighted):
+    """group_slots plans: split rows are combined inside the workgroup (no partial buffer, no
+    finalize launch) -- oracle parity, bit-reproducible, and wrong widths are refused."""
+    from tip_amd.plan import build_gather_plan, group_slots_for
+    g = torch.Generator().manual_seed(d * 11 + chunk)
+    n_out, n_tab, E = 301, 157, 9000
+    out_row = torch.randint(0, n_out - 5, (E,), generator=g)
+    out_row[:2500] = 17                                                # hub row
+    tab_row = torch.randint(0, n_tab, (E,), generator=g)
+    w = torch.rand(E, generator=g) if weighted else None
+    table = torch.randn(n_tab, d, generator=g)
+    scale = torch.rand(n_out, generator=g) + 0.5
+    bias = torch.randn(d, generator=g)
+    G = group_slots_for(d)
+    plan = build_gather_plan(out_row, tab_row, n_out, n_tab, w, chunk, group_slots=G).to(DEV)
+    assert plan.n_slots == 0
+    want = O.gather_sum(table.double(), tab_row, out_row, n_out, None if w is None else w.double())
+    got = ops.gather_sum(plan, table.to(DEV), row_scale=scale.to(DEV), bias=bias.to(DEV), relu=True)
+    close(got, torch.relu(want * scale.double().unsqueeze(1) + bias.double()))
+    assert torch.equal(got, ops.gather_sum(plan, table.to(DEV), row_scale=scale.to(DEV), bias=bias.to(DEV), relu=True))
+    out = torch.full((n_out, d), 7.0, device=DEV)
+    ops.gather_sum(plan, table.to(DEV), out=out)
+    close(out, want)
+    assert float(out[-5:].abs().max()) == 0.0
+    if d == 128:                                                       # 64 items x 32 lanes: more than one workgroup
+        bad = build_gather_plan(out_row, tab_row, n_out, n_tab, w, chunk, group_slots=64).to(DEV)
+        with pytest.raises(Exception):
+            ops.gather_sum(bad, table.to(DEV))
+
+
 def test_gather_sum_strided_views_and_determinism(ops):
     from tip_amd.plan import build_gather_plan
     g = torch.Generator().manual_seed(5)
@@ -318,9 +350,17 @@ def test_rel_gather_fwd_bwd(ops, d):
     close(got, O.gather_sum(y.double(), rel * N + src, dst, N))
     assert torch.equal(got, ops.rel_gather(plan, y.to(DEV), backward=False))    # bitwise reproducible
     gp = torch.randn(N, d, generator=g)
-    planb = build_rel_plan(src, dst, rel, N, R, n_wg=256).to(DEV)
+    planb = build_rel_plan(src, dst, rel, N, R, n_wg=256, backward=True).to(DEV)
     gotb = ops.rel_gather(planb, gp.to(DEV), backward=True)
     close(gotb, O.gather_sum(gp.double(), dst, rel * N + src, R * N))
+    # big relations dealt to several work units (the BioSNAP plans do this for the top relations)
+    plan_u = build_rel_plan(dst, src, rel, N, R, n_wg=256, max_unit=5000).to(DEV)
+    assert plan_u.n_units > R
+    close(ops.rel_gather(plan_u, y.to(DEV), backward=False), O.gather_sum(y.double(), rel * N + src, dst, N))
+    planb_u = build_rel_plan(src, dst, rel, N, R, n_wg=256, backward=True, max_unit=5000).to(DEV)
+    out_u = ops.rel_gather(planb_u, gp.to(DEV), backward=True)
+    close(out_u, O.gather_sum(gp.double(), dst, rel * N + src, R * N))
+    assert torch.equal(out_u, ops.rel_gather(planb_u, gp.to(DEV), backward=True))
     # few workgroups (several relations each) and strided table
     plan3 = build_rel_plan(dst, src, rel, N, R, n_wg=2).to(DEV)
     wide = torch.randn(R * N, d + 8, generator=g).to(DEV)

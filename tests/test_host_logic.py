@@ -44,6 +44,44 @@ def test_gather_plan_semantics(chunk, weighted):
     assert plan.items.dtype == torch.int32 and plan.row_id.dtype == torch.int32
 
 
+@pytest.mark.parametrize('chunk,G', [(16, 32), (4, 8), (1, 128), (64, 4)])
+def test_grouped_gather_plan_semantics(chunk, G):
+    """group_slots: pieces of a split row are consecutive inside one aligned block, leader first."""
+    from tip_amd.plan import ITEM_DIRECT, ITEM_LEADER, ITEM_NULL, ITEM_PIECE, group_slots_for, pack_blocks
+    g = torch.Generator().manual_seed(chunk * 100 + G)
+    n_out, n_tab, E, d = 57, 31, 3000, 6
+    out_row = torch.randint(0, n_out - 3, (E,), generator=g)
+    out_row[:1200] = 5                                                # hub row: more than G chunks -> longer pieces
+    tab_row = torch.randint(0, n_tab, (E,), generator=g)
+    w = torch.rand(E, generator=g)
+    table = torch.randn(n_tab, d, generator=g, dtype=torch.float64)
+    plan = build_gather_plan(out_row, tab_row, n_out, n_tab, w, chunk, group_slots=G)
+    assert plan.group_slots == G and plan.n_slots == 0 and plan.split_rows.shape[0] == 0
+    got = execute_plan_reference(plan, table)                         # also asserts block containment
+    want = O.gather_sum(table, tab_row, out_row, n_out, w.double())
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-9)
+    it = plan.items.long()
+    fl = it[:, 3]
+    assert int((it[:, 1] - it[:, 0]).sum()) == E                      # every edge exactly once
+    n_grouped = int(((fl & (ITEM_PIECE | ITEM_NULL)) != 0).sum())
+    assert n_grouped % G == 0 and bool(((fl[:n_grouped] & ITEM_DIRECT) == 0).all())
+    assert bool((fl[n_grouped:] == ITEM_DIRECT).all())
+    lens = (it[:, 1] - it[:, 0])[n_grouped:]
+    assert bool((lens[:-1] >= lens[1:]).all())                        # direct items sorted by length
+    lead = it[(fl & ITEM_LEADER) != 0]
+    rows = set(lead[:, 2].tolist()) | set(it[n_grouped:, 2].tolist())
+    assert rows == set(range(n_out)) and lead.shape[0] + (it.shape[0] - n_grouped) == n_out
+    assert int((lead[:, 3] >> 8).max()) <= G
+    # packing helper: no block overflows, rows do not overlap
+    block, offset, n_blocks = pack_blocks([5, 3, 3, 8, 2, 7, 1], 8)
+    used = {}
+    for b, o, p in zip(block, offset, [5, 3, 3, 8, 2, 7, 1]):
+        assert o + p <= 8 and all(not (o < o2 + p2 and o2 < o + p) for o2, p2 in used.get(b, []))
+        used.setdefault(b, []).append((o, p))
+    assert n_blocks == 4                                              # 29 slots of 8: best fit is optimal here
+    assert [group_slots_for(d) for d in (4, 16, 32, 64, 128, 256, 3, 50)] == [128, 128, 128, 64, 32, 16, 128, 16]
+
+
 def test_gather_plan_empty_and_bounds():
     plan = build_gather_plan(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 4, 3)
     assert plan.items.shape == (4, 4) and plan.n_slots == 0
@@ -184,16 +222,23 @@ def test_rel_plan_semantics():
     dst = torch.randint(0, N - 3, (E,), generator=g)
     dst[:300] = 2                                                              # a hub node
     y = torch.randn(R * N, d, generator=g, dtype=torch.float64)
-    plan = build_rel_plan(dst, src, rel, N, R, n_wg=4)
     want = torch.zeros(N, d, dtype=torch.float64).index_add_(0, dst, y[rel * N + src])
-    torch.testing.assert_close(execute_rel_plan_reference(plan, y, False), want)
     gp = torch.randn(N, d, generator=g, dtype=torch.float64)
-    planb = build_rel_plan(src, dst, rel, N, R, n_wg=4)
     wantb = torch.zeros(R * N, d, dtype=torch.float64).index_add_(0, rel * N + src, gp[dst])
-    torch.testing.assert_close(execute_rel_plan_reference(planb, gp, True), wantb)
-    assert plan.idx.dtype == torch.uint16 and plan.runs.shape == (R, N, 2)
-    assert plan.node_at.shape == (R, N) and int(plan.node_at[0, 0]) == 2            # hub first in relation 0
-    assert sorted(plan.wg_rels.tolist()) == list(range(R)) and plan.wg_rel_ptr.tolist()[-1] == R
+    for max_unit in (10 ** 9, 64, 8):                                         # one unit per relation ... many shares
+        plan = build_rel_plan(dst, src, rel, N, R, n_wg=4, max_unit=max_unit)
+        torch.testing.assert_close(execute_rel_plan_reference(plan, y, False), want)
+        planb = build_rel_plan(src, dst, rel, N, R, n_wg=4, backward=True, max_unit=max_unit)
+        torch.testing.assert_close(execute_rel_plan_reference(planb, gp, True), wantb)   # + every row written once
+        U = plan.n_units
+        assert plan.idx.dtype == torch.uint16 and plan.runs.shape == (U, N, 2) and plan.node_at.shape == (U, N)
+        assert sorted(plan.wg_rels.tolist()) == list(range(U)) and plan.wg_rel_ptr.tolist()[-1] == U
+        assert plan.unit_rel.tolist() == sorted(plan.unit_rel.tolist()) and set(plan.unit_rel.tolist()) == set(range(R))
+        assert int(plan.node_at[0, 0]) == 2                                   # hub first in relation 0's first unit
+        if max_unit == 10 ** 9:
+            assert U == R and planb.unit_npos.tolist() == [N] * R
+        else:
+            assert U > R and int(plan.rel_len.max()) <= max(max_unit, 304) + 8 * N   # hub run of 300 edges cannot be cut
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
     loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]
     assert sorted(loads) == [14, 14]

@@ -13,6 +13,13 @@
 
 namespace {
 
+// items[:, 3]: how a work item delivers its sum (tip_amd/plan.py)
+constexpr int ITEM_DIRECT = 1;      // the whole row: epilogue + store
+constexpr int ITEM_PIECE = 2;       // piece of a row combined inside the workgroup
+constexpr int ITEM_LEADER = 4;      // first piece: adds the next (flags >> 8) - 1 slots and stores
+constexpr int ITEM_NULL = 8;        // padding of a block
+                                    // 0: piece of a row combined by tipk_gather_sum_finalize
+
 struct Epilogue {
     const float* row_scale;
     const float* bias;
@@ -66,8 +73,9 @@ struct Acc<1> {
     __device__ __forceinline__ void store(float* p) const { *p = v; }
 };
 
-template <int V, int L, bool HAS_W>
-__global__ __launch_bounds__(256) void gather_sum_kernel(
+// GROUPED: the workgroup is exactly one block of G = blockDim / L items of a `group_slots` plan.
+template <int V, int L, bool HAS_W, bool GROUPED>
+__global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
     const float* __restrict__ table, int64_t ld_table, const int32_t* __restrict__ row_id,
     const float* __restrict__ edge_w, const int4* __restrict__ items, int64_t n_items,
     float* __restrict__ out, int64_t ld_out, float* __restrict__ partial, Epilogue ep, int d) {
@@ -126,8 +134,23 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(
             }
         }
     }
-    if (!active || !col_ok) return;
-    if (it.w & 1) {
+    const int fl = active ? it.w : ITEM_NULL;
+    if (GROUPED) {
+        // pieces of a split row sit in consecutive slots of this workgroup: the leader adds them in
+        // slot order through LDS (fixed order -> reproducible; no partial buffer, no second launch)
+        extern __shared__ __attribute__((aligned(16))) unsigned char comb_raw[];
+        Acc<V>* comb = reinterpret_cast<Acc<V>*>(comb_raw);
+        if (fl & ITEM_PIECE) comb[threadIdx.x] = acc;
+        __syncthreads();
+        if ((fl & ITEM_LEADER) && col_ok) {
+            const int cnt = fl >> 8;
+            for (int j = 1; j < cnt; ++j) acc.add(comb[threadIdx.x + j * L]);
+            acc.epilogue(ep, it.z, col);
+            acc.store(out + (int64_t)it.z * ld_out + col);
+        }
+    }
+    if (!col_ok || (fl & (ITEM_PIECE | ITEM_NULL))) return;
+    if (fl & ITEM_DIRECT) {
         acc.epilogue(ep, it.z, col);
         acc.store(out + (int64_t)it.z * ld_out + col);
     } else {
@@ -194,17 +217,31 @@ int launch_finalize_small(const float* partial, const int32_t* rows, int64_t n_r
 template <int V, int L>
 int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, const float* edge_w,
                   const int32_t* items, int64_t n_items, float* out, int64_t ld_out, float* partial,
-                  Epilogue ep, int d, hipStream_t st) {
+                  Epilogue ep, int d, int group_slots, hipStream_t st) {
     constexpr int SLOTS = TIPK_WAVE / L;
+    const int4* it4 = reinterpret_cast<const int4*>(items);
+    if (group_slots > 0) {                              // one workgroup = one block of the plan
+        const int threads = group_slots * L;
+        if (threads > 1024 || threads % TIPK_WAVE != 0) return TIPK_EUNSUPPORTED;
+        const int64_t blocks = tipk_ceil_div(n_items, group_slots);
+        if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+        const size_t lds = (size_t)threads * sizeof(Acc<V>);
+        if (edge_w)
+            hipLaunchKernelGGL((gather_sum_kernel<V, L, true, true>), dim3((unsigned)blocks), dim3(threads), lds, st,
+                               table, ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
+        else
+            hipLaunchKernelGGL((gather_sum_kernel<V, L, false, true>), dim3((unsigned)blocks), dim3(threads), lds, st,
+                               table, ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
+        TIPK_RETURN_LAUNCH();
+    }
     const int64_t waves = tipk_ceil_div(n_items, SLOTS);
     const int64_t blocks = tipk_ceil_div(waves, 4);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
-    const int4* it4 = reinterpret_cast<const int4*>(items);
     if (edge_w)
-        hipLaunchKernelGGL((gather_sum_kernel<V, L, true>), dim3((unsigned)blocks), dim3(256), 0, st, table,
+        hipLaunchKernelGGL((gather_sum_kernel<V, L, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, table,
                            ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
     else
-        hipLaunchKernelGGL((gather_sum_kernel<V, L, false>), dim3((unsigned)blocks), dim3(256), 0, st, table,
+        hipLaunchKernelGGL((gather_sum_kernel<V, L, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, table,
                            ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
     TIPK_RETURN_LAUNCH();
 }
@@ -222,8 +259,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, const int32_t* row_id,
                                const float* edge_w, const int32_t* items, int64_t n_items, float* out,
                                int64_t ld_out, float* partial, const float* row_scale, const float* bias,
-                               int relu, int d, tipk_stream_t stream) {
-    if (n_items < 0 || d <= 0 || !items || !out || (n_items > 0 && (!table || !row_id))) return TIPK_EINVAL;
+                               int relu, int d, int group_slots, tipk_stream_t stream) {
+    if (n_items < 0 || d <= 0 || group_slots < 0 || !items || !out || (n_items > 0 && (!table || !row_id)))
+        return TIPK_EINVAL;
     if (n_items == 0) return TIPK_OK;
     if (!aligned16(items)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -231,7 +269,8 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, const int32
     const bool vec = d % 4 == 0 && ld_table % 4 == 0 && ld_out % 4 == 0 && aligned16(table) && aligned16(out) &&
                      (!partial || aligned16(partial)) && (!bias || aligned16(bias));
 #define TIPK_GS(V, L) \
-    return launch_gather<V, L>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, partial, ep, d, st)
+    return launch_gather<V, L>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, partial, ep, d, \
+                               group_slots, st)
     if (vec) {
         if (d > 256) return TIPK_EUNSUPPORTED;
         switch (pow2_at_least(d / 4)) {

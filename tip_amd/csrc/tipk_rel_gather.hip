@@ -17,6 +17,10 @@
 //        tipk_sum_slabs.  When table + accumulators exceed the LDS the columns are processed in
 //        `n_split` independent column blocks (blockIdx.y).
 //   BWD: the run sum IS the output row (relation, node): written straight to dY.
+// Work units: a relation much larger than the per-workgroup average (BioSNAP: 51 466 edges against
+// 32 525) would set the length of the whole launch, so the plan deals the positions of such a relation
+// round-robin to k units (each stages the relation's table again and walks every k-th position); units
+// are assigned to workgroups by a longest-processing-time deal.
 // Results are bitwise reproducible (fixed order everywhere).
 #include <stdlib.h>
 #include "tipk_common.h"
@@ -28,8 +32,9 @@ constexpr int RG_CHUNK = 16384;        // edge ids staged per pass (uint16: 32 K
 struct RgArgs {
     const float* table; int64_t ld_t;
     int n_nodes, dc;                   // dc = columns handled by one column block
-    const int32_t* wg_rel_ptr; const int32_t* wg_rels;
-    const int64_t* rel_idx_off; const int32_t* rel_len;
+    const int32_t* wg_rel_ptr; const int32_t* wg_rels;      // work units of every workgroup
+    const int32_t* unit_rel; const int32_t* unit_npos;      // unit -> relation, positions to walk
+    const int64_t* rel_idx_off; const int32_t* rel_len;     // per unit
     const uint16_t* idx; const int32_t* runs; const uint16_t* node_at;
     float* out; int64_t ld_out;
     const float* row_scale;            // BWD: g' = row_scale[node] * table[node] applied while staging (nullable)
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
         iv0 = isrc[t < n8 ? t : last];
         iv1 = isrc[1024 + t < n8 ? 1024 + t : last];
         if (!BWD) {
-            const float* src = table + (int64_t)rel * n_nodes * a.ld_t;
+            const float* src = table + (int64_t)a.unit_rel[rel] * n_nodes * a.ld_t;
             RG_TLOAD(0, tv0) RG_TLOAD(1, tv1) RG_TLOAD(2, tv2) RG_TLOAD(3, tv3)
             RG_TLOAD(4, tv4) RG_TLOAD(5, tv5) RG_TLOAD(6, tv6) RG_TLOAD(7, tv7)
         }
@@ -140,9 +145,11 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     const int ri0 = a.wg_rel_ptr[wg], ri1 = a.wg_rel_ptr[wg + 1];
     if (ri0 < ri1) prefetch(a.wg_rels[ri0]);
     for (int ri = ri0; ri < ri1; ++ri) {
-        const int rel = a.wg_rels[ri];
+        const int rel = a.wg_rels[ri];                 // a work unit: one relation, or a share of a big one
         const int64_t e0 = a.rel_idx_off[rel];         // multiple of 8 ids: 16-byte aligned segment
         const int ne = a.rel_len[rel];
+        const int npos = a.unit_npos[rel];
+        const int64_t row0 = (int64_t)a.unit_rel[rel] * n_nodes;
         __syncthreads();                               // readers of the previous relation are done
         commit(rel);
         __syncthreads();
@@ -162,11 +169,11 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 __syncthreads();
             }
             if (a.dbg & 1) continue;
-            for (int pb = 0, band = 0; pb < n_nodes; pb += NS, ++band) {
+            for (int pb = 0, band = 0; pb < npos; pb += NS, ++band) {
                 // snake deal of the length-sorted rows: band 0 ascending, band 1 descending, ... so the
                 // slot that got the longest row of one band gets the shortest of the next
                 const int p = pb + ((band & 1) ? NS - 1 - slot : slot);
-                if (p >= n_nodes) continue;
+                if (p >= npos) continue;
                 const int b = run_l[2 * p], len = run_l[2 * p + 1];
                 if (!BWD && len == 0) continue;
                 int lo = b > cb ? b : cb;                // b, len, cb, cn are multiples of 8
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 }
                 const int node = node_l[p];
                 if (BWD) {
-                    float* o = out + ((int64_t)rel * n_nodes + node) * a.ld_out + c0;
+                    float* o = out + (row0 + node) * a.ld_out + c0;
                     if (cb > 0 && lo < hi) {           // a run continued from the previous id chunk
                         const float4 old = tipk_ld4(o);
                         acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
@@ -264,10 +271,11 @@ extern "C" int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward) {
 
 extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                                int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
+                               const int32_t* unit_rel, const int32_t* unit_npos,
                                const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
                                const int32_t* runs, const uint16_t* node_at, const float* row_scale, float* out,
                                int64_t ld_out, tipk_stream_t stream) {
-    if (n_wg <= 0 || n_wg > 65535 || !table || !wg_rel_ptr || !wg_rels || !rel_idx_off || !rel_len || !idx || !runs ||
+    if (n_wg <= 0 || n_wg > 65535 || !table || !wg_rel_ptr || !wg_rels || !unit_rel || !unit_npos || !rel_idx_off || !rel_len || !idx || !runs ||
         !node_at || !out || (reinterpret_cast<uintptr_t>(idx) & 15))
         return TIPK_EINVAL;
     const int split = rel_gather_split(n_nodes, d, backward != 0);
@@ -278,7 +286,7 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     const char* dbg_env = getenv("TIPK_RG_DEBUG");
     RgArgs a;
     a.table = table; a.ld_t = ld_table; a.n_nodes = (int)n_nodes; a.dc = d / split;
-    a.wg_rel_ptr = wg_rel_ptr; a.wg_rels = wg_rels; a.rel_idx_off = rel_idx_off; a.rel_len = rel_len;
+    a.wg_rel_ptr = wg_rel_ptr; a.wg_rels = wg_rels; a.unit_rel = unit_rel; a.unit_npos = unit_npos; a.rel_idx_off = rel_idx_off; a.rel_len = rel_len;
     a.idx = idx; a.runs = runs; a.node_at = node_at; a.out = out; a.ld_out = ld_out;
     a.row_scale = backward ? row_scale : nullptr;
     a.dbg = dbg_env ? atoi(dbg_env) : 0;

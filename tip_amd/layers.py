@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import build_gather_plan, build_rel_plan, DEFAULT_CHUNK
+from .plan import build_gather_plan, build_rel_plan, group_slots_for, DEFAULT_CHUNK
 from .utils import process_edges, auprc_auroc_ap_by_range
 
 EPS = 1e-13                    # src/layers.py:15
@@ -119,9 +119,11 @@ class _Lin(nn.Module):
         self.weight.data.uniform_(-bound, bound)
 
 
-def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK):
+def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK, d=None):
     """Normalised adjacency D^-1/2 (A + I) D^-1/2 as a pair of gather plans: existing self loops
-    are replaced by exactly one unit loop per node, deg = in-degree incl. the loop, inf -> 0."""
+    are replaced by exactly one unit loop per node, deg = in-degree incl. the loop, inf -> 0.
+    d: width of the rows the plans will aggregate (enables in-workgroup combination of split rows)."""
+    G = group_slots_for(d) if d else 0
     row, col = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     keep = row != col
     loop = torch.arange(num_nodes, device=row.device)
@@ -130,8 +132,8 @@ def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK):
     dis = deg.pow(-0.5)
     dis[torch.isinf(dis)] = 0
     w = dis[row] * dis[col]
-    return ops.AggGraph(build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd'),
-                        build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd'))
+    return ops.AggGraph(build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd', G),
+                        build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd', G))
 
 
 class GCNConv(nn.Module):
@@ -151,7 +153,7 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index, fuse_relu=False):
         n = x.shape[0]
-        graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk))
+        graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels))
         if _is_identity_features(x):
             xl = ops.linear_t(None, self.lin.weight)                  # = W^T, one transpose kernel
         elif x.is_sparse:
@@ -179,7 +181,7 @@ class PPEncoder(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # A2  MyHierarchyConv   (src/layers.py:196-247)
 # ---------------------------------------------------------------------------------------------
-def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None):
+def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None, d=None):
     """mean over incoming edges in the concatenated node space, rows [n_source:] only.
     table_rows: rows of the table actually handed to the kernel (n_all for the concatenated
     tensor, n_source when only the source block is passed and no edge starts beyond it)."""
@@ -189,8 +191,9 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     n_t = n_all - n_source
     n_tab = n_all if table_rows is None else table_rows
     cnt = torch.bincount(dst, minlength=n_t).to(torch.float32).clamp_(min=1)
-    return ops.AggGraph(build_gather_plan(dst, src, n_t, n_tab, None, chunk, 'pd.fwd'),
-                        build_gather_plan(src, dst, n_tab, n_t, None, chunk, 'pd.bwd'), (1.0 / cnt).contiguous())
+    G = group_slots_for(d) if d else 0
+    return ops.AggGraph(build_gather_plan(dst, src, n_t, n_tab, None, chunk, 'pd.fwd', G),
+                        build_gather_plan(src, dst, n_tab, n_t, None, chunk, 'pd.bwd', G), (1.0 / cnt).contiguous())
 
 
 class MyHierarchyConv(nn.Module):
@@ -219,7 +222,7 @@ class MyHierarchyConv(nn.Module):
     def forward(self, x, edge_index, range_list=None):
         n_all = x.shape[0]
         graph = self._cache.get((edge_index,), lambda: hier_graph(edge_index, n_all, self.unique_source_num,
-                                                                  self.chunk))
+                                                                  self.chunk, d=self.in_dim))
         mean = ops.aggregate(x, graph)
         out = ops.matmul(mean, self.weight)
         assert out.shape[0] == self.unique_target_num
@@ -235,7 +238,7 @@ class MyHierarchyConv(nn.Module):
         def build():
             if edge_index.numel() and int(edge_index[0].max()) >= n_src:
                 return None
-            return hier_graph(edge_index, n_all, n_src, self.chunk, table_rows=n_src)
+            return hier_graph(edge_index, n_all, n_src, self.chunk, table_rows=n_src, d=self.in_dim)
         graph = self._cache_src.get((edge_index,), build)
         if graph is None:
             return None
@@ -274,7 +277,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from
         split = ops.rel_gather_split(n_nodes, d_out, False) if (d_out and src.is_cuda) else 1
         # the forward launch is (workgroups x column blocks): keep it at one workgroup per CU
         rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, max(1, n_wg // max(1, split)))
-        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, n_wg)
+        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, n_wg, backward=True)
     return ops.AggGraph(build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
                         build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd)

@@ -123,7 +123,7 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
     with _timed('gather_sum[%s,d=%d]' % (plan.tag, d)):
         check(L.tipk_gather_sum(ptr(table), table.stride(0), ptr(plan.row_id), ptr(plan.edge_w), ptr(plan.items),
                                 plan.items.shape[0], ptr(out), out.stride(0), ptr(partial), ptr(row_scale),
-                                ptr(bias), int(relu), d, st), 'tipk_gather_sum')
+                                ptr(bias), int(relu), d, plan.group_slots, st), 'tipk_gather_sum')
     if plan.n_slots:
         check(L.tipk_gather_sum_finalize(ptr(partial), ptr(plan.split_rows), plan.split_rows.shape[0], ptr(out),
                                          out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, plan.max_slots, st),
@@ -173,7 +173,8 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
         out = torch.empty((rp.n_wg, n, d), dtype=torch.float32, device=table.device)
     with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
         check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
-                                    ptr(rp.wg_rels), ptr(rp.rel_idx_off), ptr(rp.rel_len), ptr(rp.idx), ptr(rp.runs),
+                                    ptr(rp.wg_rels), ptr(rp.unit_rel), ptr(rp.unit_npos), ptr(rp.rel_idx_off), ptr(rp.rel_len),
+                                    ptr(rp.idx), ptr(rp.runs),
                                     ptr(rp.node_at), ptr(row_scale) if backward else None, ptr(out), d,
                                     stream_ptr(table.device)), 'tipk_rel_gather')
     if backward or not reduce:

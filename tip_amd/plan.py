@@ -10,7 +10,11 @@ The reference re-derives everything from COO `edge_index` on every call (PyG `pr
     up to 70 715 in-edges, SURVEY.md section 0 -- become many equal items; short rows one item);
   * items are ordered by decreasing length so the slots of one wavefront finish together;
   * rows that were split get consecutive slots in a `partial` buffer, summed in slot order by
-    `tipk_gather_sum_finalize` -> results do not depend on scheduling (no float atomics).
+    `tipk_gather_sum_finalize` -> results do not depend on scheduling (no float atomics);
+  * with `group_slots` = G the pieces of a split row are instead placed in consecutive slots of ONE
+    workgroup (blocks of G slots, best-fit packed, padded with null items) and added in order through
+    LDS by the gather kernel itself: no partial buffer and no second launch (P-P and P->D graphs,
+    where half of the rows are split and the finalize launch costs as much as a third of the gather).
 
 Everything here is index arithmetic in torch (runs on CPU or GPU; unit-tested on CPU).  The layout
 of `items` / `split_rows` is the contract of include/tipk.h section 1.
@@ -32,6 +36,9 @@ def auto_chunk(n_edges):
     return c
 
 
+ITEM_DIRECT, ITEM_PIECE, ITEM_LEADER, ITEM_NULL = 1, 2, 4, 8      # items[:, 3] bits; leader: pieces << 8
+
+
 class GatherPlan(object):
     """Device-resident plan.  Fields (all int32 unless noted):
     row_id [E]        source-table row per edge, in plan (sorted) order
@@ -39,32 +46,74 @@ class GatherPlan(object):
     items [n_items,4] (begin, end, target, flags)
     split_rows [m,3]  (out_row, first_slot, end_slot)
     perm [E] int64    plan order -> caller's edge order (for re-weighting)
+    group_slots       0, or the block size G of the in-workgroup combination (see module doc)
     """
 
-    def __init__(self, n_out, n_table, row_id, edge_w, items, split_rows, n_slots, perm, chunk, tag=''):
+    def __init__(self, n_out, n_table, row_id, edge_w, items, split_rows, n_slots, perm, chunk, tag='',
+                 group_slots=0):
         self.tag = tag
         self.n_out, self.n_table = int(n_out), int(n_table)
         self.row_id, self.edge_w = row_id, edge_w
         self.items, self.split_rows = items, split_rows
         self.n_slots, self.perm, self.chunk = int(n_slots), perm, int(chunk)
+        self.group_slots = int(group_slots)
         self.n_edges = int(row_id.numel())
         self.max_slots = int((split_rows[:, 2] - split_rows[:, 1]).max()) if split_rows.shape[0] else 0
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
         return GatherPlan(self.n_out, self.n_table, mv(self.row_id), mv(self.edge_w), mv(self.items),
-                          mv(self.split_rows), self.n_slots, mv(self.perm), self.chunk, self.tag)
+                          mv(self.split_rows), self.n_slots, mv(self.perm), self.chunk, self.tag, self.group_slots)
 
     @property
     def device(self):
         return self.items.device
 
 
-def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEFAULT_CHUNK, tag=''):
+def group_slots_for(d):
+    """Block size G for plans whose rows are d floats wide: one workgroup of G * L threads runs one
+    block (L lanes per item = next power of two of d/4 for vectorised rows, of d otherwise), at most
+    1024 threads and at least one wavefront.  G = 128 for d <= 32 (hub rows of up to 128 pieces)."""
+    lanes = 1
+    need = d // 4 if d % 4 == 0 else d
+    while lanes < need:
+        lanes *= 2
+    return max(min(128, 1024 // lanes), 64 // lanes)
+
+
+def pack_blocks(pieces, cap):
+    """Best-fit-decreasing packing of rows with `pieces[i]` (<= cap) consecutive slots into blocks of
+    `cap` slots.  -> (block, offset) per row, number of blocks.  Deterministic."""
+    order = sorted(range(len(pieces)), key=lambda i: (-pieces[i], i))
+    free = [[] for _ in range(cap + 1)]             # free[c] = blocks with c slots left (stack)
+    used = []                                       # slots used per block
+    block = [0] * len(pieces)
+    offset = [0] * len(pieces)
+    for i in order:
+        p = pieces[i]
+        b = -1
+        for c in range(p, cap + 1):
+            if free[c]:
+                b = free[c].pop()
+                break
+        if b < 0:
+            b = len(used)
+            used.append(0)
+        block[i], offset[i] = b, used[b]
+        used[b] += p
+        if cap - used[b] > 0:
+            free[cap - used[b]].append(b)
+    return block, offset, len(used)
+
+
+def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEFAULT_CHUNK, tag='', group_slots=0):
     """Plan for  out[o] = sum_{e: out_row[e]=o} edge_w[e] * table[table_row[e]].
 
     out_row, table_row: int64 [E] (any device); n_out / n_table: row counts of `out` / `table`.
     Every output row gets at least one (possibly empty) item, so the kernel also writes the zeros.
+    group_slots: 0 = split rows go through the partial buffer + finalize launch; G > 0 = split rows
+    are combined inside one workgroup (a row is cut into at most G balanced pieces; one workgroup
+    runs one block, see `group_slots_for`).
     """
     dev = out_row.device
     E = int(out_row.numel())
@@ -84,15 +133,48 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     row_ptr[1:] = torch.cumsum(counts, 0)
 
     n_chunks = torch.clamp((counts + chunk - 1) // chunk, min=1)            # items per row
+    piece_len = torch.full_like(n_chunks, chunk)
+    if group_slots:
+        n_chunks = torch.clamp(n_chunks, max=group_slots)                    # hub rows: longer pieces, one workgroup
+        piece_len = torch.clamp((counts + n_chunks - 1) // n_chunks, min=1)  # balanced pieces
     item_ptr = torch.zeros(n_out + 1, dtype=torch.long, device=dev)
     item_ptr[1:] = torch.cumsum(n_chunks, 0)
     n_items = int(item_ptr[-1])
     item_row = torch.repeat_interleave(torch.arange(n_out, device=dev), n_chunks)
     local = torch.arange(n_items, device=dev) - item_ptr[item_row]
-    begin = row_ptr[item_row] + local * chunk
-    end = torch.minimum(begin + chunk, row_ptr[item_row + 1])
-
+    row_end = row_ptr[item_row + 1]
+    begin = torch.minimum(row_ptr[item_row] + local * piece_len[item_row], row_end)
+    end = torch.minimum(begin + piece_len[item_row], row_end)
     direct = n_chunks[item_row] == 1
+
+    row_id = table_row[order].to(torch.int32).contiguous()
+    w = None if edge_w is None else edge_w[order].to(torch.float32).contiguous()
+    split = torch.nonzero(n_chunks > 1).view(-1)
+
+    if group_slots:
+        G = int(group_slots)
+        pieces = n_chunks[split].tolist()
+        block, offset, n_blocks = pack_blocks(pieces, G)
+        grouped = torch.zeros((n_blocks * G, 4), dtype=torch.long, device=dev)
+        grouped[:, 3] = ITEM_NULL
+        if split.numel():
+            base = torch.tensor(block, device=dev) * G + torch.tensor(offset, device=dev)      # first slot per row
+            pc = n_chunks[split]
+            src = torch.repeat_interleave(item_ptr[split], pc) + \
+                (torch.arange(int(pc.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(pc, 0) - pc, pc))
+            dst = torch.repeat_interleave(base, pc) + (src - torch.repeat_interleave(item_ptr[split], pc))
+            lead = src == torch.repeat_interleave(item_ptr[split], pc)
+            flags = torch.where(lead, ITEM_PIECE | ITEM_LEADER | (torch.repeat_interleave(pc, pc) << 8),
+                                torch.full_like(src, ITEM_PIECE))
+            grouped[dst] = torch.stack([begin[src], end[src], item_row[src], flags], dim=1)
+        d_idx = torch.nonzero(direct).view(-1)
+        by_len = torch.sort((end - begin)[d_idx], descending=True, stable=True).indices
+        d_idx = d_idx[by_len]
+        plain = torch.stack([begin[d_idx], end[d_idx], item_row[d_idx], torch.full_like(d_idx, ITEM_DIRECT)], dim=1)
+        items = torch.cat([grouped, plain], 0).to(torch.int32).contiguous()
+        split_rows = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+        return GatherPlan(n_out, n_table, row_id, w, items, split_rows, 0, order, chunk, tag, G)
+
     slot = torch.cumsum((~direct).long(), 0) - 1                             # slot id of split items
     target = torch.where(direct, item_row, slot)
     n_slots = int((~direct).sum())
@@ -100,15 +182,11 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     by_len = torch.sort(end - begin, descending=True, stable=True).indices
     items = torch.stack([begin, end, target, direct.long()], dim=1)[by_len].to(torch.int32).contiguous()
 
-    split = torch.nonzero(n_chunks > 1).view(-1)
     if split.numel():
         first = slot[item_ptr[split]]
         split_rows = torch.stack([split, first, first + n_chunks[split]], dim=1).to(torch.int32).contiguous()
     else:
         split_rows = torch.zeros((0, 3), dtype=torch.int32, device=dev)
-
-    row_id = table_row[order].to(torch.int32).contiguous()
-    w = None if edge_w is None else edge_w[order].to(torch.float32).contiguous()
     return GatherPlan(n_out, n_table, row_id, w, items, split_rows, n_slots, order, chunk, tag)
 
 
@@ -126,13 +204,24 @@ def execute_plan_reference(plan, table, row_scale=None):
         rows = rows * plan.edge_w[edge_pos].unsqueeze(1)
     per_item = torch.zeros((it.shape[0], d), dtype=table.dtype, device=table.device).index_add_(0, item_of_edge, rows)
     out = torch.zeros((plan.n_out, d), dtype=table.dtype, device=table.device)
-    direct = it[:, 3] == 1
+    direct = (it[:, 3] & ITEM_DIRECT) != 0
     out[it[direct, 2]] = per_item[direct]
     if plan.n_slots:
+        part = it[:, 3] == 0
         partial = torch.zeros((plan.n_slots, d), dtype=table.dtype, device=table.device)
-        partial[it[~direct, 2]] = per_item[~direct]
+        partial[it[part, 2]] = per_item[part]
         for r, a, b in plan.split_rows.tolist():
             out[r] = partial[a:b].sum(0)
+    if plan.group_slots:
+        G = plan.group_slots
+        for i in torch.nonzero((it[:, 3] & ITEM_LEADER) != 0).view(-1).tolist():
+            cnt = int(it[i, 3]) >> 8
+            assert i // G == (i + cnt - 1) // G, 'pieces of a row must stay inside one block'
+            assert bool(((it[i:i + cnt, 3] & ITEM_PIECE) != 0).all()) and bool((it[i:i + cnt, 2] == it[i, 2]).all())
+            acc = per_item[i].clone()
+            for j in range(1, cnt):                  # the kernel's order: leader first, then slot by slot
+                acc = acc + per_item[i + j]
+            out[it[i, 2]] = acc
     if row_scale is not None:
         out = out * row_scale.unsqueeze(1)
     return out
@@ -142,16 +231,22 @@ def execute_plan_reference(plan, table, row_scale=None):
 # relation-local plans (include/tipk.h section 1b): LDS-resident D-D aggregation
 # ---------------------------------------------------------------------------------------------
 class RelPlan(object):
-    """Device arrays of `tipk_rel_gather` for one direction of a multi-relational graph."""
+    """Device arrays of `tipk_rel_gather` for one direction of a multi-relational graph (layout:
+    include/tipk.h section 1b).  Per work unit: unit_rel, unit_npos, node_at, rel_idx_off, rel_len,
+    runs; wg_rel_ptr / wg_rels = units of every workgroup."""
 
-    def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_idx_off, rel_len, idx, runs, wg_rel_ptr, wg_rels):
+    def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_idx_off, rel_len, idx, runs, wg_rel_ptr, wg_rels,
+                 unit_rel, unit_npos):
         self.n_nodes, self.n_rel, self.n_wg = int(n_nodes), int(n_rel), int(n_wg)
         self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs = node_at, rel_idx_off, rel_len, idx, runs
         self.wg_rel_ptr, self.wg_rels = wg_rel_ptr, wg_rels
+        self.unit_rel, self.unit_npos = unit_rel, unit_npos
+        self.n_units = int(unit_rel.numel())
 
     def to(self, device):
         return RelPlan(self.n_nodes, self.n_rel, self.n_wg, *[t.to(device) for t in (
-            self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels)])
+            self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels,
+            self.unit_rel, self.unit_npos)])
 
 
 def assign_relations(sizes, n_wg, fixed_cost=0):
@@ -175,43 +270,70 @@ def assign_relations(sizes, n_wg, fixed_cost=0):
     return torch.tensor(ptr, dtype=torch.int32), torch.tensor(flat, dtype=torch.int32)
 
 
-def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost=2048):
+def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost=2048, backward=False,
+                   max_unit=None):
     """Relation-local plan for  result[r, o] = sum_{e in r: out_node[e]=o} table_r[tab_node[e]].
 
     out_node / tab_node / rel: int64 [E]; nodes < 65536.  Inside every relation the output nodes
-    are ordered by decreasing run length (`node_at[r, p]` = node at position p) and the edges are
-    sorted by the position of their output node, so the edges of one (relation, node) pair form one
-    contiguous run and neighbouring positions have runs of similar length."""
+    are ordered by decreasing run length and the edges are sorted by the position of their output
+    node, so the edges of one (relation, node) pair form one contiguous run and neighbouring
+    positions have runs of similar length.
+
+    Work units: a relation with more than `max_unit` (padded) ids is dealt position by position to
+    k = ceil(ids / max_unit) units, so that no single relation sets the length of the launch
+    (default max_unit: a third of the per-workgroup average).  backward: the plan drives the
+    transposed pass, where every (relation, node) row must be written -> units also walk their
+    empty positions; forward units stop at their last non-empty position."""
     dev = out_node.device
     assert n_nodes <= 65535
     E = int(out_node.numel())
-    cnt_nodes = torch.bincount(rel * n_nodes + out_node, minlength=n_rel * n_nodes).view(n_rel, n_nodes)
-    node_at = torch.sort(cnt_nodes, dim=1, descending=True, stable=True).indices          # [R, N] position -> node
-    pos_of = torch.empty_like(node_at)
-    pos_of.scatter_(1, node_at, torch.arange(n_nodes, device=dev).expand(n_rel, n_nodes).contiguous())
-    key = rel * n_nodes + pos_of.view(-1)[rel * n_nodes + out_node]
-    order = torch.sort(key, stable=True).indices
-    cnt = torch.gather(cnt_nodes, 1, node_at)                                             # run length per position
+    N = n_nodes
+    cnt_nodes = torch.bincount(rel * N + out_node, minlength=n_rel * N).view(n_rel, N)
+    order_r = torch.sort(cnt_nodes, dim=1, descending=True, stable=True).indices          # [R, N] position -> node
+    pos_of = torch.empty_like(order_r)
+    pos_of.scatter_(1, order_r, torch.arange(N, device=dev).expand(n_rel, N).contiguous())
+    cnt_r = torch.gather(cnt_nodes, 1, order_r)                                           # run length per position
+    size_r = ((cnt_r + 7) // 8 * 8).sum(1)                                                # padded ids per relation
+    if max_unit is None:
+        max_unit = int(os.environ.get('TIPK_RG_MAX_UNIT', '0')) or max(4096, int(size_r.sum()) // (3 * max(n_wg, 1)))
+    k_r = torch.clamp((size_r + max_unit - 1) // max_unit, min=1, max=max(N, 1))          # units per relation
+    unit_base = torch.cumsum(k_r, 0) - k_r
+    U = int(k_r.sum())
+    unit_rel = torch.repeat_interleave(torch.arange(n_rel, device=dev), k_r)              # [U]
+    unit_j = torch.arange(U, device=dev) - unit_base[unit_rel]                            # share index inside the relation
+    unit_k = k_r[unit_rel]
+    # position q of unit (r, j) is position q * k + j of relation r
+    P = torch.arange(N, device=dev).unsqueeze(0) * unit_k.unsqueeze(1) + unit_j.unsqueeze(1)      # [U, N]
+    valid = P < N
+    Pc = torch.where(valid, P, torch.zeros_like(P))
+    node_at = torch.where(valid, order_r[unit_rel.unsqueeze(1), Pc], torch.zeros_like(P))
+    cnt = torch.where(valid, cnt_r[unit_rel.unsqueeze(1), Pc], torch.zeros_like(P))       # [U, N] run lengths
+    npos = valid.sum(1) if backward else (cnt > 0).sum(1)
     # every run is padded to a multiple of 8 ids with the sentinel id n_nodes (its table row is
-    # zero in the kernel), so runs and relation segments start 16-byte aligned and need no masks
+    # zero in the kernel), so runs and unit segments start 16-byte aligned and need no masks
     cnt8 = (cnt + 7) // 8 * 8
-    begin8 = torch.cumsum(cnt8, 1) - cnt8                                                 # relative to the relation
+    begin8 = torch.cumsum(cnt8, 1) - cnt8                                                 # relative to the unit
     runs = torch.stack([begin8, cnt8], dim=2).to(torch.int32).contiguous()
-    rel_sizes = cnt8.sum(1)                                                               # padded ids per relation
-    off = torch.cumsum(rel_sizes, 0) - rel_sizes
-    total = int(rel_sizes.sum()) + 8
-    # destination of every (sorted) edge: relation offset + run begin + rank inside the run
+    unit_sizes = cnt8.sum(1)
+    off = torch.cumsum(unit_sizes, 0) - unit_sizes
+    total = int(unit_sizes.sum()) + 8
+    # destination of every edge: unit offset + run begin + rank inside the run
+    p_e = pos_of.view(-1)[rel * N + out_node]
+    u_e = unit_base[rel] + p_e % k_r[rel]
+    key = u_e * N + p_e // k_r[rel]
+    order = torch.sort(key, stable=True).indices
     skey = key[order]
     run_first = torch.cumsum(cnt.view(-1), 0) - cnt.view(-1)                              # first sorted edge of a run
     rank = torch.arange(E, device=dev) - run_first[skey]
-    dest = off[skey // n_nodes] + begin8.view(-1)[skey] + rank
-    idx32 = torch.full((total,), n_nodes, dtype=torch.int32, device=dev)
+    dest = off[skey // N] + begin8.view(-1)[skey] + rank
+    idx32 = torch.full((total,), N, dtype=torch.int32, device=dev)
     idx32[dest] = tab_node[order].to(torch.int32)
     idx = idx32.to(torch.uint16).contiguous()
-    wg_ptr, wg_rels = assign_relations(rel_sizes.tolist(), n_wg, fixed_cost)
-    return RelPlan(n_nodes, n_rel, n_wg, node_at.to(torch.int32).to(torch.uint16).contiguous(),
-                   off.to(torch.int64).contiguous(), rel_sizes.to(torch.int32).contiguous(), idx, runs,
-                   wg_ptr.to(dev), wg_rels.to(dev))
+    wg_ptr, wg_rels = assign_relations(unit_sizes.tolist(), n_wg, fixed_cost)
+    return RelPlan(N, n_rel, n_wg, node_at.to(torch.int32).to(torch.uint16).contiguous(),
+                   off.to(torch.int64).contiguous(), unit_sizes.to(torch.int32).contiguous(), idx, runs,
+                   wg_ptr.to(dev), wg_rels.to(dev), unit_rel.to(torch.int32).contiguous(),
+                   npos.to(torch.int32).contiguous())
 
 
 def execute_rel_plan_reference(plan, table, backward):
@@ -220,17 +342,25 @@ def execute_rel_plan_reference(plan, table, backward):
     d = table.shape[1]
     idx = plan.idx.to(torch.int64)
     runs = plan.runs.to(torch.int64)
-    node_at = plan.node_at.to(torch.int64)                 # [R, N]
+    node_at = plan.node_at.to(torch.int64)                 # [U, N]
     res = torch.zeros((R, n, d), dtype=table.dtype)
-    for r in range(R):
-        e0 = int(plan.rel_idx_off[r])
+    written = torch.zeros((R, n), dtype=torch.long)
+    for u in range(plan.n_units):
+        r = int(plan.unit_rel[u])
+        e0 = int(plan.rel_idx_off[u])
         assert e0 % 8 == 0
-        for p in range(n):
-            b, ln = int(runs[r, p, 0]), int(runs[r, p, 1])
+        for p in range(int(plan.unit_npos[u])):
+            b, ln = int(runs[u, p, 0]), int(runs[u, p, 1])
+            written[r, node_at[u, p]] += 1
             if ln:
                 assert b % 8 == 0 and ln % 8 == 0
                 rows = idx[e0 + b:e0 + b + ln]
                 rows = rows[rows < n]                                  # drop the padding sentinel
                 src = table[rows] if backward else table[r * n + rows]
-                res[r, node_at[r, p]] = src.sum(0)
-    return res.view(R * n, d) if backward else res.sum(0)
+                res[r, node_at[u, p]] = src.sum(0)
+        assert int(runs[u, int(plan.unit_npos[u]):, 1].sum()) == 0     # nothing beyond the walked positions
+    if backward:
+        assert bool((written == 1).all()), 'every (relation, node) row is written exactly once'
+        return res.view(R * n, d)
+    assert int(written.max()) <= 1
+    return res.sum(0)

@@ -6,7 +6,7 @@ from tip_amd.plan import build_rel_plan
 dd = build_data_dict(); dev = 'cuda:0'
 ei = dd['dd_train_idx'].to(dev); rg = dd['dd_train_range']; R = dd['n_dd_et']; N = 645
 rel = torch.repeat_interleave(torch.arange(R), rg[:, 1] - rg[:, 0]).to(dev)
-pf = build_rel_plan(ei[1], ei[0], rel, N, R, 256); pb = build_rel_plan(ei[0], ei[1], rel, N, R, 256)
+pf = build_rel_plan(ei[1], ei[0], rel, N, R, 256); pb = build_rel_plan(ei[0], ei[1], rel, N, R, 256, backward=True)
 def t(f, n=20):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
