@@ -104,19 +104,19 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *     list of n_units WORK UNITS: a unit is one relation, or -- for relations much larger than the
  *     per-workgroup average, which would otherwise set the length of the launch -- every k-th output
  *     position of one relation:
- *       unit_rel[n_units]       int32 relation of the unit (selects the Y_r block / the dY rows)
- *       unit_npos[n_units]      int32 positions the unit walks (backward: all its positions, so every
- *                               dY row is written exactly once; forward: those with edges)
  *       node_at[n_units][n_nodes] uint16: output node at position p of the unit; positions are
  *                               ordered by decreasing run length
- *       unit_idx_off[n_units]   int64 offset of the unit's ids in idx (multiple of 8: segments
- *                               are padded so they can be staged with 16-byte loads)
- *       unit_len[n_units]       int32 ids of the unit (runs padded to multiples of 8 with the
- *                               sentinel id n_nodes, whose table row is zero)
- *       idx[..]                 uint16 table node of each edge (16-byte aligned array); inside a
- *                               unit the edges are sorted by the position of their OUTPUT node
  *       runs[n_units][n_nodes][2] (begin relative to the unit's first id, padded length) per position
- *       wg_unit_ptr[n_wg+1], wg_units[n_units]   units handled by each of the n_wg workgroups
+ *       idx[..]                 uint16 table node of each edge (16-byte aligned array); inside a
+ *                               unit the edges are sorted by the position of their OUTPUT node; runs
+ *                               are padded to multiples of 8 ids with the sentinel id n_nodes, whose
+ *                               table row is zero
+ *       unit_meta[n_units][8]   int32 descriptors, listed in the order the workgroups process them:
+ *                               { unit (row of node_at / runs), relation (selects the Y_r block / the
+ *                               dY rows), n_pos (positions to walk: backward all of the unit's, so
+ *                               every dY row is written exactly once; forward those with edges),
+ *                               n_ids (padded), idx offset low, idx offset high (multiple of 8), 0, 0 }
+ *       wg_unit_ptr[n_wg+1]     range of unit_meta handled by each of the n_wg workgroups
  *                               (longest-processing-time deal; n_wg = number of CUs)
  */
 /* host predicate: number of column blocks the launch will use (grid = n_wg x blocks), 0 = the
@@ -124,11 +124,9 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  * rows are multiplied by row_scale[node] while they are staged (g' = g / deg fused). */
 int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
-                    int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* wg_units,
-                    const int32_t* unit_rel, const int32_t* unit_npos,
-                    const int64_t* unit_idx_off, const int32_t* unit_len, const uint16_t* idx,
-                    const int32_t* runs, const uint16_t* node_at, const float* row_scale,
-                    float* out, int64_t ld_out, tipk_stream_t stream);
+                    int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* unit_meta,
+                    const uint16_t* idx, const int32_t* runs, const uint16_t* node_at,
+                    const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).

@@ -235,6 +235,12 @@ def test_rel_plan_semantics():
         assert sorted(plan.wg_rels.tolist()) == list(range(U)) and plan.wg_rel_ptr.tolist()[-1] == U
         assert plan.unit_rel.tolist() == sorted(plan.unit_rel.tolist()) and set(plan.unit_rel.tolist()) == set(range(R))
         assert int(plan.node_at[0, 0]) == 2                                   # hub first in relation 0's first unit
+        meta = plan.unit_meta.long()                                          # descriptors in workgroup order
+        assert meta.shape == (U, 8) and meta[:, 0].tolist() == plan.wg_rels.tolist()
+        assert meta[:, 1].tolist() == plan.unit_rel[meta[:, 0]].tolist()
+        assert meta[:, 2].tolist() == plan.unit_npos[meta[:, 0]].tolist()
+        assert meta[:, 3].tolist() == plan.rel_len[meta[:, 0]].tolist()
+        assert (meta[:, 4] + (meta[:, 5] << 32)).tolist() == plan.rel_idx_off[meta[:, 0]].tolist()
         if max_unit == 10 ** 9:
             assert U == R and planb.unit_npos.tolist() == [N] * R
         else:

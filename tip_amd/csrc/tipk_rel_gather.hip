@@ -28,13 +28,13 @@
 namespace {
 
 constexpr int RG_CHUNK = 16384;        // edge ids staged per pass (uint16: 32 KB)
+constexpr int RG_META = 64;            // unit descriptors staged per batch (LDS: 2 KB)
 
 struct RgArgs {
     const float* table; int64_t ld_t;
     int n_nodes, dc;                   // dc = columns handled by one column block
-    const int32_t* wg_rel_ptr; const int32_t* wg_rels;      // work units of every workgroup
-    const int32_t* unit_rel; const int32_t* unit_npos;      // unit -> relation, positions to walk
-    const int64_t* rel_idx_off; const int32_t* rel_len;     // per unit
+    const int32_t* wg_unit_ptr;        // [n_wg + 1] range of every workgroup in unit_meta
+    const int32_t* unit_meta;          // [n_units][8] in workgroup order: unit, relation, n_pos, n_ids, idx_off lo/hi
     const uint16_t* idx; const int32_t* runs; const uint16_t* node_at;
     float* out; int64_t ld_out;
     const float* row_scale;            // BWD: g' = row_scale[node] * table[node] applied while staging (nullable)
@@ -56,6 +56,9 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     int32_t* run_l = reinterpret_cast<int32_t*>(accl + (BWD ? 0 : (int64_t)n_nodes * dc));     // [n_nodes][2]
     uint16_t* node_l = reinterpret_cast<uint16_t*>(run_l + ((2 * n_nodes + 3) & ~3));  // [n_nodes] (+pad)
     uint16_t* idx_l = node_l + ((n_nodes + 7) & ~7);                                   // [RG_CHUNK], 16-B aligned
+    // unit descriptors of this workgroup, staged once: reading them from global memory per unit cost
+    // four dependent round trips (unit id -> offsets -> ...) that nothing could hide (one workgroup per CU)
+    int32_t* meta_l = reinterpret_cast<int32_t*>(idx_l + RG_CHUNK);                    // [RG_META][8]
     const int slot = t / L, sub = t & (L - 1), c0 = sub * 4;
     const int col0 = blockIdx.y * dc;                  // column block of this workgroup
     const float* table = a.table + col0;
@@ -87,28 +90,28 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
         const int i = U * 1024 + t;                                            \
         if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, V); } \
     }
-    auto prefetch = [&](int rel) {
-        const int32_t* rsrc = a.runs + (int64_t)rel * n_nodes * 2;
+    auto prefetch = [&](const int32_t* m) {            // m = the unit's descriptor (in LDS)
+        const int unit = m[0], ne = m[3];
+        const int64_t off = (int64_t)(uint32_t)m[4] | ((int64_t)m[5] << 32);
+        const int32_t* rsrc = a.runs + (int64_t)unit * n_nodes * 2;
         rv0 = rsrc[t < 2 * n_nodes ? t : 2 * n_nodes - 1];
         rv1 = rsrc[1024 + t < 2 * n_nodes ? 1024 + t : 2 * n_nodes - 1];
-        nv = a.node_at[(int64_t)rel * n_nodes + (t < n_nodes ? t : n_nodes - 1)];
-        const int ne = a.rel_len[rel];
+        nv = a.node_at[(int64_t)unit * n_nodes + (t < n_nodes ? t : n_nodes - 1)];
         const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
         const int last = n8 > 0 ? n8 - 1 : 0;
-        const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + a.rel_idx_off[rel]);
+        const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + off);
         iv0 = isrc[t < n8 ? t : last];
         iv1 = isrc[1024 + t < n8 ? 1024 + t : last];
         if (!BWD) {
-            const float* src = table + (int64_t)a.unit_rel[rel] * n_nodes * a.ld_t;
+            const float* src = table + (int64_t)m[1] * n_nodes * a.ld_t;
             RG_TLOAD(0, tv0) RG_TLOAD(1, tv1) RG_TLOAD(2, tv2) RG_TLOAD(3, tv3)
             RG_TLOAD(4, tv4) RG_TLOAD(5, tv5) RG_TLOAD(6, tv6) RG_TLOAD(7, tv7)
         }
     };
-    auto commit = [&](int rel) {                       // registers -> LDS
+    auto commit = [&](int ne) {                        // registers -> LDS
         if (t < 2 * n_nodes) run_l[t] = rv0;
         if (1024 + t < 2 * n_nodes) run_l[1024 + t] = rv1;
         if (t < n_nodes) node_l[t] = nv;
-        const int ne = a.rel_len[rel];
         const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
         uint4* idst = reinterpret_cast<uint4*>(idx_l);
         if (t < n8) idst[t] = iv0;
@@ -142,18 +145,22 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
         }
     }
     const int wg = blockIdx.x;
-    const int ri0 = a.wg_rel_ptr[wg], ri1 = a.wg_rel_ptr[wg + 1];
-    if (ri0 < ri1) prefetch(a.wg_rels[ri0]);
-    for (int ri = ri0; ri < ri1; ++ri) {
-        const int rel = a.wg_rels[ri];                 // a work unit: one relation, or a share of a big one
-        const int64_t e0 = a.rel_idx_off[rel];         // multiple of 8 ids: 16-byte aligned segment
-        const int ne = a.rel_len[rel];
-        const int npos = a.unit_npos[rel];
-        const int64_t row0 = (int64_t)a.unit_rel[rel] * n_nodes;
-        __syncthreads();                               // readers of the previous relation are done
-        commit(rel);
+    const int ri0 = a.wg_unit_ptr[wg], ri1 = a.wg_unit_ptr[wg + 1];
+    for (int rb = ri0; rb < ri1; rb += RG_META) {      // batches of RG_META units (one batch in practice)
+    const int rn = ri1 - rb < RG_META ? ri1 - rb : RG_META;
+    __syncthreads();                                   // the previous batch's descriptors are no longer read
+    if (t < rn * 8) meta_l[t] = a.unit_meta[(int64_t)rb * 8 + t];
+    __syncthreads();
+    prefetch(meta_l);
+    for (int ri = 0; ri < rn; ++ri) {
+        const int32_t* m = meta_l + ri * 8;            // a work unit: one relation, or a share of a big one
+        const int npos = m[2], ne = m[3];
+        const int64_t e0 = (int64_t)(uint32_t)m[4] | ((int64_t)m[5] << 32);   // multiple of 8 ids: 16-byte aligned
+        const int64_t row0 = (int64_t)m[1] * n_nodes;
+        __syncthreads();                               // readers of the previous unit are done
+        commit(ne);
         __syncthreads();
-        if (ri + 1 < ri1) prefetch(a.wg_rels[ri + 1]);             // in flight during the compute below
+        if (ri + 1 < rn && !(a.dbg & 2)) prefetch(m + 8);          // in flight during the compute below
         for (int cb = 0; cb == 0 || cb < ne; cb += RG_CHUNK) {
             const int cn = ne - cb < RG_CHUNK ? ne - cb : RG_CHUNK;
             if (cb > 0) {                              // rare: a relation with more than RG_CHUNK ids
@@ -164,8 +171,12 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 const int last = n8 > 0 ? n8 - 1 : 0;
                 const uint4 j0 = isrc[t < n8 ? t : last];
                 const uint4 j1 = isrc[1024 + t < n8 ? 1024 + t : last];
-                if (t < n8) idst[t] = j0;
-                if (1024 + t < n8) idst[1024 + t] = j1;
+                // unconditional stores (2 x 1024 uint4 = the whole buffer; entries past n8 are never
+                // read): a store under `if (t < n8)` leaves the load pending on the not-taken path and
+                // the compiler then puts a vmcnt(0) wait into the position loop below, which would also
+                // wait for the next unit's prefetch -- i.e. serialise staging and compute
+                idst[t] = j0;
+                idst[1024 + t] = j1;
                 __syncthreads();
             }
             if (a.dbg & 1) continue;
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
             }
         }
     }
+    }
     if (!BWD) {
         __syncthreads();
         float* o = out + (int64_t)wg * n_nodes * a.ld_out;
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
 
 inline int64_t rel_gather_lds(int64_t n_nodes, int dc, bool bwd) {
     return (n_nodes + 1) * (dc + 4) * 4 + (bwd ? 0 : n_nodes * dc * 4) + ((2 * n_nodes + 3) & ~3LL) * 4 +
-           ((n_nodes + 7) & ~7LL) * 2 + RG_CHUNK * 2;
+           ((n_nodes + 7) & ~7LL) * 2 + RG_CHUNK * 2 + RG_META * 8 * 4;
 }
 
 constexpr int64_t RG_LDS_LIMIT = 158 * 1024;
@@ -270,13 +282,11 @@ extern "C" int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward) {
 }
 
 extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
-                               int64_t n_wg, const int32_t* wg_rel_ptr, const int32_t* wg_rels,
-                               const int32_t* unit_rel, const int32_t* unit_npos,
-                               const int64_t* rel_idx_off, const int32_t* rel_len, const uint16_t* idx,
-                               const int32_t* runs, const uint16_t* node_at, const float* row_scale, float* out,
-                               int64_t ld_out, tipk_stream_t stream) {
-    if (n_wg <= 0 || n_wg > 65535 || !table || !wg_rel_ptr || !wg_rels || !unit_rel || !unit_npos || !rel_idx_off || !rel_len || !idx || !runs ||
-        !node_at || !out || (reinterpret_cast<uintptr_t>(idx) & 15))
+                               int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* unit_meta,
+                               const uint16_t* idx, const int32_t* runs, const uint16_t* node_at,
+                               const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table || !wg_unit_ptr || !unit_meta || !idx || !runs || !node_at || !out ||
+        (reinterpret_cast<uintptr_t>(idx) & 15))
         return TIPK_EINVAL;
     const int split = rel_gather_split(n_nodes, d, backward != 0);
     if (split == 0) return TIPK_EUNSUPPORTED;
@@ -286,7 +296,7 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     const char* dbg_env = getenv("TIPK_RG_DEBUG");
     RgArgs a;
     a.table = table; a.ld_t = ld_table; a.n_nodes = (int)n_nodes; a.dc = d / split;
-    a.wg_rel_ptr = wg_rel_ptr; a.wg_rels = wg_rels; a.unit_rel = unit_rel; a.unit_npos = unit_npos; a.rel_idx_off = rel_idx_off; a.rel_len = rel_len;
+    a.wg_unit_ptr = wg_unit_ptr; a.unit_meta = unit_meta;
     a.idx = idx; a.runs = runs; a.node_at = node_at; a.out = out; a.ld_out = ld_out;
     a.row_scale = backward ? row_scale : nullptr;
     a.dbg = dbg_env ? atoi(dbg_env) : 0;

@@ -173,10 +173,9 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
         out = torch.empty((rp.n_wg, n, d), dtype=torch.float32, device=table.device)
     with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
         check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
-                                    ptr(rp.wg_rels), ptr(rp.unit_rel), ptr(rp.unit_npos), ptr(rp.rel_idx_off), ptr(rp.rel_len),
-                                    ptr(rp.idx), ptr(rp.runs),
-                                    ptr(rp.node_at), ptr(row_scale) if backward else None, ptr(out), d,
-                                    stream_ptr(table.device)), 'tipk_rel_gather')
+                                    ptr(rp.unit_meta), ptr(rp.idx), ptr(rp.runs), ptr(rp.node_at),
+                                    ptr(row_scale) if backward else None, ptr(out), d, stream_ptr(table.device)),
+              'tipk_rel_gather')
     if backward or not reduce:
         return out
     return sum_slabs(out)

@@ -232,21 +232,30 @@ def execute_plan_reference(plan, table, row_scale=None):
 # ---------------------------------------------------------------------------------------------
 class RelPlan(object):
     """Device arrays of `tipk_rel_gather` for one direction of a multi-relational graph (layout:
-    include/tipk.h section 1b).  Per work unit: unit_rel, unit_npos, node_at, rel_idx_off, rel_len,
-    runs; wg_rel_ptr / wg_rels = units of every workgroup."""
+    include/tipk.h section 1b).  Per work unit: node_at, runs (+ unit_rel, unit_npos, rel_idx_off,
+    rel_len, which the kernel reads through `unit_meta`, the descriptors in workgroup order);
+    wg_rel_ptr = range of every workgroup in unit_meta, wg_rels = the same order as unit ids."""
 
     def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_idx_off, rel_len, idx, runs, wg_rel_ptr, wg_rels,
-                 unit_rel, unit_npos):
+                 unit_rel, unit_npos, unit_meta=None):
         self.n_nodes, self.n_rel, self.n_wg = int(n_nodes), int(n_rel), int(n_wg)
         self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs = node_at, rel_idx_off, rel_len, idx, runs
         self.wg_rel_ptr, self.wg_rels = wg_rel_ptr, wg_rels
         self.unit_rel, self.unit_npos = unit_rel, unit_npos
         self.n_units = int(unit_rel.numel())
+        if unit_meta is None:
+            u = wg_rels.long()
+            off = rel_idx_off[u]
+            unit_meta = torch.stack([u, unit_rel[u].long(), unit_npos[u].long(), rel_len[u].long(),
+                                     off & 0xffffffff, off >> 32, torch.zeros_like(u), torch.zeros_like(u)], dim=1)
+            unit_meta = (unit_meta & 0xffffffff).to(torch.int64)
+            unit_meta = torch.where(unit_meta >= 2 ** 31, unit_meta - 2 ** 32, unit_meta).to(torch.int32).contiguous()
+        self.unit_meta = unit_meta
 
     def to(self, device):
         return RelPlan(self.n_nodes, self.n_rel, self.n_wg, *[t.to(device) for t in (
             self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels,
-            self.unit_rel, self.unit_npos)])
+            self.unit_rel, self.unit_npos, self.unit_meta)])
 
 
 def assign_relations(sizes, n_wg, fixed_cost=0):
@@ -281,7 +290,7 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
 
     Work units: a relation with more than `max_unit` (padded) ids is dealt position by position to
     k = ceil(ids / max_unit) units, so that no single relation sets the length of the launch
-    (default max_unit: a third of the per-workgroup average).  backward: the plan drives the
+    (default max_unit: 1.2x / 0.55x the per-workgroup average, forward / backward).  backward: the plan drives the
     transposed pass, where every (relation, node) row must be written -> units also walk their
     empty positions; forward units stop at their last non-empty position."""
     dev = out_node.device
@@ -295,7 +304,10 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
     cnt_r = torch.gather(cnt_nodes, 1, order_r)                                           # run length per position
     size_r = ((cnt_r + 7) // 8 * 8).sum(1)                                                # padded ids per relation
     if max_unit is None:
-        max_unit = int(os.environ.get('TIPK_RG_MAX_UNIT', '0')) or max(4096, int(size_r.sum()) // (3 * max(n_wg, 1)))
+        # measured on BioSNAP (tools/bench_relgather.py): forward units re-stage the relation's table, so
+        # only relations above ~1.2x the per-workgroup average are cut; backward units are cheap (0.55x)
+        mean_load = int(size_r.sum()) // max(n_wg, 1)
+        max_unit = int(os.environ.get('TIPK_RG_MAX_UNIT', '0')) or max(4096, int(mean_load * (0.55 if backward else 1.2)))
     k_r = torch.clamp((size_r + max_unit - 1) // max_unit, min=1, max=max(N, 1))          # units per relation
     unit_base = torch.cumsum(k_r, 0) - k_r
     U = int(k_r.sum())

@@ -1,3 +1,5 @@
+"""Time tipk_rel_gather on the BioSNAP D-D graph for several work-unit sizes (and debug modes).
+usage: python3 tools/bench_relgather.py [max_unit ...]   (0 = one unit per relation)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tip_amd import ops
@@ -6,13 +8,23 @@ from tip_amd.plan import build_rel_plan
 dd = build_data_dict(); dev = 'cuda:0'
 ei = dd['dd_train_idx'].to(dev); rg = dd['dd_train_range']; R = dd['n_dd_et']; N = 645
 rel = torch.repeat_interleave(torch.arange(R), rg[:, 1] - rg[:, 0]).to(dev)
-pf = build_rel_plan(ei[1], ei[0], rel, N, R, 256); pb = build_rel_plan(ei[0], ei[1], rel, N, R, 256, backward=True)
-def t(f, n=20):
+
+
+def t(f, n=30):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
-for d in (32, 16):
-    y = torch.randn(R * N, d, device=dev); g = torch.randn(N, d, device=dev)
-    for dbg in (0, 1, 2, 4, 7, 3):
-        os.environ['TIPK_RG_DEBUG'] = str(dbg)
-        print('d=%d dbg=%d  fwd %.1f us   bwd %.1f us' % (d, dbg, t(lambda: ops.rel_gather(pf, y, False)), t(lambda: ops.rel_gather(pb, g, True))))
+
+
+for mu in [int(x) for x in sys.argv[1:]] or [0]:
+    mu_ = mu or 10 ** 9
+    for d in (32, 16):
+        split = ops.rel_gather_split(N, d, False)
+        pf = build_rel_plan(ei[1], ei[0], rel, N, R, 256 // split, max_unit=mu_)
+        pb = build_rel_plan(ei[0], ei[1], rel, N, R, 256, backward=True, max_unit=mu_)
+        y = torch.randn(R * N, d, device=dev); g = torch.randn(N, d, device=dev)
+        for dbg in ((0, 1) if mu == 0 else (0,)):
+            os.environ['TIPK_RG_DEBUG'] = str(dbg)
+            print('max_unit %6d units %d/%d d=%d dbg=%d  fwd %.1f us   bwd %.1f us' % (
+                mu, pf.n_units, pb.n_units, d, dbg, t(lambda: ops.rel_gather(pf, y, False, reduce=False)),
+                t(lambda: ops.rel_gather(pb, g, True))))
