@@ -175,12 +175,15 @@ int tipk_sum_slabs(const float* in, int64_t n_slabs, int64_t slab_stride, int64_
 int tipk_sum_slabs_ex(const float* in, int64_t n_slabs, int64_t slab_stride, int64_t count,
                       float alpha, int accumulate, const float* row_scale, int64_t cols,
                       const float* addend, int relu, float* out, tipk_stream_t stream);
-/* the same for up to TIPK_GROUP_MAX independent slab sets in one launch (arguments as above) */
+/* the same for up to TIPK_GROUP_MAX independent slab sets in one launch (arguments as above);
+ * gate (nullable, [count]): out[i] = gate[i] > 0 ? value : 0 -- the ReLU backward of the layer that
+ * produced the gradient's input (src/layers.py:547), applied while the gradient is finished. */
 typedef struct tipk_slab_sum_desc {
     const float* in; int64_t n_slabs, slab_stride, count;
     float alpha; int accumulate;
     const float* row_scale; int64_t cols;
     const float* addend; int relu;
+    const float* gate;
     float* out;
 } tipk_slab_sum_desc;
 int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, int32_t count, tipk_stream_t stream);

@@ -155,6 +155,54 @@ def test_gemm_is_exact_fp32_fma_chain(ops):
     assert torch.equal(ops.gemm(eye.to(DEV), b[:45].contiguous().to(DEV)).cpu(), b[:45])
 
 
+@pytest.mark.parametrize('kind,m,n,k,ks', [
+    ('thin_k', 1097, 4100, 32, None), ('thin_k', 300, 5000, 20, None), ('thin_k', 257, 4097, 1, None),
+    ('thin_m', 32, 40000, 1097, 4), ('thin_m', 20, 33000, 300, 3), ('thin_m', 32, 33000, 257, None),
+    ('kk', 1097, 32, 20640, 57), ('kk', 500, 17, 4100, 5), ('kk', 260, 32, 4096, None)])
+def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
+    """The three wave-level streaming products (tipk_gemm.hip): Y = att.XB, dXB = att^T.dY, datt = dY.XB^T
+    shapes incl. ragged tiles / k tails; the generic LDS-tiled kernel (TIPK_NO_STREAM_GEMM) is the cross-check."""
+    import os
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(k, n, generator=g)
+    want = a.double() @ b.double()
+    ad, bd = a.to(DEV), b.to(DEV)
+    if kind == 'kk':
+        monkeypatch.setenv('TIPK_STREAM_KK', '1')                      # off by default (the tiled kernel is as fast)
+    if kind == 'thin_m':
+        ad = ad.t().contiguous().t()                                   # att^T: a view with a_sm = 1
+    if kind == 'kk':
+        bd = bd.t().contiguous().t()                                   # XB^T: k-contiguous B
+    got = ops.gemm(ad, bd, ksplit=ks)
+    close(got, want, rtol=2e-5, atol=1e-3)
+    os.environ['TIPK_NO_STREAM_GEMM'] = '1'
+    try:
+        ref = ops.gemm(ad, bd, ksplit=ks)
+    finally:
+        del os.environ['TIPK_NO_STREAM_GEMM']
+    close(ref, want, rtol=2e-5, atol=1e-3)
+    if kind != 'kk':
+        assert torch.equal(got, ref)                                   # same k order as the tiled kernel
+    # epilogue (alpha, c_in, relu) and membership in a grouped launch
+    if ks is None:
+        c0 = torch.randn(m, n, generator=g).to(DEV)
+        close(ops.gemm(ad, bd, c_in=c0, relu=True, alpha=0.5), torch.relu(0.5 * want + c0.cpu().double()), rtol=2e-5, atol=1e-3)
+    x = torch.randn(70, 40, generator=g).to(DEV)
+    y = torch.randn(40, 50, generator=g).to(DEV)
+    outs = ops.gemm_group([ops.gemm_job(x, y), ops.gemm_job(ad, bd, ksplit=ks), ops.gemm_job(y.t(), x.t())])
+    assert torch.equal(outs[1], got) and torch.equal(outs[0], ops.gemm(x, y)) and torch.equal(outs[2], ops.gemm(y.t(), x.t()))
+    # exact on integer data (any k pairing is exact)
+    ai = torch.randint(-4, 5, (m, k), generator=g).float()
+    bi = torch.randint(-4, 5, (k, n), generator=g).float()
+    aid, bid = ai.to(DEV), bi.to(DEV)
+    if kind == 'thin_m':
+        aid = aid.t().contiguous().t()
+    if kind == 'kk':
+        bid = bid.t().contiguous().t()
+    assert torch.equal(ops.gemm(aid, bid, ksplit=ks).cpu(), ai @ bi)
+
+
 def test_gemm_group_bit_identical_to_single_launches(ops):
     """tipk_gemm_f32_group / tipk_sum_slabs_group: the R-GCN backward's mix of shapes (batched, split-K,
     batch-reduced on top of another member's output, transposed views) in one launch == one by one."""

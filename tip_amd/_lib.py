@@ -38,6 +38,7 @@ class SlabSumDesc(C.Structure):
                 ('alpha', C.c_float), ('accumulate', C.c_int),
                 ('row_scale', C.c_void_p), ('cols', C.c_int64),
                 ('addend', C.c_void_p), ('relu', C.c_int),
+                ('gate', C.c_void_p),
                 ('out', C.c_void_p)]
 
 

@@ -8,6 +8,7 @@
 // barrier per K step; the next tile's global loads are in flight during the MFMAs).  LDS tiles
 // are k-major (As[k][m], Bs[k][n]) so the MFMA operand fetch (lane l: row l&31 of
 // k = 2*kk + (l>>5)) is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave.
+#include <stdlib.h>
 #include "tipk_common.h"
 
 namespace {
@@ -152,6 +153,288 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     gemm_body<WM, WN, A_KFAST, B_KFAST, NBUF, R>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming products: the three large GEMMs of an R-GCN layer are not compute problems but one
+// pass over a [relations x nodes*channels] matrix (91 MB at BioSNAP layer 1) with a 32-wide
+// reduction or output:
+//     Y    = att . XB        m = R,  n = N*d, k = B     (writes Y)        -> thin_k
+//     dXB  = att^T . dY      m = B,  n = N*d, k = R     (reads dY)        -> thin_m
+//     datt = dY . XB^T       m = R,  n = B,   k = N*d   (reads dY)        -> kk
+// The LDS-tiled kernel above runs them at 2.3-2.7 TB/s: a workgroup loads, multiplies and stores
+// in turn behind barriers, and at 129-212 VGPRs only 2-3 workgroups share a CU.  Here every WAVE
+// works alone -- MFMA operands are loaded straight from global memory in the register layout of
+// v_mfma_f32_32x32x2_f32 (A: lane = row, B: lane = column, k split over lane halves and registers),
+// the next operands are in flight during the MFMAs, no LDS, no barriers, ~80 VGPRs.
+// Each body gets the linear workgroup index inside its problem (so it also runs as a member of
+// gemm_f32_group_kernel).
+// ---------------------------------------------------------------------------------------------
+constexpr int THIN_K_NT = 4;           // 32-column tiles per wave (128 consecutive columns)
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, float* c_z, const float* cin_z,
+                                           int64_t m0, int64_t n0, int lane) {
+    const int64_t col = n0 + (lane & 31);
+    if (col >= g.n) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t rowi = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (rowi < g.m) {
+            float v = g.alpha * acc[r];
+            if (cin_z) v += cin_z[rowi * g.cin_sm + col];
+            if (g.relu) v = fmaxf(v, 0.f);
+            c_z[rowi * g.c_sm + col] = v;
+        }
+    }
+}
+
+// Coding rules that keep hipcc from undoing the design (all seen in the ISA of earlier versions):
+//  * wave-uniform quantities go through readfirstlane so that operand bases live in SGPRs, and lane
+//    offsets are 32-bit BYTE offsets (stream_kind checks the extents): every load is
+//    `global_load v, v_off, s[base]` -- one VGPR per address instead of a 64-bit pair;
+//  * loads are never guarded and never feed a select: out-of-range rows / columns are clamped (their
+//    products land in output rows / columns that are not stored) and out-of-range k is clamped and
+//    its A value is zeroed with a bitwise AND (a `cond ? v : 0` makes the compiler sink the load into
+//    a branch with a vmcnt(0) wait behind every single load);
+//  * the k loop handles both register buffers per iteration (no if/else on the buffer index, which
+//    bounced the accumulator between AGPRs and VGPRs every step);
+//  * a sched_barrier separates "issue the next operands" from "multiply the current ones": left alone
+//    the scheduler sinks each load next to its use to save registers (36 VGPRs, one exposed memory
+//    round trip per load).
+typedef unsigned int u32;
+
+__device__ __forceinline__ float and_mask(float v, u32 mask) { return __uint_as_float(__float_as_uint(v) & mask); }
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float ldg(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldg4(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// store of one 32x32 accumulator through a scalar base + 32-bit byte offsets (row stride c_sm floats)
+__device__ __forceinline__ void store_tile32(const GemmArgs& g, const f32x16& acc, float* c_z, const float* cin_z,
+                                             int m0, int n0, int lane) {
+    const int col = n0 + (lane & 31);
+    if (col >= (int)g.n) return;
+    const u32 c_sm = (u32)g.c_sm * 4u, cin_sm = (u32)g.cin_sm * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rowi = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (rowi < (int)g.m) {
+            float v = g.alpha * acc[r];
+            if (cin_z) v += ldg(cin_z, (u32)rowi * cin_sm + (u32)col * 4u);
+            if (g.relu) v = fmaxf(v, 0.f);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(c_z) + ((u32)rowi * c_sm + (u32)col * 4u)) = v;
+        }
+    }
+}
+
+// k <= 32, B rows contiguous in n, one k step: wave = (32-row tile, THIN_K_NT column tiles)
+__device__ __forceinline__ void gemm_thin_k_body(const GemmArgs& g, int64_t block) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, kh = lane >> 5;
+    const int M = (int)g.m, N = (int)g.n, K = (int)g.k;
+    const int m_tiles = (M + 31) / 32;
+    const int n_chunks = (N + 32 * THIN_K_NT - 1) / (32 * THIN_K_NT);
+    const int gw = uniform((int)block * 4 + (int)(threadIdx.x >> 6));   // the waves of a workgroup share the column chunk
+    const int z = uniform(gw / (m_tiles * n_chunks));
+    const int rem = gw - z * (m_tiles * n_chunks);
+    const int chunk = uniform(rem / m_tiles), mt = uniform(rem - chunk * m_tiles);
+    if (z >= g.kbatch) return;                             // kbatch holds the batch count here
+    const int m0 = mt * 32;
+    const float* __restrict__ a_z = g.a + z * g.a_sz;
+    const float* __restrict__ b_z = g.b + z * g.b_sz;
+    float* c_z = g.c + z * g.c_sz;
+    const float* cin_z = g.c_in ? g.c_in + z * g.cin_sz : nullptr;
+    const u32 a_sk = (u32)g.a_sk * 4u, b_sk = (u32)g.b_sk * 4u;
+    const u32 aoff = (u32)(m0 + row < M ? m0 + row : M - 1) * (u32)g.a_sm * 4u;
+    float av[16];
+    u32 koff[16];                                          // row offsets of B, shared by every tile
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 2 * kk + kh;
+        const u32 kc = (u32)(k < K ? k : K - 1);
+        av[kk] = and_mask(ldg(a_z, aoff + kc * a_sk), k < K ? 0xffffffffu : 0u);
+        koff[kk] = kc * b_sk;
+    }
+    // All THIN_K_NT operand tiles are requested before the first product: vmcnt counts loads AND stores
+    // (gfx9), so a load issued after a tile's stores cannot be waited for without also waiting for the
+    // write acknowledgements of those stores -- a ~2 us stall per tile when loads and stores alternate.
+    float bt[THIN_K_NT][16];
+    const int nb = chunk * (32 * THIN_K_NT);
+#pragma unroll
+    for (int j = 0; j < THIN_K_NT; ++j) {
+        const int col = nb + 32 * j + row;
+        const u32 cc = (u32)(col < N ? col : N - 1) * 4u;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) bt[j][kk] = ldg(b_z, koff[kk] + cc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < THIN_K_NT; ++j) {
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bt[j][kk], acc, 0, 0, 0);
+        store_tile32(g, acc, c_z, cin_z, m0, nb + 32 * j, lane);
+    }
+}
+
+// m <= 32, B rows contiguous in n, long k (split into slabs): wave = (slab, 32-column tile)
+__device__ __forceinline__ void gemm_thin_m_body(const GemmArgs& g, int64_t block) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, kh = lane >> 5;
+    const int M = (int)g.m, N = (int)g.n;
+    const int n_tiles = (N + 31) / 32;
+    const int gw = uniform((int)block * 4 + (int)(threadIdx.x >> 6));   // consecutive waves: consecutive column tiles of one slab
+    const int zs = uniform(gw / n_tiles);
+    const int nt = gw - zs * n_tiles;
+    const int z = uniform(zs / (int)g.ksplit);
+    const int slab = zs - z * (int)g.ksplit;
+    if (z >= g.kbatch) return;
+    const int k_lo = slab * (int)g.kchunk;
+    const int k_hi = (k_lo + (int)g.kchunk < (int)g.k) ? k_lo + (int)g.kchunk : (int)g.k;
+    const float* __restrict__ a_z = g.a + z * g.a_sz;
+    const float* __restrict__ b_z = g.b + z * g.b_sz;
+    const int n0 = nt * 32;
+    const int col = n0 + row;
+    const u32 cc = (u32)(col < N ? col : N - 1) * 4u;
+    const u32 a_sk = (u32)g.a_sk * 4u, b_sk = (u32)g.b_sk * 4u;
+    const u32 ar = (u32)(row < M ? row : M - 1) * (u32)g.a_sm * 4u;
+    // two operand buffers (a 4-deep ring was measured 30 % slower: the pass is not latency-bound)
+    float a0[16], b0[16], a1[16], b1[16];
+#define TIPK_LOAD_AB(A, B, K0)                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 16; ++kk) {                        \
+        const int k_ = (K0) + 2 * kk + kh;                                     \
+        const u32 kc_ = (u32)(k_ < k_hi ? k_ : k_hi - 1);                      \
+        A[kk] = ldg(a_z, ar + kc_ * a_sk);                                     \
+        B[kk] = ldg(b_z, kc_ * b_sk + cc);                                     \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define TIPK_MMA(A, B, K0)                                                     \
+    _Pragma("unroll") for (int kk = 0; kk < 16; ++kk)                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(A[kk], (K0) + 2 * kk + kh < k_hi ? 0xffffffffu : 0u), \
+                                                   B[kk], acc, 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc = zero16();
+    if (k_lo < k_hi) {
+        TIPK_LOAD_AB(a0, b0, k_lo)
+#pragma unroll 1
+        for (int k0 = k_lo; k0 < k_hi; k0 += 64) {         // a step beyond k_hi multiplies zeros (k mask applied at use)
+            TIPK_LOAD_AB(a1, b1, k0 + 32)
+            TIPK_MMA(a0, b0, k0)
+            TIPK_LOAD_AB(a0, b0, k0 + 64)
+            TIPK_MMA(a1, b1, k0 + 32)
+        }
+    }
+#undef TIPK_LOAD_AB
+#undef TIPK_MMA
+    float* c_z = g.c + z * g.c_sz + (int64_t)slab * g.c_ss;
+    const float* cin_z = g.c_in ? g.c_in + z * g.cin_sz : nullptr;
+    store_tile32(g, acc, c_z, cin_z, 0, n0, lane);
+}
+
+// n <= 32, BOTH operands contiguous in k (A [m x k] rows, B given as [n x k] rows), long k in slabs:
+// wave = (slab, 32-row tile).  A lane loads 4 consecutive k of its row per dwordx4; lane half h takes
+// k0 + 8q + 4h .. +3, so MFMA step (q, s) multiplies k = k0 + 8q + s (h = 0) and k0 + 8q + 4 + s
+// (h = 1) -- any pairing of k is a valid order of the fp32 sum as long as A and B agree.
+__device__ __forceinline__ void gemm_kk_body(const GemmArgs& g, int64_t block) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane & 31, kh = lane >> 5;
+    const int M = (int)g.m, N = (int)g.n;
+    const int m_tiles = (M + 31) / 32;
+    const int gw = uniform((int)block * 4 + (int)(threadIdx.x >> 6));
+    const int zs = uniform(gw / m_tiles);
+    const int mt = gw - zs * m_tiles;
+    const int z = uniform(zs / (int)g.ksplit);
+    const int slab = zs - z * (int)g.ksplit;
+    if (z >= g.kbatch) return;
+    const int k_lo = slab * (int)g.kchunk;
+    const int k_hi = (k_lo + (int)g.kchunk < (int)g.k) ? k_lo + (int)g.kchunk : (int)g.k;     // multiples of 4 (host checks)
+    const int m0 = mt * 32;
+    const float* __restrict__ a_z = g.a + z * g.a_sz;
+    const float* __restrict__ b_z = g.b + z * g.b_sz;
+    const u32 ar = (u32)(m0 + row < M ? m0 + row : M - 1) * (u32)g.a_sm * 4u;
+    const u32 br = (u32)(row < N ? row : N - 1) * (u32)g.b_sn * 4u;
+    float4 a0[4], b0[4], a1[4], b1[4];
+#define TIPK_LOAD_AB(A, B, K0)                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                            \
+        const int k_ = (K0) + 8 * q + 4 * kh;                                  \
+        const u32 kc_ = (u32)(k_ < k_hi ? k_ : k_hi - 4) * 4u;                 \
+        A[q] = ldg4(a_z, ar + kc_);                                            \
+        B[q] = ldg4(b_z, br + kc_);                                            \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define TIPK_KK_STEP(A, B, K0)                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                            \
+        const u32 mk_ = (K0) + 8 * q + 4 * kh < k_hi ? 0xffffffffu : 0u;       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(A[q].x, mk_), B[q].x, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(A[q].y, mk_), B[q].y, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(A[q].z, mk_), B[q].z, acc, 0, 0, 0); \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(A[q].w, mk_), B[q].w, acc, 0, 0, 0); \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc = zero16();
+    if (k_lo < k_hi) {
+        TIPK_LOAD_AB(a0, b0, k_lo)
+#pragma unroll 1
+        for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+            TIPK_LOAD_AB(a1, b1, k0 + 32)
+            TIPK_KK_STEP(a0, b0, k0)
+            TIPK_LOAD_AB(a0, b0, k0 + 64)
+            TIPK_KK_STEP(a1, b1, k0 + 32)
+        }
+    }
+#undef TIPK_LOAD_AB
+#undef TIPK_KK_STEP
+    float* c_z = g.c + z * g.c_sz + (int64_t)slab * g.c_ss;
+    const float* cin_z = g.c_in ? g.c_in + z * g.cin_sz : nullptr;
+    store_tile32(g, acc, c_z, cin_z, m0, 0, lane);
+}
+
+enum { STREAM_NONE = 0, STREAM_THIN_K = 1, STREAM_THIN_M = 2, STREAM_KK = 3 };
+
+// which streaming body serves this product (GemmArgs as filled by fill_args, batch = z count)
+inline int stream_kind(const GemmArgs& g, int64_t batch) {
+    if (g.kbatch != 1) return STREAM_NONE;
+    const bool big = g.m * g.n >= (1 << 20) || g.n * g.k >= (1 << 20) || g.m * g.k >= (1 << 20);
+    if (!big) return STREAM_NONE;
+    // 32-bit element offsets inside one operand (positive strides only)
+    const int64_t lim = 0x3fffffffLL;                     // byte offsets fit 32 bits
+    if (g.a_sm < 0 || g.a_sk < 0 || g.b_sk < 0 || g.b_sn < 0 || g.m > lim || g.n > lim || g.k > lim) return STREAM_NONE;
+    if ((g.m - 1) * g.a_sm + (g.k - 1) * g.a_sk >= lim || (g.k - 1) * g.b_sk + (g.n - 1) * g.b_sn >= lim) return STREAM_NONE;
+    if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && g.m >= 256 && g.n >= 1024) return STREAM_THIN_K;
+    if (g.m <= 32 && g.b_sn == 1 && g.n >= 1024 && g.k >= 256) return STREAM_THIN_M;
+    // lane-per-row dwordx4 loads keep the texture addresser 70 % busy (PMC) and the LDS-tiled kernel is as
+    // fast on this shape: the kk body only runs when asked for (TIPK_STREAM_KK=1, tests)
+    if (getenv("TIPK_STREAM_KK") && g.n <= 32 && g.a_sk == 1 && g.b_sk == 1 && g.m >= 256 && g.k >= 1024 && g.k % 4 == 0 && g.a_sm % 4 == 0 &&
+        g.b_sn % 4 == 0 && g.a_sz % 4 == 0 && g.b_sz % 4 == 0 && (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(g.b) & 15) == 0)
+        return STREAM_KK;
+    return STREAM_NONE;
+}
+
+// workgroups (4 waves each) of a streaming problem
+inline int64_t stream_blocks(int kind, const GemmArgs& g, int64_t batch) {
+    int64_t waves = 0;
+    if (kind == STREAM_THIN_K) waves = batch * tipk_ceil_div(g.m, 32) * tipk_ceil_div(g.n, 32 * THIN_K_NT);
+    if (kind == STREAM_THIN_M) waves = batch * g.ksplit * tipk_ceil_div(g.n, 32);
+    if (kind == STREAM_KK) waves = batch * g.ksplit * tipk_ceil_div(g.m, 32);
+    return tipk_ceil_div(waves, 4);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs g) {
+    if (KIND == STREAM_THIN_K) gemm_thin_k_body(g, blockIdx.x);
+    if (KIND == STREAM_THIN_M) gemm_thin_m_body(g, blockIdx.x);
+    if (KIND == STREAM_KK) gemm_kk_body(g, blockIdx.x);
+}
+
 // Several independent products in ONE launch (tipk_gemm_f32_group): the backward of an R-GCN layer
 // needs d basis, d root and the two halves of dX at the same moment, each far too small to fill
 // 256 CUs; as separate launches they cost ~5 us apiece on the dependent chain of the step.
@@ -189,6 +472,9 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs ga) {
         TIPK_CASE(1, 1, 4)
         TIPK_CASE(2, 2, 2)
 #undef TIPK_CASE
+    case 100 + STREAM_THIN_K: gemm_thin_k_body(g, local); break;
+    case 100 + STREAM_THIN_M: gemm_thin_m_body(g, local); break;
+    case 100 + STREAM_KK: gemm_kk_body(g, local); break;
     }
 }
 
@@ -246,7 +532,7 @@ __global__ __launch_bounds__(64 * LANES) void sum_slabs_kernel(const float* __re
 
 struct SlabArgs {
     const float* in; int64_t n_slabs, slab_stride, count; float alpha; int accumulate;
-    const float* row_scale; int64_t cols; const float* addend; int relu; float* out; int lanes;
+    const float* row_scale; int64_t cols; const float* addend; int relu; const float* gate; float* out; int lanes;
 };
 struct SlabGroupArgs {
     int count;
@@ -281,6 +567,7 @@ __global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa)
         if (a.addend) s += a.addend[i];
         if (a.accumulate) s += a.out[i];
         if (a.relu) s = fmaxf(s, 0.f);
+        if (a.gate && !(a.gate[i] > 0.f)) s = 0.f;
         a.out[i] = s;
     }
 }
@@ -309,6 +596,19 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
     const int rc = fill_args(d, g);
     if (rc != TIPK_OK) return rc > 0 ? TIPK_OK : rc;
     hipStream_t st = (hipStream_t)stream;
+    const int kind = getenv("TIPK_NO_STREAM_GEMM") ? STREAM_NONE : stream_kind(g, d->batch);
+    if (kind != STREAM_NONE) {
+        const int64_t blocks = stream_blocks(kind, g, d->batch);
+        if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+        g.kbatch = d->batch;                            // the streaming bodies find the batch count here
+        if (kind == STREAM_THIN_K)
+            hipLaunchKernelGGL(gemm_stream_kernel<STREAM_THIN_K>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else if (kind == STREAM_THIN_M)
+            hipLaunchKernelGGL(gemm_stream_kernel<STREAM_THIN_M>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL(gemm_stream_kernel<STREAM_KK>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+        TIPK_RETURN_LAUNCH();
+    }
     if (d->n <= 32) return launch<4, 1>(g, d->batch, st);
     if (d->m <= 32) return launch<1, 4>(g, d->batch, st);
     if (d->m >= 512 && d->n >= 512 && d->ksplit == 1) return launch<2, 2, 2>(g, d->batch, st);   // 128 x 128 tiles
@@ -320,11 +620,26 @@ extern "C" int tipk_gemm_f32_group(const tipk_gemm_desc* descs, int32_t count, t
     GemmGroupArgs ga;
     ga.count = 0;
     int64_t blocks = 0;
+    const bool no_stream = getenv("TIPK_NO_STREAM_GEMM") != nullptr;
     for (int i = 0; i < count; ++i) {
         GemmArgs& g = ga.g[ga.count];
         const int rc = fill_args(descs + i, g);
         if (rc < 0) return rc;
         if (rc > 0) continue;
+        const int kind = no_stream ? STREAM_NONE : stream_kind(g, descs[i].batch);
+        if (kind != STREAM_NONE) {
+            const int64_t nb = stream_blocks(kind, g, descs[i].batch);
+            if (nb > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+            g.kbatch = descs[i].batch;
+            ga.cfg[ga.count] = 100 + kind;
+            ga.gx[ga.count] = 1;
+            ga.gy[ga.count] = 1;
+            ga.first_block[ga.count] = (int)blocks;
+            blocks += nb;
+            if (blocks > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+            ++ga.count;
+            continue;
+        }
         const int shape = g.n <= 32 ? 0 : (g.m <= 32 ? 1 : 2);
         const int bm = shape == 0 ? 128 : (shape == 1 ? 32 : 64), bn = shape == 0 ? 32 : (shape == 1 ? 128 : 64);
         const bool akf = g.a_sk == 1 || g.a_sm != 1;
@@ -358,7 +673,7 @@ extern "C" int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs, int32_t cou
         SlabArgs& a = sa.s[sa.count];
         a.in = d.in; a.n_slabs = d.n_slabs; a.slab_stride = d.slab_stride; a.count = d.count; a.alpha = d.alpha;
         a.accumulate = d.accumulate; a.row_scale = d.row_scale; a.cols = d.cols; a.addend = d.addend; a.relu = d.relu;
-        a.out = d.out;
+        a.gate = d.gate; a.out = d.out;
         // same slab-lane rule as tipk_sum_slabs_ex, so grouped and single launches add in the same order
         a.lanes = (d.n_slabs >= 32 && tipk_ceil_div(d.count, 64) < 2048) ? 16 : 4;
         sa.first_block[sa.count] = (int)blocks;

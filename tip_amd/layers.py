@@ -155,12 +155,11 @@ class GCNConv(nn.Module):
         n = x.shape[0]
         graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels))
         if _is_identity_features(x):
-            xl = ops.linear_t(None, self.lin.weight)                  # = W^T, one transpose kernel
-        elif x.is_sparse:
+            return ops.gcn_conv(None, self.lin.weight, self.bias, graph, fuse_relu)      # lin(I) = W^T
+        if x.is_sparse:
             xl = self._feat.apply_table(x, ops.linear_t(None, self.lin.weight))
-        else:
-            xl = ops.linear_t(x, self.lin.weight)
-        return ops.aggregate(xl, graph, bias=self.bias, relu=fuse_relu)
+            return ops.aggregate(xl, graph, bias=self.bias, relu=fuse_relu)
+        return ops.gcn_conv(x, self.lin.weight, self.bias, graph, fuse_relu)
 
     def __repr__(self):
         return 'GCNConv(%d, %d)' % (self.in_channels, self.out_channels)
@@ -244,6 +243,21 @@ class MyHierarchyConv(nn.Module):
             return None
         return ops.matmul(ops.aggregate(x_src, graph), self.weight)
 
+    def mean_sources(self, x_src, edge_index):
+        """The mean aggregate of `forward_sources` WITHOUT the dense map (the caller applies
+        `self.weight` fused with what follows, ops.drug_mix_mm); None if unusable."""
+        n_src = self.unique_source_num
+        n_all = n_src + self.unique_target_num
+
+        def build():
+            if edge_index.numel() and int(edge_index[0].max()) >= n_src:
+                return None
+            return hier_graph(edge_index, n_all, n_src, self.chunk, table_rows=n_src, d=self.in_dim)
+        graph = self._cache_src.get((edge_index,), build)
+        if graph is None:
+            return None
+        return ops.aggregate(x_src, graph)
+
     def __repr__(self):
         return 'MyHierarchyConv(%d, %d)' % (self.in_dim, self.out_dim)
 
@@ -308,11 +322,13 @@ class _RGCNBase(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
-    def _run(self, x, graph, fuse_relu=False):
+    def _run(self, x, graph, fuse_relu=False, gate_input=False):
         if self.bias is not None:
             out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard) + self.bias
+            if gate_input or fuse_relu == 'gated_downstream':
+                raise NotImplementedError('ReLU-mask hand-over between layers is only wired for bias=False')
             return torch.relu(out) if fuse_relu else out
-        return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu)
+        return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu, gate_input=gate_input)
 
     def __repr__(self):
         return '%s(%d, %d, num_relations=%d)' % (self.__class__.__name__, self.in_channels, self.out_channels,
@@ -323,9 +339,10 @@ class MyRGCNConv2(_RGCNBase):
     """Range-list variant (:102-193): relation r owns edges `range_list[r] = (start, end)`;
     `edge_type` is accepted and ignored, as in the reference."""
 
-    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False):
+    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False):
         """`fuse_relu` (extension): apply the ReLU that follows the layer in FMEncoder
-        (src/layers.py:547) inside the layer's last kernel."""
+        (src/layers.py:547) inside the layer's last kernel; 'gated_downstream' additionally leaves
+        the ReLU's backward mask to the one consumer, which is called with `gate_input=True`."""
         n = x.shape[0]
 
         def build():
@@ -337,7 +354,7 @@ class MyRGCNConv2(_RGCNBase):
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
             return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, d_out=self.out_channels)
         graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
-        return self._run(x, graph, fuse_relu)
+        return self._run(x, graph, fuse_relu, gate_input)
 
 
 class MyRGCNConv(_RGCNBase):
@@ -382,15 +399,18 @@ class FMEncoder(nn.Module):
     def forward(self, x_drug, dd_edge_index, dd_edge_type, dd_range_list, d_norm,
                 x_prot, pp_edge_index, dp_edge_index, dp_range_list):
         h_prot = self.pp_encoder(x_prot, pp_edge_index)                               # P-P GCN x2
-        pd = self.hgcn.forward_sources(h_prot, dp_edge_index)                         # P -> D, no cat (:526-528)
-        if pd is None:                                                                # an edge starts at a drug row
+        xd = self._drug_feat.apply_table(x_drug, self.embed)                          # x_drug @ embed
+        mean = self.hgcn.mean_sources(h_prot, dp_edge_index)                          # P -> D mean, no cat (:526-528)
+        if mean is not None:                                                          # dense map + /d_norm + cat|add fused
+            x0 = ops.drug_mix_mm(xd, mean, self.hgcn.weight, d_norm, self.mod == 'cat')
+        else:                                                                         # an edge starts at a drug row
             if self.hdrug.device != h_prot.device:
                 self.hdrug = self.hdrug.to(h_prot.device)
             pd = self.hgcn(torch.cat((h_prot, self.hdrug)), dp_edge_index, dp_range_list)
-        xd = self._drug_feat.apply_table(x_drug, self.embed)                          # x_drug @ embed
-        x0 = ops.drug_mix(xd, pd, d_norm, self.mod == 'cat')                          # /d_norm, cat|add
-        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu=True)   # ReLU (:547) fused
-        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list)
+            x0 = ops.drug_mix(xd, pd, d_norm, self.mod == 'cat')                      # /d_norm, cat|add
+        # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
+        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream')
+        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True)
 
 
 class FMEncoderCat(FMEncoder):

@@ -201,7 +201,7 @@ class GemmJob(object):
     """One product prepared for launch: the descriptor, the slab buffer of a split reduction and
     the ordered slab sum that finishes it.  `gemm` runs one job; `gemm_group` runs several
     independent jobs in one grouped launch (+ one grouped slab sum)."""
-    __slots__ = ('desc', 'label', 'slabs', 'n_slabs', 'per', 'alpha', 'accumulate', 'out', 'keep')
+    __slots__ = ('desc', 'label', 'slabs', 'n_slabs', 'per', 'alpha', 'accumulate', 'out', 'keep', 'gate')
 
 
 def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
@@ -281,6 +281,7 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     job = GemmJob()
     job.desc, job.slabs, job.n_slabs, job.per, job.alpha, job.out = g, slabs, n_slabs, per, alpha, out
     job.accumulate = c_in is not None
+    job.gate = None                                                  # set by the caller: mask of the finished sum
     job.keep = (a, b, c_in)                                          # operands stay alive until launched
     job.label = '%dx%dx%d,z=%d%s' % (m, n, k, z, ',slabs=%s%d' % (slab_mode, n_slabs) if slab_mode else '')
     return job
@@ -303,7 +304,7 @@ class SlabJob(object):
     __slots__ = ('desc', 'out', 'keep')
 
 
-def slab_job(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, addend=None, relu=False):
+def slab_job(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, addend=None, relu=False, gate=None):
     assert slabs.is_contiguous()
     per = slabs[0].numel()
     if out is None:
@@ -318,8 +319,11 @@ def slab_job(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, adden
     d.cols = slabs.shape[-1]
     d.addend = addend.data_ptr() if addend is not None else None
     d.relu, d.out = int(relu), out.data_ptr()
+    if gate is not None:
+        assert gate.is_contiguous() and gate.numel() == per
+        d.gate = gate.data_ptr()
     job = SlabJob()
-    job.desc, job.out, job.keep = d, out, (slabs, row_scale, addend)
+    job.desc, job.out, job.keep = d, out, (slabs, row_scale, addend, gate)
     return job
 
 
@@ -328,6 +332,9 @@ def _slab_desc_of(job):
     d.in_, d.n_slabs, d.slab_stride, d.count = job.slabs.data_ptr(), job.n_slabs, job.per, job.per
     d.alpha, d.accumulate = job.alpha, int(job.accumulate)
     d.row_scale, d.cols, d.addend, d.relu, d.out = None, 0, None, 0, job.out.data_ptr()
+    if job.gate is not None:
+        assert job.gate.is_contiguous() and job.gate.numel() == job.per
+        d.gate = job.gate.data_ptr()
     return d
 
 
@@ -611,7 +618,11 @@ class _RGCN(torch.autograd.Function):
     are all-reduced in one packed collective on the way back."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, graph, shard, relu):
+    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False):
+        """relu: False | True | 'gated_downstream' (ReLU applied here, its backward mask applied by the
+        consumer, which must be the ONLY consumer and run with gate_input=True).
+        gate_input: x is the ReLU output of the producing layer; dX is masked with (x > 0) while it is
+        finished, i.e. the producer's ReLU backward is fused into this layer's last kernel."""
         x, basis, att, root = _f32c(x), basis.contiguous(), att.contiguous(), root.contiguous()
         n, d_in = x.shape
         nb, _, d_out = basis.shape
@@ -632,7 +643,7 @@ class _RGCN(torch.autograd.Function):
             # LDS-resident gather -> per-workgroup partial slabs; the ordered slab sum also applies
             # 1/deg, adds X root and the ReLU: the layer is finished in one pass
             part = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False, reduce=False)
-            out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=relu)
+            out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=bool(relu))
         else:
             if use_rl:
                 agg = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False)
@@ -644,10 +655,10 @@ class _RGCN(torch.autograd.Function):
                 from .dist import all_reduce_packed
                 all_reduce_packed([agg], shard.group)
                 rows_affine(agg, row_mul=graph.scale, out=agg)
-            out = gemm(x, root, out=agg, c_in=agg, relu=relu)            # + X root (, ReLU)
+            out = gemm(x, root, out=agg, c_in=agg, relu=bool(relu))      # + X root (, ReLU)
         del y
-        ctx.graph, ctx.shard, ctx.relu = graph, shard, relu
-        ctx.save_for_backward(x, basis, att, att_l, root, xb, out if relu else None)
+        ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
+        ctx.save_for_backward(x, basis, att, att_l, root, xb, out if relu is True else None)
         return out
 
     @staticmethod
@@ -655,7 +666,7 @@ class _RGCN(torch.autograd.Function):
         x, basis, att, att_l, root, xb, out = ctx.saved_tensors
         graph, shard = ctx.graph, ctx.shard
         g = _f32c(g).contiguous()
-        if ctx.relu:
+        if ctx.relu is True:
             g = rows_affine(g, gate=out)                                 # ReLU gate of the fused epilogue
         n, d_in = x.shape
         nb, _, d_out = basis.shape
@@ -683,10 +694,14 @@ class _RGCN(torch.autograd.Function):
             g_x = j_xr.out
             j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
             if j_xq.slabs is not None:                                   # summed on top of g root^T afterwards
+                if ctx.gate_input:
+                    j_xq.gate = x                                        # ... and masked with (x > 0) in the same pass
                 gemm_group([j_basis, j_root, j_xr, j_xq])
             else:                                                        # reads g_x while accumulating
                 gemm_group([j_basis, j_root, j_xr])
                 gemm_group([j_xq])
+                if ctx.gate_input:
+                    g_x = rows_affine(g_x, gate=x)
             g_basis, g_root = j_basis.out, j_root.out
         else:
             from .dist import all_reduce_packed
@@ -696,11 +711,13 @@ class _RGCN(torch.autograd.Function):
             g_att.index_copy_(0, shard.rel_ids_on(att.device), g_att_l)
             all_reduce_packed([g_x, g_basis, g_att], shard.group)
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
-        return g_x, g_basis, g_att, g_root, None, None, None
+            if ctx.gate_input:
+                g_x = rows_affine(g_x, gate=x)
+        return g_x, g_basis, g_att, g_root, None, None, None, None
 
 
-def rgcn(x, basis, att, root, graph, shard=None, relu=False):
-    return _RGCN.apply(x, basis, att, root, graph, shard, relu)
+def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False):
+    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input)
 
 
 class _DrugMix(torch.autograd.Function):
@@ -733,6 +750,96 @@ class _DrugMix(torch.autograd.Function):
 
 def drug_mix(xd, pd, d_norm, cat):
     return _DrugMix.apply(xd, pd, d_norm, cat)
+
+
+class _DrugMixMM(torch.autograd.Function):
+    """x0 = cat(embed / d_norm, mean @ W) or embed / d_norm + mean @ W: the dense map of
+    MyHierarchyConv (src/layers.py:239) writes straight into the mixed feature matrix
+    (:532-539), and its gradient is read from a column-slice view on the way back."""
+
+    @staticmethod
+    def forward(ctx, xd, mean, weight, d_norm, cat):
+        xd, mean, weight = _f32c(xd), _f32c(mean), _f32c(weight)
+        n, ne = xd.shape
+        pd_dim = weight.shape[1]
+        if cat:
+            out = torch.empty((n, ne + pd_dim), dtype=torch.float32, device=xd.device)
+            rows_affine(xd, row_div=d_norm, out=out[:, :ne])
+            gemm(mean, weight, out=out[:, ne:])
+        else:
+            out = rows_affine(xd, row_div=d_norm)
+            gemm(mean, weight, out=out, c_in=out)
+        ctx.cat, ctx.ne = cat, ne
+        ctx.save_for_backward(mean, weight, d_norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mean, weight, d_norm = ctx.saved_tensors
+        g = _f32c(g)
+        g_pd = g[:, ctx.ne:] if ctx.cat else g
+        g_xd = rows_affine(g[:, :ctx.ne] if ctx.cat else g, row_div=d_norm)
+        j_w = gemm_job(mean.t(), g_pd)
+        j_m = gemm_job(g_pd, weight.t()) if ctx.needs_input_grad[1] else None
+        gemm_group([j for j in (j_w, j_m) if j is not None])
+        return g_xd, (j_m.out if j_m else None), j_w.out, None, None
+
+
+def drug_mix_mm(xd, mean, weight, d_norm, cat):
+    return _DrugMixMM.apply(xd, mean, weight, d_norm, cat)
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (int(n), str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones((1, int(n)), dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+class _GCNConv(torch.autograd.Function):
+    """out = relu?(A_hat (x W^T) + bias): GCNConv as one node of the autograd graph, so that the
+    three gradients that only need the transposed aggregate -- d W, d x and d bias (= 1^T g as a
+    1-row product) -- leave in ONE grouped launch (PyG GCNConv.forward; src/layers.py:392-394)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, graph, relu):
+        ctx.identity = x is None
+        if x is None:
+            xl = transpose(weight)                                       # lin(I) = W^T
+        else:
+            x = _f32c(x)
+            xl = gemm(x, weight.t())
+        out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=relu)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
+        ctx.save_for_backward(x, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        graph = ctx.graph
+        g = _f32c(g).contiguous()
+        g_pre = rows_affine(g, gate=out) if ctx.relu else g
+        g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
+        g_table = gather_sum(graph.bwd, g_agg)
+        j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre) if ctx.has_bias else None
+        if ctx.identity:
+            g_w = transpose(g_table)
+            if j_b is not None:
+                gemm_group([j_b])
+            return None, g_w, (j_b.out.view(-1) if j_b else None), None, None
+        j_w = gemm_job(g_table.t(), x)
+        j_x = gemm_job(g_table, weight) if ctx.needs_input_grad[0] else None
+        gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
+        return (j_x.out if j_x else None), j_w.out, (j_b.out.view(-1) if j_b else None), None, None
+
+
+def gcn_conv(x, weight, bias, graph, relu=False):
+    """x = None means identity features."""
+    return _GCNConv.apply(x, weight, bias, graph, relu)
 
 
 class _DistMult(torch.autograd.Function):

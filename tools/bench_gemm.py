@@ -9,17 +9,24 @@ dev = torch.device('cuda:0')
 R, B = 1097, 32
 
 
-def timeit(fn, iters=50):
-    for _ in range(5):
+def timeit(fn, iters=20):
+    """GPU time per call: the calls are captured into one hipGraph (no host launch cost in the number)."""
+    for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(5):
+        g.replay()
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters * 1e3
+    return a.elapsed_time(b) / (5 * iters) * 1e3
 
 
 for ncol in [int(x) for x in sys.argv[1:]] or [20640, 10320]:
@@ -37,6 +44,15 @@ for ncol in [int(x) for x in sys.argv[1:]] or [20640, 10320]:
         print('ncol %d  dAtt k%-3d    %7.1f us  %.2f TB/s' % (ncol, ks, t, mb / t))
     t = timeit(lambda: ops.gemm_group([ops.gemm_job(gy, xb2.t()), ops.gemm_job(att.t(), gy)]))
     print('ncol %d  group(dAtt,dXB) %7.1f us  %.2f TB/s (one read)' % (ncol, t, mb / t))
+    import os
+    os.environ['TIPK_NO_STREAM_GEMM'] = '1'
+    t = timeit(lambda: ops.gemm(att, xb2))
+    print('ncol %d  [tiled] Y       %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
+    t = timeit(lambda: ops.gemm(att.t(), gy, ksplit=4))
+    print('ncol %d  [tiled] dXB k4  %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
+    t = timeit(lambda: ops.gemm(gy, xb2.t(), ksplit=57))
+    print('ncol %d  [tiled] dAtt k57 %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
+    del os.environ['TIPK_NO_STREAM_GEMM']
     t = timeit(lambda: gy.copy_(xb2[:1].expand(R, ncol)))
     print('ncol %d  torch fill      %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
     t = timeit(lambda: gy.sum())
