@@ -28,31 +28,43 @@ struct GemmArgs {
     int relu;
 };
 
-// Loads a (ROWS x BK) operand tile into registers: element (r, kk) = p[r*s_r + kk*s_k] or 0.
-// K_FAST: consecutive threads walk k (operand is k-contiguous), else they walk the row index.
-template <int ROWS, bool K_FAST>
+typedef unsigned int u32;
+
+// uniform base pointer + 32-bit byte offset: compiles to `global_load v, v_off, s[base]`
+__device__ __forceinline__ float ldg(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldg4(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// Loads a (ROWS x BK) operand tile into registers: element (r, kk) = tile[r*s_r + kk*s_k] or 0, with
+// `tile` the (wave-uniform) address of the tile origin and 32-bit offsets inside the tile (the host
+// checks 128*s_r + 32*s_k < 2^30) -- one VGPR per address; 64-bit per-element address arithmetic made
+// each specialised body 11 KB of code and the grouped kernel twice the instruction cache.
+// kfast: consecutive threads walk k (operand is k-contiguous), else they walk the row index.
+template <int ROWS>
 struct TileLoader {
     static constexpr int PER = ROWS * BK / 256;
     float v[PER];
-    __device__ __forceinline__ static void coord(int i, int t, int& r, int& kk) {
-        if (K_FAST) { kk = t % BK; r = t / BK + (256 / BK) * i; }
-        else        { r = t % ROWS; kk = t / ROWS + (256 / ROWS) * i; }
+    __device__ __forceinline__ static void coord(bool kfast, int i, int t, int& r, int& kk) {
+        // selects, not if/else: with a runtime flag hipcc built the two candidates as a scratch array
+        r = kfast ? t / BK + (256 / BK) * i : t % ROWS;
+        kk = kfast ? t % BK : t / ROWS + (256 / ROWS) * i;
     }
-    __device__ __forceinline__ void load(const float* p, int64_t s_r, int64_t s_k, int64_t r0, int64_t r_end,
-                                         int64_t k0, int64_t k_end, int t) {
+    __device__ __forceinline__ void load(bool kfast, const float* tile, u32 s_r, u32 s_k, int rows_left, int k_left, int t) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             int r, kk;
-            coord(i, t, r, kk);
-            const int64_t gr = r0 + r, gk = k0 + kk;
-            v[i] = (gr < r_end && gk < k_end) ? p[gr * s_r + gk * s_k] : 0.f;
+            coord(kfast, i, t, r, kk);
+            v[i] = (r < rows_left && kk < k_left) ? ldg(tile, ((u32)r * s_r + (u32)kk * s_k) * 4u) : 0.f;
         }
     }
-    __device__ __forceinline__ void store(float (*lds)[ROWS + PAD], int t) const {
+    __device__ __forceinline__ void store(bool kfast, float (*lds)[ROWS + PAD], int t) const {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             int r, kk;
-            coord(i, t, r, kk);
+            coord(kfast, i, t, r, kk);
             lds[kk][r] = v[i];
         }
     }
@@ -62,8 +74,11 @@ struct TileLoader {
 // whose K fits one tile (Y = att . XB, K = 32): half the LDS, twice the resident workgroups.
 // R = register tile per wave: R x R accumulators of 32x32 (R = 2: a 128x128 workgroup tile, each LDS
 // operand read feeds two MFMAs -- used for the large square-ish products such as Y = att . XB).
-template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF, int R = 1>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, int64_t bx, int64_t by, int64_t bz, float* smem) {
+// A_KFAST / B_KFAST: plain arguments -- the single-product kernels pass template constants, the
+// grouped kernel runtime flags.
+template <int WM, int WN, int NBUF, int R = 1>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int64_t bx, int64_t by, int64_t bz, float* smem,
+                                          const bool A_KFAST, const bool B_KFAST) {
     constexpr int BM = WM * 32 * R, BN = WN * 32 * R;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     float (*As)[BK][BM + PAD] = reinterpret_cast<float (*)[BK][BM + PAD]>(smem);
@@ -76,14 +91,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int64_t bx, int64_t
     const int64_t z = bz / g.ksplit, slab = bz % g.ksplit;
     const int64_t k_lo = slab * g.kchunk;
     const int64_t k_hi = (k_lo + g.kchunk < g.k) ? k_lo + g.kchunk : g.k;
-    const int64_t tiles_per_q = (k_hi > k_lo) ? (k_hi - k_lo + BK - 1) / BK : 0;
-    const int64_t n_tiles = tiles_per_q * g.kbatch;
+    const int tiles_per_q = (k_hi > k_lo) ? (int)((k_hi - k_lo + BK - 1) / BK) : 0;
+    const int n_tiles = tiles_per_q * (int)g.kbatch;
 
-    const float* a_z = g.a + z * g.a_sz;
-    const float* b_z = g.b + z * g.b_sz;
+    // tile origins (uniform); the per-element offsets inside a tile are 32-bit
+    const float* a_z = g.a + z * g.a_sz + m0 * g.a_sm + k_lo * g.a_sk;
+    const float* b_z = g.b + z * g.b_sz + n0 * g.b_sn + k_lo * g.b_sk;
+    const u32 a_sm = (u32)g.a_sm, a_sk = (u32)g.a_sk, b_sn = (u32)g.b_sn, b_sk = (u32)g.b_sk;
+    const int m_left = (int)(g.m - m0 < BM ? g.m - m0 : BM), n_left = (int)(g.n - n0 < BN ? g.n - n0 : BN);
 
-    TileLoader<BM, A_KFAST> la;
-    TileLoader<BN, B_KFAST> lb;
+    TileLoader<BM> la;
+    TileLoader<BN> lb;
     f32x16 acc[R][R];
 #pragma unroll
     for (int a = 0; a < R; ++a)
@@ -92,20 +110,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int64_t bx, int64_t
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    auto fetch = [&](int64_t tile) {
-        const int64_t q = tile / tiles_per_q;
-        const int64_t k0 = k_lo + (tile % tiles_per_q) * BK;
-        la.load(a_z + q * g.a_sq, g.a_sm, g.a_sk, m0, g.m, k0, k_hi, t);
-        lb.load(b_z + q * g.b_sq, g.b_sn, g.b_sk, n0, g.n, k0, k_hi, t);
+    auto fetch = [&](int tile) {
+        const int q = tile / tiles_per_q;
+        const int kt = tile - q * tiles_per_q;
+        const int k_left = (int)(k_hi - k_lo) - kt * BK;
+        la.load(A_KFAST, a_z + (int64_t)q * g.a_sq + (int64_t)kt * BK * g.a_sk, a_sm, a_sk, m_left, k_left, t);
+        lb.load(B_KFAST, b_z + (int64_t)q * g.b_sq + (int64_t)kt * BK * g.b_sk, b_sn, b_sk, n_left, k_left, t);
     };
 
     if (n_tiles > 0) fetch(0);
-    for (int64_t tile = 0; tile < n_tiles; ++tile) {
-        const int buf = NBUF == 2 ? (int)(tile & 1) : 0;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int buf = NBUF == 2 ? (tile & 1) : 0;
         // buffer `buf` was last read two steps ago; the barrier of the previous step fences it
         if (NBUF == 1 && tile > 0) __syncthreads();
-        la.store(As[buf], t);
-        lb.store(Bs[buf], t);
+        la.store(A_KFAST, As[buf], t);
+        lb.store(B_KFAST, Bs[buf], t);
         __syncthreads();
         if (tile + 1 < n_tiles) fetch(tile + 1);
         const int row = lane & 31, kh = lane >> 5;
@@ -150,7 +169,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int64_t bx, int64_t
 template <int WM, int WN, bool A_KFAST, bool B_KFAST, int NBUF, int R = 1>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[NBUF * BK * (WM * 32 * R + WN * 32 * R + 2 * PAD)];
-    gemm_body<WM, WN, A_KFAST, B_KFAST, NBUF, R>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    gemm_body<WM, WN, NBUF, R>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem, A_KFAST, B_KFAST);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -206,16 +225,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc,
 //  * a sched_barrier separates "issue the next operands" from "multiply the current ones": left alone
 //    the scheduler sinks each load next to its use to save registers (36 VGPRs, one exposed memory
 //    round trip per load).
-typedef unsigned int u32;
-
 __device__ __forceinline__ float and_mask(float v, u32 mask) { return __uint_as_float(__float_as_uint(v) & mask); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float ldg(const float* base, u32 byte_off) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-__device__ __forceinline__ float4 ldg4(const float* base, u32 byte_off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
 
 // store of one 32x32 accumulator through a scalar base + 32-bit byte offsets (row stride c_sm floats)
 __device__ __forceinline__ void store_tile32(const GemmArgs& g, const f32x16& acc, float* c_z, const float* cin_z,
@@ -462,16 +473,11 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs ga) {
         }
     const int local = (int)blockIdx.x - first;
     const int64_t bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
-    switch (cfg) {
-#define TIPK_CASE(S, WM, WN)                                                  \
-    case S * 4 + 0: gemm_body<WM, WN, false, false, 2>(g, bx, by, bz, smem); break; \
-    case S * 4 + 1: gemm_body<WM, WN, false, true, 2>(g, bx, by, bz, smem); break;  \
-    case S * 4 + 2: gemm_body<WM, WN, true, false, 2>(g, bx, by, bz, smem); break;  \
-    case S * 4 + 3: gemm_body<WM, WN, true, true, 2>(g, bx, by, bz, smem); break;
-        TIPK_CASE(0, 4, 1)
-        TIPK_CASE(1, 1, 4)
-        TIPK_CASE(2, 2, 2)
-#undef TIPK_CASE
+    const bool akf = (cfg & 2) != 0, bkf = (cfg & 1) != 0;
+    switch (cfg >= 100 ? cfg : cfg >> 2) {
+    case 0: gemm_body<4, 1, 2>(g, bx, by, bz, smem, akf, bkf); break;
+    case 1: gemm_body<1, 4, 2>(g, bx, by, bz, smem, akf, bkf); break;
+    case 2: gemm_body<2, 2, 2>(g, bx, by, bz, smem, akf, bkf); break;
     case 100 + STREAM_THIN_K: gemm_thin_k_body(g, local); break;
     case 100 + STREAM_THIN_M: gemm_thin_m_body(g, local); break;
     case 100 + STREAM_KK: gemm_kk_body(g, local); break;
@@ -580,6 +586,9 @@ static int fill_args(const tipk_gemm_desc* d, GemmArgs& g) {
     if (d->m == 0 || d->n == 0 || d->batch == 0) return 1;
     if (!d->a || !d->b || !d->c) return TIPK_EINVAL;
     if (d->ksplit > 1 && (d->c_in || d->relu)) return TIPK_EINVAL;
+    // offsets inside one operand tile are 32-bit byte offsets (strides must be non-negative)
+    if (d->a_sm < 0 || d->a_sk < 0 || d->b_sk < 0 || d->b_sn < 0) return TIPK_EINVAL;
+    if (128 * d->a_sm + 32 * d->a_sk >= (1LL << 30) || 128 * d->b_sn + 32 * d->b_sk >= (1LL << 30)) return TIPK_EUNSUPPORTED;
     g.m = d->m; g.n = d->n; g.k = d->k; g.kbatch = d->kbatch; g.ksplit = d->ksplit;
     g.kchunk = tipk_ceil_div(tipk_ceil_div(d->k, d->ksplit), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
