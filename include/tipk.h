@@ -189,6 +189,23 @@ typedef struct tipk_slab_sum_desc {
 int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, int32_t count, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 2b. Both consumers of dY (the gradient of Y = att . XB, src/layers.py:163-172 under autograd) in
+ *     one pass over dY [n_rel x n_cols] (n_cols = nodes * out channels; 91 MB at BioSNAP layer 1):
+ *
+ *        dXB [b, c] = sum_r att[r, b] * dY[r, c]       datt[r, b] = sum_c dY[r, c] * XB[b, c]
+ *
+ *     Results arrive as slabs to be added in order (tipk_sum_slabs_group):
+ *        dxb_slabs  [row_slabs][n_bases x n_cols]   one per range of relations
+ *        datt_slabs [col_slabs][n_rel x n_bases]    one per chunk of 512 columns
+ *     `tipk_rgcn_dy_products_plan` returns the slab counts (both 0: shape not supported -- n_bases > 32
+ *     or so many columns that one datt slab per chunk would not pay; use two tipk_gemm_f32 then).
+ */
+int tipk_rgcn_dy_products_plan(int64_t n_rel, int64_t n_cols, int n_bases, int* col_slabs, int* row_slabs);
+int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int64_t ld_att,
+                          const float* xb, int64_t ld_xb, int64_t n_rel, int64_t n_cols, int n_bases,
+                          float* dxb_slabs, float* datt_slabs, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).
  */
 /* out[c, r] = in[r, c]  -- `lin(x)` for identity features is W^T (src/layers.py:392 with

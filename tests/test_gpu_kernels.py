@@ -203,6 +203,36 @@ def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
     assert torch.equal(ops.gemm(aid, bid, ksplit=ks).cpu(), ai @ bi)
 
 
+@pytest.mark.parametrize('r,nc,nb', [(1097, 20640, 32), (1097, 10320, 32), (70, 645 * 4, 7), (33, 513, 32), (5, 31, 1)])
+def test_dy_products_fused(ops, r, nc, nb, monkeypatch):
+    """tipk_rgcn_dy_products: d att = dY XB^T and d XB = att^T dY from one pass over dY, ragged row
+    ranges / column chunks / base counts; reproducible; the two-GEMM path is the cross-check."""
+    g = torch.Generator().manual_seed(r + nc + nb)
+    gy = torch.randn(r, nc, generator=g)
+    att = torch.randn(r, nb, generator=g)
+    xb = torch.randn(nb, nc, generator=g)
+    want_att = gy.double() @ xb.double().t()
+    want_xb = att.double().t() @ gy.double()
+    gyd, attd, xbd = gy.to(DEV), att.to(DEV), xb.to(DEV)
+    g_att, g_xb = ops.dy_products(gyd, attd, xbd)
+    tol = dict(rtol=2e-5, atol=2e-5 * float(want_att.abs().max()))
+    close(g_att, want_att, **tol)
+    close(g_xb, want_xb, rtol=2e-5, atol=2e-5 * float(want_xb.abs().max()))
+    again = ops.dy_products(gyd, attd, xbd)
+    assert torch.equal(again[0], g_att) and torch.equal(again[1], g_xb)
+    monkeypatch.setenv('TIPK_NO_DY_FUSED', '1')
+    ref_att, ref_xb = ops.dy_products(gyd, attd, xbd)
+    close(ref_att, want_att, **tol)
+    close(ref_xb, want_xb, rtol=2e-5, atol=2e-5 * float(want_xb.abs().max()))
+    # exact on integers (every summation order is exact)
+    gi = torch.randint(-3, 4, (r, nc), generator=g).float()
+    ai = torch.randint(-3, 4, (r, nb), generator=g).float()
+    xi = torch.randint(-3, 4, (nb, nc), generator=g).float()
+    monkeypatch.delenv('TIPK_NO_DY_FUSED')
+    e_att, e_xb = ops.dy_products(gi.to(DEV), ai.to(DEV), xi.to(DEV))
+    assert torch.equal(e_att.cpu(), gi @ xi.t()) and torch.equal(e_xb.cpu(), ai.t() @ gi)
+
+
 def test_gemm_group_bit_identical_to_single_launches(ops):
     """tipk_gemm_f32_group / tipk_sum_slabs_group: the R-GCN backward's mix of shapes (batched, split-K,
     batch-reduced on top of another member's output, transposed views) in one launch == one by one."""

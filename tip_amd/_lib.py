@@ -58,6 +58,8 @@ SIGNATURES = {
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),
     'tipk_sum_slabs_group': (_I, [C.POINTER(SlabSumDesc), C.c_int32, _P]),
+    'tipk_rgcn_dy_products_plan': (_I, [_L, _L, _I, C.POINTER(_I), C.POINTER(_I)]),
+    'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _P, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

@@ -299,6 +299,30 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     return job.out
 
 
+def dy_products(g_y, att, xb2):
+    """(d att, d XB) = (g_y @ xb2^T, att^T @ g_y) in ONE pass over g_y [R, N*out] (include/tipk.h
+    section 2b); falls back to two grouped GEMMs for shapes the fused kernel does not take."""
+    import ctypes as C
+    r, nc = g_y.shape
+    nb = att.shape[1]
+    s_c, s_r = C.c_int(0), C.c_int(0)
+    if not os.environ.get('TIPK_NO_DY_FUSED') and g_y.stride(1) == 1 and att.stride(1) == 1 and xb2.stride(1) == 1:
+        check(lib().tipk_rgcn_dy_products_plan(r, nc, nb, C.byref(s_c), C.byref(s_r)), 'tipk_rgcn_dy_products_plan')
+    if s_c.value == 0:
+        g_att, g_xb = gemm_group([gemm_job(g_y, xb2.t()), gemm_job(att.t(), g_y)])
+        return g_att, g_xb
+    dev = g_y.device
+    dxb_slabs = torch.empty((s_r.value, nb, nc), dtype=torch.float32, device=dev)
+    datt_slabs = torch.empty((s_c.value, r, nb), dtype=torch.float32, device=dev)
+    with _timed('dy_products[%dx%dx%d]' % (r, nc, nb)):
+        check(lib().tipk_rgcn_dy_products(ptr(g_y), g_y.stride(0), ptr(att), att.stride(0), ptr(xb2), xb2.stride(0),
+                                          r, nc, nb, ptr(dxb_slabs), ptr(datt_slabs), stream_ptr(dev)),
+              'tipk_rgcn_dy_products')
+    j_xb, j_att = slab_job(dxb_slabs), slab_job(datt_slabs)
+    gemm_group([], [j_xb, j_att])
+    return j_att.out, j_xb.out
+
+
 class SlabJob(object):
     """An ordered slab sum with the fused epilogue of `sum_slabs`, prepared for a grouped launch."""
     __slots__ = ('desc', 'out', 'keep')
@@ -679,8 +703,8 @@ class _RGCN(torch.autograd.Function):
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
-            # both consumers of dY in one grouped launch (+ one grouped slab sum)
-            g_att_l, g_xb = gemm_group([gemm_job(g_y, xb2.t()), gemm_job(att_l.t(), g_y)])
+            # both consumers of dY in one pass over it (+ one grouped slab sum)
+            g_att_l, g_xb = dy_products(g_y, att_l, xb2)
             g_xb = g_xb.view(nb, n, d_out)
         else:
             g_att_l = torch.zeros((0, nb), dtype=torch.float32, device=x.device)

@@ -42,6 +42,8 @@ for ncol in [int(x) for x in sys.argv[1:]] or [20640, 10320]:
     for ks in (19, 38, 57, 114, 128):
         t = timeit(lambda: ops.gemm(gy, xb2.t(), ksplit=ks))
         print('ncol %d  dAtt k%-3d    %7.1f us  %.2f TB/s' % (ncol, ks, t, mb / t))
+    t = timeit(lambda: ops.dy_products(gy, att, xb2))
+    print('ncol %d  dy_products     %7.1f us  %.2f TB/s (one read, incl. slab sums)' % (ncol, t, mb / t))
     t = timeit(lambda: ops.gemm_group([ops.gemm_job(gy, xb2.t()), ops.gemm_job(att.t(), gy)]))
     print('ncol %d  group(dAtt,dXB) %7.1f us  %.2f TB/s (one read)' % (ncol, t, mb / t))
     import os
