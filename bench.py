@@ -276,10 +276,15 @@ def main():
         alg_bytes = n_launch_edges * (4 + 4 * d_row)
         achieved = alg_bytes / (gs[dom][1] * 1e-3) / 1e9
         traffic = pmc_traffic(enc, dom, d_row)
-        lds_note = None
+        lds_note, lds_roof = None, None
         if dom.startswith('rel_gather'):
             lds_note = ('rows are gathered from LDS (relation-local kernel): algorithmic GB/s exceeds the HBM peak by '
-                        'design; HBM only carries the ids and one coalesced read of Y (fwd) / write of dY (bwd) -- see traffic')
+                        'design; HBM only carries the ids and one coalesced read of Y (fwd) / write of dY (bwd) -- see '
+                        'traffic; the bound that applies is lds_roofline')
+            # the kernel's real ceiling: every gathered row is a ds_read_b128 stream out of the CU's LDS
+            # (128 B/clk/CU x 256 CUs x 2.4 GHz, MI355X_MICROARCH "LDS"); same algorithmic bytes
+            lds_peak = 128 * 256 * 2.4e9 / 1e9
+            lds_roof = {'bound': 'lds', 'achieved': achieved, 'peak': lds_peak, 'unit': 'GB/s', 'frac': achieved / lds_peak}
         out = {
             'metric': 'D-D edges aggregated/sec (encoder fwd+bwd)',
             'value': E * args.steps / elapsed, 'unit': 'edges/s',
@@ -293,7 +298,8 @@ def main():
                        else 'eager (one ctypes call per kernel)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'launch_ms': gs[dom][1], 'algorithmic_bytes_per_launch': alg_bytes, 'note': lds_note},
+                         'launch_ms': gs[dom][1], 'algorithmic_bytes_per_launch': alg_bytes, 'note': lds_note,
+                         'lds_roofline': lds_roof},
             'kernels_ms': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
                            for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])},
             'preprocess_s': preprocess_s,

@@ -180,36 +180,66 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 __syncthreads();
             }
             if (a.dbg & 1) continue;
+            // Runs are short (BioSNAP: 13.6 padded ids = 1.7 steps on average), so what a slot does AROUND
+            // a run -- fetch (begin, length) and the node, read-modify-write the accumulator -- is a chain
+            // of dependent LDS round trips as long as the run itself.  The next position's descriptor is
+            // therefore requested one band ahead (one 8-byte read + the node), and the forward pass
+            // requests the old accumulator value before the run instead of after it.
+            if (npos <= 0) continue;
+            int p_next = slot;                          // band 0 is ascending
+            int2 run_next;
+            unsigned node_next;
+            {
+                const int pc = p_next < npos ? p_next : npos - 1;
+                run_next = *reinterpret_cast<const int2*>(run_l + 2 * pc);
+                node_next = node_l[pc];
+            }
             for (int pb = 0, band = 0; pb < npos; pb += NS, ++band) {
                 // snake deal of the length-sorted rows: band 0 ascending, band 1 descending, ... so the
                 // slot that got the longest row of one band gets the shortest of the next
-                const int p = pb + ((band & 1) ? NS - 1 - slot : slot);
+                const int p = p_next;
+                const int b = run_next.x, len = run_next.y;
+                const unsigned node = node_next;
+                p_next = pb + NS + (((band + 1) & 1) ? NS - 1 - slot : slot);
+                {
+                    const int pc = p_next < npos ? p_next : npos - 1;         // clamped, unconditional
+                    run_next = *reinterpret_cast<const int2*>(run_l + 2 * pc);
+                    node_next = node_l[pc];
+                }
                 if (p >= npos) continue;
-                const int b = run_l[2 * p], len = run_l[2 * p + 1];
                 if (!BWD && len == 0) continue;
                 int lo = b > cb ? b : cb;                // b, len, cb, cn are multiples of 8
                 int hi = b + len < cb + cn ? b + len : cb + cn;
                 lo -= cb;
                 hi -= cb;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 old_acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!BWD && lo < hi) old_acc = tipk_ld4(accl + node * dc + c0);   // this slot is the only one touching `node` now
                 // 8 edges per step.  Runs are padded to multiples of 8 ids with the sentinel id
                 // n_nodes, whose table row is all zeros: no masks, no tails -- a step is one 16-byte id
                 // read (same address for the slot's lanes = broadcast) + 8 row reads + 8 adds.
+                // (the next step's ids are requested before this step's rows; row address = 24-bit multiply:
+                // a plain `idj * ldt` compiled to the quarter-rate v_mul_lo_u32 -- 8 of them were half of
+                // the loop's VALU time, which is what bounds the kernel together with the LDS pipe)
+                const char* tabb = reinterpret_cast<const char*>(tab + c0);
+                const unsigned ldt4 = (unsigned)ldt * 4u;
+                uint4 pk = lo < hi ? *reinterpret_cast<const uint4*>(idx_l + lo) : make_uint4(0, 0, 0, 0);
                 for (int eb = lo; eb < hi; eb += 8) {
-                    const uint4 pk = *reinterpret_cast<const uint4*>(idx_l + eb);
                     const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+                    const int nxt = eb + 8 < hi ? eb + 8 : eb;               // clamped: the last step re-reads its own ids
+                    pk = *reinterpret_cast<const uint4*>(idx_l + nxt);
+                    __builtin_amdgcn_sched_barrier(0);                       // keep the id read ahead of the row reads
                     float4 v[8];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
-                        const unsigned idj = (w4[jj >> 1] >> (16 * (jj & 1))) & 0xffffu;
-                        v[jj] = tipk_ld4(tab + idj * ldt + c0);
+                        const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
+                        v[jj] = *reinterpret_cast<const float4*>(tabb + __umul24(idj, ldt4));
                     }
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
                         acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w;
                     }
                 }
-                const int node = node_l[p];
                 if (BWD) {
                     float* o = out + (row0 + node) * a.ld_out + c0;
                     if (cb > 0 && lo < hi) {           // a run continued from the previous id chunk
@@ -218,10 +248,8 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                     }
                     if (cb == 0 || lo < hi) tipk_st4(o, acc);
                 } else if (lo < hi) {
-                    float* o = accl + node * dc + c0;  // this slot is the only one touching `node` now
-                    const float4 old = tipk_ld4(o);
-                    acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
-                    tipk_st4(o, acc);
+                    acc.x += old_acc.x; acc.y += old_acc.y; acc.z += old_acc.z; acc.w += old_acc.w;
+                    tipk_st4(accl + node * dc + c0, acc);
                 }
             }
         }
