@@ -167,6 +167,14 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     import torch.distributed as dist
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout (seen
+    # after the JSON line, when its stdio buffer is flushed): while collectives may run, fd 1 points at
+    # stderr; it is restored -- after flushing C stdio -- just before the result is printed.
+    stdout_fd = None
+    if world > 1 or os.environ.get('TIPK_FORCE_SHARD'):
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -282,8 +290,8 @@ def main():
                         'design; HBM only carries the ids and one coalesced read of Y (fwd) / write of dY (bwd) -- see '
                         'traffic; the bound that applies is lds_roofline')
             # the kernel's real ceiling: every gathered row is a ds_read_b128 stream out of the CU's LDS
-            # (128 B/clk/CU x 256 CUs x 2.4 GHz, MI355X_MICROARCH "LDS"); same algorithmic bytes
-            lds_peak = 128 * 256 * 2.4e9 / 1e9
+            # (ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz, MI355X_MICROARCH "LDS"); same algorithmic bytes
+            lds_peak = 256 * 256 * 2.4e9 / 1e9
             lds_roof = {'bound': 'lds', 'achieved': achieved, 'peak': lds_peak, 'unit': 'GB/s', 'frac': achieved / lds_peak}
         out = {
             'metric': 'D-D edges aggregated/sec (encoder fwd+bwd)',
@@ -307,10 +315,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dd, dims, args.mod, args.cpu_seconds)
-        print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if stdout_fd is not None:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)                         # the banner (if any) goes to stderr
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -241,9 +241,14 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     if reduce_batch and plain and tiles * 2 <= 256 and z > 1:
         slab_mode, n_slabs = 'q', z
     elif ksplit is None:
-        want = min(k // 64, -(-512 // tiles))
+        # a workgroup's K loop is a chain of dependent ~1.5 us load round trips: small products are cut
+        # until a slab is one or two K tiles (knobs for sweeps: TIPK_KSPLIT_GRAIN / _WGS / _MAX)
+        grain = int(os.environ.get('TIPK_KSPLIT_GRAIN', '64'))
+        wgs = int(os.environ.get('TIPK_KSPLIT_WGS', '512'))
+        cap = int(os.environ.get('TIPK_KSPLIT_MAX', '128'))
+        want = min(k // grain, -(-wgs // tiles))
         if plain and not reduce_batch and want >= 2 and tiles < 256:
-            slab_mode, n_slabs = 'k', int(min(128, want))
+            slab_mode, n_slabs = 'k', int(min(cap, want))
     elif ksplit > 1:
         assert plain and not reduce_batch
         slab_mode, n_slabs = 'k', int(ksplit)
