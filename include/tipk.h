@@ -222,6 +222,15 @@ int tipk_rows_affine(const float* in, int64_t ld_in,
                      float* out, int64_t ld_out,
                      int64_t rows, int64_t cols, int accumulate, tipk_stream_t stream);
 
+/* out[r, c] = in[r, c] * (gate[r, c] > 0)  AND  scratch[g, c] = the column sums of out over the rows
+ * of workgroup g (g < tipk_gate_colsum_groups(rows, cols); 0 = unsupported, cols > 256): the ReLU
+ * backward of GCNConv 1 (src/layers.py:393) and stage 1 of its bias gradient in one pass; the groups
+ * are added in order by tipk_sum_slabs. */
+int tipk_gate_colsum_groups(int64_t rows, int64_t cols);
+int tipk_gate_colsum(const float* in, int64_t ld_in, const float* gate, int64_t ld_gate,
+                     float* out, int64_t ld_out, int64_t rows, int64_t cols, float* scratch,
+                     tipk_stream_t stream);
+
 /* out[c] = sum_r in[r, c]  (bias gradients of GCNConv).  `scratch` holds >= 256*cols floats. */
 int tipk_col_sum(const float* in, int64_t ld_in, int64_t rows, int64_t cols,
                  float* scratch, float* out, tipk_stream_t stream);

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
     const float* __restrict__ edge_w, const int4* __restrict__ items, int64_t n_items,
     float* __restrict__ out, int64_t ld_out, float* __restrict__ partial, Epilogue ep, int d) {
     constexpr int SLOTS = TIPK_WAVE / L;
-    constexpr int U = L < 8 ? L : 8;                       // row loads kept in flight per lane
+    constexpr int U = 8;                                   // row loads kept in flight per lane
+    constexpr int IPL = L < U ? U / L : 1;                 // edge ids held per lane: narrow slots (d <= 16) used to
+    constexpr int STEP = L * IPL;                          // keep only L rows in flight -> twice the dependent batches
     const int lane = tipk_lane();
     const int sub = lane & (L - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / TIPK_WAVE;
@@ -93,30 +95,47 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
 
     Acc<V> acc;
     acc.zero();
-    // software-pipelined ids: the slot's next L edge ids are requested before the current L rows
-    int id_next = -1;
-    float w_next = 0.f;
-    if (it.x + sub < it.y) {
-        id_next = row_id[it.x + sub];
-        if (HAS_W) w_next = edge_w[it.x + sub];
+    // software-pipelined ids: the slot's next STEP edge ids are requested before the current rows;
+    // lane `sub` holds the ids of edges e0 + q * L + sub (coalesced per q)
+    int id_next[IPL];
+    float w_next[IPL];
+#pragma unroll
+    for (int q = 0; q < IPL; ++q) {
+        id_next[q] = -1;
+        w_next[q] = 0.f;
+        const int e = it.x + q * L + sub;
+        if (e < it.y) {
+            id_next[q] = row_id[e];
+            if (HAS_W) w_next[q] = edge_w[e];
+        }
     }
-    for (int e0 = it.x; e0 < it.y; e0 += L) {
-        const int id = id_next;
-        const float wgt = w_next;
-        const int nxt = e0 + L + sub;
-        id_next = -1;
-        if (nxt < it.y) {
-            id_next = row_id[nxt];
-            if (HAS_W) w_next = edge_w[nxt];
+    for (int e0 = it.x; e0 < it.y; e0 += STEP) {
+        int id[IPL];
+        float wgt[IPL];
+#pragma unroll
+        for (int q = 0; q < IPL; ++q) {
+            id[q] = id_next[q];
+            wgt[q] = w_next[q];
+            const int nxt = e0 + STEP + q * L + sub;
+            id_next[q] = -1;
+            if (nxt < it.y) {
+                id_next[q] = row_id[nxt];
+                if (HAS_W) w_next[q] = edge_w[nxt];
+            }
         }
 #pragma unroll 1                          // one batch of U rows in flight: unrolling L/U batches cost 167 VGPRs at L = 32
-        for (int j0 = 0; j0 < L; j0 += U) {
+        for (int j0 = 0; j0 < STEP; j0 += U) {
             int ids[U];
             float ws[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                ids[j] = __shfl(id, j0 + j, L);
-                if (HAS_W) ws[j] = __shfl(wgt, j0 + j, L);
+                if (IPL == 1) {
+                    ids[j] = __shfl(id[0], j0 + j, L);
+                    if (HAS_W) ws[j] = __shfl(wgt[0], j0 + j, L);
+                } else {                                   // STEP == U: edge j of the step sits in register j / L of lane j % L
+                    ids[j] = __shfl(id[j / L], j % L, L);
+                    if (HAS_W) ws[j] = __shfl(wgt[j / L], j % L, L);
+                }
             }
             // all row loads of the batch are issued before the first use: a load whose result is
             // consumed inside its own exec-masked branch is waited for on the spot (U dependent memory

@@ -66,7 +66,55 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __res
     }
 }
 
+// ReLU backward gate fused with stage 1 of the column sum of its result (the bias gradient of the
+// layer): workgroup g handles rows g*R + rl, stepping by G*R (R = 256 / cols row lanes), writes
+// out = in * (gate > 0) and its partial column sums -> scratch[g][c] (fixed order).
+__global__ __launch_bounds__(256) void gate_colsum_kernel(const float* __restrict__ in, int64_t ld_in,
+                                                          const float* __restrict__ gate, int64_t ld_gate,
+                                                          float* __restrict__ out, int64_t ld_out, int64_t rows,
+                                                          int cols, float* __restrict__ scratch) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    const int lanes_r = 256 / cols;
+    const int c = t % cols, rl = t / cols;
+    float s = 0.f;
+    if (rl < lanes_r)
+        for (int64_t r = (int64_t)blockIdx.x * lanes_r + rl; r < rows; r += (int64_t)gridDim.x * lanes_r) {
+            float v = in[r * ld_in + c];
+            if (!(gate[r * ld_gate + c] > 0.f)) v = 0.f;
+            out[r * ld_out + c] = v;
+            s += v;
+        }
+    red[t] = s;
+    __syncthreads();
+    if (rl == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < lanes_r; ++k) tot += red[k * cols + c];
+        scratch[(int64_t)blockIdx.x * cols + c] = tot;
+    }
+}
+
 }  // namespace
+
+extern "C" int tipk_gate_colsum_groups(int64_t rows, int64_t cols) {
+    if (rows <= 0 || cols <= 0 || cols > 256) return 0;
+    const int64_t lanes_r = 256 / cols;
+    int64_t groups = tipk_ceil_div(rows, lanes_r * 4);
+    if (groups > 1024) groups = 1024;
+    return (int)groups;
+}
+
+extern "C" int tipk_gate_colsum(const float* in, int64_t ld_in, const float* gate, int64_t ld_gate, float* out,
+                                int64_t ld_out, int64_t rows, int64_t cols, float* scratch, tipk_stream_t stream) {
+    if (rows < 0 || cols < 0) return TIPK_EINVAL;
+    if (rows == 0 || cols == 0) return TIPK_OK;
+    if (!in || !gate || !out || !scratch) return TIPK_EINVAL;
+    const int groups = tipk_gate_colsum_groups(rows, cols);
+    if (groups == 0) return TIPK_EUNSUPPORTED;
+    hipLaunchKernelGGL(gate_colsum_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, in, ld_in, gate,
+                       ld_gate, out, ld_out, rows, (int)cols, scratch);
+    TIPK_RETURN_LAUNCH();
+}
 
 extern "C" int tipk_transpose(const float* in, int64_t rows, int64_t cols, float* out, tipk_stream_t stream) {
     if (rows < 0 || cols < 0) return TIPK_EINVAL;

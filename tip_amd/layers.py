@@ -191,8 +191,11 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     n_tab = n_all if table_rows is None else table_rows
     cnt = torch.bincount(dst, minlength=n_t).to(torch.float32).clamp_(min=1)
     G = group_slots_for(d) if d else 0
+    scale = (1.0 / cnt).contiguous()
+    # the transposed plan carries 1/count as per-edge weights: no scaling pass before the backward gather
     return ops.AggGraph(build_gather_plan(dst, src, n_t, n_tab, None, chunk, 'pd.fwd', G),
-                        build_gather_plan(src, dst, n_tab, n_t, None, chunk, 'pd.bwd', G), (1.0 / cnt).contiguous())
+                        build_gather_plan(src, dst, n_tab, n_t, scale[dst], chunk, 'pd.bwd', G), scale,
+                        bwd_scaled=True)
 
 
 class MyHierarchyConv(nn.Module):

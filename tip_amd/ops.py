@@ -416,6 +416,21 @@ def rows_affine(x, row_mul=None, row_div=None, gate=None, out=None, accumulate=F
     return out
 
 
+def gate_colsum(x, gate):
+    """(x * (gate > 0), partial column sums [G, 1, cols] of it) in one pass; None if unsupported."""
+    x, gate = _f32c(x), _f32c(gate)
+    require_device(x, gate)
+    rows, cols = x.shape
+    groups = int(lib().tipk_gate_colsum_groups(rows, cols))
+    if groups == 0:
+        return None
+    out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((groups, 1, cols), dtype=torch.float32, device=x.device)
+    check(lib().tipk_gate_colsum(ptr(x), x.stride(0), ptr(gate), gate.stride(0), ptr(out), out.stride(0), rows, cols,
+                                 ptr(scratch), stream_ptr(x.device)), 'tipk_gate_colsum')
+    return out, scratch
+
+
 def col_sum(x):
     x = _f32c(x)
     require_device(x)
@@ -541,9 +556,10 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
-    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None):
+    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False):
         self.fwd, self.bwd, self.scale = fwd, bwd, scale
         self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
+        self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
 
 
 # ---------------------------------------------------------------------------------------------
@@ -570,7 +586,9 @@ class _Aggregate(torch.autograd.Function):
         if ctx.has_bias:
             with fork(g.device):
                 g_bias = col_sum(g_pre)
-        g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
+        g_agg = g_pre
+        if graph.scale is not None and not graph.bwd_scaled:
+            g_agg = rows_affine(g_pre, row_mul=graph.scale)
         g_table = gather_sum(graph.bwd, g_agg) if ctx.needs_input_grad[0] else None
         join(g.device)
         return g_table, g_bias, None, None
@@ -851,15 +869,31 @@ class _GCNConv(torch.autograd.Function):
         x, weight, out = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g).contiguous()
-        g_pre = rows_affine(g, gate=out) if ctx.relu else g
+        bias_parts = None
+        if ctx.relu and ctx.has_bias:                                   # ReLU gate + stage 1 of d bias in one pass
+            fused = gate_colsum(g, out)
+            if fused is not None:
+                g_pre, bias_parts = fused
+        if bias_parts is None:
+            g_pre = rows_affine(g, gate=out) if ctx.relu else g
         g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
         g_table = gather_sum(graph.bwd, g_agg)
-        j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre) if ctx.has_bias else None
+        j_b = None
+        if ctx.has_bias and bias_parts is None:
+            j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre)
         if ctx.identity:
             g_w = transpose(g_table)
+            if bias_parts is not None:
+                return None, g_w, sum_slabs(bias_parts).view(-1), None, None
             if j_b is not None:
                 gemm_group([j_b])
             return None, g_w, (j_b.out.view(-1) if j_b else None), None, None
+        if bias_parts is not None:                                      # rides in the grouped slab sum below
+            s_b = slab_job(bias_parts)
+            j_w = gemm_job(g_table.t(), x)
+            j_x = gemm_job(g_table, weight) if ctx.needs_input_grad[0] else None
+            gemm_group([j for j in (j_w, j_x) if j is not None], [s_b])
+            return (j_x.out if j_x else None), j_w.out, s_b.out.view(-1), None, None
         j_w = gemm_job(g_table.t(), x)
         j_x = gemm_job(g_table, weight) if ctx.needs_input_grad[0] else None
         gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
