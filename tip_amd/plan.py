@@ -29,9 +29,12 @@ TARGET_ITEMS = 65536          # ~ 256 CUs x 32 waves x 8 slots: one item per slo
 
 def auto_chunk(n_edges):
     """Power-of-two chunk in [16, 128] that yields about TARGET_ITEMS work items: short chains
-    (few dependent index->row round trips per slot) while every CU still has a full set of waves."""
+    (few dependent index->row round trips per slot) while every CU still has a full set of waves.
+    Graphs of up to ~4 M edges (P-P: 1.45 M) are latency-bound, not bandwidth-bound, and run 10 %
+    faster with twice the items (measured: chunk 16 vs 32 on the BioSNAP P-P graph)."""
+    target = TARGET_ITEMS * 2 if n_edges <= (1 << 22) else TARGET_ITEMS
     c = 16
-    while c < 128 and n_edges // c > TARGET_ITEMS:
+    while c < 128 and n_edges // c > target:
         c *= 2
     return c
 
