@@ -233,6 +233,21 @@ def test_dy_products_fused(ops, r, nc, nb, monkeypatch):
     assert torch.equal(e_att.cpu(), gi @ xi.t()) and torch.equal(e_xb.cpu(), ai.t() @ gi)
 
 
+def test_gemm_output_beyond_4GB(ops):
+    """Y of the synthetic config is 10 GB: rows past the 4 GB mark must land where they belong
+    (32-bit offsets are tile-local only)."""
+    g = torch.Generator().manual_seed(3)
+    m, k, n = 2100, 32, 600000                                         # C = 5.04 GB
+    a = torch.randn(m, k, generator=g).to(DEV)
+    b = torch.randn(k, n, generator=g).to(DEV)
+    c = ops.gemm(a, b)
+    for r in (0, 1, 1000, 1789, 1790, 2099):                           # 1790 * 600000 * 4 B > 2^32
+        want = (a[r].double() @ b.double()).cpu()
+        close(c[r], want, rtol=2e-5, atol=1e-4)
+    del c
+    torch.cuda.empty_cache()
+
+
 def test_gemm_group_bit_identical_to_single_launches(ops):
     """tipk_gemm_f32_group / tipk_sum_slabs_group: the R-GCN backward's mix of shapes (batched, split-K,
     batch-reduced on top of another member's output, transposed views) in one launch == one by one."""

@@ -228,20 +228,25 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc,
 __device__ __forceinline__ float and_mask(float v, u32 mask) { return __uint_as_float(__float_as_uint(v) & mask); }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// store of one 32x32 accumulator through a scalar base + 32-bit byte offsets (row stride c_sm floats)
+// store of one 32x32 accumulator: 64-bit (wave-uniform) address of the tile origin + 32-bit byte
+// offsets inside the tile (32 rows of c_sm floats: the host checks 32 * c_sm * 4 < 2^32), so outputs
+// larger than 4 GB (synthetic config: Y is 10 GB) are addressed correctly
 __device__ __forceinline__ void store_tile32(const GemmArgs& g, const f32x16& acc, float* c_z, const float* cin_z,
                                              int m0, int n0, int lane) {
     const int col = n0 + (lane & 31);
     if (col >= (int)g.n) return;
+    float* c_t = c_z + (int64_t)m0 * g.c_sm + n0;
+    const float* cin_t = cin_z ? cin_z + (int64_t)m0 * g.cin_sm + n0 : nullptr;
     const u32 c_sm = (u32)g.c_sm * 4u, cin_sm = (u32)g.cin_sm * 4u;
+    const u32 cb = (u32)(lane & 31) * 4u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int rowi = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (rowi < (int)g.m) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m0 + rl < (int)g.m) {
             float v = g.alpha * acc[r];
-            if (cin_z) v += ldg(cin_z, (u32)rowi * cin_sm + (u32)col * 4u);
+            if (cin_t) v += ldg(cin_t, (u32)rl * cin_sm + cb);
             if (g.relu) v = fmaxf(v, 0.f);
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(c_z) + ((u32)rowi * c_sm + (u32)col * 4u)) = v;
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(c_t) + ((u32)rl * c_sm + cb)) = v;
         }
     }
 }
@@ -419,6 +424,7 @@ inline int stream_kind(const GemmArgs& g, int64_t batch) {
     const int64_t lim = 0x3fffffffLL;                     // byte offsets fit 32 bits
     if (g.a_sm < 0 || g.a_sk < 0 || g.b_sk < 0 || g.b_sn < 0 || g.m > lim || g.n > lim || g.k > lim) return STREAM_NONE;
     if ((g.m - 1) * g.a_sm + (g.k - 1) * g.a_sk >= lim || (g.k - 1) * g.b_sk + (g.n - 1) * g.b_sn >= lim) return STREAM_NONE;
+    if (g.c_sm < 0 || g.cin_sm < 0 || 32 * g.c_sm >= lim || 32 * g.cin_sm >= lim) return STREAM_NONE;   // tile-local C offsets
     if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && g.m >= 256 && g.n >= 1024) return STREAM_THIN_K;
     if (g.m <= 32 && g.b_sn == 1 && g.n >= 1024 && g.k >= 256) return STREAM_THIN_M;
     // lane-per-row dwordx4 loads keep the texture addresser 70 % busy (PMC) and the LDS-tiled kernel is as
