@@ -197,8 +197,8 @@ int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, in
  *     Results arrive as slabs to be added in order (tipk_sum_slabs_group):
  *        dxb_slabs  [row_slabs][n_bases x n_cols]   one per range of relations
  *        datt_slabs [col_slabs][n_rel x n_bases]    one per chunk of 512 columns
- *     `tipk_rgcn_dy_products_plan` returns the slab counts (both 0: shape not supported -- n_bases > 32
- *     or so many columns that one datt slab per chunk would not pay; use two tipk_gemm_f32 then).
+ *     `tipk_rgcn_dy_products_plan` returns the slab counts (both 0: shape not supported -- n_bases > 32;
+ *     use two tipk_gemm_f32 then).  The datt slabs are n_bases / 512 of the size of dY.
  */
 int tipk_rgcn_dy_products_plan(int64_t n_rel, int64_t n_cols, int n_bases, int* col_slabs, int* row_slabs);
 int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int64_t ld_att,

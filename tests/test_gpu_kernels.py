@@ -203,7 +203,8 @@ def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
     assert torch.equal(ops.gemm(aid, bid, ksplit=ks).cpu(), ai @ bi)
 
 
-@pytest.mark.parametrize('r,nc,nb', [(1097, 20640, 32), (1097, 10320, 32), (70, 645 * 4, 7), (33, 513, 32), (5, 31, 1)])
+@pytest.mark.parametrize('r,nc,nb', [(1097, 20640, 32), (1097, 10320, 32), (70, 645 * 4, 7), (33, 513, 32), (5, 31, 1),
+                                     (40, 70000, 32)])
 def test_dy_products_fused(ops, r, nc, nb, monkeypatch):
     """tipk_rgcn_dy_products: d att = dY XB^T and d XB = att^T dY from one pass over dY, ragged row
     ranges / column chunks / base counts; reproducible; the two-GEMM path is the cross-check."""

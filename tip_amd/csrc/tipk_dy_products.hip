@@ -73,12 +73,16 @@ __global__ __launch_bounds__(1024) void dy_products_kernel(DpArgs a) {
 
     float dyv[16], atv[16];
     auto load_tile = [&](int r0) {                      // dY tile in B-operand layout + att^T in A-operand layout
+        // 64-bit (wave-uniform) address of the tile's first row + 32-bit offsets inside the 32 rows:
+        // dY may be far larger than 4 GB (synthetic config: 10 GB)
+        const float* dy_t = a.dy + (int64_t)r0 * a.ld_dy;
+        const float* att_t = a.att + (int64_t)r0 * a.ld_att;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int r = r0 + 2 * kk + kh;
-            const u32 rc = (u32)(r < r_hi ? r : r_hi - 1);
-            dyv[kk] = ldg(a.dy, rc * ld_dy + col_b);
-            atv[kk] = ldg(a.att, rc * ld_att + (u32)(row < NB ? row : NB - 1) * 4u);
+            const u32 rl = (u32)((r < r_hi ? r : r_hi - 1) - r0);
+            dyv[kk] = ldg(dy_t, rl * ld_dy + col_b);
+            atv[kk] = ldg(att_t, rl * ld_att + (u32)(row < NB ? row : NB - 1) * 4u);
         }
     };
     if (r_lo < r_hi) load_tile(r_lo);
@@ -141,8 +145,8 @@ extern "C" int tipk_rgcn_dy_products_plan(int64_t n_rel, int64_t n_cols, int n_b
     if (!col_slabs || !row_slabs) return TIPK_EINVAL;
     *col_slabs = *row_slabs = 0;
     if (n_rel <= 0 || n_cols <= 0 || n_bases <= 0 || n_bases > 32 || n_rel > 0x7fffffffLL || n_cols > 0x1fffffffLL) return TIPK_OK;
-    const int64_t s_c = tipk_ceil_div(n_cols, DP_CHUNK);
-    if (s_c > 128) return TIPK_OK;                      // huge column counts: one datt slab per chunk would not pay
+    const int64_t s_c = tipk_ceil_div(n_cols, DP_CHUNK);  // the datt slabs are always n_bases / 512 = 6 % of dY
+    if (s_c > 65535) return TIPK_OK;
     int64_t s_r = 256 / s_c;                            // about one workgroup per CU
     if (s_r < 1) s_r = 1;
     const int64_t per = tipk_ceil_div(tipk_ceil_div(n_rel, s_r), 32) * 32;
@@ -160,8 +164,8 @@ extern "C" int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float
     if (rc != TIPK_OK) return rc;
     if (s_c == 0) return TIPK_EUNSUPPORTED;
     if (!dy || !att || !xb || !dxb_slabs || !datt_slabs || ld_dy < n_cols || ld_att < n_bases || ld_xb < n_cols) return TIPK_EINVAL;
-    // 32-bit byte offsets inside dY / att / XB
-    if (n_rel * ld_dy >= (1LL << 30) || n_rel * ld_att >= (1LL << 30) || n_bases * ld_xb >= (1LL << 30)) return TIPK_EUNSUPPORTED;
+    // 32-bit byte offsets inside one 32-row tile of dY / att and inside XB
+    if (32 * ld_dy >= (1LL << 30) || 32 * ld_att >= (1LL << 30) || n_bases * ld_xb >= (1LL << 30)) return TIPK_EUNSUPPORTED;
     DpArgs a;
     a.dy = dy; a.att = att; a.xb = xb;
     a.R = (int)n_rel; a.NC = (int)n_cols; a.NB = n_bases;

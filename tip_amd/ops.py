@@ -323,7 +323,11 @@ def dy_products(g_y, att, xb2):
         check(lib().tipk_rgcn_dy_products(ptr(g_y), g_y.stride(0), ptr(att), att.stride(0), ptr(xb2), xb2.stride(0),
                                           r, nc, nb, ptr(dxb_slabs), ptr(datt_slabs), stream_ptr(dev)),
               'tipk_rgcn_dy_products')
-    j_xb, j_att = slab_job(dxb_slabs), slab_job(datt_slabs)
+    j_att = slab_job(datt_slabs)
+    if s_r.value == 1:                                   # one row range: the slab IS d XB
+        gemm_group([], [j_att])
+        return j_att.out, dxb_slabs[0]
+    j_xb = slab_job(dxb_slabs)
     gemm_group([], [j_xb, j_att])
     return j_att.out, j_xb.out
 
