@@ -295,8 +295,9 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from
         # the forward launch is (workgroups x column blocks): keep it at one workgroup per CU
         rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, max(1, n_wg // max(1, split)))
         rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, n_wg, backward=True)
-    return ops.AggGraph(build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
-                        build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
+    # the generic plans are built on first use: with the relation-local kernels they are never needed
+    return ops.AggGraph(lambda: build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
+                        lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd)
 
 

@@ -561,9 +561,23 @@ class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
     def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False):
-        self.fwd, self.bwd, self.scale = fwd, bwd, scale
+        """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
+        generic D-D plans are only needed where the relation-local kernel does not apply)."""
+        self._fwd, self._bwd, self.scale = fwd, bwd, scale
         self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
+
+    @property
+    def fwd(self):
+        if callable(self._fwd):
+            self._fwd = self._fwd()
+        return self._fwd
+
+    @property
+    def bwd(self):
+        if callable(self._bwd):
+            self._bwd = self._bwd()
+        return self._bwd
 
 
 # ---------------------------------------------------------------------------------------------
@@ -679,8 +693,11 @@ class _RGCN(torch.autograd.Function):
         nb, _, d_out = basis.shape
         att_l = att if shard is None else att.index_select(0, shard.rel_ids_on(att.device))
         r = att_l.shape[0]
-        assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
+        if use_rl:
+            assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
+        else:
+            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         fused = use_rl and shard is None
         if fused:                                                        # XB and X root: one grouped launch
             xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])
