@@ -161,6 +161,15 @@ def test_tip_end_to_end_small():
         np.testing.assert_allclose(rec, g['record'].numpy(), rtol=1e-4, atol=1e-4)
         # default path: negatives drawn on device, loss finite and close to the recorded one
         assert abs(float(model()) - float(g['loss'])) < 0.5
+        # serving helper: top-k side effects of drug pairs == a dense re-computation from the embeddings
+        pairs = torch.tensor([[0, 1, 2, 3, 5], [1, 0, 4, 3, 2]])
+        vals, ids = model.pred_topk(pairs, k=3, max_triples=2 * g['n_dd_et'])          # forces several slices
+        z, w = model.embeddings.detach().double().cpu(), model.decoder.weight.detach().double().cpu()
+        dense = torch.sigmoid((z[pairs[0]] * z[pairs[1]]) @ w.t())
+        want = torch.topk(dense, 3, dim=1)
+        close(vals, want.values, rtol=1e-5)
+        assert torch.equal(ids.cpu(), want.indices) and vals.shape == (5, 3)
+        assert model.pred(pairs[:, :2].to(DEV), torch.tensor([0, 1]).to(DEV)).shape == (2,)
 
 
 def test_biosnap_slice_against_reference_golden():

@@ -551,6 +551,30 @@ class TIP(nn.Module):
     def pred(self, dd_idx, dd_et):
         return self.decoder(self.embeddings, dd_idx, dd_et)
 
+    def pred_topk(self, dd_pairs, k=10, max_triples=1 << 24):
+        """Serving helper (extension): for every drug pair (u, v) of
+        `dd_pairs` [2, P] the k most likely side effects -> (scores [P, k], relation ids [P, k]).
+        All num_et relations of a pair are scored by the decoder kernel in one launch (pairs are
+        processed in slices of at most `max_triples` triples)."""
+        R = self.data.n_dd_et
+        k = min(int(k), R)
+        pairs = dd_pairs.to(self.embeddings.device).to(torch.int64)
+        P = pairs.shape[1]
+        et_all = torch.arange(R, device=pairs.device)
+        vals, ids = [], []
+        step = max(1, max_triples // R)
+        with torch.no_grad():
+            for p0 in range(0, P, step):
+                sl = pairs[:, p0:p0 + step]
+                n = sl.shape[1]
+                s = self.decoder(self.embeddings, sl.repeat_interleave(R, dim=1), et_all.repeat(n)).view(n, R)
+                top = torch.topk(s, k, dim=1)
+                vals.append(top.values)
+                ids.append(top.indices)
+        if not vals:
+            return (torch.zeros((0, k), device=pairs.device), torch.zeros((0, k), dtype=torch.int64, device=pairs.device))
+        return torch.cat(vals), torch.cat(ids)
+
     def test(self, print_output=True):
         self.eval()
         d = self.data
