@@ -236,7 +236,10 @@ def main():
                 step()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # with a process group alive the RCCL watchdog thread makes HIP calls of its own: only this
+            # thread's calls may invalidate the capture
+            mode = {'capture_error_mode': 'thread_local'} if dist.is_initialized() else {}
+            with torch.cuda.graph(graph, **mode):
                 step()
         except Exception as exc:                               # noqa: BLE001
             sys.stderr.write('graph capture failed on rank %d (%r): eager launches\n' % (rank, exc))
