@@ -11,8 +11,6 @@ import torch
 
 from . import _lib
 from ._lib import SlabSumDesc, GemmDesc, check, lib, ptr, stream_ptr, require_device
-from .plan import GatherPlan
-
 
 def _f32c(t):
     """fp32, unit column stride (row stride free)."""

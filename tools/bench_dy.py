@@ -2,7 +2,7 @@
 product / reduction, 4 no first product) at BioSNAP sizes; kernel-only time via a captured graph."""
 import os, sys, torch, ctypes as C
 sys.path.insert(0, '.')
-from tip_amd import ops
+
 from tip_amd._lib import lib, ptr, stream_ptr, check
 dev = torch.device('cuda:0')
 R, B = 1097, 32
