@@ -263,7 +263,7 @@ def test_gemm_group_bit_identical_to_single_launches(ops):
     def build(gx_buf):
         j_basis = ops.gemm_job(x.t(), g_xb)
         j_root = ops.gemm_job(x.t(), gr)
-        j_xr = ops.gemm_job(gr, root.t(), out=gx_buf)
+        j_xr = ops.gemm_job(gr, root.t(), out=gx_buf, ksplit=1)      # its output is accumulated onto by j_xq
         j_xq = ops.gemm_job(g_xb, basis.transpose(1, 2), out=gx_buf, c_in=gx_buf, reduce_batch=True)
         return [j_basis, j_root, j_xr, j_xq]
 

@@ -194,6 +194,35 @@ def test_biosnap_slice_against_reference_golden():
             close(prm.grad, g['grad.' + k], rtol=2e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize('dims', [
+    dict(prot_drug_dim=32, n_embed=32, n_hid1=64, n_hid2=32, num_base=16, mod='cat'),
+    dict(prot_drug_dim=24, n_embed=24, n_hid1=16, n_hid2=8, num_base=5, mod='add'),
+    dict(prot_drug_dim=8, n_embed=20, n_hid1=128, n_hid2=4, num_base=32, mod='cat')])
+def test_encoder_other_dimensions_vs_oracle(dims):
+    """Layer widths other than tip.py's (column-split / non-split LDS kernels, num_base != 32, d_in
+    not a power of two): z and every gradient vs the oracle on a 40-relation BioSNAP slice."""
+    from tip_amd.data import build_data_dict, Data
+    from tip_amd.layers import FMEncoder
+    dims = dict(dims)
+    mod = dims.pop('mod')
+    dd = build_data_dict(max_relations=40)
+    R = dd['n_dd_et']
+    p = O.init_params(dd['n_drug'], dd['n_prot'], R, mod=mod, seed=7, **dims)
+    enc = FMEncoder(DEV, dd['n_drug'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], mod=mod, **dims)
+    enc = load_params(enc, p)
+    d = Data.from_dict(dd).to(DEV)
+    z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices,
+            d.dp_edge_index, d.dp_range_list)
+    torch.manual_seed(1)
+    up = torch.randn(dd['n_drug'], dims['n_hid2'])
+    (z * up.to(DEV)).sum().backward()
+    zo, saved = O.fm_encoder_fwd(p, dd, mod)
+    go = O.fm_encoder_bwd(up, p, dd, saved, mod)
+    close(z, zo, rtol=1e-3)
+    for k, prm in enc.named_parameters():
+        close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+
+
 @pytest.fixture(scope='module')
 def biosnap_full():
     from tip_amd.data import build_data_dict

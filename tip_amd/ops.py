@@ -379,6 +379,16 @@ def gemm_group(jobs, slab_jobs=()):
         return []
     dev = (jobs[0].out if jobs else slab_jobs[0].out).device
     st = stream_ptr(dev)
+    # two members may share an output only as "written by the GEMM launch" + "slab sum accumulated on top"
+    by_out = {}
+    for j in jobs:
+        by_out.setdefault(j.out.data_ptr(), []).append(j)
+    for same in by_out.values():
+        if len(same) > 1:
+            direct = [j for j in same if j.slabs is None]
+            assert len(direct) == 1 and all(j.accumulate for j in same if j.slabs is not None), \
+                'group members sharing an output: one un-split product + accumulating slab sums only'
+            assert len(same) == 2, 'at most one accumulating member per output (order of the sums)'
     for i in range(0, len(jobs), _lib.GROUP_MAX):
         part = jobs[i:i + _lib.GROUP_MAX]
         arr = (GemmDesc * len(part))(*[j.desc for j in part])
@@ -756,8 +766,8 @@ class _RGCN(torch.autograd.Function):
         j_root = gemm_job(x.t(), g)
         if shard is None:
             g_att = g_att_l
-            j_xr = gemm_job(g, root.t())
-            g_x = j_xr.out
+            j_xr = gemm_job(g, root.t(), ksplit=1)                       # written by the GEMM launch itself: the
+            g_x = j_xr.out                                               # basis half is summed on top of it afterwards
             j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
             if j_xq.slabs is not None:                                   # summed on top of g root^T afterwards
                 if ctx.gate_input:
