@@ -462,6 +462,31 @@ def test_rel_gather_fwd_bwd(ops, d):
           O.gather_sum(wide[:, 4:4 + d].cpu().double(), rel * N + src, dst, N))
 
 
+@pytest.mark.parametrize('N,d', [(1000, 32), (1000, 16), (1024, 8), (300, 64), (17, 128)])
+def test_rel_gather_other_node_counts(ops, N, d):
+    """Node counts other than BioSNAP's 645: the table-prefetch width (TU) and the column split change."""
+    from tip_amd.plan import build_rel_plan
+    from tip_amd import _lib
+    g = torch.Generator().manual_seed(N + d)
+    R = 5
+    sizes = torch.tensor([30000, 0, 7, 12000, 2500])
+    E = int(sizes.sum())
+    rel = torch.repeat_interleave(torch.arange(R), sizes)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, max(1, N - 3), (E,), generator=g)
+    split_f = _lib.lib().tipk_rel_gather_supported(N, d, 0)
+    split_b = _lib.lib().tipk_rel_gather_supported(N, d, 1)
+    assert split_f >= 1 and split_b >= 1
+    y = torch.randn(R * N, d, generator=g)
+    plan = build_rel_plan(dst, src, rel, N, R, n_wg=max(1, 256 // split_f)).to(DEV)
+    close(ops.rel_gather(plan, y.to(DEV), backward=False), O.gather_sum(y.double(), rel * N + src, dst, N))
+    gp = torch.randn(N, d, generator=g)
+    scale = torch.rand(N, generator=g) + 0.5
+    planb = build_rel_plan(src, dst, rel, N, R, n_wg=256, backward=True).to(DEV)
+    close(ops.rel_gather(planb, gp.to(DEV), backward=True, row_scale=scale.to(DEV)),
+          O.gather_sum(gp.double() * scale.double().unsqueeze(1), dst, rel * N + src, R * N))
+
+
 def test_rel_gather_unsupported_shapes():
     from tip_amd import _lib
     L = _lib.lib()
