@@ -223,6 +223,33 @@ def test_encoder_other_dimensions_vs_oracle(dims):
         close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
 
 
+def test_synthetic_encoder_large_node_set_vs_oracle():
+    """More drugs than the LDS-resident kernel takes (N > 1024): the fabric-gather path, its finalize
+    launch, dy_products with hundreds of column chunks -- the route BASELINE config 5 takes -- vs the oracle."""
+    from tip_amd.data import synthetic_data_dict, Data
+    from tip_amd.layers import FMEncoder
+    from tip_amd import ops
+    dd = synthetic_data_dict(n_drug=1500, n_rel=12, n_edges=60000, seed=5, with_protein_graph=True,
+                             n_prot=700, pp_edges=4000, dp_edges=900)
+    assert ops.rel_gather_split(1500, 64, False) == 0
+    dims = dict(prot_drug_dim=16, n_embed=48, n_hid1=64, n_hid2=32, num_base=32)
+    R = dd['n_dd_et']
+    p = O.init_params(dd['n_drug'], dd['n_prot'], R, mod='cat', seed=3, **dims)
+    enc = FMEncoder(DEV, dd['n_drug'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], mod='cat', **dims)
+    enc = load_params(enc, p)
+    d = Data.from_dict(dd).to(DEV)
+    z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices,
+            d.dp_edge_index, d.dp_range_list)
+    torch.manual_seed(2)
+    up = torch.randn(dd['n_drug'], dims['n_hid2'])
+    (z * up.to(DEV)).sum().backward()
+    zo, saved = O.fm_encoder_fwd(p, dd, 'cat')
+    go = O.fm_encoder_bwd(up, p, dd, saved, 'cat')
+    close(z, zo, rtol=1e-3)
+    for k, prm in enc.named_parameters():
+        close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+
+
 @pytest.fixture(scope='module')
 def biosnap_full():
     from tip_amd.data import build_data_dict
