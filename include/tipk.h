@@ -247,8 +247,12 @@ int tipk_distmult_fwd(const float* z, int64_t n_nodes, int k, const float* rel_w
 
 /* g_z [n_nodes x k] and g_w [n_rel x k] are ACCUMULATED into (caller zeroes them);
  * `score` is the forward output when sigmoid != 0 (unused otherwise).
- * tasks (nullable): int32 [n_tasks, 3] = (relation, begin, end) -- ranges of AT MOST 2048 positions
- * that share one relation, covering [0, n_triples), largest first.  TIP's triples are grouped by relation
+ * tasks (nullable): int32 [n_tasks, 4] = (relation, begin, end, pos_weight) -- ranges of AT MOST 2048
+ * positions that share one relation, covering [0, n_triples), largest first.  pos_weight is read by
+ * tipk_distmult_loss only: the weight (1, or 2 / 0) of the task's POSITIVE triples -- when every relation
+ * lists each pair in both directions ([u<v half | mirrored half], src/utils.py:35-65) the host may give
+ * the first half weight 2 and the mirrored half weight 0 (identical scores and gradients): the objective
+ * and all gradients are unchanged, a quarter of the work disappears.  TIP's triples are grouped by relation
  * (src/utils.py:57-63), so the host builds this once; with it (and k a power of two in 4..64,
  * 2*n_nodes*(k+4)*4 B <= 150 KB) the LDS-resident fast kernel runs, otherwise the generic one. */
 int tipk_distmult_bwd(const float* g_score, const float* score,

@@ -360,6 +360,41 @@ def test_distmult_fused_objective(ops):
     close(loss_only, O.tip_loss(ps, ns).view(1), rtol=2e-5)
 
 
+def test_distmult_fused_objective_mirrored_positives(ops, monkeypatch):
+    """TIP's positives list every pair in both directions per relation: the mirrored half is skipped and
+    the first half counted twice -- same loss and gradients as the plain evaluation and as the oracle."""
+    g = torch.Generator().manual_seed(8)
+    n, r, k = 645, 23, 16
+    sizes = torch.randint(1, 4000, (r,), generator=g)
+    sizes[3] = 0
+    halves = [torch.randint(0, n, (2, int(c)), generator=g) for c in sizes]
+    pos = torch.cat([torch.cat([h, h.flip(0)], dim=1) for h in halves], dim=1)
+    et = torch.repeat_interleave(torch.arange(r), 2 * sizes)
+    m = pos.shape[1]
+    neg = torch.randint(0, n, (2, m), generator=g)
+    z = torch.randn(n, k, generator=g) * 0.7
+    w = torch.randn(r, k, generator=g) * 0.5
+    zd, wd, posd, negd, etd = z.to(DEV), w.to(DEV), pos.to(DEV), neg.to(DEV), et.to(DEV)
+    tasks = ops.relation_tasks(etd, posd)
+    assert set(tasks[:, 3].tolist()) == {0, 2}
+    loss, gz, gw = ops.distmult_loss(zd, wd, posd, negd, etd)
+    z64, w64 = z.double(), w.double()
+    ps, ns = O.distmult_fwd(z64, pos, et, w64), O.distmult_fwd(z64, neg, et, w64)
+    close(loss, O.tip_loss(ps, ns).view(1), rtol=2e-5)
+    gp, gn = O.tip_loss_bwd(ps, ns)
+    gz1, gw1 = O.distmult_bwd(gp, z64, pos, et, w64)
+    gz2, gw2 = O.distmult_bwd(gn, z64, neg, et, w64)
+    close(gz, gz1 + gz2, atol=2e-6)
+    close(gw, gw1 + gw2, atol=2e-6)
+    monkeypatch.setenv('TIPK_NO_SYMMETRIC_POS', '1')
+    posd2 = posd.clone()                                               # new tensor: new cache entry
+    assert bool((ops.relation_tasks(etd, posd2)[:, 3] == 1).all())
+    loss2, gz2d, gw2d = ops.distmult_loss(zd, wd, posd2, negd, etd)
+    close(loss2, loss.cpu(), rtol=1e-5)
+    close(gz2d, gz.cpu(), rtol=1e-4, atol=1e-6)
+    close(gw2d, gw.cpu(), rtol=1e-4, atol=1e-6)
+
+
 # ------------------------------------------------------------------ negative sampler
 def test_negative_sampler_bit_exact_vs_spec_and_properties():
     from tip_amd import neg_sampling as NS

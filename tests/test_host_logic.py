@@ -256,8 +256,8 @@ def test_relation_tasks_and_sampler_keys_host_side():
     from oracle.philox_sampler import call_key
     et = torch.repeat_interleave(torch.arange(5), torch.tensor([10000, 0, 3, 4097, 1]))
     tasks = ops.relation_tasks(et)
-    assert tasks.dtype == torch.int32 and tasks.shape[1] == 3
-    t = tasks.long()
+    assert tasks.dtype == torch.int32 and tasks.shape[1] == 4 and bool((tasks[:, 3] == 1).all())
+    t = tasks.long()[:, :3]
     assert int((t[:, 2] - t[:, 1]).sum()) == et.numel() and int((t[:, 2] - t[:, 1]).max()) <= ops.TASK_POSITIONS
     assert bool(((t[:-1, 2] - t[:-1, 1]) >= (t[1:, 2] - t[1:, 1])).all())        # largest first
     for r, a, b in t.tolist():
@@ -267,6 +267,14 @@ def test_relation_tasks_and_sampler_keys_host_side():
         covered[a:b] += 1
     assert bool((covered == 1).all())
     assert ops.relation_tasks(torch.tensor([0, 1, 0, 1])) is None                 # not grouped by relation
+    # mirrored positives ([pairs | flipped pairs] per relation, src/utils.py:35-65): first halves weigh 2, the rest 0
+    half = [torch.tensor([[0, 1, 2], [3, 4, 5]]), torch.tensor([[7], [2]]), torch.zeros((2, 0), dtype=torch.long)]
+    pos = torch.cat([torch.cat([h, h.flip(0)], dim=1) for h in half], dim=1)
+    et2 = torch.repeat_interleave(torch.tensor([0, 2, 5]), torch.tensor([6, 2, 0]))
+    tk = ops.relation_tasks(et2, pos).long()
+    assert sorted(tk.tolist()) == sorted([[0, 0, 3, 2], [0, 3, 6, 0], [2, 6, 7, 2], [2, 7, 8, 0]])
+    broken = pos.clone(); broken[0, 4] = 9                                        # one pair not mirrored: plain weights
+    assert bool((ops.relation_tasks(et2, broken)[:, 3] == 1).all())
     for seed, n in ((0, 0), (1111, 7), ((1 << 64) - 1, 123456)):
         assert NS.call_key(seed, n) == call_key(seed, n)
     assert len({call_key(5, n) for n in range(100)}) == 100

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         if (MODE == 0) {
             float sg = 0.f;
             for (int task = blockIdx.x; task < n_tasks; task += gridDim.x)
-                for (int p = tasks[3 * task + 1] + t; p < tasks[3 * task + 2]; p += 1024) sg += fabsf(g_score[p]);
+                for (int p = tasks[4 * task + 1] + t; p < tasks[4 * task + 2]; p += 1024) sg += fabsf(g_score[p]);
             bound *= block_sum_1024(sg, red, t);
         }
         int ex = 60;
@@ -244,7 +244,13 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     float loss = 0.f;
 
     for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-        const int rel = tasks[3 * task], tb = tasks[3 * task + 1], te = tasks[3 * task + 2];
+        const int rel = tasks[4 * task], tb = tasks[4 * task + 1], te = tasks[4 * task + 2];
+        // weight of the task's POSITIVE triples in the fused objective: 1, or -- when the caller has verified
+        // that every relation lists each pair in both directions (the data contract of the path:
+        // [u<v half | mirrored half], src/utils.py:35-65) -- 2 for the first half and 0 for the mirrored
+        // half, whose scores and gradients are identical: a quarter of the LDS atomics and of the
+        // transcendentals disappear.  The negatives of every position are always evaluated.
+        const int pos_w = MODE == 1 ? tasks[4 * task + 3] : 1;
         const float4 wr = tipk_ld4(w + (int64_t)rel * k + c0);
         float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
         // The task's ids are staged into LDS as 16-bit values with ONE batch of coalesced loads per
@@ -282,9 +288,11 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0, a1 = a0, b1 = a0;
             float d0 = 0.f, d1 = 0.f;
             if (valid) {
-                a0 = tipk_ld4(zl + cu0 * ld + c0);
-                b0 = tipk_ld4(zl + cv0 * ld + c0);
-                d0 = a0.x * b0.x * wr.x + a0.y * b0.y * wr.y + a0.z * b0.z * wr.z + a0.w * b0.w * wr.w;
+                if (pos_w != 0) {
+                    a0 = tipk_ld4(zl + cu0 * ld + c0);
+                    b0 = tipk_ld4(zl + cv0 * ld + c0);
+                    d0 = a0.x * b0.x * wr.x + a0.y * b0.y * wr.y + a0.z * b0.z * wr.z + a0.w * b0.w * wr.w;
+                }
                 if (MODE == 1) {
                     a1 = tipk_ld4(zl + cu1 * ld + c0);
                     b1 = tipk_ld4(zl + cv1 * ld + c0);
@@ -306,14 +314,15 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 const float val = neg_lane ? 1.f - sg : sg;
                 const float lg = logf(val + TIP_EPS);
                 const float qq = inv_n * sg * (1.f - sg) / (val + TIP_EPS);
+                const float pw = (float)pos_w;
                 if (KL > 1) {
-                    if (valid && sub < 2) loss -= lg;
-                    q0 = -__shfl(qq, 0, KL);
+                    if (valid && sub < 2) loss -= neg_lane ? lg : pw * lg;
+                    q0 = -pw * __shfl(qq, 0, KL);
                     q1 = __shfl(qq, 1, KL);
                 } else {                                   // k = 4: one lane per position does both
                     const float sn = sigmoidf(d1);
-                    if (valid) loss -= lg + logf(1.f - sn + TIP_EPS);
-                    q0 = -qq;
+                    if (valid) loss -= pw * lg + logf(1.f - sn + TIP_EPS);
+                    q0 = -pw * qq;
                     q1 = inv_n * sn * (1.f - sn) / (1.f - sn + TIP_EPS);
                 }
                 if (!valid) { q0 = 0.f; q1 = 0.f; }
@@ -322,14 +331,16 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 if (sig) { const float sg = sigmoidf(d0); q0 *= sg * (1.f - sg); }
             }
             if (want_grad && valid) {
-                unsigned long long* gu = gzl + cu0 * lg + c0;
-                unsigned long long* gv = gzl + cv0 * lg + c0;
-                fx_add(gu + 0, q0 * b0.x * wr.x, scale); fx_add(gu + 1, q0 * b0.y * wr.y, scale);
-                fx_add(gu + 2, q0 * b0.z * wr.z, scale); fx_add(gu + 3, q0 * b0.w * wr.w, scale);
-                fx_add(gv + 0, q0 * a0.x * wr.x, scale); fx_add(gv + 1, q0 * a0.y * wr.y, scale);
-                fx_add(gv + 2, q0 * a0.z * wr.z, scale); fx_add(gv + 3, q0 * a0.w * wr.w, scale);
-                gw.x = fmaf(q0, a0.x * b0.x, gw.x); gw.y = fmaf(q0, a0.y * b0.y, gw.y);
-                gw.z = fmaf(q0, a0.z * b0.z, gw.z); gw.w = fmaf(q0, a0.w * b0.w, gw.w);
+                if (pos_w != 0) {
+                    unsigned long long* gu = gzl + cu0 * lg + c0;
+                    unsigned long long* gv = gzl + cv0 * lg + c0;
+                    fx_add(gu + 0, q0 * b0.x * wr.x, scale); fx_add(gu + 1, q0 * b0.y * wr.y, scale);
+                    fx_add(gu + 2, q0 * b0.z * wr.z, scale); fx_add(gu + 3, q0 * b0.w * wr.w, scale);
+                    fx_add(gv + 0, q0 * a0.x * wr.x, scale); fx_add(gv + 1, q0 * a0.y * wr.y, scale);
+                    fx_add(gv + 2, q0 * a0.z * wr.z, scale); fx_add(gv + 3, q0 * a0.w * wr.w, scale);
+                    gw.x = fmaf(q0, a0.x * b0.x, gw.x); gw.y = fmaf(q0, a0.y * b0.y, gw.y);
+                    gw.z = fmaf(q0, a0.z * b0.z, gw.z); gw.w = fmaf(q0, a0.w * b0.w, gw.w);
+                }
                 if (MODE == 1) {
                     unsigned long long* hu = gzl + cu1 * lg + c0;
                     unsigned long long* hv = gzl + cv1 * lg + c0;

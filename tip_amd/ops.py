@@ -471,10 +471,15 @@ _TASK_CACHE = {}
 TASK_POSITIONS = 2048          # = TASK_MAX in tipk_distmult.hip (a task's ids are staged in LDS)
 
 
-def relation_tasks(edge_type):
-    """int32 [T,3] (relation, begin, end) tasks for the LDS-resident decoder kernels, or None when
-    the triples are not grouped by relation (include/tipk.h section 4).  Built once per tensor."""
-    key = (edge_type.data_ptr(), tuple(edge_type.shape), edge_type._version, str(edge_type.device))
+def relation_tasks(edge_type, pos_index=None):
+    """int32 [T,4] (relation, begin, end, pos_weight) tasks for the LDS-resident decoder kernels, or
+    None when the triples are not grouped by relation (include/tipk.h section 4).  Built once per tensor.
+
+    pos_index: the positive triples of the fused objective.  If every relation's block is
+    [pairs | the same pairs mirrored] (the data contract of the path, src/utils.py:35-65 -- verified
+    here, element by element), the first half gets weight 2 and the mirrored half weight 0."""
+    key = (edge_type.data_ptr(), tuple(edge_type.shape), edge_type._version, str(edge_type.device),
+           None if pos_index is None else (pos_index.data_ptr(), pos_index._version))
     hit = _TASK_CACHE.get(key)
     if hit is not None:
         return hit[0]
@@ -483,17 +488,37 @@ def relation_tasks(edge_type):
         rels, counts = torch.unique_consecutive(edge_type, return_counts=True)
         if torch.unique(rels).numel() == rels.numel():                      # each relation is one run
             start = torch.cumsum(counts, 0) - counts
-            n_chunks = (counts + TASK_POSITIONS - 1) // TASK_POSITIONS
-            run = torch.repeat_interleave(torch.arange(rels.numel(), device=rels.device), n_chunks)
-            first = torch.cumsum(n_chunks, 0) - n_chunks
-            local = torch.arange(run.numel(), device=rels.device) - first[run]
-            begin = start[run] + local * TASK_POSITIONS
-            end = torch.minimum(begin + TASK_POSITIONS, start[run] + counts[run])
-            order = torch.sort(end - begin, descending=True, stable=True).indices
-            tasks = torch.stack([rels[run], begin, end], dim=1)[order].to(torch.int32).contiguous()
+            dev = rels.device
+            mirrored = False
+            if pos_index is not None and not os.environ.get('TIPK_NO_SYMMETRIC_POS') and bool((counts % 2 == 0).all()):
+                half = counts // 2
+                pos = torch.arange(edge_type.numel(), device=dev)
+                run_of = torch.repeat_interleave(torch.arange(rels.numel(), device=dev), counts)
+                first = pos < (start + half)[run_of]
+                partner = torch.where(first, pos + half[run_of], pos - half[run_of])
+                u, v = pos_index[0], pos_index[1]
+                mirrored = bool(((u == v[partner]) & (v == u[partner])).all())
+            if mirrored:                                                    # two segments per relation
+                seg_rel = torch.repeat_interleave(rels, 2)
+                seg_cnt = torch.repeat_interleave(counts // 2, 2)
+                seg_start = torch.stack([start, start + counts // 2], dim=1).view(-1)
+                seg_w = torch.tensor([2, 0], device=dev).repeat(rels.numel())
+            else:
+                seg_rel, seg_cnt, seg_start = rels, counts, start
+                seg_w = torch.ones_like(rels)
+            n_chunks = (seg_cnt + TASK_POSITIONS - 1) // TASK_POSITIONS
+            run = torch.repeat_interleave(torch.arange(seg_rel.numel(), device=dev), n_chunks)
+            first_c = torch.cumsum(n_chunks, 0) - n_chunks
+            local = torch.arange(run.numel(), device=dev) - first_c[run]
+            begin = seg_start[run] + local * TASK_POSITIONS
+            end = torch.minimum(begin + TASK_POSITIONS, seg_start[run] + seg_cnt[run])
+            # heavier tasks first: a weight-2 / weight-1 position costs two evaluations, a weight-0 one
+            cost = (end - begin) * (1 + (seg_w[run] > 0).long())
+            order = torch.sort(cost, descending=True, stable=True).indices
+            tasks = torch.stack([seg_rel[run], begin, end, seg_w[run]], dim=1)[order].to(torch.int32).contiguous()
     if len(_TASK_CACHE) > 16:
         _TASK_CACHE.clear()
-    _TASK_CACHE[key] = (tasks, edge_type)                                    # pin the tensor: pointer stays unique
+    _TASK_CACHE[key] = (tasks, edge_type, pos_index)                         # pin the tensors: pointers stay unique
     return tasks
 
 
@@ -536,7 +561,7 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     loss = torch.zeros((1,), dtype=torch.float32, device=z.device)
     g_z = torch.zeros_like(z) if need_grad else None
     g_w = torch.zeros_like(weight) if need_grad else None
-    tasks = relation_tasks(et)
+    tasks = relation_tasks(et, pos_index)
     check(lib().tipk_distmult_loss(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pu), ptr(pv),
                                    ptr(nu), ptr(nv), _idx_bytes(pu), ptr(et), _idx_bytes(et), pu.numel(),
                                    ptr(tasks), 0 if tasks is None else tasks.shape[0],
