@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 2
+#define TIPK_ABI_VERSION 3
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
