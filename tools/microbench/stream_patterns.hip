@@ -124,6 +124,20 @@ int main() {
 #define WR(MODE, WAVES, NAME)                                                                   \
     { const int w = (WAVES); float us = timeit([&] { hipLaunchKernelGGL(wr<MODE>, dim3((w + 3) / 4), dim3(256), 0, 0, a, w); }); \
       printf("write %-34s waves %6d  %7.1f us  %.2f TB/s\n", NAME, w, us, mb / us); }
+    {   // the same patterns over SIX buffers in turn (546 MB > the 256 MB Infinity Cache): what a step sees,
+        // where Y / dY are written once and read once
+        float* bufs[6];
+        for (int i = 0; i < 6; ++i) { hipMalloc(&bufs[i], bytes); hipMemset(bufs[i], 0, bytes); }
+        int it = 0;
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<10>, dim3(4096), dim3(256), 0, 0, bufs[it++ % 6], 16384); });
+          printf("write linear x4, 6 rotating buffers            %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<11>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 6], 35 * 161); });
+          printf("write tile32 dword, 6 rotating buffers         %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(rd<0>, dim3(4096), dim3(256), 0, 0, bufs[it++ % 6], out, 16384); });
+          printf("read  linear x4, 6 rotating buffers            %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(rd<1>, dim3((645 * 8 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 6], out, 645 * 8); });
+          printf("read  tile32 dword, 6 rotating buffers         %7.1f us  %.2f TB/s\n", us, mb / us); }
+    }
     RD(0, 4096, "linear x4") RD(0, 8192, "linear x4") RD(0, 16384, "linear x4")
     RD(1, 645 * 4, "tile32 dword, 4 row splits") RD(1, 645 * 8, "tile32 dword, 8 row splits") RD(1, 645 * 16, "tile32 dword, 16 row splits")
     RD(2, 162 * 8, "tile128 x4, 8 row splits") RD(2, 162 * 16, "tile128 x4, 16 row splits") RD(2, 162 * 32, "tile128 x4, 32 row splits")
