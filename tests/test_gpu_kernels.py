@@ -182,7 +182,7 @@ def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
     finally:
         del os.environ['TIPK_NO_STREAM_GEMM']
     close(ref, want, rtol=2e-5, atol=1e-3)
-    if kind != 'kk':
+    if kind == 'thin_m':
         assert torch.equal(got, ref)                                   # same k order as the tiled kernel
     # epilogue (alpha, c_in, relu) and membership in a grouped launch
     if ks is None:
@@ -191,7 +191,11 @@ def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
     x = torch.randn(70, 40, generator=g).to(DEV)
     y = torch.randn(40, 50, generator=g).to(DEV)
     outs = ops.gemm_group([ops.gemm_job(x, y), ops.gemm_job(ad, bd, ksplit=ks), ops.gemm_job(y.t(), x.t())])
-    assert torch.equal(outs[1], got) and torch.equal(outs[0], ops.gemm(x, y)) and torch.equal(outs[2], ops.gemm(y.t(), x.t()))
+    assert torch.equal(outs[0], ops.gemm(x, y)) and torch.equal(outs[2], ops.gemm(y.t(), x.t()))
+    if kind == 'thin_m':
+        assert torch.equal(outs[1], got)
+    else:                                                              # grouped members use other bodies / k orders
+        close(outs[1], want, rtol=2e-5, atol=1e-3)
     # exact on integer data (any k pairing is exact)
     ai = torch.randint(-4, 5, (m, k), generator=g).float()
     bi = torch.randint(-4, 5, (k, n), generator=g).float()

@@ -252,6 +252,7 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, const f32x16& ac
 }
 
 // k <= 32, B rows contiguous in n, one k step: wave = (32-row tile, THIN_K_NT column tiles)
+template <bool WIDE>
 __device__ __forceinline__ void gemm_thin_k_body(const GemmArgs& g, int64_t block) {
     const int lane = threadIdx.x & 63;
     const int row = lane & 31, kh = lane >> 5;
@@ -272,18 +273,71 @@ __device__ __forceinline__ void gemm_thin_k_body(const GemmArgs& g, int64_t bloc
     const u32 aoff = (u32)(m0 + row < M ? m0 + row : M - 1) * (u32)g.a_sm * 4u;
     float av[16];
     u32 koff[16];                                          // row offsets of B, shared by every tile
+    // MFMA step kk multiplies k = kmap(kk, lane half).  Narrow body: k = 2 kk + kh (the tiled kernel's order,
+    // bit-identical results).  Wide body: k = 16 kh + kk, so a lane's 16 values of A are 16 CONSECUTIVE
+    // floats of its row = 4 dwordx4 loads instead of 16 strided dword loads (any pairing of k is a valid
+    // order of the fp32 sum as long as A and B agree).
+    const bool a_vec = WIDE && g.a_sk == 1 && (g.a_sm & 3) == 0 && (g.a_sz & 3) == 0 && K == 32 &&
+                       (reinterpret_cast<uintptr_t>(g.a) & 15) == 0;
+    if (a_vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = ldg4(a_z, aoff + (u32)(16 * kh + 4 * q) * 4u);
+            av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+        }
+    }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-        const int k = 2 * kk + kh;
+        const int k = WIDE ? 16 * kh + kk : 2 * kk + kh;
         const u32 kc = (u32)(k < K ? k : K - 1);
-        av[kk] = and_mask(ldg(a_z, aoff + kc * a_sk), k < K ? 0xffffffffu : 0u);
+        if (!a_vec) av[kk] = and_mask(ldg(a_z, aoff + kc * a_sk), k < K ? 0xffffffffu : 0u);
         koff[kk] = kc * b_sk;
+    }
+    const int nb = chunk * (32 * THIN_K_NT);
+    // WIDE path (the normal case: 16-byte aligned rows, n % 4 == 0): the wave's 128 columns are taken as
+    // four INTERLEAVED 32-column tiles -- tile s = columns 4j + s -- so lane j owns four consecutive columns:
+    // the B operand arrives as 16 dwordx4 loads instead of 64 dword loads and the result leaves as 16
+    // dwordx4 stores instead of 64.  Measured (tools/microbench/stream_patterns.hip, same work): 24 us vs
+    // 36 us -- it is the NUMBER of vector-memory instructions, not their bytes, that bounds these streams.
+    // (the host checks: n % 4 == 0, row strides % 4 == 0, 16-byte aligned bases -- thin_k_wide_ok)
+    if (WIDE) {
+        const int col = nb + 4 * row;                       // first of the lane's four columns
+        const u32 cc = (u32)(col < N ? col : N - 4) * 4u;
+        float4 b4[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) b4[kk] = ldg4(b_z, koff[kk] + cc);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 a0 = zero16(), a1 = zero16(), a2 = zero16(), a3 = zero16();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b4[kk].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b4[kk].y, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b4[kk].z, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b4[kk].w, a3, 0, 0, 0);
+        }
+        if (col >= N) return;
+        float* c_t = c_z + (int64_t)m0 * g.c_sm + nb;       // 64-bit tile origin + 32-bit offsets (outputs > 4 GB)
+        const float* cin_t = cin_z ? cin_z + (int64_t)m0 * g.cin_sm + nb : nullptr;
+        const u32 c_sm = (u32)g.c_sm * 4u, cin_sm = (u32)g.cin_sm * 4u, cb = (u32)row * 16u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m0 + rl < M) {
+                float4 v = make_float4(g.alpha * a0[r], g.alpha * a1[r], g.alpha * a2[r], g.alpha * a3[r]);
+                if (cin_t) {
+                    const float4 ci = ldg4(cin_t, (u32)rl * cin_sm + cb);
+                    v.x += ci.x; v.y += ci.y; v.z += ci.z; v.w += ci.w;
+                }
+                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(c_t) + ((u32)rl * c_sm + cb)) = v;
+            }
+        }
+        return;
     }
     // All THIN_K_NT operand tiles are requested before the first product: vmcnt counts loads AND stores
     // (gfx9), so a load issued after a tile's stores cannot be waited for without also waiting for the
     // write acknowledgements of those stores -- a ~2 us stall per tile when loads and stores alternate.
     float bt[THIN_K_NT][16];
-    const int nb = chunk * (32 * THIN_K_NT);
 #pragma unroll
     for (int j = 0; j < THIN_K_NT; ++j) {
         const int col = nb + 32 * j + row;
@@ -413,7 +467,14 @@ __device__ __forceinline__ void gemm_kk_body(const GemmArgs& g, int64_t block) {
     store_tile32(g, acc, c_z, cin_z, m0, 0, lane);
 }
 
-enum { STREAM_NONE = 0, STREAM_THIN_K = 1, STREAM_THIN_M = 2, STREAM_KK = 3 };
+enum { STREAM_NONE = 0, STREAM_THIN_K = 1, STREAM_THIN_M = 2, STREAM_KK = 3, STREAM_THIN_K4 = 4 };
+
+inline bool thin_k_wide_ok(const GemmArgs& g, int64_t batch) {
+    static_assert(THIN_K_NT == 4, "the wide body owns four interleaved tiles");
+    if ((g.n & 3) || ((g.b_sk | g.c_sm | g.b_sz | g.c_sz) & 3)) return false;
+    if (g.c_in && ((g.cin_sm | g.cin_sz) & 3)) return false;
+    return ((reinterpret_cast<uintptr_t>(g.b) | reinterpret_cast<uintptr_t>(g.c) | reinterpret_cast<uintptr_t>(g.c_in)) & 15) == 0;
+}
 
 // which streaming body serves this product (GemmArgs as filled by fill_args, batch = z count)
 inline int stream_kind(const GemmArgs& g, int64_t batch) {
@@ -425,7 +486,8 @@ inline int stream_kind(const GemmArgs& g, int64_t batch) {
     if (g.a_sm < 0 || g.a_sk < 0 || g.b_sk < 0 || g.b_sn < 0 || g.m > lim || g.n > lim || g.k > lim) return STREAM_NONE;
     if ((g.m - 1) * g.a_sm + (g.k - 1) * g.a_sk >= lim || (g.k - 1) * g.b_sk + (g.n - 1) * g.b_sn >= lim) return STREAM_NONE;
     if (g.c_sm < 0 || g.cin_sm < 0 || 32 * g.c_sm >= lim || 32 * g.cin_sm >= lim) return STREAM_NONE;   // tile-local C offsets
-    if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && g.m >= 256 && g.n >= 1024) return STREAM_THIN_K;
+    if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && g.m >= 256 && g.n >= 1024)
+        return (thin_k_wide_ok(g, batch) && !getenv("TIPK_THIN_K_NARROW")) ? STREAM_THIN_K4 : STREAM_THIN_K;
     if (g.m <= 32 && g.b_sn == 1 && g.n >= 1024 && g.k >= 256) return STREAM_THIN_M;
     // lane-per-row dwordx4 loads keep the texture addresser 70 % busy (PMC) and the LDS-tiled kernel is as
     // fast on this shape: the kk body only runs when asked for (TIPK_STREAM_KK=1, tests)
@@ -439,7 +501,7 @@ inline int stream_kind(const GemmArgs& g, int64_t batch) {
 // workgroups (4 waves each) of a streaming problem
 inline int64_t stream_blocks(int kind, const GemmArgs& g, int64_t batch) {
     int64_t waves = 0;
-    if (kind == STREAM_THIN_K) waves = batch * tipk_ceil_div(g.m, 32) * tipk_ceil_div(g.n, 32 * THIN_K_NT);
+    if (kind == STREAM_THIN_K || kind == STREAM_THIN_K4) waves = batch * tipk_ceil_div(g.m, 32) * tipk_ceil_div(g.n, 32 * THIN_K_NT);
     if (kind == STREAM_THIN_M) waves = batch * g.ksplit * tipk_ceil_div(g.n, 32);
     if (kind == STREAM_KK) waves = batch * g.ksplit * tipk_ceil_div(g.m, 32);
     return tipk_ceil_div(waves, 4);
@@ -447,7 +509,8 @@ inline int64_t stream_blocks(int kind, const GemmArgs& g, int64_t batch) {
 
 template <int KIND>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs g) {
-    if (KIND == STREAM_THIN_K) gemm_thin_k_body(g, blockIdx.x);
+    if (KIND == STREAM_THIN_K) gemm_thin_k_body<false>(g, blockIdx.x);
+    if (KIND == STREAM_THIN_K4) gemm_thin_k_body<true>(g, blockIdx.x);
     if (KIND == STREAM_THIN_M) gemm_thin_m_body(g, blockIdx.x);
     if (KIND == STREAM_KK) gemm_kk_body(g, blockIdx.x);
 }
@@ -484,7 +547,6 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs ga) {
     case 0: gemm_body<4, 1, 2>(g, bx, by, bz, smem, akf, bkf); break;
     case 1: gemm_body<1, 4, 2>(g, bx, by, bz, smem, akf, bkf); break;
     case 2: gemm_body<2, 2, 2>(g, bx, by, bz, smem, akf, bkf); break;
-    case 100 + STREAM_THIN_K: gemm_thin_k_body(g, local); break;
     case 100 + STREAM_THIN_M: gemm_thin_m_body(g, local); break;
     case 100 + STREAM_KK: gemm_kk_body(g, local); break;
     }
@@ -618,6 +680,8 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
         g.kbatch = d->batch;                            // the streaming bodies find the batch count here
         if (kind == STREAM_THIN_K)
             hipLaunchKernelGGL(gemm_stream_kernel<STREAM_THIN_K>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+        else if (kind == STREAM_THIN_K4)
+            hipLaunchKernelGGL(gemm_stream_kernel<STREAM_THIN_K4>, dim3((unsigned)blocks), dim3(256), 0, st, g);
         else if (kind == STREAM_THIN_M)
             hipLaunchKernelGGL(gemm_stream_kernel<STREAM_THIN_M>, dim3((unsigned)blocks), dim3(256), 0, st, g);
         else
@@ -641,7 +705,8 @@ extern "C" int tipk_gemm_f32_group(const tipk_gemm_desc* descs, int32_t count, t
         const int rc = fill_args(descs + i, g);
         if (rc < 0) return rc;
         if (rc > 0) continue;
-        const int kind = no_stream ? STREAM_NONE : stream_kind(g, descs[i].batch);
+        int kind = no_stream ? STREAM_NONE : stream_kind(g, descs[i].batch);
+        if (kind == STREAM_THIN_K || kind == STREAM_THIN_K4) kind = STREAM_NONE;   // never grouped in the path: keeps the grouped kernel's registers down
         if (kind != STREAM_NONE) {
             const int64_t nb = stream_blocks(kind, g, descs[i].batch);
             if (nb > 0x3fffffffLL) return TIPK_EUNSUPPORTED;

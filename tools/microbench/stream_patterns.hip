@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void rd(const float* __restrict__ a, float* __
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void wr(float* __restrict__ a, int waves_total) {
+__global__ __launch_bounds__(256) void wr(float* __restrict__ a, int waves_total, const float* __restrict__ src = nullptr) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (MODE == 10) {
@@ -87,6 +87,137 @@ __global__ __launch_bounds__(256) void wr(float* __restrict__ a, int waves_total
                 const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < R) a[(size_t)row * C + ch * 128 + j * 32 + (lane & 31)] = (float)r;
             }
+    } else if (MODE == 13 || MODE == 14) {                // tile32 stores behind a chain of 16 fp32 MFMAs (+ 16 operand loads)
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int m_tiles = (R + 31) / 32, chunks = C / 128;
+        const int mt = gw % m_tiles, ch = gw / m_tiles;
+        if (ch >= chunks) return;
+        float av[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) av[kk] = (float)(lane + kk);
+        for (int j = 0; j < 4; ++j) {
+            float bv[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                bv[kk] = MODE == 14 ? src[(size_t)(2 * kk + (lane >> 5)) * C + ch * 128 + j * 32 + (lane & 31)] : (float)(kk + j);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) a[(size_t)row * C + ch * 128 + j * 32 + (lane & 31)] = acc[r];
+            }
+        }
+    } else if (MODE == 20) {                              // as 14 with dwordx4 operand loads and stores: lane j owns columns 4j..4j+3
+        typedef float f32x16 __attribute__((ext_vector_type(16)));    // = one column of each of four interleaved 32-column tiles
+        const int m_tiles = (R + 31) / 32, chunks = C / 128;
+        const int mt = gw % m_tiles, ch = gw / m_tiles;
+        if (ch >= chunks) return;
+        float av[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) av[kk] = (float)(lane + kk);
+        float4 bv[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            bv[kk] = *reinterpret_cast<const float4*>(src + (size_t)(2 * kk + (lane >> 5)) * C + ch * 128 + (lane & 31) * 4);
+        f32x16 acc[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s4][i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk].w, acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < R) *reinterpret_cast<float4*>(a + (size_t)row * C + ch * 128 + (lane & 31) * 4) =
+                make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+    } else if (MODE == 19) {                              // as 14, but every wave reads the SAME 16 KB of operands (certainly cached)
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int m_tiles = (R + 31) / 32, chunks = C / 128;
+        const int mt = gw % m_tiles, ch = gw / m_tiles;
+        if (ch >= chunks) return;
+        float av[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) av[kk] = (float)(lane + kk);
+        for (int j = 0; j < 4; ++j) {
+            float bv[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                bv[kk] = src[(size_t)(2 * kk + (lane >> 5)) * 128 + j * 32 + (lane & 31)];
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) a[(size_t)row * C + ch * 128 + j * 32 + (lane & 31)] = acc[r];
+            }
+        }
+    } else if (MODE == 17 || MODE == 18) {                // as 14 with NON-TEMPORAL stores (17) / + non-temporal... loads stay cached
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int m_tiles = (R + 31) / 32, chunks = C / 128;
+        const int mt = gw % m_tiles, ch = gw / m_tiles;
+        if (ch >= chunks) return;
+        float av[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) av[kk] = (float)(lane + kk);
+        for (int j = 0; j < 4; ++j) {
+            float bv[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                bv[kk] = src[(size_t)(2 * kk + (lane >> 5)) * C + ch * 128 + j * 32 + (lane & 31)];
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) __builtin_nontemporal_store(acc[r], a + (size_t)row * C + ch * 128 + j * 32 + (lane & 31));
+            }
+        }
+    } else if (MODE == 15 || MODE == 16) {                // as 14, all 64 operand loads issued before the first MFMA / store
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int m_tiles = (R + 31) / 32, chunks = C / 128;
+        const int mt = gw % m_tiles, ch = gw / m_tiles;
+        if (ch >= chunks) return;
+        float av[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) av[kk] = (float)(lane + kk);
+        float bv[4][16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                bv[j][kk] = src[(size_t)(2 * kk + (lane >> 5)) * C + ch * 128 + j * 32 + (lane & 31)];
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 16) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every load is home before the first store
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[j][kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < R) a[(size_t)row * C + ch * 128 + j * 32 + (lane & 31)] = acc[r];
+            }
+        }
     } else if (MODE == 12) {                              // same tile, lane = 4 columns: 16 x4 stores of 2 rows x 512 B
         const int m_tiles = (R + 31) / 32, chunks = C / 128;
         const int mt = gw % m_tiles, ch = gw / m_tiles;
@@ -133,6 +264,20 @@ int main() {
           printf("write linear x4, 6 rotating buffers            %7.1f us  %.2f TB/s\n", us, mb / us); }
         { float us = timeit([&] { hipLaunchKernelGGL(wr<11>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 6], 35 * 161); });
           printf("write tile32 dword, 6 rotating buffers         %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<13>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 6], 35 * 161, bufs[5]); });
+          printf("write tile32 dword + 16 MFMA/tile, 6 rotating  %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<14>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 5], 35 * 161, bufs[5]); });
+          printf("write tile32 dword + 16 loads + 16 MFMA/tile   %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<20>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 5], 35 * 161, bufs[5]); });
+          printf("  same work with dwordx4 loads / stores        %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<19>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 5], 35 * 161, bufs[5]); });
+          printf("  same as +16 loads, all waves read one 16 KB   %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<17>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 5], 35 * 161, bufs[5]); });
+          printf("  same as +16 loads, NON-TEMPORAL stores       %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<15>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 5], 35 * 161, bufs[5]); });
+          printf("  same, all 64 loads first                     %7.1f us  %.2f TB/s\n", us, mb / us); }
+        { float us = timeit([&] { hipLaunchKernelGGL(wr<16>, dim3((35 * 161 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 5], 35 * 161, bufs[5]); });
+          printf("  same, all loads first + vmcnt(0) before MFMA %7.1f us  %.2f TB/s\n", us, mb / us); }
         { float us = timeit([&] { hipLaunchKernelGGL(rd<0>, dim3(4096), dim3(256), 0, 0, bufs[it++ % 6], out, 16384); });
           printf("read  linear x4, 6 rotating buffers            %7.1f us  %.2f TB/s\n", us, mb / us); }
         { float us = timeit([&] { hipLaunchKernelGGL(rd<1>, dim3((645 * 8 + 3) / 4), dim3(256), 0, 0, bufs[it++ % 6], out, 645 * 8); });
