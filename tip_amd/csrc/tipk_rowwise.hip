@@ -100,7 +100,7 @@ extern "C" int tipk_gate_colsum_groups(int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0 || cols > 256) return 0;
     const int64_t lanes_r = 256 / cols;
     int64_t groups = tipk_ceil_div(rows, lanes_r * 4);
-    if (groups > 128) groups = 128;                   // the ordered sum of the groups is a single workgroup's chain
+    if (groups > 256) groups = 256;                   // the ordered sum of the groups is a single workgroup's chain
     return (int)groups;
 }
 
