@@ -587,8 +587,18 @@ __global__ __launch_bounds__(64 * LANES) void sum_slabs_kernel(const float* __re
     const int e = threadIdx.x & 63, j = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float s = 0.f;
-    if (i < count)
-        for (int64_t k = j; k < n_slabs; k += LANES) s += in[k * slab_stride + i];
+    if (i < count) {
+        // four loads in flight per lane, added in the original order (bitwise the same sum): a slab sum is a
+        // chain of dependent ~1 us round trips otherwise (256 partial slabs / 16 lanes = 16 of them)
+        const float* p = in + i;
+        int64_t k = j;
+        for (; k + 3 * LANES < n_slabs; k += 4 * LANES) {
+            const float v0 = p[k * slab_stride], v1 = p[(k + LANES) * slab_stride];
+            const float v2 = p[(k + 2 * LANES) * slab_stride], v3 = p[(k + 3 * LANES) * slab_stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < n_slabs; k += LANES) s += p[k * slab_stride];
+    }
     red[j][e] = s;
     __syncthreads();
     if (j == 0 && i < count) {
@@ -629,8 +639,16 @@ __global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa)
     const int64_t i = (int64_t)((int)blockIdx.x - first) * epb + e;
     const float* __restrict__ in = a.in;
     float s = 0.f;
-    if (i < a.count)
-        for (int64_t k = j; k < a.n_slabs; k += lanes) s += in[k * a.slab_stride + i];
+    if (i < a.count) {
+        const float* p = in + i;                           // four loads in flight, original order of additions
+        int64_t k = j;
+        for (; k + 3 * lanes < a.n_slabs; k += 4 * lanes) {
+            const float v0 = p[k * a.slab_stride], v1 = p[(k + lanes) * a.slab_stride];
+            const float v2 = p[(k + 2 * lanes) * a.slab_stride], v3 = p[(k + 3 * lanes) * a.slab_stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < a.n_slabs; k += lanes) s += p[k * a.slab_stride];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (j == 0 && i < a.count) {
