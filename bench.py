@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='biosnap', choices=['biosnap', 'biosnap963', 'synthetic', 'synthetic-small'])
     ap.add_argument('--mod', default='cat', choices=['cat', 'add'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
