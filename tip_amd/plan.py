@@ -81,7 +81,8 @@ def group_slots_for(d):
     need = d // 4 if d % 4 == 0 else d
     while lanes < need:
         lanes *= 2
-    return max(min(128, 1024 // lanes), 64 // lanes)
+    cap = int(os.environ.get('TIPK_GROUP_SLOTS', '128'))               # sweep knob (power of two)
+    return max(min(cap, 1024 // lanes), 64 // lanes)
 
 
 def pack_blocks(pieces, cap):
