@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""The reference's `tip.py` training script on the MI355X-native modules (same flow, same
-constants; the only change is the import line).  Run from the repo root:
+"""The reference's `tip.py` training script on the MI355X-native modules: same flow, same constants,
+same final `torch.save(model, ...)`.  Differences: the import line, the device (no CPU path), and by
+default the epoch loop is replayed as one hipGraph (`--eager` runs the reference's loop line for line).
+Run from the repo root:
 
     python examples/tip.py [cat|add] [epochs]
 
@@ -57,4 +59,4 @@ print('%d epochs in %.2f s (%.1f ms/epoch, %.2f M train edges/s incl. sampler, d
 model.test()
 
 os.makedirs('saved_model', exist_ok=True)
-torch.save(model.state_dict(), f'saved_model/tip-{model.mod}-example.pt')
+torch.save(model, f'saved_model/tip-{model.mod}-example.pt')      # whole model, as tip.py:36 (load: weights_only=False)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 3
+#define TIPK_ABI_VERSION 4
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -38,6 +38,21 @@ typedef void* tipk_stream_t;          /* hipStream_t */
 
 int         tipk_abi_version(void);
 const char* tipk_strerror(int status);
+/* digest (16 hex digits) of the sources the library was compiled from; "+debug" appended in
+ * -DTIPK_DEBUG builds.  tip_amd/_lib.py refuses a library whose digest differs from the sources
+ * next to it (a stale prebuilt .so would silently run old kernels). */
+const char* tipk_build_id(void);
+/* 0. Host-side options (process-wide; set before launching, never read from the environment):
+ *      "gemm_no_stream"      1 = every product through the LDS-tiled kernel (cross-check in tests)
+ *      "gemm_thin_k_narrow"  1 = dword body of the Y = att.XB streaming kernel
+ *      "gemm_stream_kk"      1 = lane-per-row streaming body for d att
+ *      "rg_debug", "dp_debug"  bit masks that SKIP parts of tipk_rel_gather / tipk_rgcn_dy_products
+ *                            (timing decompositions): accepted by -DTIPK_DEBUG builds only; a release
+ *                            library returns TIPK_EUNSUPPORTED for a non-zero value and its kernels
+ *                            contain no skip code.
+ *    Unknown name: TIPK_EINVAL. */
+int         tipk_set_option(const char* name, int value);
+int         tipk_get_option(const char* name, int* value);
 /* host query: fills whatever is non-NULL; returns TIPK_OK or a HIP error (e.g. no device). */
 int         tipk_device_info(int device, int* n_cu, int* lds_bytes_per_cu, int* wavefront, char* arch, int arch_len);
 
@@ -302,13 +317,15 @@ int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
  * wg_rel_ptr / wg_rels (nullable): edge-balanced deal of the relations to n_wg workgroups; with it and
  * n_nodes^2 bits <= 150 KB each workgroup tests candidates against an LDS bitmap of its relation's
  * positives instead of searching the sorted keys (same output bit for bit, ~6x faster on BioSNAP).
- * call_counter != NULL: the Philox key is splitmix64(seed + (*call_counter + 1) * 0x9E3779B97F4A7C15)
- * instead of `seed` itself -- a sampler STREAM whose position lives on the device, so that a captured
- * hipGraph draws new negatives on every replay (`tipk_counter_advance` is the next node).
+ * call_counter != NULL: a sampler STREAM whose state lives on the device, uint64[2] = { position, seed }:
+ * the Philox key is splitmix64(state[1] + (state[0] + 1) * 0x9E3779B97F4A7C15) and the host `seed`
+ * argument is ignored -- a captured hipGraph draws new negatives on every replay
+ * (`tipk_counter_advance` on state[0] is the next node), and re-seeding after capture (a device-side
+ * write of the two words) takes effect in the replays.
  */
 int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
-                                 const uint64_t* call_counter /* nullable device word, see below */,
+                                 const uint64_t* call_counter /* nullable device uint64[2], see above */,
                                  const int32_t* wg_rel_ptr /* nullable */, const int32_t* wg_rels, int64_t n_wg,
                                  void* out_u, void* out_v, int idx_bytes,
                                  int64_t n_positions /* = rel_ptr[n_rel], host copy */,

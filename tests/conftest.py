@@ -15,6 +15,10 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the library is git-ignored: a clean checkout (or one whose kernels were edited) builds it here,
+    # before any test -- and before anything touches the GPU (child `make`, no exec)
+    from tip_amd import _lib
+    _lib.ensure_built()
 
 
 def pytest_collection_modifyitems(config, items):

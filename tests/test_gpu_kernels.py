@@ -161,26 +161,26 @@ def test_gemm_is_exact_fp32_fma_chain(ops):
     ('kk', 1097, 32, 20640, 57), ('kk', 500, 17, 4100, 5), ('kk', 260, 32, 4096, None)])
 def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
     """The three wave-level streaming products (tipk_gemm.hip): Y = att.XB, dXB = att^T.dY, datt = dY.XB^T
-    shapes incl. ragged tiles / k tails; the generic LDS-tiled kernel (TIPK_NO_STREAM_GEMM) is the cross-check."""
+    shapes incl. ragged tiles / k tails; the generic LDS-tiled kernel (option gemm_no_stream) is the cross-check."""
     import os
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g)
     b = torch.randn(k, n, generator=g)
     want = a.double() @ b.double()
     ad, bd = a.to(DEV), b.to(DEV)
-    if kind == 'kk':
-        monkeypatch.setenv('TIPK_STREAM_KK', '1')                      # off by default (the tiled kernel is as fast)
+    from tip_amd import _lib
+    _lib.set_option('gemm_stream_kk', 1 if kind == 'kk' else 0)        # off by default (the tiled kernel is as fast)
     if kind == 'thin_m':
         ad = ad.t().contiguous().t()                                   # att^T: a view with a_sm = 1
     if kind == 'kk':
         bd = bd.t().contiguous().t()                                   # XB^T: k-contiguous B
     got = ops.gemm(ad, bd, ksplit=ks)
     close(got, want, rtol=2e-5, atol=1e-3)
-    os.environ['TIPK_NO_STREAM_GEMM'] = '1'
+    _lib.set_option('gemm_no_stream', 1)
     try:
         ref = ops.gemm(ad, bd, ksplit=ks)
     finally:
-        del os.environ['TIPK_NO_STREAM_GEMM']
+        _lib.set_option('gemm_no_stream', 0)
     close(ref, want, rtol=2e-5, atol=1e-3)
     if kind == 'thin_m':
         assert torch.equal(got, ref)                                   # same k order as the tiled kernel
@@ -205,6 +205,7 @@ def test_gemm_streaming_kernels(ops, kind, m, n, k, ks, monkeypatch):
     if kind == 'kk':
         bid = bid.t().contiguous().t()
     assert torch.equal(ops.gemm(aid, bid, ksplit=ks).cpu(), ai @ bi)
+    _lib.set_option('gemm_stream_kk', 0)
 
 
 @pytest.mark.parametrize('r,nc,nb', [(1097, 20640, 32), (1097, 10320, 32), (70, 645 * 4, 7), (33, 513, 32), (5, 31, 1),

@@ -278,3 +278,68 @@ def test_relation_tasks_and_sampler_keys_host_side():
     for seed, n in ((0, 0), (1111, 7), ((1 << 64) - 1, 123456)):
         assert NS.call_key(seed, n) == call_key(seed, n)
     assert len({call_key(5, n) for n in range(100)}) == 100
+
+
+# ------------------------------------------------------------------ hygiene
+def test_library_matches_its_sources_and_reads_no_environment():
+    """The loaded .so was compiled from the sources next to it (content digest, not mtime), and no
+    kernel launch path reads the environment: switches are explicit options, and the compute-skipping
+    debug switches are refused by the release build."""
+    assert _lib.build_id() == _lib.source_digest()
+    csrc = os.path.join(ROOT, 'tip_amd', 'csrc')
+    for fn in os.listdir(csrc):
+        if fn.endswith(('.hip', '.cpp', '.h')):
+            assert 'getenv' not in open(os.path.join(csrc, fn)).read(), fn
+    assert _lib.get_option('gemm_no_stream') == 0
+    _lib.set_option('gemm_no_stream', 1)
+    assert _lib.get_option('gemm_no_stream') == 1
+    _lib.set_option('gemm_no_stream', 0)
+    for name in ('rg_debug', 'dp_debug'):
+        with pytest.raises(_lib.TipkError):
+            _lib.set_option(name, 1)                                   # release build: no skip code inside
+        _lib.set_option(name, 0)
+    with pytest.raises(_lib.TipkError):
+        _lib.set_option('no_such_option', 1)
+
+
+def test_modules_pickle_after_caching_plans():
+    """`torch.save(model, ...)` as the reference's tip.py:36: plan caches (device arrays + closures) are
+    derived state and are dropped by pickling / deepcopy; they rebuild on first use."""
+    import copy
+    import io
+    from tip_amd.layers import MyRGCNConv2, GCNConv, MyHierarchyConv, FMEncoder
+    enc = FMEncoder(torch.device('cpu'), 9, 3, 11, 11, 9, prot_drug_dim=4, num_base=2, n_embed=4, n_hid1=4, n_hid2=4)
+    for m in enc.modules():
+        if hasattr(m, '_cache'):
+            m._cache.key, m._cache.value, m._cache.pins = ('k',), (lambda: 1), (torch.zeros(1),)
+    buf = io.BytesIO()
+    torch.save(enc, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    for k, v in enc.state_dict().items():
+        assert torch.equal(back.state_dict()[k], v)
+    assert all(m._cache.value is None for m in back.modules() if hasattr(m, '_cache'))
+    assert copy.deepcopy(enc).rgcn1._cache.value is None
+    assert enc.rgcn1._cache.value is not None                         # the original keeps its cache
+
+
+def test_tip_missing_explicit_data_path_raises():
+    """Only the reference's DEFAULT pickle location may be absent (bundled graph); a mistyped explicit
+    path must not silently train on other data (reference: FileNotFoundError, src/layers.py:284)."""
+    from tip_amd.layers import TIP, Setting
+    with pytest.raises(FileNotFoundError):
+        TIP(Setting(), torch.device('cpu'), data_path='/nonexistent/data_dict.pkl')
+
+
+def test_triple_validation_is_cached_and_raises():
+    from tip_amd import ops
+    ei = torch.tensor([[0, 1, 2], [2, 1, 0]])
+    et = torch.tensor([0, 0, 1])
+    ops.validate_triples(ei, et, 3, 2)
+    assert any(k[0] == ei.data_ptr() for k in ops._VALID)
+    with pytest.raises(IndexError):
+        ops.validate_triples(ei, et, 2, 2)                             # node id 2 of 2 nodes
+    with pytest.raises(IndexError):
+        ops.validate_triples(ei, et, 3, 1)                             # relation id 1 of 1 relation
+    with pytest.raises(IndexError):
+        ops.validate_triples(torch.tensor([[0, -1], [0, 0]]), None, 3, 1)

@@ -5,6 +5,8 @@ The library is built in-tree (`tip_amd/libtipk.so`, see `__graft_entry__.build()
 a non-zero status, an exception is raised -- the product path never computes on the CPU.
 """
 import ctypes as C
+import glob
+import hashlib
 import os
 import subprocess
 
@@ -14,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TipkError(RuntimeError):
@@ -50,6 +52,9 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     'tipk_abi_version': (_I, []),
     'tipk_strerror': (C.c_char_p, [_I]),
+    'tipk_build_id': (C.c_char_p, []),
+    'tipk_set_option': (_I, [C.c_char_p, _I]),
+    'tipk_get_option': (_I, [C.c_char_p, C.POINTER(_I)]),
     'tipk_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     'tipk_gather_sum': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
@@ -79,35 +84,107 @@ SIGNATURES = {
 
 _lib = None
 
+# environment switch -> library option (translated ONCE, when the library is loaded; the library
+# itself never reads the environment).  Tests and tools flip options with `set_option`.
+_ENV_OPTIONS = {'TIPK_NO_STREAM_GEMM': 'gemm_no_stream', 'TIPK_THIN_K_NARROW': 'gemm_thin_k_narrow',
+                'TIPK_STREAM_KK': 'gemm_stream_kk'}
 
-def build(verbose=False):
-    """Compile libtipk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    out = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+
+def source_digest():
+    """sha1 (16 hex digits) over csrc/*.hip, csrc/*.cpp, csrc/tipk_common.h (sorted by name) and
+    include/tipk.h -- the same bytes, in the same order, as csrc/Makefile's BUILD_ID."""
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+    names = sorted(names + ['tipk_common.h'])
+    h = hashlib.sha1()
+    for n in names:
+        with open(os.path.join(CSRC, n), 'rb') as f:
+            h.update(f.read())
+    with open(os.path.join(_HERE, '..', 'include', 'tipk.h'), 'rb') as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build(verbose=False, debug=False):
+    """Compile libtipk.so for gfx950 with hipcc (cross-compiles without a GPU).  Always a child
+    `make` process: a process that has touched the GPU must never exec another program."""
+    cmd = ['make', '-C', CSRC, '-j4'] + (['debug'] if debug else [])
+    out = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout)
         print(out.stderr)
     if out.returncode != 0:
         raise TipkError('building libtipk.so failed (see output above)')
+    return LIB_PATH if not debug else os.path.join(_HERE, 'libtipk_debug.so')
+
+
+def _stale_reason(path):
+    """None if `path` was built from the sources next to it, else a description."""
+    if not os.path.exists(path):
+        return '%s is missing' % path
+    import re
+    with open(path, 'rb') as f:                      # read the marker from the file: no dlopen (see tipk_api.cpp)
+        m = re.search(rb'TIPK_BUILD_ID=([0-9a-f]{16})', f.read())
+    if m is None:
+        return '%s carries no build id' % path
+    have = m.group(1).decode()
+    want = source_digest()
+    return None if have == want else '%s was built from other sources (build id %s, sources %s)' % (path, have, want)
+
+
+def ensure_built(verbose=False):
+    """Build the library if it is missing or stale (child `make`; safe before or after GPU use).
+    Called by tests/conftest.py, bench.py and __graft_entry__ before the first kernel launch."""
+    global _lib
+    why = _stale_reason(LIB_PATH)
+    if why is not None:
+        if _lib is not None:
+            raise TipkError('%s, but a library is already loaded in this process: restart' % why)
+        build(verbose=verbose)
+        why = _stale_reason(LIB_PATH)
+        if why is not None:
+            raise TipkError('rebuilt library is still stale: %s' % why)
     return LIB_PATH
 
 
 def lib():
-    """The loaded library (cached).  Raises if it has not been built -- no fallback."""
+    """The loaded library (cached).  Raises if it is missing or was built from other sources --
+    no fallback, and no silent use of stale kernels.  TIPK_LIB=<path> selects another build of the
+    SAME sources (the -DTIPK_DEBUG library of `make debug`)."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise TipkError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
-                        '(or `make -C tip_amd/csrc`); tip_amd has no CPU fallback' % LIB_PATH)
-    handle = C.CDLL(LIB_PATH)
+    path = os.environ.get('TIPK_LIB') or LIB_PATH
+    why = _stale_reason(path)
+    if why is not None:
+        raise TipkError('%s: run `python -c "import __graft_entry__ as g; g.build()"` (or `make -C tip_amd/csrc`); '
+                        'tip_amd has no CPU fallback' % why)
+    handle = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
     if handle.tipk_abi_version() != ABI_VERSION:
         raise TipkError('libtipk.so ABI %d != binding ABI %d: rebuild' % (handle.tipk_abi_version(), ABI_VERSION))
+    for env, opt in _ENV_OPTIONS.items():
+        if os.environ.get(env):
+            handle.tipk_set_option(opt.encode(), 1)
     _lib = handle
     return _lib
+
+
+def build_id():
+    return lib().tipk_build_id().decode()
+
+
+def set_option(name, value):
+    """Process-wide library option (include/tipk.h section 0)."""
+    check(lib().tipk_set_option(name.encode(), int(value)), 'tipk_set_option(%s)' % name)
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().tipk_get_option(name.encode(), C.byref(v)), 'tipk_get_option(%s)' % name)
+    return v.value
 
 
 def check(status, what):

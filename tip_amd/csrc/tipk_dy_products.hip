@@ -88,7 +88,7 @@ __global__ __launch_bounds__(1024) void dy_products_kernel(DpArgs a) {
     if (r_lo < r_hi) load_tile(r_lo);
     for (int r0 = r_lo; r0 < r_hi; r0 += 32) {
         // (1) dXB += att^T . dY : rows beyond r_hi (and bases beyond NB) are zeroed in the A operand
-        if (!(a.dbg & 4))
+        if (!TIPK_DBG(a.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const u32 mk = (r0 + 2 * kk + kh < r_hi && row < NB) ? 0xffffffffu : 0u;
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(1024) void dy_products_kernel(DpArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) tile[row * DP_TLD + 2 * kk + kh] = dyv[kk];
         __builtin_amdgcn_sched_barrier(0);
-        if (r0 + 32 < r_hi && !(a.dbg & 1)) load_tile(r0 + 32);   // next tile in flight during the second product
+        if (r0 + 32 < r_hi && !TIPK_DBG(a.dbg & 1)) load_tile(r0 + 32);   // next tile in flight during the second product
         __builtin_amdgcn_sched_barrier(0);
-        if (a.dbg & 2) continue;
+        if (TIPK_DBG(a.dbg & 2)) continue;
         // (2) datt tile = dY . XB^T : A operand lane = row r, k = column c
         f32x16 acc2;
 #pragma unroll
@@ -172,8 +172,7 @@ extern "C" int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float
     a.ld_dy = ld_dy; a.ld_att = ld_att; a.ld_xb = ld_xb;
     a.dxb = dxb_slabs; a.datt = datt_slabs;
     a.rows_per_range = (int)(tipk_ceil_div(tipk_ceil_div(n_rel, s_r), 32) * 32);
-    const char* dbg_env = getenv("TIPK_DP_DEBUG");
-    a.dbg = dbg_env ? atoi(dbg_env) : 0;
+    a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
     hipError_t e = hipFuncSetAttribute((const void*)dy_products_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS);
     if (e != hipSuccess) return tipk_hip_status(e);
     hipLaunchKernelGGL(dy_products_kernel, dim3((unsigned)s_c, (unsigned)s_r), dim3(1024), DP_LDS, (hipStream_t)stream, a);

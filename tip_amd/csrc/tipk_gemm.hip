@@ -487,11 +487,11 @@ inline int stream_kind(const GemmArgs& g, int64_t batch) {
     if ((g.m - 1) * g.a_sm + (g.k - 1) * g.a_sk >= lim || (g.k - 1) * g.b_sk + (g.n - 1) * g.b_sn >= lim) return STREAM_NONE;
     if (g.c_sm < 0 || g.cin_sm < 0 || 32 * g.c_sm >= lim || 32 * g.cin_sm >= lim) return STREAM_NONE;   // tile-local C offsets
     if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && g.m >= 256 && g.n >= 1024)
-        return (thin_k_wide_ok(g, batch) && !getenv("TIPK_THIN_K_NARROW")) ? STREAM_THIN_K4 : STREAM_THIN_K;
+        return (thin_k_wide_ok(g, batch) && !tipk_option(TIPK_OPT_GEMM_THIN_K_NARROW)) ? STREAM_THIN_K4 : STREAM_THIN_K;
     if (g.m <= 32 && g.b_sn == 1 && g.n >= 1024 && g.k >= 256) return STREAM_THIN_M;
     // lane-per-row dwordx4 loads keep the texture addresser 70 % busy (PMC) and the LDS-tiled kernel is as
     // fast on this shape: the kk body only runs when asked for (TIPK_STREAM_KK=1, tests)
-    if (getenv("TIPK_STREAM_KK") && g.n <= 32 && g.a_sk == 1 && g.b_sk == 1 && g.m >= 256 && g.k >= 1024 && g.k % 4 == 0 && g.a_sm % 4 == 0 &&
+    if (tipk_option(TIPK_OPT_GEMM_STREAM_KK) && g.n <= 32 && g.a_sk == 1 && g.b_sk == 1 && g.m >= 256 && g.k >= 1024 && g.k % 4 == 0 && g.a_sm % 4 == 0 &&
         g.b_sn % 4 == 0 && g.a_sz % 4 == 0 && g.b_sz % 4 == 0 && (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(g.b) & 15) == 0)
         return STREAM_KK;
@@ -691,7 +691,7 @@ extern "C" int tipk_gemm_f32(const tipk_gemm_desc* d, tipk_stream_t stream) {
     const int rc = fill_args(d, g);
     if (rc != TIPK_OK) return rc > 0 ? TIPK_OK : rc;
     hipStream_t st = (hipStream_t)stream;
-    const int kind = getenv("TIPK_NO_STREAM_GEMM") ? STREAM_NONE : stream_kind(g, d->batch);
+    const int kind = tipk_option(TIPK_OPT_GEMM_NO_STREAM) ? STREAM_NONE : stream_kind(g, d->batch);
     if (kind != STREAM_NONE) {
         const int64_t blocks = stream_blocks(kind, g, d->batch);
         if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
@@ -717,7 +717,7 @@ extern "C" int tipk_gemm_f32_group(const tipk_gemm_desc* descs, int32_t count, t
     GemmGroupArgs ga;
     ga.count = 0;
     int64_t blocks = 0;
-    const bool no_stream = getenv("TIPK_NO_STREAM_GEMM") != nullptr;
+    const bool no_stream = tipk_option(TIPK_OPT_GEMM_NO_STREAM) != 0;
     for (int i = 0; i < count; ++i) {
         GemmArgs& g = ga.g[ga.count];
         const int rc = fill_args(descs + i, g);

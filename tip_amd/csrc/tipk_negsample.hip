@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
                                                          int64_t n_nodes, uint64_t seed,
                                                          const uint64_t* __restrict__ call_counter,
                                                          OT* __restrict__ out_u, OT* __restrict__ out_v) {
-    const uint64_t key = call_counter ? call_key(seed, *call_counter) : seed;
+    const uint64_t key = call_counter ? call_key(call_counter[1], call_counter[0]) : seed;
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     const int64_t total = rel_ptr[n_rel];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const int32_t* __restrict__ wg_rels, int64_t n_nodes, uint64_t seed, const uint64_t* __restrict__ call_counter,
     OT* __restrict__ out_u, OT* __restrict__ out_v) {
     extern __shared__ unsigned bm[];
-    const uint64_t key = call_counter ? call_key(seed, *call_counter) : seed;
+    const uint64_t key = call_counter ? call_key(call_counter[1], call_counter[0]) : seed;
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
     const int words = (int)((nn + 31) >> 5);

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
         __syncthreads();                               // readers of the previous unit are done
         commit(ne);
         __syncthreads();
-        if (ri + 1 < rn && !(a.dbg & 2)) prefetch(m + 8);          // in flight during the compute below
+        if (ri + 1 < rn && !TIPK_DBG(a.dbg & 2)) prefetch(m + 8);          // in flight during the compute below
         for (int cb = 0; cb == 0 || cb < ne; cb += RG_CHUNK) {
             const int cn = ne - cb < RG_CHUNK ? ne - cb : RG_CHUNK;
             if (cb > 0) {                              // rare: a relation with more than RG_CHUNK ids
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 idst[1024 + t] = j1;
                 __syncthreads();
             }
-            if (a.dbg & 1) continue;
+            if (TIPK_DBG(a.dbg & 1)) continue;
             // Runs are short (BioSNAP: 13.6 padded ids = 1.7 steps on average), so what a slot does AROUND
             // a run -- fetch (begin, length) and the node, read-modify-write the accumulator -- is a chain
             // of dependent LDS round trips as long as the run itself.  The next position's descriptor is
@@ -321,13 +321,12 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     if (ld_table % 4 != 0 || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(table) & 15) ||
         (reinterpret_cast<uintptr_t>(out) & 15))
         return TIPK_EINVAL;
-    const char* dbg_env = getenv("TIPK_RG_DEBUG");
     RgArgs a;
     a.table = table; a.ld_t = ld_table; a.n_nodes = (int)n_nodes; a.dc = d / split;
     a.wg_unit_ptr = wg_unit_ptr; a.unit_meta = unit_meta;
     a.idx = idx; a.runs = runs; a.node_at = node_at; a.out = out; a.ld_out = ld_out;
     a.row_scale = backward ? row_scale : nullptr;
-    a.dbg = dbg_env ? atoi(dbg_env) : 0;
+    a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_RG_DEBUG));
     hipStream_t st = (hipStream_t)stream;
     switch (a.dc / 4) {
         case 1: return launch_rg<1>(backward != 0, a, (int)n_wg, split, st);

@@ -59,6 +59,18 @@ class _PlanCache(object):
             self.key, self.pins = key, key_tensors          # keep the tensors alive: pointers stay unique
         return self.value
 
+    # A cache is derived state (device plans, lazily built through closures): it is never pickled.
+    # `torch.save(model, ...)` as in the reference's tip.py:36, `copy.deepcopy` and multiprocessing
+    # therefore work after a forward pass; the plans are rebuilt on the first call after loading.
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.key, self.value, self.pins = None, None, None
+
+    def __deepcopy__(self, memo):
+        return _PlanCache()
+
 
 def _is_identity_features(x):
     """True for the `sparse_id(n)` features of prepare.py:22-23 (cached on the tensor object)."""
@@ -492,8 +504,9 @@ class Setting(object):
 class TIP(nn.Module):
     """`TIP(settings, device, mod='cat', data_path='./data/data_dict.pkl')` as in the reference.
 
-    data_path: a pickle written by the reference's `prepare.py` loads as is; if the default file
-    does not exist, the BioSNAP graph bundled with this package is split with seed 1111.
+    data_path: a pickle written by the reference's `prepare.py` loads as is; if the DEFAULT file
+    does not exist (or data_path is None), the BioSNAP graph bundled with this package is split with
+    seed 1111; any other missing path raises FileNotFoundError.  `.data_source` says which was used.
     `data` (extension): an already built data dict.  `fused_loss=False` computes the loss with
     torch ops on the decoder scores exactly as `src/layers.py:335-340` spells it."""
 
@@ -504,13 +517,24 @@ class TIP(nn.Module):
         self.data = self.__prepare_data(data_path, settings.sp_rate, data).to(device)
         self.__prepare_model()
 
+    DEFAULT_DATA_PATH = './data/data_dict.pkl'
+
     def __prepare_data(self, data_path, sp_rate, data_dict):
         if data_dict is None:
             if data_path is not None and os.path.exists(data_path):
                 with open(data_path, 'rb') as f:
                     data_dict = pickle.load(f)
-            else:
+                self.data_source = os.path.abspath(data_path)
+            elif data_path is None or data_path == self.DEFAULT_DATA_PATH:
+                # only the reference's DEFAULT location may be absent (this package bundles the graph
+                # that file is made from); an explicitly given path that does not exist is an error,
+                # as in the reference (src/layers.py:284-285 raises FileNotFoundError)
                 data_dict = build_data_dict(sp_rate=0.9)
+                self.data_source = 'bundled BioSNAP blob (tip_amd/data/biosnap_v1.npz), split seed 1111'
+            else:
+                raise FileNotFoundError(data_path)
+        else:
+            self.data_source = 'data dict passed by the caller'
         data = Data.from_dict(dict(data_dict))
         if sp_rate != 0.9:                                                   # :290-291
             (data.dd_train_idx, data.dd_train_et, data.dd_train_range,

@@ -22,24 +22,36 @@ from . import ops
 
 _MASK = (1 << 64) - 1
 _state = {'seed': 1111}
-_counters = {}                 # device -> int64 [1] tensor: position of the stream ON THE DEVICE
+_counters = {}                 # device -> int64 [2] tensor {position, seed}: the stream's state ON THE DEVICE
 _key_cache = {}
 
 
 def manual_seed(seed):
     """Reset the sampler stream (the analogue of `np.random.seed`, src/layers.py:14).  Call n of the
-    stream uses the Philox key `call_key(seed, n)`; n lives in device memory so that a captured
-    hipGraph (tip_amd.train.GraphedTrainStep) draws fresh negatives on every replay."""
+    stream uses the Philox key `call_key(seed, n)`; BOTH n and the seed live in device memory, so a
+    captured hipGraph (tip_amd.train.GraphedTrainStep) draws fresh negatives on every replay and
+    re-seeding after capture takes effect in the replays."""
     _state['seed'] = int(seed) & _MASK
     for c in _counters.values():
-        c.zero_()
+        c.copy_(_state_words(_state['seed']))
+
+
+def _state_words(seed):
+    """{position 0, seed} as int64 (the seed's bit pattern)."""
+    s = seed - (1 << 64) if seed >= (1 << 63) else seed
+    return torch.tensor([0, s], dtype=torch.int64)
 
 
 def _counter(device):
     c = _counters.get(device)
     if c is None:
-        c = _counters[device] = torch.zeros(1, dtype=torch.int64, device=device)
+        c = _counters[device] = _state_words(_state['seed']).to(device)
     return c
+
+
+def stream_position(device):
+    """Number of draws made on `device` since the last `manual_seed` (host copy: synchronises)."""
+    return int(_counter(torch.device(device))[0])
 
 
 def call_key(seed, n):

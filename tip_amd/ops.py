@@ -467,6 +467,37 @@ def _uv(edge_index):
     return ei[0], ei[1]
 
 
+_VALID = {}
+
+
+def validate_triples(edge_index, edge_type, n_nodes, n_rel):
+    """Range check of a triple list, done ONCE per tensor identity (the result is cached, so the
+    per-step cost is a dictionary lookup): the decoder kernels index the LDS images of z / d z with
+    16-bit node ids and `weight` rows with the relation id, so an out-of-range id would corrupt
+    memory silently where the reference raises IndexError."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+           None if edge_type is None else (edge_type.data_ptr(), tuple(edge_type.shape), edge_type._version),
+           int(n_nodes), int(n_rel))
+    if key in _VALID:
+        return
+    n = edge_index.shape[-1]
+    if n >= 2 ** 31:
+        raise ValueError('triple lists are indexed with 32-bit positions: %d >= 2^31' % n)
+    if n:
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= n_nodes:
+            raise IndexError('node id out of range: [%d, %d] for %d nodes' % (lo, hi, n_nodes))
+        if edge_type is not None:
+            if edge_type.numel() != n:
+                raise ValueError('edge_type has %d entries for %d triples' % (edge_type.numel(), n))
+            lo, hi = int(edge_type.min()), int(edge_type.max())
+            if lo < 0 or hi >= n_rel:
+                raise IndexError('relation id out of range: [%d, %d] for %d relations' % (lo, hi, n_rel))
+    if len(_VALID) > 64:
+        _VALID.clear()
+    _VALID[key] = (edge_index, edge_type)                                    # pin: pointers stay unique
+
+
 _TASK_CACHE = {}
 TASK_POSITIONS = 2048          # = TASK_MAX in tipk_distmult.hip (a task's ids are staged in LDS)
 
@@ -525,6 +556,7 @@ def relation_tasks(edge_type, pos_index=None):
 def distmult_fwd(z, weight, edge_index, edge_type, sigmoid=True):
     z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
     require_device(z, weight, edge_index, edge_type)
+    validate_triples(edge_index, edge_type, z.shape[0], weight.shape[0])
     u, v = _uv(edge_index)
     et = edge_type.contiguous()
     n = u.numel()
@@ -538,6 +570,7 @@ def distmult_fwd(z, weight, edge_index, edge_type, sigmoid=True):
 def distmult_bwd(g_score, score, z, weight, edge_index, edge_type, sigmoid=True):
     z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
     g_score = _f32c(g_score).contiguous()
+    validate_triples(edge_index, edge_type, z.shape[0], weight.shape[0])
     u, v = _uv(edge_index)
     et = edge_type.contiguous()
     g_z, g_w = torch.zeros_like(z), torch.zeros_like(weight)
@@ -554,6 +587,9 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     """(loss [1], g_z, g_w) of the fused TIP objective (include/tipk.h section 4)."""
     z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
     require_device(z, weight, pos_index, neg_index, edge_type)
+    validate_triples(pos_index, edge_type, z.shape[0], weight.shape[0])
+    if not getattr(neg_index, '_tipk_sampled', False):
+        validate_triples(neg_index, None, z.shape[0], weight.shape[0])       # sampler output is in range by construction
     pu, pv = _uv(pos_index)
     nu, nv = _uv(neg_index)
     assert pu.dtype == nu.dtype and pu.numel() == nu.numel()
@@ -571,8 +607,9 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
 
 def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64,
                                    call_counter=None, wg=None):
-    """call_counter: optional int64 device tensor [1]; then `seed` is the stream seed, the Philox key
-    is derived on the device from (seed, counter) and the counter is advanced by one afterwards."""
+    """call_counter: optional int64 device tensor [2] = {position, seed} (the stream's state): the
+    Philox key is derived on the device from it, `seed` is ignored, and the position is advanced by
+    one afterwards."""
     require_device(pos_key_sorted, rel_ptr, call_counter)
     out = torch.empty((2, n_positions), dtype=dtype, device=pos_key_sorted.device)
     st = stream_ptr(out.device)
@@ -584,6 +621,7 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
           'tipk_typed_negative_sampling')
     if call_counter is not None:
         check(lib().tipk_counter_advance(ptr(call_counter), st), 'tipk_counter_advance')
+    out._tipk_sampled = True                       # ids < n_nodes by construction: no range check downstream
     return out
 
 
@@ -1021,6 +1059,7 @@ class _PairTable(torch.autograd.Function):
         s1, s2 = _f32c(s1).contiguous(), _f32c(s2).contiguous()
         require_device(s1, s2, edge_index, edge_type)
         assert s1.shape == s2.shape
+        validate_triples(edge_index, edge_type, s1.shape[0], s1.shape[1])
         u, v = _uv(edge_index)
         et = edge_type.contiguous()
         n = u.numel()

@@ -3,7 +3,7 @@ product / reduction, 4 no first product) at BioSNAP sizes; kernel-only time via 
 import os, sys, torch, ctypes as C
 sys.path.insert(0, '.')
 
-from tip_amd._lib import lib, ptr, stream_ptr, check
+from tip_amd._lib import lib, ptr, stream_ptr, check, set_option   # needs TIPK_LIB=tip_amd/libtipk_debug.so (make debug)
 dev = torch.device('cuda:0')
 R, B = 1097, 32
 for ncol in (20640, 10320):
@@ -15,7 +15,7 @@ for ncol in (20640, 10320):
         check(lib().tipk_rgcn_dy_products(ptr(gy), ncol, ptr(att), B, ptr(xb2), ncol, R, ncol, B, ptr(dxb), ptr(datt),
                                           stream_ptr(dev)), 'dy')
     for dbg in (0, 1, 2, 4, 3, 6, 7):
-        os.environ['TIPK_DP_DEBUG'] = str(dbg)
+        set_option('dp_debug', dbg)
         for _ in range(3): run()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

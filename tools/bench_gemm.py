@@ -3,7 +3,7 @@ BioSNAP sizes for several split factors.  usage: python3 tools/bench_gemm.py [n_
 import sys
 import torch
 sys.path.insert(0, '.')
-from tip_amd import ops
+from tip_amd import ops, _lib
 
 dev = torch.device('cuda:0')
 R, B = 1097, 32
@@ -47,14 +47,14 @@ for ncol in [int(x) for x in sys.argv[1:]] or [20640, 10320]:
     t = timeit(lambda: ops.gemm_group([ops.gemm_job(gy, xb2.t()), ops.gemm_job(att.t(), gy)]))
     print('ncol %d  group(dAtt,dXB) %7.1f us  %.2f TB/s (one read)' % (ncol, t, mb / t))
     import os
-    os.environ['TIPK_NO_STREAM_GEMM'] = '1'
+    _lib.set_option('gemm_no_stream', 1)
     t = timeit(lambda: ops.gemm(att, xb2))
     print('ncol %d  [tiled] Y       %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
     t = timeit(lambda: ops.gemm(att.t(), gy, ksplit=4))
     print('ncol %d  [tiled] dXB k4  %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
     t = timeit(lambda: ops.gemm(gy, xb2.t(), ksplit=57))
     print('ncol %d  [tiled] dAtt k57 %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
-    del os.environ['TIPK_NO_STREAM_GEMM']
+    _lib.set_option('gemm_no_stream', 0)
     t = timeit(lambda: gy.copy_(xb2[:1].expand(R, ncol)))
     print('ncol %d  torch fill      %7.1f us  %.2f TB/s' % (ncol, t, mb / t))
     t = timeit(lambda: gy.sum())

@@ -3,7 +3,7 @@ TIPK_RG_DEBUG=2 -- no staging after the first unit -- still does the same amount
 dbg 0 = all, 1 = staging only, 2 = compute only."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tip_amd import ops
+from tip_amd import ops, _lib
 from tip_amd.plan import build_rel_plan
 dev = 'cuda:0'
 N, R, per = 645, 1097, 7590
@@ -25,6 +25,6 @@ for d in (32, 16):
     pb = build_rel_plan(src, dst, rel, N, R, 256, backward=True, max_unit=10 ** 9)
     y = torch.randn(R * N, d, device=dev); gg = torch.randn(N, d, device=dev)
     for dbg in (0, 1, 2, 3):
-        os.environ['TIPK_RG_DEBUG'] = str(dbg)
+        _lib.set_option('rg_debug', dbg)
         print('uniform d=%d dbg=%d  fwd %.1f us   bwd %.1f us' % (
             d, dbg, t(lambda: ops.rel_gather(pf, y, False, reduce=False)), t(lambda: ops.rel_gather(pb, gg, True))))
