@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: D-D edges aggregated / s over encoder forward + backward.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload biosnap|biosnap963|synthetic]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload biosnap|biosnap963|synthetic|synthetic-small]
 
 A "step" is one pass of the hot path over the full graph: `z = FMEncoder.forward(...)` (P-P GCN x2,
 P->D mean, two R-GCN layers) followed by its backward with a fixed upstream gradient g ~ N(0,1)
@@ -9,26 +9,42 @@ P->D mean, two R-GCN layers) followed by its backward with a fixed upstream grad
 region; graph preprocessing is timed separately (`preprocess_s`).  value = E * K / t with E the
 number of directed D-D train edges, t the max over ranks of the barrier-bracketed wall time.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the D-D relations are sharded
-over the ranks (tip_amd/dist.py), partial aggregates and the replicated-parameter gradients are
-all-reduced; total work is fixed, so "scaling" is "strong".
+N > 1: one rank per GPU over RCCL; the D-D relations are sharded over the ranks (tip_amd/dist.py),
+partial aggregates and the replicated-parameter gradients are all-reduced; total work is fixed, so
+"scaling" is "strong".  The driver may start the ranks itself (torch.distributed.run: RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) or run plain `python bench.py --gpus N`: then this
+process -- BEFORE it touches the GPU -- starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a child, relays rank 0's JSON line and exits with the child's return code.
+`--oversubscribe` lets N ranks share fewer GPUs (gloo collectives; a functional check of the N-rank
+path on a 1-GPU box, not a measurement).
 
-Extra objects on the JSON line: `roofline` (dominant kernel, HIP-event timed on its launch
-stream inside the timed region) and `cpu_baseline` (the oracle's CPU port on the host cores, rank 0,
-N = 1 only).
+Objects on the JSON line besides the contract's fields:
+  roofline      the dominant kernel: algorithmic bytes per launch ((4 + 4 d) B per edge)
+                / its launch duration, measured live with HIP events on the launch stream around a
+                hipGraph of 20 back-to-back launches of that kernel on the step's own plans (an event
+                pair around ONE eager launch adds ~8 us of host/event overhead -- VERDICT r1 #3).
+                bound = "lds" for the relation-local kernels (rows are read from LDS: the HBM figure
+                of 8(d) is not their bound; peak = ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz),
+                "hbm" otherwise.  traffic = HBM bytes per launch from the committed PMC summary of
+                this command (profiles/*_pmc_traffic.json, keyed by kernel and full grid x*y*z);
+                hbm_traffic_frac = traffic / duration / 8 TB/s.
+  whole_step    algorithmic bytes of the whole step (416 B/edge BioSNAP, 2080 B/edge synthetic) over
+                the measured step time, as a fraction of the 8 TB/s HBM spec.
+  cpu_baseline  the oracle's CPU port on the host cores (rank 0, N = 1 only), bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+LDS_PEAK_GBS = 256 * 256 * 2.4   # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 286 GB/s
 
 
 def parse():
@@ -42,9 +58,47 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--chunk', type=int, default=None, help='gather plan chunk (edges per work item)')
     ap.add_argument('--launch', default=None, choices=['graph', 'eager'],
-                    help='graph: the step is captured once into a hipGraph and replayed (default on 1 GPU); '
-                         'eager: one ctypes launch per kernel (default with collectives in the step)')
+                    help='graph: the step is captured once into a hipGraph and replayed (default); '
+                         'eager: one ctypes launch per kernel')
+    ap.add_argument('--oversubscribe', action='store_true',
+                    help='allow more ranks than GPUs (ranks share devices, gloo collectives): functional check only')
+    ap.add_argument('--no-kernel-table', action='store_true', help='skip the eager per-kernel event pass')
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# self-launch (plain `python bench.py --gpus N`): children are started before any GPU call here
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    import torch                                   # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.oversubscribe:
+        sys.stderr.write('bench.py: --gpus %d but this box has %d GPU(s); pass --oversubscribe to run %d ranks on '
+                         'them (functional check of the N-rank path, gloo collectives)\n' % (args.gpus, have, args.gpus))
+        return 3
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)        # stderr passes through
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write('bench.py: the %d-rank run failed (rc %d)\n%s\n' % (args.gpus, proc.returncode, proc.stdout[-2000:]))
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
 
 
 def make_workload(args):
@@ -72,6 +126,7 @@ def cpu_baseline(dd, dims, mod, budget_s):
     """The oracle (CPU port of the same algorithm: transform-then-gather with explicit backward)
     on this host's cores, plus the reference-shaped op sequence (PyG-CPU path: lift E x in,
     per-relation slice+mm, cat, scatter-mean, autograd backward) on a bounded relation sample."""
+    import torch
     from oracle import tip_oracle as O
     E = dd['dd_train_idx'].shape[1]
     R = dd['n_dd_et']
@@ -98,73 +153,146 @@ def cpu_baseline(dd, dims, mod, budget_s):
     out = {'value': E / dt, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
            'sample': 'full workload: %d oracle encoder fwd+bwd passes over all %d edges (%.2f s each)' % (n, E, dt)}
 
-    # reference-shaped flavour on the first relations (bounded: cost grows ~ R * E)
+    # reference-shaped flavour on the first relations (bounded: its cost grows ~ R * E because every
+    # `x_j[start:end]` slice backward zero-fills an E x in gradient, SURVEY 8(a) A4)
     try:
         r_s = min(R, 24)
         e_s = int(dd['dd_train_range'][r_s - 1, 1])
         ei = dd['dd_train_idx'][:, :e_s]
         rg = dd['dd_train_range'][:r_s]
-        x = torch.randn(dd['n_drug'], 64).requires_grad_(True)
-        prm = [p['rgcn1.basis'][:, :64].clone().requires_grad_(True), p['rgcn1.att'][:r_s].clone().requires_grad_(True),
-               p['rgcn1.root'][:64].clone().requires_grad_(True)]
+        d_in = dims['n_embed'] + dims['prot_drug_dim'] if mod == 'cat' else dims['n_embed']
+        x = torch.randn(dd['n_drug'], d_in).requires_grad_(True)
+        prm = [p['rgcn1.basis'][:, :d_in].clone().requires_grad_(True), p['rgcn1.att'][:r_s].clone().requires_grad_(True),
+               p['rgcn1.root'][:d_in].clone().requires_grad_(True)]
         g = torch.randn(dd['n_drug'], prm[0].shape[2])
         t0 = time.perf_counter()
         y = O.rgcn_fwd_reference_shaped(x, ei, rg, *prm)
         y.backward(g)
         dt_ref = time.perf_counter() - t0
-        out['reference_shaped'] = {'value': e_s / dt_ref, 'unit': 'edges/s (one R-GCN layer fwd+bwd)', 'cores': threads,
-                                   'sample': 'first %d relations, %d edges, PyG op sequence under autograd, %.2f s'
-                                             % (r_s, e_s, dt_ref)}
+        out['reference_shaped'] = {
+            'value': e_s / dt_ref, 'unit': 'edges/s (one R-GCN layer fwd+bwd, on the SAMPLE)', 'cores': threads,
+            'sample': 'first %d relations, %d edges, PyG op sequence under autograd, %.2f s' % (r_s, e_s, dt_ref),
+            # time ~ c * R_s * E_s  ->  full graph: E / (c R E) = sample rate * R_s / R
+            'full_size_estimate': e_s / dt_ref * r_s / R,
+            'full_size_estimate_note': 'sample rate x R_sample / R (cost model c*R*E of the slice backward; the survey '
+                                       'probe of the literal reference measured 0.020 M edges/s on 8 cores)'}
     except Exception as exc:                                   # never let the side leg kill the bench
         out['reference_shaped'] = {'error': repr(exc)}
     return out
 
 
-def pmc_traffic(enc, label, d_row):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary
-    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    command, corrected as MI355X_MICROARCH.md prescribes); None if no summary matches the launch."""
-    import glob
-    try:
-        graph = {'dd': enc.rgcn1 if d_row == enc.rgcn1.out_channels else enc.rgcn2}['dd']._cache.value \
-            if '[dd.' in label else None
+# ---------------------------------------------------------------------------------------------
+# the D-D aggregation launches of the step, timed alone (roofline object)
+# ---------------------------------------------------------------------------------------------
+def dd_aggregation_launches(enc, dev):
+    """[(label, kernel key for profiles/, grid 'XxYxZ', d, callable)] for the four D-D aggregations
+    of one step, on the step's own plans with random tables of the step's shapes."""
+    import torch
+    from tip_amd import ops
+    out = []
+    for layer in (enc.rgcn1, enc.rgcn2):
+        graph = layer._cache.value
         if graph is None:
-            return None
-        if label.startswith('rel_gather'):
-            bwd = '.bwd' in label
+            continue
+        d = layer.out_channels
+        n = graph.scale.numel()
+        shard = layer.shard
+        r = layer.num_relations if shard is None else int(shard.rel_ids.numel())
+        if r == 0:
+            continue
+        y = torch.randn(r * n, d, device=dev)
+        g = torch.randn(n, d, device=dev)
+        for bwd in (False, True):
             rp = graph.rl_bwd if bwd else graph.rl_fwd
-            split = 1 if (bwd or d_row <= 16) else 2          # column blocks (tipk_rel_gather.hip)
-            key_prefix = 'rel_gather_kernel<%d, %s' % (d_row // split // 4, 'true' if bwd else 'false')
-            grid = rp.n_wg * split * 1024
-        else:
-            plan = graph.fwd if '.fwd' in label else graph.bwd
-            lanes = 1
-            while lanes < d_row // 4:
-                lanes *= 2
-            waves = -(-plan.items.shape[0] // (64 // lanes))
-            grid = -(-waves // 4) * 256
-            key_prefix = 'gather_sum_kernel<4, %d, false>' % lanes
-        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+            if ops.rel_gather_usable(rp, n, d, bwd):
+                split = ops.rel_gather_split(n, d, bwd)
+                key = 'rel_gather_kernel<%d, %s' % (d // split // 4, 'true' if bwd else 'false')
+                grid = '%dx%dx1' % (rp.n_wg * 1024, split)
+                fn = (lambda rp=rp, g=g: ops.rel_gather(rp, g, True, row_scale=graph.scale)) if bwd else \
+                     (lambda rp=rp, y=y: ops.rel_gather(rp, y, False, reduce=False))
+                out.append(('rel_gather[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'lds', fn))
+            else:
+                plan = graph.bwd if bwd else graph.fwd
+                lanes = 1
+                while lanes < d // 4:
+                    lanes *= 2
+                waves = -(-plan.items.shape[0] // (64 // lanes))
+                key = 'gather_sum_kernel<4, %d' % lanes
+                grid = '%dx1x1' % (-(-waves // 4) * 256)
+                fn = (lambda plan=plan, g=g: ops.gather_sum(plan, g)) if bwd else (lambda plan=plan, y=y: ops.gather_sum(plan, y))
+                out.append(('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'hbm', fn))
+    return out
+
+
+def time_launch_us(fn, reps=20, replays=5):
+    """Device time of one launch of `fn`: HIP events on the launch stream around `replays` replays of
+    a hipGraph holding `reps` back-to-back launches."""
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(reps):
+                fn()
+        g.replay()                                         # warm
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(side)
+        for _ in range(replays):
+            g.replay()
+        b.record(side)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / (reps * replays)
+
+
+def pmc_traffic(key_prefix, grid):
+    """(HBM bytes per launch, trace us, source file) of a kernel from the newest committed summaries
+    (profiles/*_pmc_traffic.json / *_kernel_by_grid.csv: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes and the --kernel-trace of this command; bytes corrected as
+    MI355X_MICROARCH.md prescribes).  Entries are keyed by kernel name and the FULL grid XxYxZ."""
+    import csv
+    import glob
+    traffic = trace_us = src = None
+    try:
+        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
             for name, k in json.load(open(fn))['kernels'].items():
-                if name.startswith(key_prefix) and name.endswith('grid=%d' % grid):
-                    return k['hbm_bytes_per_launch']
+                if name.startswith(key_prefix) and name.endswith('grid=' + grid):
+                    traffic, src = k['hbm_bytes_per_launch'], os.path.basename(fn)
+                    break
+            if traffic is not None:
+                break
+        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_by_grid.csv')), reverse=True):
+            rows = [r for r in csv.reader(l for l in open(fn) if not l.startswith('#'))][1:]
+            hit = [r for r in rows if r[0].startswith(key_prefix) and r[0].endswith('grid=' + grid)]
+            if hit:
+                trace_us = float(hit[0][2]) / 1e3
+                break
     except Exception:
         pass
-    return None
+    return traffic, trace_us, src
 
 
 def main():
     args = parse()
+    if 'RANK' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))               # children first: this process never touches the GPU
+
+    import torch
+    from tip_amd import _lib
+    _lib.ensure_built()                            # child `make` if the .so is missing / stale (before GPU use)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev                         # --oversubscribe: ranks share devices
+    if shared and not args.oversubscribe:
+        raise SystemExit('%d ranks on %d GPU(s): pass --oversubscribe' % (world, n_dev))
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device('cuda', local_rank % n_dev)
 
     import torch.distributed as dist
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout (seen
@@ -175,16 +303,20 @@ def main():
         sys.stdout.flush()
         stdout_fd = os.dup(1)
         os.dup2(2, 1)
+    backend = 'gloo' if shared else 'nccl'         # RCCL refuses two ranks on one device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from tip_amd import ops
     from tip_amd.data import Data
     from tip_amd.layers import FMEncoder
     if args.chunk:
         os.environ['TIPK_CHUNK'] = str(args.chunk)
-    launch = args.launch or 'graph'
+    launch = args.launch or ('eager' if shared else 'graph')
 
     dd, dims, wl_name = make_workload(args)
     E = int(dd['dd_train_idx'].shape[1])
@@ -196,7 +328,7 @@ def main():
         from tip_amd.dist import shard_encoder
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         for prm in enc.parameters():                           # identical replicas
             dist.broadcast(prm.data, 0)
@@ -223,7 +355,7 @@ def main():
     preprocess_s = time.perf_counter() - t0
     run = step
     if launch == 'graph':
-        # the whole step (about 55 kernels, plus the RCCL all-reduces when sharded) becomes one
+        # the whole step (about 36 kernels, plus the RCCL all-reduces when sharded) becomes one
         # hipGraph: replay removes the per-launch host cost, which is larger than the kernels
         # themselves at BioSNAP scale.  If capture fails (e.g. a collective that cannot be captured on
         # this RCCL build) every rank falls back to eager launches together.
@@ -259,13 +391,19 @@ def main():
         run()
     fence()
     elapsed = time.perf_counter() - t0
-    # per-kernel durations: HIP events on the launch stream around every launch of an eager pass of
-    # the same steps, same process (events cannot be read back from inside a replayed graph)
-    ops.timing_start()
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
-    fence()
-    kern = ops.timing_stop()
+
+    # the D-D aggregation launches alone (roofline), then an eager per-kernel table of the whole step
+    agg_us = {}
+    launches = dd_aggregation_launches(enc, dev)
+    for label, key, grid, d_row, bound, fn in launches:
+        agg_us[label] = time_launch_us(fn)
+    kern = {}
+    if not args.no_kernel_table:
+        ops.timing_start()
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        fence()
+        kern = ops.timing_stop()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -273,29 +411,6 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        # dominant kernel = the sparse-aggregation launch with the largest share of device time
-        gs = {k: v for k, v in kern.items() if k.startswith('gather_sum') or k.startswith('rel_gather')}
-        dom = max(gs, key=lambda k: gs[k][0] * gs[k][1])
-        d_row = int(dom.split('d=')[1].rstrip(']'))
-        n_launch_edges = E if '[dd.' in dom else None
-        if n_launch_edges is None:                             # P-P / P->D launches (not expected to dominate)
-            n_launch_edges = int(dd['pp_train_indices'].shape[1]) + dd['n_prot']
-        if world > 1:
-            n_launch_edges = n_launch_edges // world           # rank 0's share (balanced by edges)
-        # one id + one d-wide fp32 row per edge and pass (ids are 4 B in the generic
-        # plans, 2 B in the relation-local ones; the figure keeps 4 B so runs stay comparable)
-        alg_bytes = n_launch_edges * (4 + 4 * d_row)
-        achieved = alg_bytes / (gs[dom][1] * 1e-3) / 1e9
-        traffic = pmc_traffic(enc, dom, d_row)
-        lds_note, lds_roof = None, None
-        if dom.startswith('rel_gather'):
-            lds_note = ('rows are gathered from LDS (relation-local kernel): algorithmic GB/s exceeds the HBM peak by '
-                        'design; HBM only carries the ids and one coalesced read of Y (fwd) / write of dY (bwd) -- see '
-                        'traffic; the bound that applies is lds_roofline')
-            # the kernel's real ceiling: every gathered row is a ds_read_b128 stream out of the CU's LDS
-            # (ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz, MI355X_MICROARCH "LDS"); same algorithmic bytes
-            lds_peak = 256 * 256 * 2.4e9 / 1e9
-            lds_roof = {'bound': 'lds', 'achieved': achieved, 'peak': lds_peak, 'unit': 'GB/s', 'frac': achieved / lds_peak}
         out = {
             'metric': 'D-D edges aggregated/sec (encoder fwd+bwd)',
             'value': E * args.steps / elapsed, 'unit': 'edges/s',
@@ -304,18 +419,49 @@ def main():
             'dtype': 'f32', 'data': 'BioSNAP graph (bundled), random-init weights, fixed N(0,1) upstream gradient'
             if args.workload.startswith('biosnap') else 'synthetic',
             'config': {'workload': wl_name, 'mod': args.mod, 'directed_dd_edges': E, 'relations': R,
-                       'parallelism': 'relation-sharded x%d' % world if world > 1 else 'single GPU',
+                       'parallelism': 'relation-sharded x%d%s' % (world, ' (ranks share GPUs, gloo: functional check)'
+                                                                  if shared else '') if world > 1 else 'single GPU',
                        'launch': 'hipGraph replay of the captured step' if launch == 'graph'
                        else 'eager (one ctypes call per kernel)'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'launch_ms': gs[dom][1], 'algorithmic_bytes_per_launch': alg_bytes, 'note': lds_note,
-                         'lds_roofline': lds_roof},
-            'kernels_ms': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
-                           for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])},
             'preprocess_s': preprocess_s,
-            'whole_step_algorithmic_GBps': E * sum(2 * (4 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2')) / (ms * 1e-3) / 1e9,
+            'build_id': _lib.build_id(),
         }
+        # dominant kernel = the D-D aggregation launch with the longest duration
+        if agg_us:
+            dom = max(agg_us, key=agg_us.get)
+            label, key, grid, d_row, bound, _ = [l for l in launches if l[0] == dom][0]
+            n_edges = E // world if world > 1 else E               # rank 0's share (balanced by edges)
+            # one id + one d-wide fp32 row per edge and pass (ids are 4 B in the generic
+            # plans, 2 B in the relation-local ones; the figure keeps 4 B so runs stay comparable)
+            alg_bytes = n_edges * (4 + 4 * d_row)
+            us = agg_us[dom]
+            achieved = alg_bytes / (us * 1e-6) / 1e9
+            peak = LDS_PEAK_GBS if bound == 'lds' else HBM_PEAK_GBS
+            traffic, trace_us, src = pmc_traffic(key, grid)
+            roof = {'bound': bound, 'kernel': dom, 'grid': grid, 'achieved': achieved, 'peak': peak, 'unit': 'GB/s',
+                    'frac': achieved / peak, 'traffic': traffic, 'launch_us': us,
+                    'timing': 'HIP events on the launch stream around a hipGraph of 20 back-to-back launches',
+                    'algorithmic_bytes_per_launch': alg_bytes}
+            if traffic is not None:
+                roof['hbm_traffic_frac'] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                roof['traffic_source'] = 'profiles/' + src
+            if trace_us is not None:
+                roof['rocprof_trace_us'] = trace_us
+            if bound == 'lds':
+                roof['note'] = ('rows are gathered from LDS (relation-local kernel): the bound is the ds_read_b128 rate, '
+                                'HBM only carries the ids and one coalesced read of Y (fwd) / write of dY (bwd)')
+            out['roofline'] = roof
+            out['dd_aggregations_us'] = {k: round(v, 2) for k, v in agg_us.items()}
+        per_edge = sum(2 * (8 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2'))     # 416 / 2080 B per edge
+        out['whole_step'] = {'alg_bytes': E * per_edge, 'bytes_per_edge': per_edge,
+                             'GBps': E * per_edge / (ms * 1e-3) / 1e9,
+                             'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if kern:
+            out['kernels_eager_ms'] = {
+                'note': 'one HIP event pair per EAGER launch: includes ~5-8 us of event/launch overhead each; '
+                        'kernel-only times: profiles/*_kernel_by_grid.csv',
+                'table': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
+                          for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dd, dims, args.mod, args.cpu_seconds)
     if dist.is_initialized():

@@ -46,6 +46,7 @@ const char* tipk_build_id(void);
  *      "gemm_no_stream"      1 = every product through the LDS-tiled kernel (cross-check in tests)
  *      "gemm_thin_k_narrow"  1 = dword body of the Y = att.XB streaming kernel
  *      "gemm_stream_kk"      1 = lane-per-row streaming body for d att
+ *      "rg_occupancy"        workgroups per CU tipk_rel_gather aims for: 1, 2 (0 = library default)
  *      "rg_debug", "dp_debug"  bit masks that SKIP parts of tipk_rel_gather / tipk_rgcn_dy_products
  *                            (timing decompositions): accepted by -DTIPK_DEBUG builds only; a release
  *                            library returns TIPK_EUNSUPPORTED for a non-zero value and its kernels
@@ -138,6 +139,10 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  * shape is not supported (use tipk_gather_sum).  row_scale (backward only, nullable): the table
  * rows are multiplied by row_scale[node] while they are staged (g' = g / deg fused). */
 int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);
+/* workgroups per CU (1 or 2) the launch of this shape reaches: with 2 the columns are cut finer so that
+ * two 1024-thread workgroups share a CU (8 waves per SIMD hide the kernel's LDS round trips); the host
+ * builds the plan for  occupancy * CUs / column-blocks  workgroups.  Option "rg_occupancy" (1 | 2). */
+int tipk_rel_gather_occupancy(int64_t n_nodes, int d, int backward);
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                     int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* unit_meta,
                     const uint16_t* idx, const int32_t* runs, const uint16_t* node_at,

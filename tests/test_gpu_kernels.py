@@ -437,6 +437,27 @@ def test_negative_sampler_bit_exact_vs_spec_and_properties():
     assert np.array_equal(a1.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(7, 0)))
     assert np.array_equal(a2.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(7, 1)))
     assert call_key(7, 1) == NS.call_key(7, 1)
+    # the stream's seed lives on the device next to its position: a captured sampler call keeps
+    # advancing on replay, and RE-SEEDING AFTER CAPTURE takes effect in the replays
+    NS.manual_seed(7)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            captured = NS.typed_negative_sampling(pos_t, n, rg)
+    torch.cuda.synchronize()
+    assert NS.stream_position(DEV) == 0                               # capture executes nothing
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(captured, a1) and NS.stream_position(DEV) == 1
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(captured, a2)
+    NS.manual_seed(99)                                                # other seed, after capture
+    graph.replay(); torch.cuda.synchronize()
+    assert np.array_equal(captured.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(99, 0)))
+    NS.manual_seed(7)
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(captured, a1)
 
 
 def test_negative_sampler_uniformity_vs_reference_distribution():

@@ -343,3 +343,26 @@ def test_triple_validation_is_cached_and_raises():
         ops.validate_triples(ei, et, 3, 1)                             # relation id 1 of 1 relation
     with pytest.raises(IndexError):
         ops.validate_triples(torch.tensor([[0, -1], [0, 0]]), None, 3, 1)
+
+
+def test_reference_pickle_fixture_schema():
+    """tests/golden/data_dict_small.pkl (written by the reference's prepare.py pipeline, see
+    oracle/make_pickle_fixture.py) has the schema of SURVEY 8(a) A0 and `tip_amd.data.Data` takes it as is."""
+    import pickle
+    from tip_amd.data import Data
+    with open(os.path.join(ROOT, 'tests', 'golden', 'data_dict_small.pkl'), 'rb') as f:
+        dd = pickle.load(f)
+    for k in ('d_feat', 'p_feat', 'dd_train_idx', 'dd_train_et', 'dd_train_range', 'dd_test_idx', 'dd_test_et',
+              'dd_test_range', 'd_norm', 'pp_train_indices', 'dp_edge_index', 'dp_range_list', 'n_drug', 'n_prot',
+              'n_dd_et', 'n_drug_feat', 'dd_adj_list', 'dp_adj', 'pp_adj', 'dd_edge_index'):
+        assert k in dd, k
+    assert dd['dd_train_idx'].dtype == torch.int64 and dd['dd_train_range'].shape == (dd['n_dd_et'], 2)
+    assert dd['dp_range_list'].dtype == torch.float32 and dd['d_feat'].is_sparse
+    import scipy.sparse as sp
+    assert sp.issparse(dd['pp_adj']) and sp.issparse(dd['dd_adj_list'][0])          # the unused fields came along
+    d = Data.from_dict(dd).to(torch.device('cpu'))
+    assert d.n_drug == 645 and d.dd_train_et.numel() == d.dd_train_idx.shape[1]
+    # every relation block is [pairs | mirrored pairs] (src/utils.py:53)
+    for a, b in d.dd_train_range.tolist():
+        h = (b - a) // 2
+        assert torch.equal(d.dd_train_idx[:, a:a + h], d.dd_train_idx[:, a + h:b].flip(0))

@@ -59,6 +59,7 @@ SIGNATURES = {
     'tipk_gather_sum': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
+    'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),
@@ -87,7 +88,7 @@ _lib = None
 # environment switch -> library option (translated ONCE, when the library is loaded; the library
 # itself never reads the environment).  Tests and tools flip options with `set_option`.
 _ENV_OPTIONS = {'TIPK_NO_STREAM_GEMM': 'gemm_no_stream', 'TIPK_THIN_K_NARROW': 'gemm_thin_k_narrow',
-                'TIPK_STREAM_KK': 'gemm_stream_kk'}
+                'TIPK_STREAM_KK': 'gemm_stream_kk', 'TIPK_RG_OCC': 'rg_occupancy'}
 
 
 def source_digest():
@@ -167,7 +168,7 @@ def lib():
         raise TipkError('libtipk.so ABI %d != binding ABI %d: rebuild' % (handle.tipk_abi_version(), ABI_VERSION))
     for env, opt in _ENV_OPTIONS.items():
         if os.environ.get(env):
-            handle.tipk_set_option(opt.encode(), 1)
+            handle.tipk_set_option(opt.encode(), int(os.environ[env]))
     _lib = handle
     return _lib
 

@@ -19,9 +19,9 @@ static const char tipk_build_marker[] = "TIPK_BUILD_ID=" TIPK_BUILD_ID;
 #endif
 extern "C" const char* tipk_build_id(void) { return tipk_build_marker + 14; }
 
-static int g_options[TIPK_OPT_COUNT] = {0, 0, 0, 0, 0};
+static int g_options[TIPK_OPT_COUNT] = {0, 0, 0, 0, 0, 0};
 static const char* const g_option_names[TIPK_OPT_COUNT] = {"gemm_no_stream", "gemm_thin_k_narrow", "gemm_stream_kk",
-                                                            "rg_debug", "dp_debug"};
+                                                            "rg_debug", "dp_debug", "rg_occupancy"};
 
 int tipk_option(int id) { return (id >= 0 && id < TIPK_OPT_COUNT) ? g_options[id] : 0; }
 

@@ -29,7 +29,8 @@ enum {
     TIPK_OPT_GEMM_STREAM_KK = 2,      // lane-per-row streaming body for d att
     TIPK_OPT_RG_DEBUG = 3,            // debug builds only
     TIPK_OPT_DP_DEBUG = 4,            // debug builds only
-    TIPK_OPT_COUNT = 5
+    TIPK_OPT_RG_OCCUPANCY = 5,        // tipk_rel_gather: workgroups per CU to aim for (0 = default, 1, 2)
+    TIPK_OPT_COUNT = 6
 };
 int tipk_option(int id);
 #ifdef TIPK_DEBUG

@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int RG_CHUNK = 16384;        // edge ids staged per pass (uint16: 32 KB)
+constexpr int RG_CHUNK_MAX = 16384;    // edge ids staged per pass (uint16: 32 KB); 8192 when that lets two workgroups share a CU
 constexpr int RG_META = 64;            // unit descriptors staged per batch (LDS: 2 KB)
 
 struct RgArgs {
@@ -38,6 +38,7 @@ struct RgArgs {
     const uint16_t* idx; const int32_t* runs; const uint16_t* node_at;
     float* out; int64_t ld_out;
     const float* row_scale;            // BWD: g' = row_scale[node] * table[node] applied while staging (nullable)
+    int chunk;                         // ids staged per pass (8192 or 16384)
     int dbg;
 };
 
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     float* accl = tab + (int64_t)(n_nodes + 1) * ldt;                                  // FWD: [n_nodes][dc]
     int32_t* run_l = reinterpret_cast<int32_t*>(accl + (BWD ? 0 : (int64_t)n_nodes * dc));     // [n_nodes][2]
     uint16_t* node_l = reinterpret_cast<uint16_t*>(run_l + ((2 * n_nodes + 3) & ~3));  // [n_nodes] (+pad)
-    uint16_t* idx_l = node_l + ((n_nodes + 7) & ~7);                                   // [RG_CHUNK], 16-B aligned
+    const int RG_CHUNK = a.chunk;
+    uint16_t* idx_l = node_l + ((n_nodes + 7) & ~7);                                   // [chunk], 16-B aligned
     // unit descriptors of this workgroup, staged once: reading them from global memory per unit cost
     // four dependent round trips (unit id -> offsets -> ...) that nothing could hide (one workgroup per CU)
     int32_t* meta_l = reinterpret_cast<int32_t*>(idx_l + RG_CHUNK);                    // [RG_META][8]
@@ -171,12 +173,12 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 const int last = n8 > 0 ? n8 - 1 : 0;
                 const uint4 j0 = isrc[t < n8 ? t : last];
                 const uint4 j1 = isrc[1024 + t < n8 ? 1024 + t : last];
-                // unconditional stores (2 x 1024 uint4 = the whole buffer; entries past n8 are never
-                // read): a store under `if (t < n8)` leaves the load pending on the not-taken path and
-                // the compiler then puts a vmcnt(0) wait into the position loop below, which would also
-                // wait for the next unit's prefetch -- i.e. serialise staging and compute
+                // unconditional stores (the whole buffer; entries past n8 are never read): a store under
+                // `if (t < n8)` leaves the load pending on the not-taken path and the compiler then puts
+                // a vmcnt(0) wait into the position loop below, which would also wait for the next
+                // unit's prefetch -- i.e. serialise staging and compute
                 idst[t] = j0;
-                idst[1024 + t] = j1;
+                if (RG_CHUNK > 8192) idst[1024 + t] = j1;                    // wave-uniform
                 __syncthreads();
             }
             if (TIPK_DBG(a.dbg & 1)) continue;
@@ -265,28 +267,42 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     }
 }
 
-inline int64_t rel_gather_lds(int64_t n_nodes, int dc, bool bwd) {
+inline int64_t rel_gather_lds(int64_t n_nodes, int dc, bool bwd, int chunk) {
     return (n_nodes + 1) * (dc + 4) * 4 + (bwd ? 0 : n_nodes * dc * 4) + ((2 * n_nodes + 3) & ~3LL) * 4 +
-           ((n_nodes + 7) & ~7LL) * 2 + RG_CHUNK * 2 + RG_META * 8 * 4;
+           ((n_nodes + 7) & ~7LL) * 2 + (int64_t)chunk * 2 + RG_META * 8 * 4;
 }
 
 constexpr int64_t RG_LDS_LIMIT = 158 * 1024;
 
-// column blocks needed so that one block's table (+ accumulators) fits in LDS; 0 = impossible
-inline int rel_gather_split(int64_t n_nodes, int d, bool bwd) {
-    if (n_nodes <= 0 || n_nodes > 1024 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
-    for (int split = 1; d / split >= 4; split *= 2) {
-        const int dc = d / split;
-        if (dc > 64) continue;                          // L = dc/4 <= 16 lanes per slot
-        if (n_nodes * (dc / 4) > 8192) continue;       // table rows are prefetched in 8 float4 per thread
-        if (rel_gather_lds(n_nodes, dc, bwd) <= RG_LDS_LIMIT) return split;
-    }
-    return 0;
+// The launch shape: `split` column blocks (grid.y), `occ` workgroups per CU the LDS footprint
+// admits (1 or 2), `chunk` ids staged per pass.  The kernel is a chain of dependent LDS round trips at
+// 4 waves per SIMD (PMC: half of the wave cycles wait, profiles/r02a_lds.json); cutting the columns
+// finer lets TWO 1024-thread workgroups share a CU (8 waves per SIMD; <= 64 VGPRs) at the price of
+// walking the run tables once more per extra column block -- `want_occ` (option "rg_occupancy",
+// default measured best) picks.  split = 0: shape not supported.
+struct RgShape { int split, occ, chunk; };
+inline RgShape rel_gather_shape(int64_t n_nodes, int d, bool bwd, int want_occ) {
+    RgShape none = {0, 0, 0};
+    if (n_nodes <= 0 || n_nodes > 1024 || d < 4 || d > 256 || (d & (d - 1)) != 0) return none;
+    for (int occ = want_occ >= 2 ? 2 : 1; occ >= 1; --occ)
+        for (int split = 1; d / split >= 4; split *= 2) {
+            const int dc = d / split;
+            if (dc > 64) continue;                          // L = dc/4 <= 16 lanes per slot
+            if (n_nodes * (dc / 4) > 8192) continue;       // table rows are prefetched in 8 float4 per thread
+            if (occ == 2 && dc < 8) continue;               // 4-column blocks: the run tables dominate
+            for (int chunk = RG_CHUNK_MAX; chunk >= 8192; chunk /= 2)
+                if (rel_gather_lds(n_nodes, dc, bwd, chunk) * occ <= RG_LDS_LIMIT + (occ - 1) * 2048) {
+                    RgShape s = {split, occ, chunk};
+                    return s;
+                }
+        }
+    return none;
 }
+inline int rg_want_occ() { const int o = tipk_option(TIPK_OPT_RG_OCCUPANCY); return o == 0 ? 1 : o; }
 
 template <int L, bool BWD, int TU>
 int launch_rg3(const RgArgs& a, int n_wg, int split, hipStream_t st) {
-    const size_t lds = (size_t)rel_gather_lds(a.n_nodes, a.dc, BWD);
+    const size_t lds = (size_t)rel_gather_lds(a.n_nodes, a.dc, BWD, a.chunk);
     auto kern = rel_gather_kernel<L, BWD, TU>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return tipk_hip_status(e);
@@ -306,7 +322,11 @@ int launch_rg(bool bwd, const RgArgs& a, int n_wg, int split, hipStream_t st) {
 }  // namespace
 
 extern "C" int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward) {
-    return rel_gather_split(n_nodes, d, backward != 0);
+    return rel_gather_shape(n_nodes, d, backward != 0, rg_want_occ()).split;
+}
+
+extern "C" int tipk_rel_gather_occupancy(int64_t n_nodes, int d, int backward) {
+    return rel_gather_shape(n_nodes, d, backward != 0, rg_want_occ()).occ;
 }
 
 extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
@@ -316,7 +336,8 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     if (n_wg <= 0 || n_wg > 65535 || !table || !wg_unit_ptr || !unit_meta || !idx || !runs || !node_at || !out ||
         (reinterpret_cast<uintptr_t>(idx) & 15))
         return TIPK_EINVAL;
-    const int split = rel_gather_split(n_nodes, d, backward != 0);
+    const RgShape shape = rel_gather_shape(n_nodes, d, backward != 0, rg_want_occ());
+    const int split = shape.split;
     if (split == 0) return TIPK_EUNSUPPORTED;
     if (ld_table % 4 != 0 || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(table) & 15) ||
         (reinterpret_cast<uintptr_t>(out) & 15))
@@ -326,6 +347,7 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     a.wg_unit_ptr = wg_unit_ptr; a.unit_meta = unit_meta;
     a.idx = idx; a.runs = runs; a.node_at = node_at; a.out = out; a.ld_out = ld_out;
     a.row_scale = backward ? row_scale : nullptr;
+    a.chunk = shape.chunk;
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_RG_DEBUG));
     hipStream_t st = (hipStream_t)stream;
     switch (a.dc / 4) {

@@ -302,11 +302,13 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from
     rl_fwd = rl_bwd = None
     if n_nodes <= 1024 and n_rel > 0:
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
-        n_wg = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
-        split = ops.rel_gather_split(n_nodes, d_out, False) if (d_out and src.is_cuda) else 1
-        # the forward launch is (workgroups x column blocks): keep it at one workgroup per CU
-        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, max(1, n_wg // max(1, split)))
-        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, n_wg, backward=True)
+        n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
+        on_dev = bool(d_out and src.is_cuda)
+        # launch = (workgroups x column blocks), sized for 1 or 2 workgroups per CU (tipk_rel_gather_occupancy)
+        wg_f = (ops.rel_gather_wgs(n_nodes, d_out, False, n_cu) if on_dev else 0) or n_cu
+        wg_b = (ops.rel_gather_wgs(n_nodes, d_out, True, n_cu) if on_dev else 0) or n_cu
+        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f)
+        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True)
     # the generic plans are built on first use: with the relation-local kernels they are never needed
     return ops.AggGraph(lambda: build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
@@ -541,6 +543,14 @@ class TIP(nn.Module):
              data.dd_test_idx, data.dd_test_et, data.dd_test_range) = process_edges(data.dd_edge_index, p=sp_rate)
         self._test_neg_host = None
         return data
+
+    def __getstate__(self):
+        """`torch.save(model, ...)` (tip.py:36): the embeddings of the last forward are saved as data,
+        not with their autograd history."""
+        st = self.__dict__.copy()
+        if torch.is_tensor(st.get('embeddings')):
+            st['embeddings'] = st['embeddings'].detach()
+        return st
 
     def __encode(self):
         d = self.data

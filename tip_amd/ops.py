@@ -153,6 +153,16 @@ def rel_gather_split(n_nodes, d, backward):
     return int(lib().tipk_rel_gather_supported(n_nodes, d, int(backward)))
 
 
+def rel_gather_wgs(n_nodes, d, backward, n_cu):
+    """workgroups per column block the relation-local plan of this shape should be built for:
+    occupancy (1 or 2 workgroups per CU) * CUs / column blocks."""
+    split = rel_gather_split(n_nodes, d, backward)
+    if split == 0:
+        return 0
+    occ = int(lib().tipk_rel_gather_occupancy(n_nodes, d, int(backward)))
+    return max(1, occ * n_cu // split)
+
+
 def rel_gather_usable(rp, n_nodes, d, backward):
     return rp is not None and rel_gather_split(n_nodes, d, backward) > 0
 

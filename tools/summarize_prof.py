@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output (tools/profile_gpu.sh) into the small summaries kept under profiles/.
 
-  profiles/<tag>_kernel_stats.csv   per-kernel calls / total / average / min / max (ns), the
-                                    rocprofv3 --kernel-trace --stats table for libtipk kernels and the
-                                    largest torch kernels, names shortened
-  profiles/<tag>_pmc_traffic.json   per kernel: average FETCH_SIZE / WRITE_SIZE per launch and the
-                                    HBM bytes derived as the MI355X guide prescribes
-                                    (bytes = KB * 1024; gfx950 reads: FETCH_SIZE doubled)
+  profiles/<tag>_kernel_stats.csv    per-kernel calls / total / average / min / max (ns): the rocprofv3
+                                     --kernel-trace --stats table, names shortened
+  profiles/<tag>_kernel_by_grid.csv  the same trace split by FULL grid XxYxZ (one line per launch shape)
+  profiles/<tag>_pmc_traffic.json    per (kernel, grid XxYxZ): average FETCH_SIZE / WRITE_SIZE per launch
+                                     and the HBM bytes derived as the MI355X guide prescribes
+                                     (bytes = KB * 1024; gfx950 reads: FETCH_SIZE doubled)
+  profiles/<tag>_lds.json            per (kernel, grid): SQ / LDS counters of the relation-local kernels
+                                     (tools/pmc_relgather.sh passes, if present under <src>/pmc_sq*)
+
+PMC rows carry only the flattened grid size; the x*y*z shape is joined in from the kernel trace of the
+same pass by Dispatch_Id, so launches that differ only in their grid shape (d=32 forward: 131072x2,
+d=16 forward: 262144x1) stay separate.
 """
 import csv
 import glob
@@ -18,6 +24,7 @@ from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 os.makedirs('profiles', exist_ok=True)
+csv.field_size_limit(1 << 30)
 
 
 def short(name):
@@ -30,8 +37,12 @@ def short(name):
 
 
 def find(pattern):
-    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
     return hits[0] if hits else None
+
+
+def grid_of(row):
+    return '%sx%sx%s' % (row.get('Grid_Size_X', '?'), row.get('Grid_Size_Y', '?'), row.get('Grid_Size_Z', '?'))
 
 
 stats = find('trace/**/*kernel_stats.csv')
@@ -44,44 +55,74 @@ if stats:
             f.write('"%s",%s,%s,%.0f,%s,%s,%s\n' % (short(r['Name']), r['Calls'], r['TotalDurationNs'],
                                                   float(r['AverageNs']), r['Percentage'], r['MinNs'], r['MaxNs']))
 
-# per-dispatch trace: split the gather_sum launches by grid size so that dd.fwd / dd.bwd / pp are separate
 trace = find('trace/**/*kernel_trace.csv')
 if trace:
     agg = defaultdict(list)
     for r in csv.DictReader(open(trace)):
         n = short(r['Kernel_Name'])
-        if 'gather_sum_kernel' in n or 'gemm_f32' in n or 'rel_gather' in n:
-            key = '%s grid=%sx%sx%s' % (n, r.get('Grid_Size_X', '?'), r.get('Grid_Size_Y', '?'), r.get('Grid_Size_Z', '?'))
-            agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        if n.startswith('at::') or n.startswith('rocprim') or 'elementwise' in n:
+            continue                                                   # torch glue of the setup phase
+        agg['%s grid=%s' % (n, grid_of(r))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     with open('profiles/%s_kernel_by_grid.csv' % tag, 'w') as f:
-        f.write('# libtipk launches of the same command, split by grid size (one line per distinct launch shape)\n')
+        f.write('# libtipk launches of the same command, split by full grid XxYxZ (one line per distinct launch shape)\n')
         f.write('kernel_and_grid,calls,avg_ns,min_ns,max_ns\n')
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             f.write('"%s",%d,%.0f,%d,%d\n' % (k, len(v), sum(v) / len(v), min(v), max(v)))
 
-pmc = {}
-for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+
+def counters_by_launch(sub):
+    """{(kernel, grid): {counter: [values]}} of one --pmc pass directory (joined with its kernel trace)."""
     fn = find(sub + '/**/*counter_collection.csv')
     if not fn:
-        continue
-    per = defaultdict(list)
+        return {}
+    tr = find(sub + '/**/*kernel_trace.csv')
+    shape = {}
+    if tr:
+        for r in csv.DictReader(open(tr)):
+            shape[r['Dispatch_Id']] = grid_of(r)
+    per = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(fn)):
-        if r.get('Counter_Name') != counter:
-            continue
         n = short(r['Kernel_Name'])
-        if 'gather_sum_kernel' in n or 'gemm_f32' in n or 'finalize' in n or 'rel_gather' in n:
-            n = '%s grid=%s' % (n, r.get('Grid_Size', r.get('Grid_Size_X', '?')))
-        per[n].append(float(r['Counter_Value']))
-    for n, v in per.items():
-        pmc.setdefault(n, {})[counter + '_KB_avg'] = sum(v) / len(v)
-        pmc[n]['launches_' + counter] = len(v)
+        g = shape.get(r['Dispatch_Id'], '%sx?x?' % r.get('Grid_Size', '?'))
+        per['%s grid=%s' % (n, g)][r['Counter_Name']].append(float(r['Counter_Value']))
+    return per
+
+
+pmc = {}
+for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    for key, cs in counters_by_launch(sub).items():
+        v = cs.get(counter)
+        if v:
+            pmc.setdefault(key, {})[counter + '_KB_avg'] = sum(v) / len(v)
+            pmc[key]['launches_' + counter] = len(v)
 for n, d in pmc.items():
     f_kb, w_kb = d.get('FETCH_SIZE_KB_avg', 0.0), d.get('WRITE_SIZE_KB_avg', 0.0)
     d['hbm_bytes_per_launch'] = (2.0 * f_kb + w_kb) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 of wide reads
     d['hbm_bytes_per_launch_uncorrected'] = (f_kb + w_kb) * 1024.0
 if pmc:
-    top = dict(sorted(pmc.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:40])
+    keep = {k: v for k, v in pmc.items() if not (k.startswith('at::') or k.startswith('rocprim'))}
+    top = dict(sorted(keep.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:48])
     json.dump({'note': 'FETCH_SIZE/WRITE_SIZE in KB per launch (separate rocprofv3 --pmc passes of bench.py --launch eager); '
-                       'hbm_bytes = (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md HBM section', 'kernels': top},
+                       'hbm_bytes = (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md HBM section; keys = kernel + full grid XxYxZ '
+                       '(joined from the kernel trace of the same pass by Dispatch_Id)', 'kernels': top},
               open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
+
+lds = {}
+for sub in sorted(glob.glob(os.path.join(src, 'pmc_sq*'))):
+    for key, cs in counters_by_launch(os.path.basename(sub)).items():
+        if 'rel_gather' not in key and 'gather_sum' not in key and 'dy_products' not in key and 'rgcn_' not in key:
+            continue
+        for c, v in cs.items():
+            lds.setdefault(key, {})[c] = sum(v) / len(v)
+if lds:
+    for key, d in lds.items():
+        if d.get('SQ_LDS_IDX_ACTIVE'):
+            d['lds_bank_conflict_share'] = d.get('SQ_LDS_BANK_CONFLICT', 0.0) / d['SQ_LDS_IDX_ACTIVE']
+        if d.get('SQ_WAVE_CYCLES'):
+            d['wait_any_share'] = d.get('SQ_WAIT_ANY', 0.0) / d['SQ_WAVE_CYCLES']
+            d['wait_inst_lds_share'] = d.get('SQ_WAIT_INST_LDS', 0.0) / d['SQ_WAVE_CYCLES']
+    json.dump({'note': 'rocprofv3 --pmc SQ/LDS counters per launch (averages; each counter group collected in its own pass of '
+                       'tools/pmc_relgather.py); SQ_LDS_BANK_CONFLICT = extra LDS cycles, SQ_LDS_IDX_ACTIVE = all LDS-array '
+                       'cycles, SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles', 'kernels': lds},
+              open('profiles/%s_lds.json' % tag, 'w'), indent=1)
 print('summaries written for', tag)
