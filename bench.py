@@ -321,19 +321,27 @@ def main():
     dd, dims, wl_name = make_workload(args)
     E = int(dd['dd_train_idx'].shape[1])
     R = dd['n_dd_et']
-    torch.manual_seed(1111)
-    enc = FMEncoder(dev, dd['n_drug_feat'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], mod=args.mod, **dims).to(dev)
     sharded = world > 1 or bool(os.environ.get('TIPK_FORCE_SHARD'))       # (the env switch exercises the
-    if sharded:                                                            # collective path on one rank)
-        from tip_amd.dist import shard_encoder
+    shard = None                                                           # collective path on one rank)
+    if sharded:
+        from tip_amd.dist import make_shard, shard_data_dict, attach_shard
         if not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', str(free_port()))
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-        for prm in enc.parameters():                           # identical replicas
-            dist.broadcast(prm.data, 0)
-        shard_encoder(enc, dd['dd_train_range'], rank, world)
-    d = Data.from_dict({k: v for k, v in dd.items() if k != 'dd_edge_index'}).to(dev)
+        shard = make_shard(dd['dd_train_range'], rank, world)
+        dd_rank = shard_data_dict(dd, shard)                   # this rank's relations' edges only
+    else:
+        dd_rank = dd
+    torch.manual_seed(1111)
+    enc = FMEncoder(dev, dd['n_drug_feat'], dd_rank['n_dd_et'], dd['n_prot'], dd['n_prot'], dd['n_drug'],
+                    mod=args.mod, **dims).to(dev)
+    if sharded:
+        for name, prm in enc.named_parameters():               # identical replicas (att rows are shard-local)
+            if not name.endswith('.att'):
+                dist.broadcast(prm.data, 0)
+        attach_shard(enc, shard)
+    d = Data.from_dict({k: v for k, v in dd_rank.items() if k != 'dd_edge_index'}).to(dev)
     g_up = torch.randn(dd['n_drug'], dims['n_hid2'], generator=torch.Generator().manual_seed(0)).to(dev)
 
     def step():
@@ -430,7 +438,7 @@ def main():
         if agg_us:
             dom = max(agg_us, key=agg_us.get)
             label, key, grid, d_row, bound, _ = [l for l in launches if l[0] == dom][0]
-            n_edges = E // world if world > 1 else E               # rank 0's share (balanced by edges)
+            n_edges = int(dd_rank['dd_train_idx'].shape[1])        # rank 0's share when sharded
             # one id + one d-wide fp32 row per edge and pass (ids are 4 B in the generic
             # plans, 2 B in the relation-local ones; the figure keeps 4 B so runs stay comparable)
             alg_bytes = n_edges * (4 + 4 * d_row)

@@ -7,6 +7,7 @@ seeded graphs plus explicit weights, and records inputs, outputs and every param
 (autograd of the reference).  The fixtures are data only; no reference source is stored.
 
     python oracle/make_golden.py            # rewrites tests/golden/
+    python oracle/make_golden.py drug_features check_loader     # only the named fixture(s)
 """
 import os
 import pickle
@@ -268,6 +269,48 @@ def golden_biosnap_slice():
            'grad.pp_encoder.conv1.lin.weight.rowsum': gw1.sum(1)})
 
 
+def golden_drug_features(seed):
+    """the reference's FMEncoder fed the REAL sparse drug features
+    ([I | mono side effects], 645 x 10 829, data/utils.py:117-132) and a non-unit d_norm, cat and add.
+    Also pins tip_amd.data.mono_drug_features against the reference's own loader."""
+    from tip_amd.data import mono_drug_features
+    d_feat, d_norm = mono_drug_features()
+    if not ONLY or 'check_loader' in ONLY:
+        cwd = os.getcwd()
+        os.chdir('/root/reference')
+        try:
+            from data.utils import load_data_torch
+            et = pickle.load(open('./data/decagon_et.pkl', 'rb'))
+            ref_feat = load_data_torch('./data/', et, mono=True)['d_feat'].coalesce()
+        finally:
+            os.chdir(cwd)
+        assert ref_feat.shape == d_feat.shape and torch.equal(ref_feat.indices(), d_feat.indices()) \
+            and torch.equal(ref_feat.values(), d_feat.values()), 'mono_drug_features != load_data_torch(mono=True)'
+        print('d_feat identical to the reference loader: %s, %d entries' % (tuple(d_feat.shape), d_feat._nnz()))
+    n_drug, n_feat = d_feat.shape
+    g = small_graph(seed, n_drug=n_drug, n_prot=211, sizes=(400, 1, 60, 900, 30, 170, 2500))
+    for mod in ('cat', 'add'):
+        torch.manual_seed(seed)
+        kw = dict(prot_drug_dim=8, num_base=5, n_embed=12 if mod == 'cat' else 8, n_hid1=8, n_hid2=4)
+        enc = ref.FMEncoder('cpu', n_feat, g['n_rel'], g['n_prot'], g['n_prot'], n_drug, mod=mod, **kw)
+        randomize_(enc, seed)
+        up = torch.randn(n_drug, 4)
+        z = enc(d_feat, g['dd_idx'], g['dd_et'], g['dd_range'], d_norm, ref_sparse_id(g['n_prot']), g['pp_idx'],
+                g['dp_idx'], None)
+        (z * up).sum().backward()
+        gg = {k: v for k, v in g.items() if k != 'd_norm'}
+        npz('encoder_mono_%s' % mod, z=z, upstream=up, mod=mod, n_feat=n_feat, **gg, **params_of(enc), **grads_of(enc),
+            **{'cfg.' + k: v for k, v in kw.items()})
+
+
+ONLY = [a for a in sys.argv[1:]]
+
+if __name__ == '__main__' and ONLY:
+    os.makedirs(OUT, exist_ok=True)
+    if 'drug_features' in ONLY:
+        golden_drug_features(23)
+    sys.exit(0)
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     golden_rgcn(11, 10, 6, 5, True, 'rgcn_sym')
@@ -280,3 +323,4 @@ if __name__ == '__main__':
     golden_encoder(17, 'add', 'encoder_add_small')
     golden_tip(18)
     golden_biosnap_slice()
+    golden_drug_features(23)

@@ -199,18 +199,31 @@ def rgcn_fwd_reference_shaped(x, edge_index, range_list, basis, att, root):
 # ---------------------------------------------------------------------------------------------
 # A3 + composition: FMEncoder.forward  (src/layers.py:520-550)
 # ---------------------------------------------------------------------------------------------
+def _nonidentity_features(data, embed):
+    f = data.get('d_feat') if isinstance(data, dict) else None
+    if f is None or not f.is_sparse or f.shape[0] == f.shape[1]:
+        return None
+    return f.to(embed.dtype)
+
+
 def fm_encoder_fwd(p, data, mod='cat'):
     """p: dict of parameters under the reference's state_dict names (without 'encoder.'):
     embed, pp_encoder.conv{1,2}.lin.weight/.bias, hgcn.weight, rgcn{1,2}.{basis,att,root}.
     data: dict with dd_train_idx, dd_train_range, d_norm, pp_train_indices, dp_edge_index,
-    n_drug, n_prot (identity drug/protein features).  Returns (z, saved)."""
+    n_drug, n_prot; drug features are the identity unless data['d_feat'] is a NON-identity sparse
+    matrix (the mono side-effect features of data/utils.py:117-132), protein features the identity.
+    Returns (z, saved)."""
     n_prot, n_drug = data['n_prot'], data['n_drug']
     h2, s_pp = pp_encoder_fwd(p['pp_encoder.conv1.lin.weight'], p['pp_encoder.conv1.bias'],
                               p['pp_encoder.conv2.lin.weight'], p['pp_encoder.conv2.bias'],
                               data['pp_train_indices'], n_prot)
     x_all = torch.cat([h2, torch.zeros((n_drug, h2.shape[1]), dtype=h2.dtype)])          # :526
     pd, s_h = hier_conv_fwd(x_all, data['dp_edge_index'], p['hgcn.weight'], n_prot)       # :528
-    xd = p['embed'] / data['d_norm'].to(p['embed'].dtype).view(-1, 1)                     # :532-534
+    emb = p['embed']
+    feat = _nonidentity_features(data, emb)
+    if feat is not None:
+        emb = torch.sparse.mm(feat, emb)                                                  # :532 torch.matmul(x_drug, embed)
+    xd = emb / data['d_norm'].to(emb.dtype).view(-1, 1)                                   # :534
     x0 = torch.cat([xd, pd], dim=1) if mod == 'cat' else xd + pd                          # :536-539
     a1, s_r1 = rgcn_fwd(x0, data['dd_train_idx'], data['dd_train_range'],
                         p['rgcn1.basis'], p['rgcn1.att'], p['rgcn1.root'])                # :545
@@ -235,6 +248,9 @@ def fm_encoder_bwd(g_z, p, data, saved, mod='cat'):
     else:
         g_xd, g_pd = g_x0, g_x0
     g['embed'] = g_xd / data['d_norm'].to(g_xd.dtype).view(-1, 1)
+    feat = _nonidentity_features(data, p['embed'])
+    if feat is not None:
+        g['embed'] = torch.sparse.mm(feat.t(), g['embed'].contiguous())
     g_x_all, g['hgcn.weight'] = hier_conv_bwd(g_pd, saved['x_all_rows'], data['dp_edge_index'],
                                               p['hgcn.weight'], data['n_prot'], saved['h'])
     g_h2 = g_x_all[:data['n_prot']]

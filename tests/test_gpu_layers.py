@@ -133,6 +133,29 @@ def test_fm_encoder_golden(name):
         close(p.grad, g['grad.' + k])
 
 
+@pytest.mark.parametrize('mod', ['cat', 'add'])
+def test_fm_encoder_real_drug_features_golden(mod):
+    """the CSR SpMM path of `x_drug @ embed` (`_FeatureInput` -> tipk_gather_sum over the
+    sparse feature matrix, forward and transposed) with the REAL drug features -- [I | mono side effects],
+    645 x 10 829, built as data/utils.py:117-132 builds them -- and a non-unit d_norm, against the
+    reference's FMEncoder on the same inputs."""
+    from tip_amd.data import mono_drug_features
+    from tip_amd.layers import FMEncoder
+    from tip_amd.utils import sparse_id
+    g = load_golden('encoder_mono_' + mod)
+    d_feat, d_norm = mono_drug_features()
+    cfg = {k[4:]: int(v) for k, v in g.items() if isinstance(k, str) and k.startswith('cfg.')}
+    enc = FMEncoder(DEV, int(g['n_feat']), g['n_rel'], g['n_prot'], g['n_prot'], g['n_drug'], mod=mod, **cfg)
+    enc = load_params(enc, g)
+    z = enc(d_feat.to(DEV), g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV), d_norm.to(DEV),
+            sparse_id(g['n_prot']).to(DEV), g['pp_idx'].to(DEV), g['dp_idx'].to(DEV), None)
+    close(z, g['z'])
+    (z * g['upstream'].to(DEV)).sum().backward()
+    for k, p in enc.named_parameters():
+        close(p.grad, g['grad.' + k])
+    assert enc._drug_feat._cache.value is not None                     # the sparse-feature plans were used
+
+
 def test_tip_end_to_end_small():
     """TIP(...) construction, forward() loss with the recorded negatives, backward, test()."""
     from tip_amd.layers import TIP, Setting
@@ -313,47 +336,73 @@ def test_full_biosnap_size_independent_properties(biosnap_full):
 
 # ------------------------------------------------------------------ multi-rank (2 processes, one GPU, gloo)
 def _shard_worker(rank, world, port, ret):
+    """One rank of the relation-sharded TRAINING STEP: local edges, local att /
+    decoder.weight rows, sharded sampler + objective, flat-buffer collectives -- against the unsharded
+    model in the same process: loss, every gradient (local rows vs the matching rows), parameters after
+    an Adam step, embeddings and the gathered test() record."""
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from tip_amd.data import build_data_dict, Data
-        from tip_amd.dist import shard_encoder
-        from tip_amd.layers import FMEncoder
+        from tip_amd.data import build_data_dict
+        from tip_amd.dist import make_shard, shard_state_dict, gather_state_dict, shard_edges, LOCAL_ROWS
+        from tip_amd.layers import TIP, Setting
+        from tip_amd.neg_sampling import typed_negative_sampling
         dd = build_data_dict(max_relations=12)
         R = dd['n_dd_et']
-        p = O.init_params(dd['n_drug'], dd['n_prot'], R, seed=3)
-        d = Data.from_dict({k: v for k, v in dd.items() if k != 'dd_edge_index'}).to(DEV)
-        torch.manual_seed(0)
-        up = torch.randn(dd['n_drug'], 16).to(DEV)
-        outs = []
-        for sharded in (False, True):
-            enc = FMEncoder(DEV, dd['n_drug'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], prot_drug_dim=16,
-                            num_base=32, n_embed=48, n_hid1=32, n_hid2=16, mod='cat')
-            enc = load_params(enc, p)
-            if sharded:
-                shard = shard_encoder(enc, dd['dd_train_range'], rank, world)
-                assert 0 < shard.rel_ids.numel() < R
-            z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat,
-                    d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
-            (z * up).sum().backward()
-            outs.append((z.detach().cpu(), {k: v.grad.cpu() for k, v in enc.named_parameters()}))
-        (z0, g0), (z1, g1) = outs
-        ok = torch.allclose(z0, z1, rtol=1e-4, atol=1e-5)
-        for k in g0:
-            ok = ok and torch.allclose(g0[k], g1[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(g0[k].abs().max())))
+        st = Setting()
+        torch.manual_seed(3)
+        ref = TIP(st, torch.device(DEV), data=dd)                          # unsharded
+        full_sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+        shard = make_shard(dd['dd_train_range'], rank, world)
+        assert 0 < shard.rel_ids.numel() < R
+        model = TIP(st, torch.device(DEV), data=dd, shard=shard)           # this rank's relations only
+        assert model.data.dd_train_idx.shape[1] == shard.n_train_local < shard.n_train_total
+        assert model.decoder.weight.shape[0] == model.encoder.rgcn1.att.shape[0] == shard.rel_ids.numel()
+        model.load_state_dict(shard_state_dict(full_sd, shard))
+        model.test_neg_index, _ = shard_edges(ref.test_neg_index, dd['dd_test_range'], shard.rel_ids)
+        neg = typed_negative_sampling(ref.data.dd_train_idx, ref.data.n_drug, ref.data.dd_train_range, seed=5)
+        neg_l, _ = shard_edges(neg, dd['dd_train_range'], shard.rel_ids)
+        opt_r = torch.optim.Adam(ref.parameters(), lr=0.01)
+        opt_s = torch.optim.Adam(model.parameters(), lr=0.01)
+        ok = True
+        for step in range(2):
+            opt_r.zero_grad(); opt_s.zero_grad()
+            loss_r = ref(neg_index=neg)
+            loss_r.backward()
+            loss_s = model(neg_index=neg_l.contiguous())
+            loss_s.backward()
+            ok = ok and abs(float(loss_r) - float(loss_s)) <= 1e-5 * abs(float(loss_r))
+            ok = ok and torch.allclose(model.embeddings, ref.embeddings, rtol=1e-4, atol=1e-5)
+            gr = dict(ref.named_parameters())
+            for k, p in model.named_parameters():
+                want = gr[k].grad
+                if k in LOCAL_ROWS:
+                    want = want[shard.rel_ids_on(want.device)]
+                good = torch.allclose(p.grad, want, rtol=2e-3, atol=2e-5 * max(1e-6, float(want.abs().max())))
+                if not good:
+                    print('rank', rank, 'step', step, 'grad mismatch', k, float((p.grad - want).abs().max()), flush=True)
+                ok = ok and good
+            opt_r.step(); opt_s.step()
+        # after two Adam steps: gathered full state == the unsharded model's state
+        got = gather_state_dict(model, shard)
+        for k, v in ref.state_dict().items():
+            good = torch.allclose(got[k], v.cpu(), rtol=0, atol=2e-3)      # 20 % of one Adam step of 0.01
+            if not good:
+                print('rank', rank, 'state mismatch', k, float((got[k] - v.cpu()).abs().max()), flush=True)
+            ok = ok and good
+        rec_s = model.test(print_output=False)
+        rec_r = ref.test(print_output=False)
+        ok = ok and rec_s.shape == (3, R) and bool(np.allclose(rec_s, rec_r, atol=2e-4))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_sharded_encoder_two_ranks():
-    """Relation-sharded encoder (tip_amd/dist.py) == single-rank encoder: z and all gradients.
-    Two processes share cuda:0 and exchange partial sums over gloo (RCCL needs one GPU per rank;
-    the collective semantics are the backend's, the sharding logic is what is under test)."""
+def test_sharded_training_step_two_ranks():
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()

@@ -114,6 +114,25 @@ def test_fm_encoder(name):
         close(v, g['grad.' + k])
 
 
+@pytest.mark.parametrize('mod', ['cat', 'add'])
+def test_fm_encoder_real_drug_features(mod):
+    """the oracle with the sparse [I | mono] drug features and the non-unit d_norm
+    against the reference's FMEncoder on the same inputs (fixture from oracle/make_golden.py)."""
+    from tip_amd.data import mono_drug_features
+    g = load_golden('encoder_mono_' + mod)
+    d_feat, d_norm = mono_drug_features()
+    assert d_feat.shape == (g['n_drug'], int(g['n_feat'])) and float(d_norm.max()) > 100
+    data = dict(d_feat=d_feat, d_norm=d_norm, dd_train_idx=g['dd_idx'], dd_train_range=g['dd_range'],
+                pp_train_indices=g['pp_idx'], dp_edge_index=g['dp_idx'], n_drug=g['n_drug'], n_prot=g['n_prot'])
+    p = {k: v for k, v in g.items() if torch.is_tensor(v) and not k.startswith('grad.') and v.is_floating_point()}
+    z, saved = O.fm_encoder_fwd(p, data, mod)
+    close(z, g['z'])
+    grads = O.fm_encoder_bwd(g['upstream'], p, data, saved, mod)
+    assert set(grads) == set(p)
+    for k, v in grads.items():
+        close(v, g['grad.' + k])
+
+
 def test_biosnap_slice_encoder():
     from tip_amd.data import build_data_dict
     g = load_golden('biosnap_slice8')

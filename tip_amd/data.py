@@ -16,6 +16,29 @@ import torch
 from .utils import process_edges, process_prot_edge, sparse_id, to_bidirection, get_range_list
 
 BIOSNAP_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'biosnap_v1.npz')
+MONO_BLOB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'biosnap_mono_v1.npz')
+
+
+def mono_drug_features(blob_path=MONO_BLOB):
+    """(d_feat, d_norm) with the REAL drug features the reference prepared but never switched on
+    (`prepare.py:21` "TODO: add drug feature"):
+
+    d_feat  sparse fp32 [n_drug, n_drug + n_mono] = [ I | mono side-effect indicators ], built exactly as
+            `data/utils.py:117-132` (mono=True) builds it: identity entries first, then the mono entries
+            with their column offset by n_drug, all values 1;
+    d_norm  fp32 [n_drug] = features per drug (1 + its mono side effects).  The reference defines no
+            working normaliser for this case (`prepare.py:25` sizes `d_norm` by the feature count, which
+            cannot divide the 645 rows at `src/layers.py:534`); dividing by the row sum makes
+            `x_drug @ embed / d_norm` the MEAN of a drug's feature embeddings."""
+    z = np.load(blob_path)
+    n_drug, n_mono = int(z['n_drug']), int(z['n_mono'])
+    pairs = z['mono_pairs'].astype(np.int64)
+    row = np.r_[np.arange(n_drug), pairs[0]]
+    col = np.r_[np.arange(n_drug), pairs[1] + n_drug]
+    d_feat = torch.sparse_coo_tensor(torch.from_numpy(np.stack([row, col])), torch.ones(row.size),
+                                     (n_drug, n_drug + n_mono)).coalesce()
+    d_norm = torch.from_numpy(np.bincount(row, minlength=n_drug).astype(np.float32))
+    return d_feat, d_norm
 
 
 class Data(object):
@@ -56,9 +79,12 @@ def _dp_tables(dp_pairs, n_drug, n_prot):
     return torch.stack([prot, drug + n_prot]), dp_range
 
 
-def build_data_dict(blob_path=BIOSNAP_BLOB, sp_rate=0.9, seed=1111, min_pairs=None, max_relations=None):
+def build_data_dict(blob_path=BIOSNAP_BLOB, sp_rate=0.9, seed=1111, min_pairs=None, max_relations=None,
+                    mono=False):
     """BioSNAP `data_dict` (tensors on CPU).
 
+    mono         False: identity drug features and unit `d_norm`, as `prepare.py:22-25` ships them;
+                 True: the real features of `mono_drug_features` (n_drug_feat = 10 829).
     seed         legacy numpy seed for the Bernoulli split (`np.random.seed(1111)`,
                  `src/layers.py:14`); draw order = `prepare.py:16-17`: all D-D relations, then P-P.
     min_pairs    keep only relations with at least this many undirected pairs (500 -> the 963
@@ -89,6 +115,9 @@ def build_data_dict(blob_path=BIOSNAP_BLOB, sp_rate=0.9, seed=1111, min_pairs=No
     d['n_drug'], d['n_prot'], d['n_dd_et'] = n_drug, n_prot, len(keep)
     d['n_drug_feat'] = n_drug
     d['d_norm'] = torch.ones(n_drug)
+    if mono:
+        d['d_feat'], d['d_norm'] = mono_drug_features()
+        d['n_drug_feat'] = int(d['d_feat'].shape[1])
     d['et_list'] = [int(z['et_list'][r]) for r in keep]
     return d
 

@@ -1,23 +1,34 @@
-"""Relation-sharded multi-GPU execution of the D-D stage (one process per GPU, RCCL over xGMI).
+"""Relation-sharded multi-GPU execution of the TIP training step (one process per GPU, RCCL over xGMI).
 
-The reference is single-GPU (`README.md:58`).  The D-D R-GCN layer is a sum over relations of
-independent partial aggregates of the same N x d output, so it shards by relation id
-(BASELINE.json north_star):
+The reference is single-GPU (`README.md:58`).  A D-D R-GCN layer is a sum over relations of
+independent partial aggregates of the same N x d output, and the DistMult objective is a sum over
+triples that are grouped by relation, so the whole step shards by relation id (BASELINE.json
+north_star):
 
-  * every rank holds all parameters (replicas) and the full edge tensors it is handed through
-    the reference `forward()` signature, but builds gather plans only for ITS relations
-    (greedy edge-count balancing: relation sizes span 450 ... 51 546 edges);
-  * forward: partial `sum_{r in shard} A_r Y_r`  --all-reduce(sum)-->  x 1/deg(global) + X root;
-  * backward: partial dX, d basis and the shard's rows of d att are packed into ONE buffer and
-    all-reduced (one collective per layer and direction; messages are 40 KB - 0.5 MB, i.e.
-    latency-bound on BioSNAP: the synthetic 50 M-edge graph is the scaling case);
-  * the P-P and P->D stages (< 2 % of the work) are computed redundantly on every rank, so their
-    gradients are identical everywhere and need no collective.
+  * relations are dealt to ranks by a greedy longest-processing-time rule on their edge counts
+    (sizes span 450 ... 51 546 edges); a rank holds ONLY its relations' edges (train and test), its
+    rows of `rgcn*.att` and of `decoder.weight` -- `shard_data_dict`, `shard_state_dict`;
+  * `basis`, `root`, `embed` and the P-P / P->D parameters are replicated; the P-P and P->D stages
+    (< 2 % of the work) are computed redundantly on every rank, so their gradients are identical
+    everywhere and need no collective;
+  * collectives per training step (all SUM all-reduce, fp32), each on ONE flat buffer that the
+    producing kernels write into directly (no pack / unpack copies):
+        forward   per R-GCN layer: the partial aggregate  sum_{r in shard} A_r Y_r   [N, d_out]
+                  (division by the GLOBAL in-degree, + X root and the ReLU follow the reduce);
+                  the loss: one scalar (each rank's objective is weighted by its share of the triples);
+        backward  d z [N, n_hid2] of the decoder; per R-GCN layer [partial dX | partial d basis];
+    d att / d decoder.weight rows are shard-local and never travel; `gather_state_dict` assembles a
+    full checkpoint when one is wanted.
 
-`torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests of this logic.
+At BioSNAP size the collectives are pure latency (41 ... 430 KB) next to ~100 us kernels, so
+sub-linear scaling is expected there; the synthetic 50 M-edge graph is the scaling case.
+`torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests of this logic and by
+the 2-ranks-on-one-GPU tests.
 """
 import torch
 import torch.distributed as dist
+
+LOCAL_ROWS = ('encoder.rgcn1.att', 'encoder.rgcn2.att', 'decoder.weight')     # parameters held as shard-local rows
 
 
 def partition_relations(sizes, world):
@@ -35,16 +46,40 @@ def partition_relations(sizes, world):
 
 
 class RelationShard(object):
-    """This rank's share of the relations plus the process group used for the partial sums."""
+    """This rank's share of the relations, the process group of the partial sums, and what the local
+    layers need to know about the WHOLE graph: the in-degree over all relations (the scatter-mean
+    denominator, src/layers.py:123 aggr='mean') and the total number of training triples (the
+    objective's mean)."""
 
-    def __init__(self, rel_ids, rank, world, group=None):
+    def __init__(self, rel_ids, rank, world, group=None, n_relations=None):
         self.rel_ids = torch.as_tensor(rel_ids, dtype=torch.int64)
         self.rank, self.world, self.group = rank, world, group
+        self.n_relations = n_relations            # relations of the whole graph
+        self.in_degree = None                     # int64 [N]: D-D in-degree over ALL relations
+        self.n_train_total = None                 # directed training edges over all ranks
+        self.n_train_local = None
 
     def rel_ids_on(self, device):
         if self.rel_ids.device != device:
             self.rel_ids = self.rel_ids.to(device)
         return self.rel_ids
+
+    def all_reduce(self, flat):
+        """In-place SUM all-reduce of one flat buffer."""
+        if self.world > 1 or dist.is_initialized():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    @property
+    def loss_weight(self):
+        return float(self.n_train_local) / float(max(1, self.n_train_total))
+
+
+def make_shard(range_list, rank, world, group=None):
+    """Partition by the edge counts of `range_list` [R, 2] -> this rank's `RelationShard`."""
+    rg = torch.as_tensor(range_list).to(torch.int64).cpu()
+    parts = partition_relations((rg[:, 1] - rg[:, 0]).tolist(), world)
+    return RelationShard(parts[rank], rank, world, group, n_relations=rg.shape[0])
 
 
 def shard_edges(edge_index, range_list, rel_ids):
@@ -60,24 +95,111 @@ def shard_edges(edge_index, range_list, rel_ids):
     return torch.cat(blocks, dim=1), rel_local
 
 
-def all_reduce_packed(tensors, group=None):
-    """Sum-all-reduce several tensors with ONE collective (flat pack / unpack, in place)."""
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
-        off += n
-    return tensors
-
-
-def shard_encoder(encoder, range_list, rank, world, group=None):
-    """Attach the same relation shard to both R-GCN layers of an `FMEncoder`."""
+def _local_ranges(range_list, rel_ids):
     rg = torch.as_tensor(range_list).to(torch.int64).cpu()
-    parts = partition_relations((rg[:, 1] - rg[:, 0]).tolist(), world)
-    shard = RelationShard(parts[rank], rank, world, group)
+    sizes = (rg[:, 1] - rg[:, 0])[torch.as_tensor(rel_ids, dtype=torch.int64)] if len(rel_ids) else \
+        torch.zeros(0, dtype=torch.int64)
+    end = torch.cumsum(sizes, 0)
+    return torch.stack([end - sizes, end], dim=1)
+
+
+def shard_data_dict(dd, shard):
+    """The `data_dict` of ONE rank: its relations' train and test edges with local
+    relation ids and ranges, `n_dd_et` = local relation count; everything else (features, P-P, P->D)
+    is shared.  Records the global in-degree and triple count on `shard`."""
+    ids = shard.rel_ids.tolist()
+    out = {k: v for k, v in dd.items() if not k.startswith('dd_')}
+    n = dd['n_drug']
+    shard.in_degree = torch.bincount(dd['dd_train_idx'][1].to(torch.int64).cpu(), minlength=n)
+    shard.n_train_total = int(dd['dd_train_idx'].shape[1])
+    for split in ('train', 'test'):
+        idx_k, rg_k = 'dd_%s_idx' % split, 'dd_%s_range' % split
+        if idx_k not in dd:
+            continue
+        ei, rel = shard_edges(dd[idx_k], dd[rg_k], ids)
+        out[idx_k], out['dd_%s_et' % split], out[rg_k] = ei.contiguous(), rel, _local_ranges(dd[rg_k], ids)
+    shard.n_train_local = int(out['dd_train_idx'].shape[1])
+    out['n_dd_et'] = len(ids)
+    out['dd_rel_ids'] = shard.rel_ids.clone()
+    if 'dd_edge_index' in dd:
+        out['dd_edge_index'] = [dd['dd_edge_index'][r] for r in ids]
+    return out
+
+
+def shard_state_dict(full_sd, shard):
+    """Rows of the per-relation parameters that belong to this rank (everything else unchanged)."""
+    ids = shard.rel_ids
+    out = {}
+    for k, v in full_sd.items():
+        out[k] = v.index_select(0, ids.to(v.device)).clone() if k in LOCAL_ROWS or ('encoder.' + k) in LOCAL_ROWS \
+            else v.clone()
+    return out
+
+
+def gather_state_dict(model, shard):
+    """Full (unsharded) state_dict on every rank: the shard-local rows are all-gathered once -- for
+    checkpoints (`torch.save`, tip.py:36); never needed during training."""
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    if shard.world == 1 and not dist.is_initialized():
+        gathered = [(shard.rel_ids, {k: sd[k].cpu() for k in LOCAL_ROWS if k in sd})]
+    else:
+        gathered = [None] * shard.world
+        dist.all_gather_object(gathered, (shard.rel_ids.cpu(), {k: sd[k].cpu() for k in LOCAL_ROWS if k in sd}),
+                               group=shard.group)
+    full = {k: v.cpu().clone() for k, v in sd.items() if k not in LOCAL_ROWS}
+    for k in LOCAL_ROWS:
+        if k not in sd:
+            continue
+        rows = torch.zeros((shard.n_relations,) + tuple(sd[k].shape[1:]), dtype=sd[k].dtype)
+        for ids, part in gathered:
+            rows[ids] = part[k]
+        full[k] = rows
+    return full
+
+
+def attach_shard(encoder, shard):
+    """Make both R-GCN layers of an `FMEncoder` (built for the LOCAL relation count over the local edge
+    tensors of `shard_data_dict`) reduce their partial sums over the shard's group."""
     for layer in (encoder.rgcn1, encoder.rgcn2):
+        assert layer.num_relations == int(shard.rel_ids.numel()), 'build the encoder for the local relation count'
         layer.shard = shard
         layer._cache.key = None                 # plans of an earlier (unsharded) call are stale
     return shard
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """total = sum over ranks of a (scalar or small) tensor; d total / d local = 1 on every rank."""
+
+    @staticmethod
+    def forward(ctx, t, shard):
+        out = t.detach().clone()
+        shard.all_reduce(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _SumGradOverRanks(torch.autograd.Function):
+    """Identity on a tensor that is identical on every rank and consumed by shard-local work: its
+    gradient is the SUM of the ranks' partial gradients (the d z all-reduce of SURVEY 8(e))."""
+
+    @staticmethod
+    def forward(ctx, t, shard):
+        ctx.shard = shard
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.shard.all_reduce(g)
+        return g, None
+
+
+def all_reduce_sum(t, shard):
+    return _AllReduceSum.apply(t, shard)
+
+
+def sum_grad_over_ranks(t, shard):
+    return _SumGradOverRanks.apply(t, shard)

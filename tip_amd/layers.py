@@ -282,25 +282,32 @@ class MyHierarchyConv(nn.Module):
 # ---------------------------------------------------------------------------------------------
 def relation_of_edges(range_list, n_edges, device):
     rg = torch.as_tensor(range_list).to(torch.int64).cpu()
+    if rg.numel() == 0:                                       # a rank without relations (more ranks than relations)
+        if n_edges:
+            raise ValueError('empty range_list for %d edges' % n_edges)
+        return torch.zeros(0, dtype=torch.int64, device=device)
     sizes = rg[:, 1] - rg[:, 0]
     if not (int(sizes.sum()) == n_edges and int(rg[0, 0]) == 0 and bool((rg[1:, 0] == rg[:-1, 1]).all())):
         raise ValueError('range_list must be consecutive blocks covering all %d edges' % n_edges)
     return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
 
 
-def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, degree_from=None, d_out=None):
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
-    scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `degree_from`:
-    destination ids of the FULL edge list when `edge_index` is only one rank's shard."""
+    scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `in_degree`: [N]
+    in-degree of the WHOLE graph when `edge_index` is only one rank's shard (tip_amd/dist.py)."""
     src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     rel = rel.to(torch.int64)
     if rel.numel() and (int(rel.min()) < 0 or int(rel.max()) >= n_rel):
         raise IndexError('edge_type out of range')
     yrow = rel * n_nodes + src
-    all_dst = dst if degree_from is None else degree_from.to(torch.int64)
-    deg = torch.bincount(all_dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
+    if in_degree is None:
+        deg = torch.bincount(dst, minlength=n_nodes).to(torch.float32).clamp_(min=1)
+    else:
+        assert in_degree.numel() == n_nodes
+        deg = in_degree.to(src.device).to(torch.float32).clamp_(min=1)
     rl_fwd = rl_bwd = None
-    if n_nodes <= 1024 and n_rel > 0:
+    if n_nodes <= 1024 and n_rel > 0 and src.numel() > 0:
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
         on_dev = bool(d_out and src.is_cuda)
@@ -340,6 +347,10 @@ class _RGCNBase(nn.Module):
         if self.bias is not None:
             self.bias.data.zero_()
 
+    def _global_degree(self):
+        """in-degree over the relations of ALL ranks when this layer holds one shard of them."""
+        return None if self.shard is None else self.shard.in_degree
+
     def _run(self, x, graph, fuse_relu=False, gate_input=False):
         if self.bias is not None:
             out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard) + self.bias
@@ -364,13 +375,9 @@ class MyRGCNConv2(_RGCNBase):
         n = x.shape[0]
 
         def build():
-            if self.shard is not None:                       # this rank's relations only
-                from .dist import shard_edges
-                ei, rel = shard_edges(edge_index, range_list, self.shard.rel_ids)
-                return rgcn_graph(ei, rel, n, int(self.shard.rel_ids.numel()), self.chunk, degree_from=edge_index[1],
-                                  d_out=self.out_channels)
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
-            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, d_out=self.out_channels)
+            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
+                              d_out=self.out_channels)
         graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
         return self._run(x, graph, fuse_relu, gate_input)
 
@@ -381,11 +388,9 @@ class MyRGCNConv(_RGCNBase):
 
     def forward(self, x, edge_index, edge_type):
         n = x.shape[0]
-        if self.shard is not None:
-            raise NotImplementedError('relation sharding needs the range-list variant MyRGCNConv2')
         graph = self._cache.get((edge_index, edge_type),
                                 lambda: rgcn_graph(edge_index, edge_type, n, self.num_relations, self.chunk,
-                                                   d_out=self.out_channels))
+                                                   in_degree=self._global_degree(), d_out=self.out_channels))
         return self._run(x, graph)
 
 
@@ -512,10 +517,14 @@ class TIP(nn.Module):
     `data` (extension): an already built data dict.  `fused_loss=False` computes the loss with
     torch ops on the decoder scores exactly as `src/layers.py:335-340` spells it."""
 
-    def __init__(self, settings, device, mod='cat', data_path='./data/data_dict.pkl', data=None, fused_loss=True):
+    def __init__(self, settings, device, mod='cat', data_path='./data/data_dict.pkl', data=None, fused_loss=True,
+                 shard=None):
+        """shard (extension): a `tip_amd.dist.RelationShard` -- this process holds only its relations'
+        edges, `rgcn*.att` rows and `decoder.weight` rows; see tip_amd/dist.py."""
         super().__init__()
         assert mod in {'cat', 'add'}
         self.mod, self.device, self.settings, self.fused_loss = mod, device, settings, fused_loss
+        self.shard = shard
         self.data = self.__prepare_data(data_path, settings.sp_rate, data).to(device)
         self.__prepare_model()
 
@@ -537,10 +546,15 @@ class TIP(nn.Module):
                 raise FileNotFoundError(data_path)
         else:
             self.data_source = 'data dict passed by the caller'
-        data = Data.from_dict(dict(data_dict))
+        data_dict = dict(data_dict)
         if sp_rate != 0.9:                                                   # :290-291
-            (data.dd_train_idx, data.dd_train_et, data.dd_train_range,
-             data.dd_test_idx, data.dd_test_et, data.dd_test_range) = process_edges(data.dd_edge_index, p=sp_rate)
+            (data_dict['dd_train_idx'], data_dict['dd_train_et'], data_dict['dd_train_range'],
+             data_dict['dd_test_idx'], data_dict['dd_test_et'], data_dict['dd_test_range']) = \
+                process_edges(data_dict['dd_edge_index'], p=sp_rate)
+        if self.shard is not None:                                           # this rank's relations only
+            from .dist import shard_data_dict
+            data_dict = shard_data_dict(data_dict, self.shard)
+        data = Data.from_dict(data_dict)
         self._test_neg_host = None
         return data
 
@@ -563,6 +577,9 @@ class TIP(nn.Module):
         self.encoder = FMEncoder(self.device, d.n_drug_feat, d.n_dd_et, d.n_prot, d.n_prot, d.n_drug,
                                  s.prot_drug_dim, s.num_base, s.n_embed, s.n_hid1, s.n_hid2,
                                  mod=self.mod).to(self.device)
+        if self.shard is not None:
+            from .dist import attach_shard
+            attach_shard(self.encoder, self.shard)
         with torch.no_grad():                            # initial pass (:319, with self.device); it only
             self.embeddings = self.__encode()            # fills .embeddings and the plan caches
         self.decoder = MultiInnerProductDecoder(s.n_hid2, d.n_dd_et).to(self.device)
@@ -576,11 +593,30 @@ class TIP(nn.Module):
         if neg_index is None:
             neg_index = typed_negative_sampling(d.dd_train_idx, d.n_drug, d.dd_train_range)
         neg_index = neg_index.type_as(pos_index)
+        if self.shard is not None:
+            return self.__sharded_objective(pos_index, neg_index)
         if self.fused_loss:
             return self.decoder.objective(self.embeddings, pos_index, neg_index, d.dd_train_et)
         pos_score = self.decoder(self.embeddings, pos_index, d.dd_train_et)
         neg_score = self.decoder(self.embeddings, neg_index, d.dd_train_et)
         return -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()
+
+    def __sharded_objective(self, pos_index, neg_index):
+        """The objective over ALL ranks' triples from shard-local work: both means of
+        :338-340 run over the global triple count, so a rank's local objective (means over ITS E_k
+        triples) enters with weight E_k / E; one scalar all-reduce going forward, one d z all-reduce
+        going back (`sum_grad_over_ranks`), d decoder.weight rows stay local."""
+        from .dist import all_reduce_sum, sum_grad_over_ranks
+        z = sum_grad_over_ranks(self.embeddings, self.shard)
+        if pos_index.shape[1] == 0:                                          # a rank without relations
+            local = z.sum() * 0.0
+        elif self.fused_loss:
+            local = self.decoder.objective(z, pos_index, neg_index, self.data.dd_train_et)
+        else:
+            pos_score = self.decoder(z, pos_index, self.data.dd_train_et)
+            neg_score = self.decoder(z, neg_index, self.data.dd_train_et)
+            local = -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()
+        return all_reduce_sum(local * self.shard.loss_weight, self.shard)
 
     def pred(self, dd_idx, dd_et):
         return self.decoder(self.embeddings, dd_idx, dd_et)
@@ -615,7 +651,28 @@ class TIP(nn.Module):
         with torch.no_grad():
             pos_score = self.decoder(self.embeddings, d.dd_test_idx, d.dd_test_et)
             neg_score = self.decoder(self.embeddings, self.test_neg_index, d.dd_test_et)
+        if self.shard is not None:
+            return self.__sharded_test(pos_score, neg_score, print_output)
         return self.compute_auprc_auroc_ap_by_et(pos_score, neg_score, d.dd_test_range, print_output)
+
+    def __sharded_test(self, pos_score, neg_score, print_output):
+        """Per-relation metrics of the local relations, all-gathered into the full [3, R] record."""
+        import torch.distributed as dist
+        sh = self.shard
+        local = auprc_auroc_ap_by_range(pos_score, neg_score, self.data.dd_test_range) if sh.rel_ids.numel() \
+            else np.zeros((3, 0))
+        parts = [None] * sh.world
+        if dist.is_initialized():
+            dist.all_gather_object(parts, (sh.rel_ids.cpu().numpy(), np.asarray(local)), group=sh.group)
+        else:
+            parts = [(sh.rel_ids.cpu().numpy(), np.asarray(local))]
+        record = np.zeros((3, sh.n_relations))
+        for ids, rec in parts:
+            record[:, ids] = rec
+        if print_output and sh.rank == 0:
+            auprc, auroc, ap = record.sum(axis=1) / sh.n_relations
+            print('On test set: auprc:{:0.4f}   auroc:{:0.4f}   ap@50:{:0.4f}    '.format(auprc, auroc, ap))
+        return record
 
     def compute_auprc_auroc_ap_by_et(self, pos_score, neg_score, dd_range, print_out):
         record = auprc_auroc_ap_by_range(pos_score, neg_score, dd_range)      # [3, R]

@@ -759,9 +759,10 @@ class _RGCN(torch.autograd.Function):
     evaluated basis-first / transform-then-gather: XB_b = X basis_b, Y = att . XB, then one
     gather-sum over the rows of Y (no E x d intermediates).
 
-    With a `shard` (tip_amd/dist.py) the graph holds only this rank's relations: the partial
-    aggregate is all-reduced before the 1/deg scaling, and the partial dX / d basis / d att rows
-    are all-reduced in one packed collective on the way back."""
+    With a `shard` (tip_amd/dist.py) the graph, `att` and its gradient hold only this rank's relations
+    (`graph.scale` = 1 / GLOBAL in-degree): the partial aggregate is all-reduced before the 1/deg
+    scaling, and [partial dX | partial d basis] are all-reduced as ONE flat buffer that the GEMMs write
+    into directly; d att rows are shard-local and never travel."""
 
     @staticmethod
     def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False):
@@ -772,55 +773,48 @@ class _RGCN(torch.autograd.Function):
         x, basis, att, root = _f32c(x), basis.contiguous(), att.contiguous(), root.contiguous()
         n, d_in = x.shape
         nb, _, d_out = basis.shape
-        att_l = att if shard is None else att.index_select(0, shard.rel_ids_on(att.device))
-        r = att_l.shape[0]
+        r = att.shape[0]
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
-        else:
+        elif r > 0:
             assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
-        fused = use_rl and shard is None
-        if fused:                                                        # XB and X root: one grouped launch
-            xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])
-        else:
-            xb = gemm(x, basis)                                          # [B, N, out]
-        if r > 0:
-            y = gemm(att_l, xb.view(nb, n * d_out))                      # [R, N*out]
-        else:
-            y = torch.zeros((0, n * d_out), dtype=torch.float32, device=x.device)
-        if fused:
-            # LDS-resident gather -> per-workgroup partial slabs; the ordered slab sum also applies
-            # 1/deg, adds X root and the ReLU: the layer is finished in one pass
-            part = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False, reduce=False)
-            out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=bool(relu))
-        else:
+        xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
+        y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out) if r > 0 else None     # [R N, out]
+        if shard is None:
             if use_rl:
-                agg = rel_gather(graph.rl_fwd, y.view(r * n, d_out), backward=False)
-            elif shard is None:
-                agg = gather_sum(graph.fwd, y.view(r * n, d_out), row_scale=graph.scale)
+                # LDS-resident gather -> per-workgroup partial slabs; the ordered slab sum also applies
+                # 1/deg, adds X root and the ReLU: the layer is finished in one pass
+                part = rel_gather(graph.rl_fwd, y, backward=False, reduce=False)
+                out = sum_slabs(part, row_scale=graph.scale, addend=xroot, relu=bool(relu))
             else:
-                agg = gather_sum(graph.fwd, y.view(r * n, d_out))
-            if shard is not None:
-                from .dist import all_reduce_packed
-                all_reduce_packed([agg], shard.group)
-                rows_affine(agg, row_mul=graph.scale, out=agg)
-            out = gemm(x, root, out=agg, c_in=agg, relu=bool(relu))      # + X root (, ReLU)
+                agg = gather_sum(graph.fwd, y, row_scale=graph.scale)
+                out = sum_slabs(agg.view(1, n, d_out), addend=xroot, relu=bool(relu))
+        else:
+            # partial aggregate of this rank's relations -> one all-reduce -> 1/deg(global), + X root, ReLU
+            if r == 0:
+                agg = torch.zeros((n, d_out), dtype=torch.float32, device=x.device)
+            elif use_rl:
+                agg = sum_slabs(rel_gather(graph.rl_fwd, y, backward=False, reduce=False))
+            else:
+                agg = gather_sum(graph.fwd, y)
+            shard.all_reduce(agg)
+            out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
         del y
         ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
-        ctx.save_for_backward(x, basis, att, att_l, root, xb, out if relu is True else None)
+        ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, basis, att, att_l, root, xb, out = ctx.saved_tensors
+        x, basis, att, root, xb, out = ctx.saved_tensors
         graph, shard = ctx.graph, ctx.shard
         g = _f32c(g).contiguous()
         if ctx.relu is True:
             g = rows_affine(g, gate=out)                                 # ReLU gate of the fused epilogue
         n, d_in = x.shape
         nb, _, d_out = basis.shape
-        r = att_l.shape[0]
-        dev = x.device
+        r = att.shape[0]
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
             if rel_gather_usable(graph.rl_bwd, n, d_out, True):          # dY_r = A_r^T (D^-1 g), 1/deg fused
@@ -829,16 +823,15 @@ class _RGCN(torch.autograd.Function):
                 gs = rows_affine(g, row_mul=graph.scale)
                 g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
             # both consumers of dY in one pass over it (+ one grouped slab sum)
-            g_att_l, g_xb = dy_products(g_y, att_l, xb2)
+            g_att, g_xb = dy_products(g_y, att, xb2)
             g_xb = g_xb.view(nb, n, d_out)
         else:
-            g_att_l = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
+            g_att = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
             g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
         # d basis, d root and both halves of dX are independent given dXB and g: one grouped launch
-        j_basis = gemm_job(x.t(), g_xb)                                  # [B, in, out]
         j_root = gemm_job(x.t(), g)
         if shard is None:
-            g_att = g_att_l
+            j_basis = gemm_job(x.t(), g_xb)                              # [B, in, out]
             j_xr = gemm_job(g, root.t(), ksplit=1)                       # written by the GEMM launch itself: the
             g_x = j_xr.out                                               # basis half is summed on top of it afterwards
             j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
@@ -853,12 +846,17 @@ class _RGCN(torch.autograd.Function):
                     g_x = rows_affine(g_x, gate=x)
             g_basis, g_root = j_basis.out, j_root.out
         else:
-            from .dist import all_reduce_packed
-            j_xq = gemm_job(g_xb, basis.transpose(1, 2), reduce_batch=True)   # partial over this shard
-            g_basis, g_root, g_x = gemm_group([j_basis, j_root, j_xq])
-            g_att = torch.zeros_like(att)
-            g_att.index_copy_(0, shard.rel_ids_on(att.device), g_att_l)
-            all_reduce_packed([g_x, g_basis, g_att], shard.group)
+            # [partial dX | partial d basis] live in ONE flat buffer the products write into: a single
+            # all-reduce, no pack / unpack copies; d att (this rank's rows) and d root (replicated
+            # operands: identical on every rank) need no collective
+            flat = torch.empty(n * d_in + nb * d_in * d_out, dtype=torch.float32, device=x.device)
+            g_x = flat[:n * d_in].view(n, d_in)
+            g_basis = flat[n * d_in:].view(nb, d_in, d_out)
+            j_basis = gemm_job(x.t(), g_xb, out=g_basis)
+            j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, reduce_batch=True)   # partial over this shard
+            gemm_group([j_basis, j_root, j_xq])
+            g_root = j_root.out
+            shard.all_reduce(flat)
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
             if ctx.gate_input:
                 g_x = rows_affine(g_x, gate=x)
