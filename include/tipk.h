@@ -352,6 +352,30 @@ int tipk_counter_advance(uint64_t* call_counter /* device */, tipk_stream_t stre
 int tipk_rank_metrics(const float* pos_score, const float* neg_score, const int64_t* range_ptr /* [n_rel+1] */,
                       int64_t n_rel, int64_t max_pairs, double* out, tipk_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * 7. Train / test split on device -- replaces `process_edges`, src/utils.py:35-65 (host numpy: one
+ *    `np.random.binomial(1, p, E_r)` per relation from the global Mersenne state, Python lists, then
+ *    `to_bidirection`), SURVEY.md section 8(f) item 2.
+ *
+ *    The undirected pairs of all relations arrive concatenated (pairs_u/pairs_v [n_pairs], 2-byte or
+ *    8-byte ids; rel_ptr [n_rel + 1]).  Pair i is a TRAINING pair iff
+ *        Philox4x32-10(counter = (i lo, i hi, 0, 0x53504C54), key = (seed lo, seed hi)).x0 < floor(p * 2^32)
+ *    (p = 1 keeps every pair) -- specified bit-exactly in oracle/philox_split.py.
+ *    tipk_split_flags  writes take[i] (1 = train) and ADDS the kept pairs per relation to n_train[r]
+ *                      (uint64, caller zeroes).
+ *    tipk_split_scatter  with train_ptr / test_ptr [n_rel + 1] = offsets of every relation's block of
+ *                      DIRECTED edges in the outputs (2 * kept, 2 * dropped: exclusive sums the caller
+ *                      forms from n_train), writes per relation r the kept pairs in list order as
+ *                      [ (u,v) ... | (v,u) ... ] into train_u/v with train_et = r, the dropped ones the same
+ *                      way into test_* -- the layout of `to_bidirection` (src/utils.py:17-23, :53).
+ *    Outputs are int64 (the reference's dtype). */
+int tipk_split_flags(const int64_t* rel_ptr, int64_t n_rel, int64_t n_pairs, double p_train, uint64_t seed,
+                     uint8_t* take, uint64_t* n_train, tipk_stream_t stream);
+int tipk_split_scatter(const void* pairs_u, const void* pairs_v, int idx_bytes, const int64_t* rel_ptr, int64_t n_rel,
+                       const uint8_t* take, const int64_t* train_ptr, const int64_t* test_ptr,
+                       int64_t* train_u, int64_t* train_v, int64_t* train_et,
+                       int64_t* test_u, int64_t* test_v, int64_t* test_et, tipk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

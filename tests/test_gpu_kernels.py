@@ -588,3 +588,69 @@ def test_rank_metrics_vs_sklearn():
                            torch.tensor([0, big], device=DEV), big) is None
     got2 = auprc_auroc_ap_by_range(torch.from_numpy(p2).to(DEV), torch.from_numpy(n2).to(DEV), torch.tensor([[0, big]]))
     np.testing.assert_allclose(got2[:, 0], O.auprc_auroc_ap(np.r_[np.ones(big), np.zeros(big)], np.r_[p2, n2]), rtol=1e-9)
+
+
+# ------------------------------------------------------------------ device-side train/test split
+def test_device_split_bit_exact_vs_spec():
+    """tipk_split_flags + tipk_split_scatter == oracle/philox_split.py (the reference's post-draw layout:
+    kept pairs in list order, mirrored halves appended, edge types, ranges) -- empty / single-pair / large
+    relations, int64 and uint16 pair ids, p in {0, 0.9, 1}."""
+    from oracle.philox_split import process_edges_spec
+    from tip_amd.data import device_process_edges
+    rng = np.random.RandomState(2)
+    sizes = [0, 700, 1, 0, 4097, 256, 255, 257, 30000]
+    ptr = np.r_[0, np.cumsum(sizes)].astype(np.int64)
+    pairs = np.stack([rng.randint(0, 645, ptr[-1]), rng.randint(0, 645, ptr[-1])]).astype(np.int64)
+    for p, seed in ((0.9, 1111), (0.5, (1 << 63) + 12345), (1.0, 1), (0.0, 2)):
+        want = process_edges_spec(pairs, ptr, p, seed)
+        for dt in (torch.int64, torch.uint16):
+            got = device_process_edges(torch.from_numpy(pairs).to(dt).to(DEV), torch.from_numpy(ptr).to(DEV), p, seed)
+            for g_, w_ in zip(got, want):
+                assert g_.dtype == torch.int64 and g_.is_cuda
+                assert np.array_equal(g_.cpu().numpy(), w_), (p, dt)
+
+
+def test_device_built_biosnap_data_dict_trains():
+    """The whole ingest on device (blob -> HBM -> Philox split + mirroring of the 4.6 M D-D pairs and the
+    P-P graph): schema of SURVEY 8(a) A0, the data contract (every block = [pairs | mirrored pairs]),
+    Bernoulli(0.9) sizes, bit-exact against the host spec at full size, and a TIP model trains on it."""
+    from oracle.philox_split import split_flags_spec
+    from tip_amd.data import build_data_dict_device, BIOSNAP_BLOB
+    from tip_amd.layers import TIP, Setting
+    d = build_data_dict_device(DEV)
+    z = np.load(BIOSNAP_BLOB)
+    P = z['dd_pairs'].shape[1]
+    R = d['n_dd_et']
+    assert R == 1097 and d['dd_train_idx'].is_cuda and d['dd_train_idx'].dtype == torch.int64
+    n_tr, n_te = d['dd_train_idx'].shape[1], d['dd_test_idx'].shape[1]
+    assert n_tr + n_te == 2 * P and abs(n_tr / 2 - 0.9 * P) < 5 * np.sqrt(P * 0.09)
+    take = split_flags_spec(P, 0.9, 1111)
+    ptr = z['dd_ptr'].astype(np.int64)
+    kept = np.add.reduceat(take.astype(np.int64), ptr[:-1])
+    rg = d['dd_train_range'].cpu().numpy()
+    assert np.array_equal(rg[:, 1] - rg[:, 0], 2 * kept)
+    for r in (0, 1, 500, R - 1):                                             # contents of a few relations
+        a, b = ptr[r], ptr[r + 1]
+        sel = z['dd_pairs'][:, a:b][:, take[a:b]].astype(np.int64)
+        blk = d['dd_train_idx'][:, rg[r, 0]:rg[r, 1]].cpu().numpy()
+        assert np.array_equal(blk, np.concatenate([sel, sel[::-1]], 1))
+        assert bool((d['dd_train_et'][rg[r, 0]:rg[r, 1]] == r).all())
+    h = (rg[:, 1] - rg[:, 0]) // 2                                           # mirrored halves everywhere
+    first = torch.cat([torch.arange(a, a + k) for a, k in zip(rg[:, 0].tolist(), h.tolist())]).to(DEV)
+    second = torch.cat([torch.arange(a + k, a + 2 * k) for a, k in zip(rg[:, 0].tolist(), h.tolist())]).to(DEV)
+    assert torch.equal(d['dd_train_idx'][:, first], d['dd_train_idx'][:, second].flip(0))
+    pp = d['pp_train_indices']
+    assert pp.shape[1] % 2 == 0 and torch.equal(pp[:, :pp.shape[1] // 2], pp[:, pp.shape[1] // 2:].flip(0))
+    torch.manual_seed(0)
+    model = TIP(Setting(), torch.device(DEV), data=d)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert abs(losses[0] - 2 * np.log(2)) < 0.05 and losses[-1] < losses[0]
+    rec = model.test(print_output=False)
+    assert rec.shape == (3, R) and np.isfinite(rec).all()

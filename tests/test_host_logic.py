@@ -366,3 +366,88 @@ def test_reference_pickle_fixture_schema():
     for a, b in d.dd_train_range.tolist():
         h = (b - a) // 2
         assert torch.equal(d.dd_train_idx[:, a:a + h], d.dd_train_idx[:, a + h:b].flip(0))
+
+
+# ------------------------------------------------------------------ device split: host-side spec
+def test_split_spec_layout_and_distribution_next_to_the_reference_draw():
+    """oracle/philox_split.py (the bit-exact spec of tipk_split_*): block layout = `to_bidirection` of the
+    kept pairs in list order; the kept fraction is Binomial(n, p) like the reference's numpy draw
+    (src/utils.py:45), held to the same z-score bar."""
+    from oracle.philox_split import process_edges_spec, split_flags_spec
+    from tip_amd.utils import process_edges
+    rng = np.random.RandomState(0)
+    sizes = [0, 5000, 1, 300, 20000]
+    ptr = np.r_[0, np.cumsum(sizes)]
+    pairs = np.stack([rng.randint(0, 600, ptr[-1]), rng.randint(0, 600, ptr[-1])]).astype(np.int64)
+    tr, tr_et, tr_rg, te, te_et, te_rg = process_edges_spec(pairs, ptr, 0.9, 1111)
+    take = split_flags_spec(ptr[-1], 0.9, 1111)
+    for r in range(len(sizes)):
+        a, b = ptr[r], ptr[r + 1]
+        kept = pairs[:, a:b][:, take[a:b]]
+        blk = tr[:, tr_rg[r, 0]:tr_rg[r, 1]]
+        h = kept.shape[1]
+        assert blk.shape[1] == 2 * h and np.array_equal(blk[:, :h], kept) and np.array_equal(blk[:, h:], kept[::-1])
+        assert (tr_et[tr_rg[r, 0]:tr_rg[r, 1]] == r).all()
+        assert te_rg[r, 1] - te_rg[r, 0] == 2 * ((b - a) - h)
+    assert tr.shape[1] + te.shape[1] == 2 * ptr[-1]
+    # same Bernoulli(p) law as the reference's draw: |kept - n p| within 4 sigma for both, per relation
+    ref = process_edges([torch.from_numpy(pairs[:, ptr[r]:ptr[r + 1]]) for r in range(len(sizes))], p=0.9,
+                        rng=np.random.RandomState(5))
+    for r, n in enumerate(sizes):
+        sd = max(1.0, np.sqrt(n * 0.9 * 0.1))
+        assert abs((tr_rg[r, 1] - tr_rg[r, 0]) / 2 - 0.9 * n) <= 4 * sd
+        assert abs(int(ref[2][r, 1] - ref[2][r, 0]) / 2 - 0.9 * n) <= 4 * sd
+    assert split_flags_spec(1000, 1.0, 3).all() and not split_flags_spec(1000, 0.0, 3).any()
+    assert not np.array_equal(split_flags_spec(1000, 0.5, 3), split_flags_spec(1000, 0.5, 4))
+
+
+def test_sym_adj_csr_ingest_matches_triu_pairs():
+    """`sym_adj_to_pairs`: the reference's sym_adj layout (stacked symmetric CSR) -> the upper-triangular pair
+    list of data/utils.py:60,151, without per-relation lists; checked against scipy."""
+    import scipy.sparse as sp
+    from tip_amd.data import sym_adj_to_pairs
+    rng = np.random.RandomState(1)
+    n, mats = 23, []
+    for m in (40, 0, 7, 150):
+        u, v = rng.randint(0, n, m), rng.randint(0, n, m)
+        keep = u != v
+        a = sp.coo_matrix((np.ones(keep.sum()), (u[keep], v[keep])), shape=(n, n)).tocsr()
+        a = ((a + a.T) > 0).astype(np.float32).tocsr()
+        a.sort_indices()
+        mats.append(a)
+    indptr = torch.from_numpy(np.stack([a.indptr for a in mats]).astype(np.int64))
+    indices = torch.from_numpy(np.concatenate([a.indices for a in mats]).astype(np.int64))
+    pairs, rel_ptr = sym_adj_to_pairs(indptr, indices, n)
+    for r, a in enumerate(mats):
+        coo = sp.triu(a).tocsr().tocoo()
+        got = pairs[:, rel_ptr[r]:rel_ptr[r + 1]].numpy()
+        assert np.array_equal(got, np.stack([coo.row, coo.col]))
+
+
+def test_segmented_gather_plan_semantics_and_launch_order():
+    """`build_gather_plan_segmented` (large D-D graphs): same sums as the default plan; items run
+    segment by segment; every row's pieces get consecutive partial slots; rows without edges are written."""
+    from tip_amd.plan import build_gather_plan_segmented, relations_per_segment
+    g = torch.Generator().manual_seed(0)
+    N, R, E, d = 57, 23, 4000, 4
+    rel = torch.sort(torch.randint(0, R, (E,), generator=g)).values
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N - 4, (E,), generator=g)                     # the last 4 rows stay empty
+    dst[:700] = 3                                                        # a hub row
+    y = torch.randn(R * N, d, generator=g, dtype=torch.float64)
+    want = torch.zeros(N, d, dtype=torch.float64).index_add_(0, dst, y[rel * N + src])
+    for B, chunk in ((4, 16), (1, 8), (100, 32), (5, 1000)):
+        plan = build_gather_plan_segmented(dst, rel * N + src, rel // B, N, R * N, chunk)
+        torch.testing.assert_close(execute_plan_reference(plan, y), want)
+        torch.testing.assert_close(execute_plan_reference(plan, y, torch.full((N,), 0.5, dtype=torch.float64)), want * 0.5)
+        it = plan.items.long()
+        nonempty = it[:, 1] > it[:, 0]
+        segs = (plan.row_id.long()[it[nonempty, 0]] // N) // B
+        assert bool((segs[1:] >= segs[:-1]).all())                       # segment-major launch order
+        assert int((it[:, 1] - it[:, 0]).max()) <= chunk
+        sr = plan.split_rows.long()
+        assert int((sr[:, 2] - sr[:, 1]).sum()) == plan.n_slots and plan.max_slots == int((sr[:, 2] - sr[:, 1]).max())
+        assert bool((sr[1:, 1] == sr[:-1, 2]).all())                     # slots tile [0, n_slots) row by row
+    with pytest.raises(ValueError):                                      # edges not grouped by relation
+        build_gather_plan_segmented(dst, rel * N + src, torch.flip(rel, [0]) // 4, N, R * N, 16)
+    assert relations_per_segment(10000, 128) == 13 and relations_per_segment(10 ** 9, 128) == 1

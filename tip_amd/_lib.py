@@ -81,6 +81,8 @@ SIGNATURES = {
     'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _P, _P, _L, _P, _P, _I, _L, _P]),
     'tipk_counter_advance': (_I, [_P, _P]),
     'tipk_rank_metrics': (_I, [_P, _P, _P, _L, _L, _P, _P]),
+    'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),
+    'tipk_split_scatter': (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -122,6 +122,92 @@ def build_data_dict(blob_path=BIOSNAP_BLOB, sp_rate=0.9, seed=1111, min_pairs=No
     return d
 
 
+def sym_adj_to_pairs(indptr, indices, n_nodes):
+    """Undirected pair list of a stack of SYMMETRIC adjacency matrices in the layout of the
+    reference's `data/sym_adj/drug-sparse-adj/type_*.npz` (scipy CSR), without per-relation Python
+    lists: `indptr` int64 [R, n_nodes + 1] (row pointers of every relation, each relative to that
+    relation's first entry), `indices` int64 [nnz] (all relations' column ids, concatenated).
+    -> (pairs int64 [2, P] with row < col in CSR order, rel_ptr int64 [R + 1]) on the arrays' device:
+    what `sp.triu(adj).tocsr().tocoo()` yields per relation (data/utils.py:60,151)."""
+    R = indptr.shape[0]
+    nnz_r = indptr[:, -1]
+    base = torch.cumsum(nnz_r, 0) - nnz_r
+    counts = (indptr[:, 1:] - indptr[:, :-1]).reshape(-1)                       # entries per (relation, row)
+    row = torch.repeat_interleave(torch.arange(n_nodes, device=indices.device).repeat(R), counts)
+    rel = torch.repeat_interleave(torch.arange(R, device=indices.device), nnz_r)
+    keep = row < indices
+    pairs = torch.stack([row[keep], indices[keep]])
+    rel_ptr = torch.zeros(R + 1, dtype=torch.int64, device=indices.device)
+    rel_ptr[1:] = torch.cumsum(torch.bincount(rel[keep], minlength=R), 0)
+    del base
+    return pairs, rel_ptr
+
+
+def device_process_edges(pairs, rel_ptr, p=0.9, seed=1111):
+    """`process_edges` (src/utils.py:35-65) on the GPU: seeded Philox Bernoulli(p) split of the
+    concatenated undirected pairs + mirroring, two launches (`tipk_split_flags`, `tipk_split_scatter`),
+    no per-relation host work.  pairs: [2, P] device tensor (int64 or uint16 stored as int16 is not
+    accepted: int64 / uint16); rel_ptr int64 [R + 1].  Returns the reference's six tensors, on the
+    device: train_idx [2,E], train_et, train_range [R,2], test_idx, test_et, test_range."""
+    from . import _lib
+    from ._lib import check, lib, ptr, stream_ptr, require_device
+    require_device(pairs, rel_ptr)
+    assert pairs.dim() == 2 and pairs.shape[0] == 2 and rel_ptr.dtype == torch.int64
+    if pairs.dtype not in (torch.int64, torch.uint16):
+        raise _lib.TipkError('pairs must be int64 or uint16, got %s' % pairs.dtype)
+    pairs = pairs.contiguous()
+    dev = pairs.device
+    P, R = pairs.shape[1], rel_ptr.numel() - 1
+    st = stream_ptr(dev)
+    take = torch.empty(P, dtype=torch.uint8, device=dev)
+    n_train = torch.zeros(R, dtype=torch.int64, device=dev)
+    check(lib().tipk_split_flags(ptr(rel_ptr), R, P, float(p), int(seed) & ((1 << 64) - 1), ptr(take), ptr(n_train), st),
+          'tipk_split_flags')
+    n_all = rel_ptr[1:] - rel_ptr[:-1]
+    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+    train_ptr = torch.cat([zero, torch.cumsum(2 * n_train, 0)])
+    test_ptr = torch.cat([zero, torch.cumsum(2 * (n_all - n_train), 0)])
+    e_tr, e_te = int(train_ptr[-1]), int(test_ptr[-1])                       # the only host sync (allocation sizes)
+    tr = torch.empty((2, e_tr), dtype=torch.int64, device=dev)
+    te = torch.empty((2, e_te), dtype=torch.int64, device=dev)
+    tr_et = torch.empty(e_tr, dtype=torch.int64, device=dev)
+    te_et = torch.empty(e_te, dtype=torch.int64, device=dev)
+    check(lib().tipk_split_scatter(ptr(pairs[0]), ptr(pairs[1]), 8 if pairs.dtype == torch.int64 else 2, ptr(rel_ptr), R,
+                                   ptr(take), ptr(train_ptr), ptr(test_ptr), ptr(tr[0]), ptr(tr[1]), ptr(tr_et),
+                                   ptr(te[0]), ptr(te[1]), ptr(te_et), st), 'tipk_split_scatter')
+    return (tr, tr_et, torch.stack([train_ptr[:-1], train_ptr[1:]], 1),
+            te, te_et, torch.stack([test_ptr[:-1], test_ptr[1:]], 1))
+
+
+def build_data_dict_device(device, blob_path=BIOSNAP_BLOB, sp_rate=0.9, seed=1111, max_relations=None):
+    """The BioSNAP `data_dict` built ON THE DEVICE: the blob's pair
+    arrays go to HBM once and the D-D and P-P splits + mirroring run there (`device_process_edges`),
+    replacing the reference's prepare.py -> 476 MB pickle -> unpickle round trip.  Same schema as
+    `build_data_dict`; the split is this build's seeded Philox stream (same distribution as the
+    reference's Bernoulli draw, not the same sample)."""
+    z = np.load(blob_path)
+    n_drug, n_prot = int(z['n_drug']), int(z['n_prot'])
+    ptr_np = z['dd_ptr'].astype(np.int64)
+    R = len(ptr_np) - 1 if max_relations is None else min(max_relations, len(ptr_np) - 1)
+    dev = torch.device(device)
+    pairs = torch.from_numpy(z['dd_pairs'][:, :ptr_np[R]].astype(np.int64)).to(dev)
+    rel_ptr = torch.from_numpy(ptr_np[:R + 1]).to(dev)
+    d = {}
+    (d['dd_train_idx'], d['dd_train_et'], d['dd_train_range'],
+     d['dd_test_idx'], d['dd_test_et'], d['dd_test_range']) = device_process_edges(pairs, rel_ptr, sp_rate, seed)
+    pp = torch.from_numpy(z['pp_pairs'].astype(np.int64)).to(dev)
+    pp_ptr = torch.tensor([0, pp.shape[1]], dtype=torch.int64, device=dev)
+    tr, _, _, te, _, _ = device_process_edges(pp, pp_ptr, sp_rate, seed + 1)     # data/utils.py:212-229
+    d['pp_train_indices'], d['pp_test_indices'] = tr, te
+    dp_idx, dp_rg = _dp_tables(z['dp_pairs'], n_drug, n_prot)
+    d['dp_edge_index'], d['dp_range_list'] = dp_idx.to(dev), dp_rg.to(dev)
+    d['d_feat'], d['p_feat'] = sparse_id(n_drug).to(dev), sparse_id(n_prot).to(dev)
+    d['n_drug'], d['n_prot'], d['n_dd_et'], d['n_drug_feat'] = n_drug, n_prot, R, n_drug
+    d['d_norm'] = torch.ones(n_drug, device=dev)
+    d['et_list'] = [int(t) for t in z['et_list'][:R]]
+    return d
+
+
 def lognormal_sizes(total, n, sigma, rng, minimum=2):
     """n even block sizes ~ lognormal(sigma) rescaled to sum to `total` (BioSNAP's measured skew
     is sigma_ln = 1.17)."""

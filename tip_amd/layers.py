@@ -22,7 +22,8 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import build_gather_plan, build_rel_plan, group_slots_for, DEFAULT_CHUNK
+from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, group_slots_for,
+                   relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
 EPS = 1e-13                    # src/layers.py:15
@@ -316,8 +317,18 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         wg_b = (ops.rel_gather_wgs(n_nodes, d_out, True, n_cu) if on_dev else 0) or n_cu
         rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f)
         rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True)
+    def fwd_plan():
+        # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by
+        # relation block, so that a row of Y gathered by several edges crosses the fabric once
+        y_bytes = n_rel * n_nodes * (d_out or 0) * 4
+        ordered = rel.numel() < 2 or bool((rel[1:] >= rel[:-1]).all())
+        if y_bytes > (192 << 20) and ordered and not os.environ.get('TIPK_NO_SEGMENTS'):
+            seg = rel // relations_per_segment(n_nodes, d_out)
+            return build_gather_plan_segmented(dst, yrow, seg, n_nodes, n_rel * n_nodes, chunk, 'dd.fwd')
+        return build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd')
+
     # the generic plans are built on first use: with the relation-local kernels they are never needed
-    return ops.AggGraph(lambda: build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd'),
+    return ops.AggGraph(fwd_plan,
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd)
 

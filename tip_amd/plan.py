@@ -194,6 +194,89 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     return GatherPlan(n_out, n_table, row_id, w, items, split_rows, n_slots, order, chunk, tag)
 
 
+def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chunk=DEFAULT_CHUNK, tag=''):
+    """`build_gather_plan` for tables far larger than the caches (a D-D forward pass over
+    Y = [R N, d] on a big graph: 10 GB in BASELINE config 5), where the ORDER in which the work items
+    run decides the HBM traffic.
+
+    segment: int64 [E], a coarse id of the table region an edge reads (relation block =
+    relation // B with B relations x N rows x d floats ~ a quarter of the 256 MB Infinity Cache),
+    non-decreasing along the caller's edge order inside every output row (TIP's edge lists are
+    grouped by relation).  Every (output row, segment) group is cut into items of <= chunk edges and
+    the items are launched SEGMENT BY SEGMENT (inside a segment by decreasing length): all items in
+    flight at any time read the same few relations' rows, so a row of Y that several edges gather
+    (2.5 on average in config 5) comes from HBM once and from the Infinity Cache afterwards.  The
+    default plan launches row by row: every item then spans ~50 relations of one output row and the
+    launch touches the whole table at random -- each row crosses the fabric once PER EDGE.
+    Rows consist of several items (one per segment at least): their pieces are added in slot order by
+    `tipk_gather_sum_finalize` (deterministic), exactly as for split rows of the default plan."""
+    dev = out_row.device
+    E = int(out_row.numel())
+    if chunk is None:
+        chunk = int(os.environ.get('TIPK_CHUNK', '0')) or auto_chunk(E)
+    if E >= 2 ** 31 - 1 or n_out >= 2 ** 31 - 1 or n_table >= 2 ** 31 - 1:
+        raise ValueError('graph too large for int32 plans')
+    if E:
+        lo, hi = int(out_row.min()), int(out_row.max())
+        tlo, thi = int(table_row.min()), int(table_row.max())
+        if lo < 0 or hi >= n_out or tlo < 0 or thi >= n_table:
+            raise IndexError('edge index out of range: out rows [%d,%d] of %d, table rows [%d,%d] of %d'
+                             % (lo, hi, n_out, tlo, thi, n_table))
+    n_seg = (int(segment.max()) + 1) if E else 1
+    order = torch.sort(out_row, stable=True).indices
+    key = out_row[order] * n_seg + segment[order]
+    if E and bool((key[1:] < key[:-1]).any()):
+        raise ValueError('segment ids must be non-decreasing inside every output row (edges grouped by relation)')
+    gkey, gcount = torch.unique_consecutive(key, return_counts=True)
+    grow = gkey // n_seg
+    # rows without edges still get one (empty, direct) item so that the kernel writes their zeros
+    has = torch.zeros(n_out, dtype=torch.bool, device=dev)
+    has[grow] = True
+    empty = torch.nonzero(~has).view(-1)
+    gbegin = torch.cumsum(gcount, 0) - gcount
+    if empty.numel():
+        gkey = torch.cat([gkey, empty * n_seg])
+        gcount = torch.cat([gcount, torch.zeros_like(empty)])
+        gbegin = torch.cat([gbegin, torch.zeros_like(empty)])
+        o = torch.sort(gkey, stable=True).indices
+        gkey, gcount, gbegin = gkey[o], gcount[o], gbegin[o]
+        grow = gkey // n_seg
+    gseg = gkey % n_seg
+    n_chunks = torch.clamp((gcount + chunk - 1) // chunk, min=1)
+    item_grp = torch.repeat_interleave(torch.arange(gkey.numel(), device=dev), n_chunks)
+    first_item = torch.cumsum(n_chunks, 0) - n_chunks
+    local = torch.arange(item_grp.numel(), device=dev) - first_item[item_grp]
+    gend = gbegin + gcount
+    begin = torch.minimum(gbegin[item_grp] + local * chunk, gend[item_grp])
+    end = torch.minimum(begin + chunk, gend[item_grp])
+    item_row = grow[item_grp]
+    items_per_row = torch.bincount(item_row, minlength=n_out)
+    direct = items_per_row[item_row] == 1
+    slot = torch.cumsum((~direct).long(), 0) - 1                             # (row, piece) order: consecutive per row
+    target = torch.where(direct, item_row, slot)
+    n_slots = int((~direct).sum())
+    # launch order: segment-major, longest first inside a segment
+    okey = gseg[item_grp] * (chunk + 1) + (chunk - (end - begin))
+    by = torch.sort(okey, stable=True).indices
+    items = torch.stack([begin, end, target, direct.long()], dim=1)[by].to(torch.int32).contiguous()
+    row_id = table_row[order].to(torch.int32).contiguous()
+    split = torch.nonzero(items_per_row > 1).view(-1)
+    if split.numel():
+        row_first_item = torch.cumsum(items_per_row, 0) - items_per_row
+        first = slot[row_first_item[split]]
+        split_rows = torch.stack([split, first, first + items_per_row[split]], dim=1).to(torch.int32).contiguous()
+    else:
+        split_rows = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+    return GatherPlan(n_out, n_table, row_id, None, items, split_rows, n_slots, order, chunk, tag)
+
+
+def relations_per_segment(n_nodes, d, budget_bytes=64 << 20):
+    """Relations per segment of `build_gather_plan_segmented`: their rows of Y (N x d fp32 each)
+    take about `budget_bytes` -- a quarter of the Infinity Cache, so that the two or three segments in
+    flight at a time stay resident next to the streamed ids and partial sums."""
+    return max(1, int(budget_bytes // max(1, n_nodes * d * 4)))
+
+
 def execute_plan_reference(plan, table, row_scale=None):
     """Pure-torch interpretation of a plan (item by item semantics, vectorised).  Used by the CPU
     unit tests of the plan builder and of the host logic; NOT used by the product path."""
