@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 4
+#define TIPK_ABI_VERSION 5
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -103,6 +103,17 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
                              int d, int max_slots, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 1c. CSR rows -- the TRANSPOSED D-D pass of a large graph (autograd backward of K5/K6,
+ *     src/layers.py:159-180): out[r] = sum_{e in [row_ptr[r], row_ptr[r+1])} table[row_id[e]] for every one
+ *     of the n_out rows (all written, also empty ones), where rows are short (config 5: R*N = 20 M rows
+ *     (relation, source), 2.5 edges each, table = g' [N x d] cache-resident).  A slot takes 8
+ *     consecutive rows: one coalesced pointer load, contiguous ids, 8 gathered rows in flight, one
+ *     contiguous output stream -- no work-item descriptors.  Edges sorted by output row (stable);
+ *     row_ptr int32 [n_out + 1]; d % 4 == 0, 8 <= d <= 256. */
+int tipk_gather_rows_csr(const float* table, int64_t ld_table, const int32_t* row_ptr, const int32_t* row_id,
+                         int64_t n_out, float* out, int64_t ld_out, int d, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 1b. Relation-local gather -- the D-D aggregation (K5/K6, src/layers.py:159-180) when one
  *     relation's node table fits in LDS (BioSNAP: 645 drugs x 32 floats).  Same sums as
  *     `tipk_gather_sum` over the plan of the same graph, with every gathered row read from LDS:
@@ -123,10 +134,16 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *       node_at[n_units][n_nodes] uint16: output node at position p of the unit; positions are
  *                               ordered by decreasing run length
  *       runs[n_units][n_nodes][2] (begin relative to the unit's first id, padded length) per position
- *       idx[..]                 uint16 table node of each edge (16-byte aligned array); inside a
- *                               unit the edges are sorted by the position of their OUTPUT node; runs
- *                               are padded to multiples of 8 ids with the sentinel id n_nodes, whose
- *                               table row is zero
+ *       idx[..]                 uint16 table node of each edge TIMES idx_unit (16-byte aligned array;
+ *                               idx_unit = 1, or a power of two up to the bytes of one column-block
+ *                               row with n_nodes * idx_unit <= 65535: then a row's LDS address is
+ *                               base + idx with no multiply); inside a unit the edges are sorted by
+ *                               the position of their OUTPUT node; runs are padded to multiples of 8
+ *                               ids with the sentinel n_nodes * idx_unit, whose table row is zero.
+ *                               The order of the ids INSIDE a run is free (it only fixes the order of
+ *                               the fp32 sum): tip_amd/plan.py orders them so that the slots of one
+ *                               ds_read_b128 lane group read different bank quarters (table rows are
+ *                               unpadded: node mod (256 / row bytes) is the quarter)
  *       unit_meta[n_units][8]   int32 descriptors, listed in the order the workgroups process them:
  *                               { unit (row of node_at / runs), relation (selects the Y_r block / the
  *                               dY rows), n_pos (positions to walk: backward all of the unit's, so
@@ -143,9 +160,12 @@ int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);
  * two 1024-thread workgroups share a CU (8 waves per SIMD hide the kernel's LDS round trips); the host
  * builds the plan for  occupancy * CUs / column-blocks  workgroups.  Option "rg_occupancy" (1 | 2). */
 int tipk_rel_gather_occupancy(int64_t n_nodes, int d, int backward);
+/* ids staged into LDS per pass for this shape (8192 or 16384): a forward work unit with more ids than
+ * this reloads its id chunk synchronously, so the host cuts forward units at this size. */
+int tipk_rel_gather_chunk(int64_t n_nodes, int d, int backward);
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                     int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* unit_meta,
-                    const uint16_t* idx, const int32_t* runs, const uint16_t* node_at,
+                    const uint16_t* idx, int idx_unit, const int32_t* runs, const uint16_t* node_at,
                     const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

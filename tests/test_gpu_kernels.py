@@ -654,3 +654,30 @@ def test_device_built_biosnap_data_dict_trains():
     assert abs(losses[0] - 2 * np.log(2)) < 0.05 and losses[-1] < losses[0]
     rec = model.test(print_output=False)
     assert rec.shape == (3, R) and np.isfinite(rec).all()
+
+
+# ------------------------------------------------------------------ CSR rows (transposed pass of large graphs)
+@pytest.mark.parametrize('d', [8, 12, 16, 32, 64, 128, 200, 256])
+def test_gather_rows_csr_vs_reference(ops, d):
+    """tipk_gather_rows_csr == per-row sums in fp64: empty rows (also whole empty tasks, leading / trailing),
+    a heavy row, row counts that are not a multiple of the rows per slot; bitwise reproducible."""
+    from tip_amd.plan import build_csr_plan, execute_csr_reference
+    g = torch.Generator().manual_seed(d)
+    n_out, n_tab, E = 1003, 77, 2600
+    out_row = torch.randint(40, n_out - 30, (E,), generator=g)               # rows < 40 and the last 30 stay empty
+    out_row[:400] = 500                                                      # a heavy row
+    out_row[400:420] = torch.arange(600, 620)
+    tab_row = torch.randint(0, n_tab, (E,), generator=g)
+    table = torch.randn(n_tab, d, generator=g)
+    plan = build_csr_plan(out_row, tab_row, n_out, n_tab)
+    want = execute_csr_reference(plan, table.double())
+    dev_plan = build_csr_plan(out_row.to(DEV), tab_row.to(DEV), n_out, n_tab)
+    got = ops.gather_rows_csr(dev_plan, table.to(DEV))
+    close(got, want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(got, ops.gather_rows_csr(dev_plan, table.to(DEV)))
+    # strided table view and an all-empty graph
+    wide = torch.randn(n_tab, d + 8, generator=g).to(DEV)
+    close(ops.gather_rows_csr(dev_plan, wide[:, 4:4 + d]), execute_csr_reference(plan, wide[:, 4:4 + d].cpu().double()),
+          rtol=1e-5, atol=1e-5)
+    empty = build_csr_plan(torch.zeros(0, dtype=torch.long, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV), 13, n_tab)
+    assert float(ops.gather_rows_csr(empty, table.to(DEV)).abs().max()) == 0.0

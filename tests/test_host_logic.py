@@ -245,6 +245,32 @@ def test_rel_plan_semantics():
             assert U == R and planb.unit_npos.tolist() == [N] * R
         else:
             assert U > R and int(plan.rel_len.max()) <= max(max_unit, 304) + 8 * N   # hub run of 300 edges cannot be cut
+    # launch-shape-aware plans: ids of a run reordered for conflict-free LDS reads + pre-scaled offsets
+    # (same sums -- the order inside a run only fixes the order of the fp32 additions)
+    from tip_amd.plan import bank_rotation
+    for lanes in (1, 2, 4, 8, 16):
+        for max_unit in (10 ** 9, 64):
+            plan = build_rel_plan(dst, src, rel, N, R, n_wg=4, max_unit=max_unit, lanes=lanes)
+            torch.testing.assert_close(execute_rel_plan_reference(plan, y, False), want)
+            planb = build_rel_plan(src, dst, rel, N, R, n_wg=4, backward=True, max_unit=max_unit, lanes=lanes)
+            torch.testing.assert_close(execute_rel_plan_reference(planb, gp, True), wantb)
+            unit = plan.idx_unit
+            assert unit == min(lanes * 16, 2048) and int(plan.idx.to(torch.int32).max()) == N * unit <= 65535
+        n_cls, rot = bank_rotation(lanes)
+        assert n_cls == max(1, 16 // lanes) and len(rot) == 64 // lanes
+    # L = 4: inside a run the classes (node mod 4) are sorted starting at the slot's rotation
+    plan = build_rel_plan(dst, src, rel, N, R, n_wg=4, lanes=4)
+    ids = (plan.idx.to(torch.int64) // plan.idx_unit)
+    n_cls, rot = bank_rotation(4)
+    for u in range(plan.n_units):
+        e0 = int(plan.rel_idx_off[u])
+        for p in range(int(plan.unit_npos[u])):
+            b, ln = plan.runs[u, p].tolist()
+            run = ids[e0 + b:e0 + b + ln]
+            run = run[run < N]
+            slot = p % 256                                              # band 0 of a 256-slot workgroup (N < 256 positions)
+            key = (run % n_cls - rot[slot % 16]) % n_cls
+            assert bool((key[1:] >= key[:-1]).all())
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
     loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]
     assert sorted(loads) == [14, 14]

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TipkError(RuntimeError):
@@ -58,9 +58,11 @@ SIGNATURES = {
     'tipk_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     'tipk_gather_sum': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
+    'tipk_gather_rows_csr': (_I, [_P, _L, _P, _P, _L, _P, _L, _I, _P]),
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
-    'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
+    'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),
     'tipk_sum_slabs_group': (_I, [C.POINTER(SlabSumDesc), C.c_int32, _P]),

@@ -347,3 +347,112 @@ extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* row
     }
     TIPK_RETURN_LAUNCH();
 }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// CSR rows: out[r] = sum_{e in [row_ptr[r], row_ptr[r+1])} table[row_id[e]] for EVERY row r, rows short
+// (include/tipk.h section 1c).  The transposed D-D pass of a large graph writes R*N rows of ~2.5 edges
+// each (BASELINE config 5: 20 M rows, 50 M edges): as work items of the plan above that is one 16-byte
+// descriptor, one dependent id fetch and one scattered 512-byte store per 2.5 gathered rows -- the launch
+// is a chain of dependent round trips (4.9 ms, 0.64 of the HBM roofline).  Here a slot of L lanes takes
+// RP CONSECUTIVE rows: their RP + 1 row pointers arrive with one coalesced load, the edge ids of the
+// whole range are contiguous, 8 gathered rows are in flight per lane, and the RP output rows are one
+// contiguous RP * d * 4-byte store stream.  No descriptors, no atomics; sums in edge order.
+template <int L>
+__global__ __launch_bounds__(256) void gather_rows_csr_kernel(const float* __restrict__ table, int64_t ld_table,
+                                                              const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ row_id, int64_t n_out,
+                                                              float* __restrict__ out, int64_t ld_out, int d, int rp) {
+    constexpr int SLOTS = TIPK_WAVE / L;
+    constexpr int U = L < 8 ? L : 8;                       // gathered rows in flight per lane (ids come from U lanes)
+    const int lane = tipk_lane();
+    const int sub = lane & (L - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / TIPK_WAVE;
+    const int64_t task = wave * SLOTS + lane / L;
+    const int64_t r0 = task * rp;
+    if (r0 >= n_out) return;
+    const int nr = (int)(n_out - r0 < rp ? n_out - r0 : rp);
+    const int col = sub * 4;
+    const bool col_ok = col < d;
+    // lane k of the slot holds row_ptr[r0 + k] (k <= nr <= L - 1): one coalesced load for the whole task
+    const int pk = sub <= nr ? sub : nr;
+    const int myptr = row_ptr[r0 + pk];
+    const int e_begin = __shfl(myptr, 0, L), e_end = __shfl(myptr, nr, L);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int row = 0;                                           // current output row (relative to r0)
+    int next = __shfl(myptr, 1, L);                        // first edge of the row after it
+    float* o = out + r0 * ld_out + col;
+    // ids of up to U edges per batch: lane j < U of the slot loads one, all lanes read them back by
+    // shuffle; the NEXT batch's ids are requested before this batch's rows (one round trip per batch)
+    int idn = 0;
+    if (e_begin < e_end) {
+        const int ej = e_begin + (sub & (U - 1));
+        idn = row_id[ej < e_end ? ej : e_end - 1];
+    }
+    for (int e0 = e_begin; e0 < e_end; e0 += U) {
+        const int idv = idn;
+        {
+            const int ej = e0 + U + (sub & (U - 1));
+            idn = row_id[ej < e_end ? ej : e_end - 1];                        // clamped, unconditional
+        }
+        float4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int id = __shfl(idv, j, L);
+            v[j] = col_ok ? tipk_ld4(table + (int64_t)id * ld_table + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + j;
+            if (e < e_end) {
+                while (e >= next) {                        // rows that end before this edge (also empty ones)
+                    if (col_ok) tipk_st4(o + (int64_t)row * ld_out, acc);
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ++row;
+                    next = __shfl(myptr, row + 1 < nr ? row + 1 : nr, L);
+                }
+                acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+            }
+        }
+    }
+    for (; row < nr; ++row) {                              // the last row with edges and any empty rows behind it
+        if (col_ok) tipk_st4(o + (int64_t)row * ld_out, acc);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int L>
+int launch_rows_csr(const float* table, int64_t ld_table, const int32_t* row_ptr, const int32_t* row_id, int64_t n_out,
+                    float* out, int64_t ld_out, int d, hipStream_t st) {
+    const int rp = L <= 16 ? L - 1 : 16;                   // rows per slot (rp + 1 pointers on the slot's L lanes)
+    const int64_t tasks = tipk_ceil_div(n_out, rp);
+    const int64_t waves = tipk_ceil_div(tasks, TIPK_WAVE / L);
+    const int64_t blocks = tipk_ceil_div(waves, 4);
+    if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    hipLaunchKernelGGL((gather_rows_csr_kernel<L>), dim3((unsigned)blocks), dim3(256), 0, st, table, ld_table, row_ptr,
+                       row_id, n_out, out, ld_out, d, rp);
+    TIPK_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int tipk_gather_rows_csr(const float* table, int64_t ld_table, const int32_t* row_ptr, const int32_t* row_id,
+                                    int64_t n_out, float* out, int64_t ld_out, int d, tipk_stream_t stream) {
+    if (n_out < 0 || d < 8 || d > 256 || d % 4 != 0) return n_out < 0 || d <= 0 ? TIPK_EINVAL : TIPK_EUNSUPPORTED;
+    if (n_out == 0) return TIPK_OK;
+    if (!table || !row_ptr || !out || ld_table % 4 != 0 || ld_out % 4 != 0 ||      // row_id may be NULL for E = 0
+        (reinterpret_cast<uintptr_t>(table) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return TIPK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int lanes = 2;
+    while (lanes < d / 4) lanes *= 2;
+    switch (lanes) {
+        case 2: return launch_rows_csr<2>(table, ld_table, row_ptr, row_id, n_out, out, ld_out, d, st);
+        case 4: return launch_rows_csr<4>(table, ld_table, row_ptr, row_id, n_out, out, ld_out, d, st);
+        case 8: return launch_rows_csr<8>(table, ld_table, row_ptr, row_id, n_out, out, ld_out, d, st);
+        case 16: return launch_rows_csr<16>(table, ld_table, row_ptr, row_id, n_out, out, ld_out, d, st);
+        case 32: return launch_rows_csr<32>(table, ld_table, row_ptr, row_id, n_out, out, ld_out, d, st);
+        default: return launch_rows_csr<64>(table, ld_table, row_ptr, row_id, n_out, out, ld_out, d, st);
+    }
+}

@@ -25,10 +25,20 @@
 #include <stdlib.h>
 #include "tipk_common.h"
 
+#ifdef TIPK_DEBUG
+// debug builds only (make debug): per-wave cycle stamps of the last rel_gather launch, read back by
+// tipk_debug_rg_stamps (tools/rg_stamps.py).  [workgroup][wave][6] = { total, position loops, commit
+// (barrier to barrier), waiting at the unit's first barrier, prologue, epilogue }.  Nothing here exists in the release library.
+__device__ unsigned long long tipk_rg_stamps[512 * 16 * 8];
+#define RG_STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+#else
+#define RG_STAMP(var)
+#endif
+
 namespace {
 
 constexpr int RG_CHUNK_MAX = 16384;    // edge ids staged per pass (uint16: 32 KB); 8192 when that lets two workgroups share a CU
-constexpr int RG_META = 64;            // unit descriptors staged per batch (LDS: 2 KB)
+constexpr int RG_META = 16;            // unit descriptors staged per batch (LDS: 512 B)
 
 struct RgArgs {
     const float* table; int64_t ld_t;
@@ -39,23 +49,33 @@ struct RgArgs {
     float* out; int64_t ld_out;
     const float* row_scale;            // BWD: g' = row_scale[node] * table[node] applied while staging (nullable)
     int chunk;                         // ids staged per pass (8192 or 16384)
+    int idx_mul;                       // byte offset of a table row = idx value * idx_mul (plan stores node * idx_unit)
     int dbg;
 };
 
-// TU = float4 of one relation's table per thread (ceil(n_nodes*dc/4 / 1024)); it sizes the register
-// prefetch buffer, so it is a template parameter (a fixed 8 spills at 128 VGPRs).
-template <int L, bool BWD, int TU>
+// TU = float4 of one relation's table per thread (ceil(n_nodes*dc/4 / 1024)): LDS-DMA instructions per thread
+// and unit (forward pass).
+template <int L, bool BWD, int TU, bool UNIT>
 __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NS = 1024 / L;                       // slots per workgroup
     const int t = threadIdx.x;
     const int n_nodes = a.n_nodes, dc = a.dc;
-    const int ldt = dc + 4;                            // odd multiple of 16 B: ds_read_b128 spreads over banks
-    const int q4 = dc >> 2;                            // float4 per row (== L)
-    float* tab = lds;                                                   // [n_nodes + 1][dc+4], last row = 0
-    float* accl = tab + (int64_t)(n_nodes + 1) * ldt;                                  // FWD: [n_nodes][dc]
-    int32_t* run_l = reinterpret_cast<int32_t*>(accl + (BWD ? 0 : (int64_t)n_nodes * dc));     // [n_nodes][2]
-    uint16_t* node_l = reinterpret_cast<uint16_t*>(run_l + ((2 * n_nodes + 3) & ~3));  // [n_nodes] (+pad)
+    const int ldt = dc;                                // unpadded power-of-two rows: a row's 64-byte quarter of the 64 banks is (node mod C);
+                                                       // the PLAN orders every run so that the slots of one ds_read_b128 lane group hit different
+                                                       // quarters (tip_amd/plan.py `bank_rotation`) -- padding only randomises the conflicts
+    constexpr int q4 = L;                              // float4 per row of a column block (compile-time: the row/column
+                                                       // split of a linear index below is a shift, not a 40-instruction division)
+    // FWD: TWO table images -- the next unit's rows arrive by LDS-DMA (global_load_lds_dwordx4: no
+    // registers, no copy pass) into the image the previous unit used, while the current unit is gathered
+    float* tab = lds;                                                   // [n_nodes + 1][dc], last row = 0
+    const int tab_floats = (n_nodes + 1) * ldt;
+    float* accl = tab + (BWD ? 1 : 2) * (int64_t)tab_floats;                           // FWD: [n_nodes][dc]
+    // run table in LDS: one word per position = (begin / 8) | (length / 8) << 16 (both are multiples of 8 ids;
+    // a unit has < 2^19 ids) -- half the bytes of the plan's int32 pairs, which is what lets a second table
+    // image fit next to a 16 K id chunk
+    uint32_t* run_l = reinterpret_cast<uint32_t*>(accl + (BWD ? 0 : (int64_t)n_nodes * dc));   // [n_nodes]
+    uint16_t* node_l = reinterpret_cast<uint16_t*>(run_l + ((n_nodes + 3) & ~3));      // [n_nodes] (+pad)
     const int RG_CHUNK = a.chunk;
     uint16_t* idx_l = node_l + ((n_nodes + 7) & ~7);                                   // [chunk], 16-B aligned
     // unit descriptors of this workgroup, staged once: reading them from global memory per unit cost
@@ -72,60 +92,66 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
     // (one workgroup per CU: there is no other wave to hide it).
     // (named scalars, not arrays: hipcc keeps small arrays that are written in one lambda and read in
     // another in scratch memory, which puts a vmcnt(0) wait right behind every prefetch load)
-    float4 tv0, tv1, tv2, tv3, tv4, tv5, tv6, tv7;
-    int rv0 = 0, rv1 = 0;
+    int2 rv = make_int2(0, 0);
     uint16_t nv = 0;
     uint4 iv0, iv1;
     const int total4 = n_nodes * q4;
-    // All prefetch loads are UNCONDITIONAL (indices clamped into the valid range): a load inside an
-    // exec-masked branch makes hipcc wait vmcnt(0) at the end of the branch, which would serialise the
-    // pipeline again.  Out-of-range lanes simply re-read the last valid element and drop it in commit.
-#define RG_TLOAD(U, V)                                                         \
-    if (TU > U) {                                                              \
-        int i = U * 1024 + t;                                                  \
-        i = i < total4 ? i : total4 - 1;                                       \
-        const int r = i / q4, c = (i - r * q4) * 4;                            \
-        V = tipk_ld4(src + (int64_t)r * a.ld_t + c);                           \
-    }
-#define RG_TSTORE(U, V)                                                        \
-    if (TU > U) {                                                              \
-        const int i = U * 1024 + t;                                            \
-        if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * ldt + c, V); } \
-    }
-    auto prefetch = [&](const int32_t* m) {            // m = the unit's descriptor (in LDS)
-        const int unit = m[0], ne = m[3];
-        const int64_t off = (int64_t)(uint32_t)m[4] | ((int64_t)m[5] << 32);
-        const int32_t* rsrc = a.runs + (int64_t)unit * n_nodes * 2;
-        rv0 = rsrc[t < 2 * n_nodes ? t : 2 * n_nodes - 1];
-        rv1 = rsrc[1024 + t < 2 * n_nodes ? 1024 + t : 2 * n_nodes - 1];
-        nv = a.node_at[(int64_t)unit * n_nodes + (t < n_nodes ? t : n_nodes - 1)];
-        const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
-        const int last = n8 > 0 ? n8 - 1 : 0;
+    // The small per-unit arrays (run table, node order, first id chunk) are prefetched into registers one
+    // unit ahead; their loads are UNCONDITIONAL (indices clamped into the valid range): a load inside an
+    // exec-masked branch makes hipcc wait vmcnt(0) at the end of the branch.  The TABLE (41 KB per unit at
+    // BioSNAP) does not pass through registers: measured with in-kernel stamps (tools/rg_stamps.py), the
+    // register-staged version spent 36 % of a wave's life behind the s_waitcnt vmcnt that hipcc put after the
+    // prefetch (it moved half-loaded table registers around) and 11 % writing them to LDS.
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void global_void_t;
+    // descriptor words are wave-uniform: reading them through readfirstlane keeps the address arithmetic of
+    // the prefetches on the scalar unit (stamps: issuing a unit's prefetch cost 1 200 cycles per wave with
+    // 64-bit vector address math, 13 % of the forward launch)
+    auto sget = [&](const int32_t* m, int k) { return __builtin_amdgcn_readfirstlane(m[k]); };
+    // the ids of one chunk of one unit -> iv0 / iv1 (the plan pads the id array by a whole chunk, so the
+    // loads are unconditional and unclamped; words past the unit's end are never used)
+    auto prefetch_ids = [&](const int32_t* m, int cb) {
+        const int64_t off = ((int64_t)(uint32_t)sget(m, 4) | ((int64_t)sget(m, 5) << 32)) + cb;
         const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + off);
-        iv0 = isrc[t < n8 ? t : last];
-        iv1 = isrc[1024 + t < n8 ? 1024 + t : last];
+        iv0 = isrc[t];
+        iv1 = isrc[1024 + t];
+    };
+    auto prefetch_unit = [&](const int32_t* m, int which) {  // run table, node order, table image (by LDS-DMA)
+        const int unit = sget(m, 0);
+        const int tc = t < n_nodes ? t : n_nodes - 1;
+        rv = reinterpret_cast<const int2*>(a.runs + (int64_t)unit * n_nodes * 2)[tc];
+        nv = (a.node_at + (int64_t)unit * n_nodes)[tc];
         if (!BWD) {
-            const float* src = table + (int64_t)m[1] * n_nodes * a.ld_t;
-            RG_TLOAD(0, tv0) RG_TLOAD(1, tv1) RG_TLOAD(2, tv2) RG_TLOAD(3, tv3)
-            RG_TLOAD(4, tv4) RG_TLOAD(5, tv5) RG_TLOAD(6, tv6) RG_TLOAD(7, tv7)
+            // the LDS image is the linear order of the float4 index i = row * L + column/4, so one
+            // wave-instruction's 64 x 16 bytes land contiguously (destination = wave-uniform base + lane * 16)
+            const float* src = table + (int64_t)sget(m, 1) * n_nodes * a.ld_t;
+            float* dst = tab + (int64_t)which * tab_floats;
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int i = u * 1024 + t;
+                if (i < total4) {
+                    const int r = i / q4, c = (i - r * q4) * 4;
+                    __builtin_amdgcn_global_load_lds((global_void_t*)(src + (uint32_t)(r * (int)a.ld_t + c)),
+                                                     (lds_void_t*)(dst + (int64_t)(u * 1024 + (t & ~63)) * 4), 16, 0, 0);
+                }
+            }
         }
     };
-    auto commit = [&](int ne) {                        // registers -> LDS
-        if (t < 2 * n_nodes) run_l[t] = rv0;
-        if (1024 + t < 2 * n_nodes) run_l[1024 + t] = rv1;
-        if (t < n_nodes) node_l[t] = nv;
-        const int n8 = ((ne < RG_CHUNK ? ne : RG_CHUNK) + 7) >> 3;
+    auto commit_ids = [&]() {                          // the whole buffer (entries past the chunk are never read)
         uint4* idst = reinterpret_cast<uint4*>(idx_l);
-        if (t < n8) idst[t] = iv0;
-        if (1024 + t < n8) idst[1024 + t] = iv1;
-        if (!BWD) {
-            RG_TSTORE(0, tv0) RG_TSTORE(1, tv1) RG_TSTORE(2, tv2) RG_TSTORE(3, tv3)
-            RG_TSTORE(4, tv4) RG_TSTORE(5, tv5) RG_TSTORE(6, tv6) RG_TSTORE(7, tv7)
+        idst[t] = iv0;
+        if (RG_CHUNK > 8192) idst[1024 + t] = iv1;     // wave-uniform
+    };
+    auto commit_unit = [&]() {
+        if (t < n_nodes) {
+            run_l[t] = ((uint32_t)rv.x >> 3) | (((uint32_t)rv.y >> 3) << 16);
+            node_l[t] = nv;
         }
     };
-#undef RG_TLOAD
-#undef RG_TSTORE
-    if (t < ldt) tab[(int64_t)n_nodes * ldt + t] = 0.f;                    // the sentinel's row
+    if (t < ldt) {                                                         // the sentinel's row (of both images)
+        tab[(int64_t)n_nodes * ldt + t] = 0.f;
+        if (!BWD) tab[(int64_t)tab_floats + (int64_t)n_nodes * ldt + t] = 0.f;
+    }
     if (!BWD) {
         for (int i = t; i < n_nodes * q4; i += 1024) tipk_st4(accl + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     } else {                                           // g' is staged once and stays for the whole launch
@@ -147,40 +173,61 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
         }
     }
     const int wg = blockIdx.x;
+#ifdef TIPK_DEBUG
+    unsigned long long st_loop = 0, st_commit = 0, st_wait = 0, st_pref = 0, st_reload = 0, st_first = 0;
+    RG_STAMP(st_t0);
+#endif
     const int ri0 = a.wg_unit_ptr[wg], ri1 = a.wg_unit_ptr[wg + 1];
+#ifdef TIPK_DEBUG
+    const unsigned long long st_pro = __builtin_readcyclecounter() - st_t0;
+#endif
     for (int rb = ri0; rb < ri1; rb += RG_META) {      // batches of RG_META units (one batch in practice)
     const int rn = ri1 - rb < RG_META ? ri1 - rb : RG_META;
     __syncthreads();                                   // the previous batch's descriptors are no longer read
     if (t < rn * 8) meta_l[t] = a.unit_meta[(int64_t)rb * 8 + t];
     __syncthreads();
-    prefetch(meta_l);
+    prefetch_unit(meta_l, 0);
+    prefetch_ids(meta_l, 0);
     for (int ri = 0; ri < rn; ++ri) {
         const int32_t* m = meta_l + ri * 8;            // a work unit: one relation, or a share of a big one
-        const int npos = m[2], ne = m[3];
-        const int64_t e0 = (int64_t)(uint32_t)m[4] | ((int64_t)m[5] << 32);   // multiple of 8 ids: 16-byte aligned
-        const int64_t row0 = (int64_t)m[1] * n_nodes;
+        const int npos = sget(m, 2), ne = sget(m, 3);
+        const int64_t row0 = (int64_t)sget(m, 1) * n_nodes;
+        RG_STAMP(st_a);
+#ifdef TIPK_DEBUG
+        if (st_first == 0) st_first = st_a - st_t0;
+#endif
         __syncthreads();                               // readers of the previous unit are done
-        commit(ne);
+        RG_STAMP(st_b);
+        commit_unit();
+        commit_ids();
         __syncthreads();
-        if (ri + 1 < rn && !TIPK_DBG(a.dbg & 2)) prefetch(m + 8);          // in flight during the compute below
+        RG_STAMP(st_c);
+#ifdef TIPK_DEBUG
+        st_wait += st_b - st_a;
+        st_commit += st_c - st_b;
+#endif
+        const bool more = ri + 1 < rn && !TIPK_DBG(a.dbg & 2);
+        if (more) prefetch_unit(m + 8, (ri + 1) & 1);  // in flight during the compute below
+        asm volatile("" ::: "memory");                // hipcc otherwise sinks some of the DMA issues below the position loops
+#ifdef TIPK_DEBUG
+        st_pref += __builtin_readcyclecounter() - st_c;
+#endif
         for (int cb = 0; cb == 0 || cb < ne; cb += RG_CHUNK) {
             const int cn = ne - cb < RG_CHUNK ? ne - cb : RG_CHUNK;
-            if (cb > 0) {                              // rare: a relation with more than RG_CHUNK ids
+            if (cb > 0) {                              // a unit with more ids than one chunk: the next chunk was
+                RG_STAMP(st_r0);                       // requested into registers while the previous one was walked
                 __syncthreads();
-                const uint4* isrc = reinterpret_cast<const uint4*>(a.idx + e0 + cb);
-                uint4* idst = reinterpret_cast<uint4*>(idx_l);
-                const int n8 = (cn + 7) >> 3;
-                const int last = n8 > 0 ? n8 - 1 : 0;
-                const uint4 j0 = isrc[t < n8 ? t : last];
-                const uint4 j1 = isrc[1024 + t < n8 ? 1024 + t : last];
-                // unconditional stores (the whole buffer; entries past n8 are never read): a store under
-                // `if (t < n8)` leaves the load pending on the not-taken path and the compiler then puts
-                // a vmcnt(0) wait into the position loop below, which would also wait for the next
-                // unit's prefetch -- i.e. serialise staging and compute
-                idst[t] = j0;
-                if (RG_CHUNK > 8192) idst[1024 + t] = j1;                    // wave-uniform
+                commit_ids();
                 __syncthreads();
+#ifdef TIPK_DEBUG
+                st_reload += __builtin_readcyclecounter() - st_r0;
+#endif
             }
+            // ids of the NEXT stage (next chunk of this unit, or the first chunk of the next unit) travel
+            // while this chunk is walked: no id load is ever waited for with nothing else to do
+            if (cb + RG_CHUNK < ne) prefetch_ids(m, cb + RG_CHUNK);
+            else if (more) prefetch_ids(m + 8, 0);
+            asm volatile("" ::: "memory");
             if (TIPK_DBG(a.dbg & 1)) continue;
             // Runs are short (BioSNAP: 13.6 padded ids = 1.7 steps on average), so what a slot does AROUND
             // a run -- fetch (begin, length) and the node, read-modify-write the accumulator -- is a chain
@@ -188,24 +235,25 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
             // therefore requested one band ahead (one 8-byte read + the node), and the forward pass
             // requests the old accumulator value before the run instead of after it.
             if (npos <= 0) continue;
+            RG_STAMP(st_l0);
             int p_next = slot;                          // band 0 is ascending
-            int2 run_next;
+            uint32_t run_next;
             unsigned node_next;
             {
                 const int pc = p_next < npos ? p_next : npos - 1;
-                run_next = *reinterpret_cast<const int2*>(run_l + 2 * pc);
+                run_next = run_l[pc];
                 node_next = node_l[pc];
             }
             for (int pb = 0, band = 0; pb < npos; pb += NS, ++band) {
                 // snake deal of the length-sorted rows: band 0 ascending, band 1 descending, ... so the
                 // slot that got the longest row of one band gets the shortest of the next
                 const int p = p_next;
-                const int b = run_next.x, len = run_next.y;
+                const int b = (int)(run_next & 0xffffu) << 3, len = (int)(run_next >> 16) << 3;
                 const unsigned node = node_next;
                 p_next = pb + NS + (((band + 1) & 1) ? NS - 1 - slot : slot);
                 {
                     const int pc = p_next < npos ? p_next : npos - 1;         // clamped, unconditional
-                    run_next = *reinterpret_cast<const int2*>(run_l + 2 * pc);
+                    run_next = run_l[pc];
                     node_next = node_l[pc];
                 }
                 if (p >= npos) continue;
@@ -223,22 +271,35 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                 // (the next step's ids are requested before this step's rows; row address = 24-bit multiply:
                 // a plain `idj * ldt` compiled to the quarter-rate v_mul_lo_u32 -- 8 of them were half of
                 // the loop's VALU time, which is what bounds the kernel together with the LDS pipe)
-                const char* tabb = reinterpret_cast<const char*>(tab + c0);
-                const unsigned ldt4 = (unsigned)ldt * 4u;
-                uint4 pk = lo < hi ? *reinterpret_cast<const uint4*>(idx_l + lo) : make_uint4(0, 0, 0, 0);
+                const char* tabb = reinterpret_cast<const char*>(tab + (BWD ? 0 : (ri & 1) * tab_floats) + c0);
+                const unsigned ldt4 = (unsigned)a.idx_mul;                   // 1 when the plan pre-scaled the ids to byte offsets
+                // The loop is bound by instruction ISSUE (PMC, profiles/r02a_lds.json: the SIMDs issue 72 % of
+                // the time, VALU 41 % + scalar/waits 15 % + LDS 12 %), so every step is kept to: one id read
+                // through a running pointer (reading 16 bytes past the run is harmless: the id buffer is
+                // followed by the descriptor buffer), 8 SDWA adds that turn the pre-scaled 16-bit ids into row
+                // addresses, 8 row reads, ONE wait for all of them, 16 packed adds (rows added last to first).
+                const uint16_t* idp = idx_l + lo;
+                uint4 pk = lo < hi ? *reinterpret_cast<const uint4*>(idp) : make_uint4(0, 0, 0, 0);
                 for (int eb = lo; eb < hi; eb += 8) {
+                    // addresses first, THEN the next ids into the same registers (no copy, no wait for the
+                    // read that was just issued), then the rows
                     const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
-                    const int nxt = eb + 8 < hi ? eb + 8 : eb;               // clamped: the last step re-reads its own ids
-                    pk = *reinterpret_cast<const uint4*>(idx_l + nxt);
-                    __builtin_amdgcn_sched_barrier(0);                       // keep the id read ahead of the row reads
-                    float4 v[8];
+                    const char* ad[8];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
                         const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
-                        v[jj] = *reinterpret_cast<const float4*>(tabb + __umul24(idj, ldt4));
+                        ad[jj] = UNIT ? tabb + idj : tabb + __umul24(idj, ldt4);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    idp += 8;
+                    pk = *reinterpret_cast<const uint4*>(idp);               // next step's ids (unconditional)
+                    float4 v[8];
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const float4*>(ad[jj]);
+                    // the LAST row requested is added first: its arrival implies all the others (LDS returns in
+                    // order), so the step has one s_waitcnt instead of eight counted ones (each is an issue slot)
+#pragma unroll
+                    for (int jj = 7; jj >= 0; --jj) {
                         acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w;
                     }
                 }
@@ -254,9 +315,13 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
                     tipk_st4(accl + node * dc + c0, acc);
                 }
             }
+#ifdef TIPK_DEBUG
+            st_loop += __builtin_readcyclecounter() - st_l0;
+#endif
         }
     }
     }
+    RG_STAMP(st_epi);
     if (!BWD) {
         __syncthreads();
         float* o = out + (int64_t)wg * n_nodes * a.ld_out;
@@ -265,10 +330,27 @@ __global__ __launch_bounds__(1024) void rel_gather_kernel(RgArgs a) {
             tipk_st4(o + (int64_t)r * a.ld_out + c, tipk_ld4(accl + r * dc + c));
         }
     }
+#ifdef TIPK_DEBUG
+    if ((t & 63) == 0) {
+        const int w = (blockIdx.y * gridDim.x + blockIdx.x) * 16 + (t >> 6);
+        (void)st_pro;
+        if (w < 512 * 16) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            tipk_rg_stamps[w * 8 + 0] = now - st_t0;
+            tipk_rg_stamps[w * 8 + 1] = st_loop;
+            tipk_rg_stamps[w * 8 + 2] = st_commit;
+            tipk_rg_stamps[w * 8 + 3] = st_wait;
+            tipk_rg_stamps[w * 8 + 4] = st_first;
+            tipk_rg_stamps[w * 8 + 5] = now - st_epi;
+            tipk_rg_stamps[w * 8 + 6] = st_pref;
+            tipk_rg_stamps[w * 8 + 7] = st_reload;
+        }
+    }
+#endif
 }
 
 inline int64_t rel_gather_lds(int64_t n_nodes, int dc, bool bwd, int chunk) {
-    return (n_nodes + 1) * (dc + 4) * 4 + (bwd ? 0 : n_nodes * dc * 4) + ((2 * n_nodes + 3) & ~3LL) * 4 +
+    return (bwd ? 1 : 2) * (n_nodes + 1) * dc * 4 + (bwd ? 0 : n_nodes * dc * 4) + ((n_nodes + 3) & ~3LL) * 4 +
            ((n_nodes + 7) & ~7LL) * 2 + (int64_t)chunk * 2 + RG_META * 8 * 4;
 }
 
@@ -303,7 +385,7 @@ inline int rg_want_occ() { const int o = tipk_option(TIPK_OPT_RG_OCCUPANCY); ret
 template <int L, bool BWD, int TU>
 int launch_rg3(const RgArgs& a, int n_wg, int split, hipStream_t st) {
     const size_t lds = (size_t)rel_gather_lds(a.n_nodes, a.dc, BWD, a.chunk);
-    auto kern = rel_gather_kernel<L, BWD, TU>;
+    auto kern = a.idx_mul == 1 ? rel_gather_kernel<L, BWD, TU, true> : rel_gather_kernel<L, BWD, TU, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return tipk_hip_status(e);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)split), dim3(1024), lds, st, a);
@@ -321,8 +403,18 @@ int launch_rg(bool bwd, const RgArgs& a, int n_wg, int split, hipStream_t st) {
 
 }  // namespace
 
+#ifdef TIPK_DEBUG
+extern "C" int tipk_debug_rg_stamps(unsigned long long* host_out /* [512*16*4] */) {
+    return tipk_hip_status(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tipk_rg_stamps), sizeof(unsigned long long) * 512 * 16 * 8));
+}
+#endif
+
 extern "C" int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward) {
     return rel_gather_shape(n_nodes, d, backward != 0, rg_want_occ()).split;
+}
+
+extern "C" int tipk_rel_gather_chunk(int64_t n_nodes, int d, int backward) {
+    return rel_gather_shape(n_nodes, d, backward != 0, rg_want_occ()).chunk;
 }
 
 extern "C" int tipk_rel_gather_occupancy(int64_t n_nodes, int d, int backward) {
@@ -331,7 +423,7 @@ extern "C" int tipk_rel_gather_occupancy(int64_t n_nodes, int d, int backward) {
 
 extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                                int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* unit_meta,
-                               const uint16_t* idx, const int32_t* runs, const uint16_t* node_at,
+                               const uint16_t* idx, int idx_unit, const int32_t* runs, const uint16_t* node_at,
                                const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream) {
     if (n_wg <= 0 || n_wg > 65535 || !table || !wg_unit_ptr || !unit_meta || !idx || !runs || !node_at || !out ||
         (reinterpret_cast<uintptr_t>(idx) & 15))
@@ -348,6 +440,9 @@ extern "C" int tipk_rel_gather(int backward, const float* table, int64_t ld_tabl
     a.idx = idx; a.runs = runs; a.node_at = node_at; a.out = out; a.ld_out = ld_out;
     a.row_scale = backward ? row_scale : nullptr;
     a.chunk = shape.chunk;
+    // idx holds node * idx_unit (the sentinel: n_nodes * idx_unit <= 65535); a row is dc * 4 bytes
+    if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || (int64_t)n_nodes * idx_unit > 65535) return TIPK_EINVAL;
+    a.idx_mul = a.dc * 4 / idx_unit;
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_RG_DEBUG));
     hipStream_t st = (hipStream_t)stream;
     switch (a.dc / 4) {

@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, group_slots_for,
+from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_csr_plan, group_slots_for,
                    relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
@@ -315,8 +315,17 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         # launch = (workgroups x column blocks), sized for 1 or 2 workgroups per CU (tipk_rel_gather_occupancy)
         wg_f = (ops.rel_gather_wgs(n_nodes, d_out, False, n_cu) if on_dev else 0) or n_cu
         wg_b = (ops.rel_gather_wgs(n_nodes, d_out, True, n_cu) if on_dev else 0) or n_cu
-        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f)
-        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True)
+        # lanes per slot of the launch (columns of one column block / 4): the plans order every run for
+        # conflict-free LDS reads of that shape and pre-scale the ids to row offsets
+        split_f = ops.rel_gather_split(n_nodes, d_out, False) if on_dev else 0
+        split_b = ops.rel_gather_split(n_nodes, d_out, True) if on_dev else 0
+        lanes_f = (d_out // split_f) // 4 if split_f else None
+        lanes_b = (d_out // split_b) // 4 if split_b else None
+        if os.environ.get('TIPK_RG_PLAIN_ORDER'):
+            lanes_f = lanes_b = None
+        cap_f = None           # (cutting forward units to the id chunk was measured slower: smaller units fill fewer bands)
+        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
+        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
     def fwd_plan():
         # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by
         # relation block, so that a row of Y gathered by several edges crosses the fabric once
@@ -330,7 +339,8 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     # the generic plans are built on first use: with the relation-local kernels they are never needed
     return ops.AggGraph(fwd_plan,
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
-                        (1.0 / deg).contiguous(), rl_fwd, rl_bwd)
+                        (1.0 / deg).contiguous(), rl_fwd, rl_bwd,
+                        csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'))
 
 
 class _RGCNBase(nn.Module):

@@ -129,6 +129,19 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
     return out
 
 
+def gather_rows_csr(plan, table):
+    """out[n_out, d] = per-row sums over a CsrPlan (include/tipk.h section 1c)."""
+    table = _f32c(table)
+    require_device(table, plan.row_ptr)
+    d = table.shape[1]
+    assert table.shape[0] == plan.n_table, (table.shape, plan.n_table)
+    out = torch.empty((plan.n_out, d), dtype=torch.float32, device=table.device)
+    with _timed('gather_rows_csr[%s,d=%d]' % (plan.tag, d)):
+        check(lib().tipk_gather_rows_csr(ptr(table), table.stride(0), ptr(plan.row_ptr), ptr(plan.row_id), plan.n_out,
+                                         ptr(out), out.stride(0), d, stream_ptr(table.device)), 'tipk_gather_rows_csr')
+    return out
+
+
 def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, addend=None, relu=False):
     """out = relu?(alpha * row_scale (.) sum_s slabs[s] + addend (+ out)): ordered, deterministic
     (include/tipk.h section 2).  slabs: [S, rows, cols]."""
@@ -163,6 +176,10 @@ def rel_gather_wgs(n_nodes, d, backward, n_cu):
     return max(1, occ * n_cu // split)
 
 
+def rel_gather_chunk(n_nodes, d, backward):
+    return int(lib().tipk_rel_gather_chunk(n_nodes, d, int(backward)))
+
+
 def rel_gather_usable(rp, n_nodes, d, backward):
     return rp is not None and rel_gather_split(n_nodes, d, backward) > 0
 
@@ -181,7 +198,7 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
         out = torch.empty((rp.n_wg, n, d), dtype=torch.float32, device=table.device)
     with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
         check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
-                                    ptr(rp.unit_meta), ptr(rp.idx), ptr(rp.runs), ptr(rp.node_at),
+                                    ptr(rp.unit_meta), ptr(rp.idx), rp.idx_unit, ptr(rp.runs), ptr(rp.node_at),
                                     ptr(row_scale) if backward else None, ptr(out), d, stream_ptr(table.device)),
               'tipk_rel_gather')
     if backward or not reduce:
@@ -641,10 +658,12 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
-    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False):
+    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
-        generic D-D plans are only needed where the relation-local kernel does not apply)."""
+        generic D-D plans are only needed where the relation-local kernel does not apply).
+        csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
         self._fwd, self._bwd, self.scale = fwd, bwd, scale
+        self._csr_bwd = csr_bwd
         self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
 
@@ -659,6 +678,12 @@ class AggGraph(object):
         if callable(self._bwd):
             self._bwd = self._bwd()
         return self._bwd
+
+    @property
+    def csr_bwd(self):
+        if callable(self._csr_bwd):
+            self._csr_bwd = self._csr_bwd()
+        return self._csr_bwd
 
 
 # ---------------------------------------------------------------------------------------------
@@ -821,7 +846,11 @@ class _RGCN(torch.autograd.Function):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
-                g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
+                csr = graph.csr_bwd if (d_out % 4 == 0 and 8 <= d_out <= 256 and not os.environ.get('TIPK_NO_CSR')) else None
+                if csr is not None:                                      # R N short rows: contiguous streams, no descriptors
+                    g_y = gather_rows_csr(csr, gs).view(r, n * d_out)
+                else:
+                    g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
             # both consumers of dY in one pass over it (+ one grouped slab sum)
             g_att, g_xb = dy_products(g_y, att, xb2)
             g_xb = g_xb.view(nb, n, d_out)
