@@ -339,7 +339,9 @@ def main():
     if sharded:
         for name, prm in enc.named_parameters():               # identical replicas (att rows are shard-local)
             if not name.endswith('.att'):
-                dist.broadcast(prm.data, 0)
+                buf = prm.data.contiguous()                    # (conv weights are stored transposed: c10d wants contiguous)
+                dist.broadcast(buf, 0)
+                prm.data.copy_(buf)
         attach_shard(enc, shard)
     d = Data.from_dict({k: v for k, v in dd_rank.items() if k != 'dd_edge_index'}).to(dev)
     g_up = torch.randn(dd['n_drug'], dims['n_hid2'], generator=torch.Generator().manual_seed(0)).to(dev)

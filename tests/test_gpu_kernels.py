@@ -673,11 +673,11 @@ def test_gather_rows_csr_vs_reference(ops, d):
     want = execute_csr_reference(plan, table.double())
     dev_plan = build_csr_plan(out_row.to(DEV), tab_row.to(DEV), n_out, n_tab)
     got = ops.gather_rows_csr(dev_plan, table.to(DEV))
-    close(got, want, rtol=1e-5, atol=1e-5)
+    close(got, want, rtol=1e-4, atol=2e-4)                                   # a 400-term fp32 sum in the heavy row
     assert torch.equal(got, ops.gather_rows_csr(dev_plan, table.to(DEV)))
     # strided table view and an all-empty graph
     wide = torch.randn(n_tab, d + 8, generator=g).to(DEV)
     close(ops.gather_rows_csr(dev_plan, wide[:, 4:4 + d]), execute_csr_reference(plan, wide[:, 4:4 + d].cpu().double()),
-          rtol=1e-5, atol=1e-5)
+          rtol=1e-4, atol=2e-4)
     empty = build_csr_plan(torch.zeros(0, dtype=torch.long, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV), 13, n_tab)
     assert float(ops.gather_rows_csr(empty, table.to(DEV)).abs().max()) == 0.0

@@ -431,6 +431,9 @@ def gemm_group(jobs, slab_jobs=()):
 
 
 def transpose(x):
+    """x^T as a row-major tensor; a view when x is stored column-major already (no launch)."""
+    if x.dim() == 2 and x.t().is_contiguous() and x.dtype == torch.float32:
+        return x.t()
     x = _f32c(x).contiguous()
     require_device(x)
     out = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float32, device=x.device)
@@ -739,7 +742,8 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         g = _f32c(g)
         if ctx.identity:
-            return None, transpose(g)
+            (weight,) = ctx.saved_tensors
+            return None, (g.contiguous().t() if weight.t().is_contiguous() else transpose(g))
         x, weight = ctx.saved_tensors
         jobs = [gemm_job(g.t(), x)]
         if ctx.needs_input_grad[0]:
@@ -1011,7 +1015,9 @@ class _GCNConv(torch.autograd.Function):
         if ctx.has_bias and bias_parts is None:
             j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre)
         if ctx.identity:
-            g_w = transpose(g_table)
+            # d W = (d lin)^T: a VIEW when the parameter is stored transposed (tip_amd.layers._Lin), its strides
+            # then equal the parameter's, so the optimizer's fused / foreach paths apply
+            g_w = g_table.t() if weight.t().is_contiguous() else transpose(g_table)
             if bias_parts is not None:
                 return None, g_w, sum_slabs(bias_parts).view(-1), None, None
             if j_b is not None:
