@@ -212,10 +212,21 @@ def dd_aggregation_launches(enc, dev):
                      (lambda rp=rp, y=y: ops.rel_gather(rp, y, False, reduce=False))
                 out.append(('rel_gather[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'lds', fn))
             else:
-                plan = graph.bwd if bwd else graph.fwd
                 lanes = 1
                 while lanes < d // 4:
                     lanes *= 2
+                if bwd and d % 4 == 0 and 8 <= d <= 256 and not os.environ.get('TIPK_NO_CSR'):
+                    csr = graph.csr_bwd                        # the path _RGCN.backward takes on large graphs
+                    lanes = max(lanes, 2)
+                    rp = lanes - 1 if lanes <= 16 else 16
+                    tasks = -(-csr.n_out // rp)
+                    waves = -(-tasks // (64 // lanes))
+                    key = 'gather_rows_csr_kernel<%d' % lanes
+                    grid = '%dx1x1' % (-(-waves // 4) * 256)
+                    out.append(('gather_rows_csr[dd.bwd,d=%d]' % d, key, grid, d, 'hbm',
+                                lambda csr=csr, g=g: ops.gather_rows_csr(csr, g)))
+                    continue
+                plan = graph.bwd if bwd else graph.fwd
                 waves = -(-plan.items.shape[0] // (64 // lanes))
                 key = 'gather_sum_kernel<4, %d' % lanes
                 grid = '%dx1x1' % (-(-waves // 4) * 256)

@@ -476,7 +476,10 @@ def test_whole_model_pickle_roundtrip_after_forward(tmp_path):
     back = torch.load(path, weights_only=False)
     assert back.encoder.rgcn1._cache.value is None                   # caches were not pickled
     loss2 = back(neg)
-    assert torch.equal(loss2.detach(), loss.detach())
+    # (the objective's cross-workgroup sums are 256 float atomics per element: equal to ~1e-7, not bitwise --
+    # the encoder, which the embeddings come from, IS bitwise reproducible)
+    assert torch.equal(back.embeddings, model.embeddings)
+    assert abs(float(loss2.detach()) - float(loss.detach())) <= 1e-6 * abs(float(loss.detach()))
     assert np.array_equal(back.test(print_output=False), rec)
 
 
