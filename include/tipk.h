@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 5
+#define TIPK_ABI_VERSION 7
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -84,8 +84,10 @@ int         tipk_device_info(int device, int* n_cu, int* lds_bytes_per_cu, int* 
  *   or of d when d % 4 != 0) must be a multiple of 64 and <= 1024 (G = 128: d <= 32).
  * d = floats per row (d % 4 == 0: 4..256, or any d <= 64); ld_* = row strides in floats
  * (multiples of 4 when d % 4 == 0; table/out/partial 16-byte aligned in that case).
+ * n_table = rows of `table`: below 4 GB a gathered row is addressed as table base + 32-bit byte offset
+ * (one multiply per row instead of a 64-bit multiply-add); 0 = unknown (general path).
  */
-int tipk_gather_sum(const float* table, int64_t ld_table,
+int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_table /* rows of table (0 = unknown) */,
                     const int32_t* row_id, const float* edge_w /* nullable */,
                     const int32_t* items, int64_t n_items,
                     float* out, int64_t ld_out,
@@ -110,7 +112,8 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
  *     consecutive rows: one coalesced pointer load, contiguous ids, 8 gathered rows in flight, one
  *     contiguous output stream -- no work-item descriptors.  Edges sorted by output row (stable);
  *     row_ptr int32 [n_out + 1]; d % 4 == 0, 8 <= d <= 256. */
-int tipk_gather_rows_csr(const float* table, int64_t ld_table, const int32_t* row_ptr, const int32_t* row_id,
+int tipk_gather_rows_csr(const float* table, int64_t ld_table, int64_t n_table /* rows; table < 4 GB */,
+                         const int32_t* row_ptr, const int32_t* row_id,
                          int64_t n_out, float* out, int64_t ld_out, int d, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
@@ -306,12 +309,19 @@ int tipk_distmult_bwd(const float* g_score, const float* score,
  * positive triples and their negatives (same relation per position):
  *   loss = -mean log(sigma(pos)+1e-13) - mean log(1-sigma(neg)+1e-13)
  * loss_out[0] += loss (caller zeroes); if g_z/g_w are non-NULL they receive d loss / d z, d w
- * (accumulated; caller zeroes), so the backward pass is a scale by the upstream scalar. */
+ * (accumulated; caller zeroes), so the backward pass is a scale by the upstream scalar.
+ *
+ * workspace (nullable; tipk_distmult_workspace_bytes(...) bytes, 8-byte aligned, ZEROED before its first use;
+ * the call leaves it zeroed): with it -- and a task table, i.e. on the LDS-resident fast kernel -- the sums across
+ * workgroups of loss, d z and d w are 64-bit fixed-point integer atomics (exact, order-independent) converted by
+ * a finalize launch: the objective and its gradients are BITWISE REPRODUCIBLE from run to run (the float
+ * atomics of the default path differ at the 1e-7 level with the arrival order of 256 workgroups). */
+int64_t tipk_distmult_workspace_bytes(int64_t n_nodes, int k, int64_t n_rel);
 int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                        const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
                        int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
                        const int32_t* tasks, int64_t n_tasks,
-                       float* loss_out, float* g_z, float* g_w, tipk_stream_t stream);
+                       float* loss_out, float* g_z, float* g_w, void* workspace, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 4b. NNDecoder triple scoring (reference src/layers.py:598-637, the paper's DR-NN ablation; SURVEY

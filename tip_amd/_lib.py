@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 5
+ABI_VERSION = 7
 
 
 class TipkError(RuntimeError):
@@ -56,9 +56,9 @@ SIGNATURES = {
     'tipk_set_option': (_I, [C.c_char_p, _I]),
     'tipk_get_option': (_I, [C.c_char_p, C.POINTER(_I)]),
     'tipk_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
-    'tipk_gather_sum': (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
+    'tipk_gather_sum': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
-    'tipk_gather_rows_csr': (_I, [_P, _L, _P, _P, _L, _P, _L, _I, _P]),
+    'tipk_gather_rows_csr': (_I, [_P, _L, _L, _P, _P, _L, _P, _L, _I, _P]),
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
@@ -77,7 +77,8 @@ SIGNATURES = {
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),
     'tipk_distmult_fwd': (_I, [_P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P, _P, _P]),
-    'tipk_distmult_loss': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P]),
+    'tipk_distmult_workspace_bytes': (_L, [_L, _I, _L]),
+    'tipk_distmult_loss': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
     'tipk_pair_table_fwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_pair_table_bwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P]),
     'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _P, _P, _L, _P, _P, _I, _L, _P]),

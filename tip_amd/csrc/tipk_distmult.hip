@@ -196,7 +196,11 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     const float* __restrict__ z, int n_nodes, int k, const float* __restrict__ w, int n_rel,
     const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
     const IT* __restrict__ nu, const IT* __restrict__ nv, const float* __restrict__ g_score, int sig,
-    int64_t n_total, float* __restrict__ loss_out, float* __restrict__ g_z, float* __restrict__ g_w) {
+    int64_t n_total, float* __restrict__ loss_out, float* __restrict__ g_z, float* __restrict__ g_w,
+    unsigned long long* __restrict__ ws) {
+    // ws != NULL (fused objective only): the cross-workgroup sums of loss, d z and d w go through 64-bit FIXED-POINT
+    // integer atomics into `ws` (exact, order-independent) and det_finalize_kernel converts them: the training
+    // objective and its gradients are then bitwise reproducible; with float atomics they differ at ~1e-7.
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
     const int t = threadIdx.x;
     const int ld = k + 4;                                     // z image: float4 reads, 16-byte aligned rows
@@ -233,6 +237,21 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         if (bound > 0.f && bound < 3.0e38f) ex = 60 - (ilogbf(bound) + 1);
         ex = ex > 180 ? 180 : ex;
         scale = ldexp(1.0, ex);
+    }
+    // fixed-point scales of the deterministic path: identical in every workgroup (they depend on z and w only)
+    double scale_w = 1.0;
+    const double scale_l = 1125899906842624.0;                // 2^50: the objective is < 2^7
+    if (ws && MODE == 1) {
+        const float bw = 4.f * zmax * zmax;
+        int ex = 60;
+        if (bw > 0.f && bw < 3.0e38f) ex = 60 - (ilogbf(bw) + 1);
+        scale_w = ldexp(1.0, ex > 180 ? 180 : ex);
+        if (blockIdx.x == 0 && t == 0) {                      // the finalize kernel divides by them
+            const int64_t base = (int64_t)n_nodes * k + (int64_t)n_rel * k + 1;
+            reinterpret_cast<double*>(ws)[base] = scale;
+            reinterpret_cast<double*>(ws)[base + 1] = scale_w;
+            reinterpret_cast<double*>(ws)[base + 2] = scale_l;
+        }
     }
     __syncthreads();
     const int KL = k >> 2;                                    // lanes per position (power of two <= 16)
@@ -364,7 +383,10 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
             if (t < k) {
                 float tot = 0.f;
                 for (int wv = 0; wv < 16; ++wv) tot += red[wv * k + t];
-                atomicAdd(g_w + (int64_t)rel * k + t, tot);
+                if (ws && MODE == 1)
+                    atomicAdd(ws + (int64_t)n_nodes * k + (int64_t)rel * k + t, (unsigned long long)(long long)((double)tot * scale_w));
+                else
+                    atomicAdd(g_w + (int64_t)rel * k + t, tot);
             }
             __syncthreads();
         }
@@ -376,7 +398,8 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         if (t == 0) {
             float tot = 0.f;
             for (int wv = 0; wv < 16; ++wv) tot += red[16 * k + wv];
-            atomicAdd(loss_out, tot * inv_n);
+            if (ws) atomicAdd(ws + (int64_t)n_nodes * k + (int64_t)n_rel * k, (unsigned long long)(long long)((double)(tot * inv_n) * scale_l));
+            else atomicAdd(loss_out, tot * inv_n);
         }
     }
     if (want_grad) {
@@ -385,7 +408,8 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         for (int i = t; i < n_nodes * k; i += 1024) {
             const int r = i / k, c = i - r * k;
             const long long a = (long long)gzl[r * lg + c];
-            if (a != 0) atomicAdd(g_z + i, (float)((double)a * inv_scale));
+            if (ws && MODE == 1) { if (a != 0) atomicAdd(ws + i, (unsigned long long)a); }
+            else if (a != 0) atomicAdd(g_z + i, (float)((double)a * inv_scale));
         }
     }
 }
@@ -398,18 +422,42 @@ inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
     return *lds_bytes <= 158 * 1024;
 }
 
+// ws layout (u64 words): [n_nodes*k] d z | [n_rel*k] d w | [1] loss | 3 doubles: the three scales.
+// Converts, ADDS into the outputs (same contract as the float path) and zeroes the words again, so the caller's
+// workspace is reusable without a memset.
+__global__ __launch_bounds__(256) void det_finalize_kernel(unsigned long long* ws, int64_t n_z, int64_t n_w,
+                                                           float* loss_out, float* g_z, float* g_w) {
+    const double* sc = reinterpret_cast<const double*>(ws + n_z + n_w + 1);
+    const double inv_z = 1.0 / sc[0], inv_w = 1.0 / sc[1], inv_l = 1.0 / sc[2];
+    const int64_t total = n_z + n_w + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long a = (long long)ws[i];
+        if (a == 0) continue;
+        ws[i] = 0ull;
+        if (i < n_z) { if (g_z) g_z[i] += (float)((double)a * inv_z); }
+        else if (i < n_z + n_w) { if (g_w) g_w[i - n_z] += (float)((double)a * inv_w); }
+        else loss_out[0] += (float)((double)a * inv_l);
+    }
+}
+
 template <typename IT, int MODE>
 int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, int64_t n_rel, const int32_t* tasks,
                  int64_t n_tasks, const void* pu, const void* pv, const void* nu, const void* nv,
                  const float* g_score, int sig, int64_t n_total, float* loss_out, float* g_z, float* g_w,
-                 int64_t lds_bytes, hipStream_t st) {
+                 int64_t lds_bytes, hipStream_t st, unsigned long long* ws = nullptr) {
     auto kern = distmult_task_kernel<IT, MODE>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return tipk_hip_status(e);
     int64_t grid = n_tasks < 256 ? n_tasks : 256;              // one persistent workgroup per CU
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), (size_t)lds_bytes, st, z, (int)n_nodes, k, w, (int)n_rel,
                        tasks, (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, g_score, sig,
-                       n_total, loss_out, g_z, g_w);
+                       n_total, loss_out, g_z, g_w, MODE == 1 ? ws : nullptr);
+    if (ws && MODE == 1) {
+        const int64_t n_z = n_nodes * k, n_w = n_rel * k;
+        const int64_t blocks = tipk_ceil_div(n_z + n_w + 1, 256);
+        hipLaunchKernelGGL(det_finalize_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, ws, n_z,
+                           n_w, loss_out, g_z, g_w);
+    }
     TIPK_RETURN_LAUNCH();
 }
 
@@ -513,12 +561,19 @@ extern "C" int tipk_distmult_bwd(const float* g_score, const float* score, const
 #undef CALL
 }
 
+extern "C" int64_t tipk_distmult_workspace_bytes(int64_t n_nodes, int k, int64_t n_rel) {
+    if (n_nodes < 0 || k <= 0 || n_rel < 0) return 0;
+    return (n_nodes * k + n_rel * k + 1 + 3) * 8;
+}
+
 extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                                   const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
                                   int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
                                   const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
-                                  tipk_stream_t stream) {
+                                  void* workspace, tipk_stream_t stream) {
     if (n_triples <= 0 || k <= 0 || n_nodes < 0 || n_rel < 0 || n_tasks < 0) return TIPK_EINVAL;
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7)) return TIPK_EINVAL;
+    unsigned long long* ws = reinterpret_cast<unsigned long long*>(workspace);
     if (!z || !rel_w || !pos_u || !pos_v || !neg_u || !neg_v || !edge_type || !loss_out) return TIPK_EINVAL;
     if ((g_z == nullptr) != (g_w == nullptr)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -527,10 +582,10 @@ extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const 
     if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
         if (idx_bytes == 8)
             return launch_tasks<int64_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
-                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st);
+                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws);
         if (idx_bytes == 4)
             return launch_tasks<int32_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
-                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st);
+                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws);
         return TIPK_EINVAL;
     }
 #define CALL(IT, ET)                                                                                             \

@@ -42,6 +42,9 @@ struct Acc<4> {
     }
     __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
     __device__ __forceinline__ void load(const float* p) { v = tipk_ld4(p); }
+    __device__ __forceinline__ void load_off(const float* base, unsigned byte_off) {   // scalar base + 32-bit lane offset
+        v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+    }
     __device__ __forceinline__ void fma_acc(const Acc& o, float w) {
         v.x = fmaf(w, o.v.x, v.x); v.y = fmaf(w, o.v.y, v.y); v.z = fmaf(w, o.v.z, v.z); v.w = fmaf(w, o.v.w, v.w);
     }
@@ -63,6 +66,9 @@ struct Acc<1> {
     __device__ __forceinline__ void add_row(const float* p) { v += *p; }
     __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
     __device__ __forceinline__ void load(const float* p) { v = *p; }
+    __device__ __forceinline__ void load_off(const float* base, unsigned byte_off) {
+        v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+    }
     __device__ __forceinline__ void fma_acc(const Acc& o, float w) { v = fmaf(w, o.v, v); }
     __device__ __forceinline__ void add_shfl_xor(int o) { v += __shfl_xor(v, o); }
     __device__ __forceinline__ void epilogue(const Epilogue& ep, int row, int col) {
@@ -74,7 +80,11 @@ struct Acc<1> {
 };
 
 // GROUPED: the workgroup is exactly one block of G = blockDim / L items of a `group_slots` plan.
-template <int V, int L, bool HAS_W, bool GROUPED>
+// SMALL: the table is < 4 GB: a gathered row's address is the (scalar) table base + a 32-bit byte offset =
+// ONE 24-bit or 32-bit multiply per row; the general path pays a 64-bit multiply-add (three quarter-rate
+// v_mul_lo_u32 / v_mad_u64_u32 and two adds) per row, which made the narrow-row launches (P-P graph: 32- and
+// 16-float rows, 8 rows per wave-instruction) issue-bound rather than L2-bound.
+template <int V, int L, bool HAS_W, bool GROUPED, bool SMALL>
 __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
     const float* __restrict__ table, int64_t ld_table, const int32_t* __restrict__ row_id,
     const float* __restrict__ edge_w, const int4* __restrict__ items, int64_t n_items,
@@ -92,6 +102,8 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
     if (active) it = items[w];
     const int col = sub * V;
     const bool col_ok = col < d;
+    const unsigned ldb = (unsigned)ld_table * 4u;          // SMALL: row stride in bytes (table bytes < 2^32)
+    const float* table_c = table + (col_ok ? col : 0);
 
     Acc<V> acc;
     acc.zero();
@@ -145,7 +157,10 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 rows[j].zero();
-                if (ids[j] >= 0 && col_ok) rows[j].load(table + col + (int64_t)ids[j] * ld_table);
+                if (ids[j] >= 0 && col_ok) {
+                    if (SMALL) rows[j].load_off(table_c, (unsigned)ids[j] * ldb);
+                    else rows[j].load(table + col + (int64_t)ids[j] * ld_table);
+                }
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -236,7 +251,7 @@ int launch_finalize_small(const float* partial, const int32_t* rows, int64_t n_r
 template <int V, int L>
 int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, const float* edge_w,
                   const int32_t* items, int64_t n_items, float* out, int64_t ld_out, float* partial,
-                  Epilogue ep, int d, int group_slots, hipStream_t st) {
+                  Epilogue ep, int d, int group_slots, bool small, hipStream_t st) {
     constexpr int SLOTS = TIPK_WAVE / L;
     const int4* it4 = reinterpret_cast<const int4*>(items);
     if (group_slots > 0) {                              // one workgroup = one block of the plan
@@ -245,23 +260,19 @@ int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, c
         const int64_t blocks = tipk_ceil_div(n_items, group_slots);
         if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
         const size_t lds = (size_t)threads * sizeof(Acc<V>);
-        if (edge_w)
-            hipLaunchKernelGGL((gather_sum_kernel<V, L, true, true>), dim3((unsigned)blocks), dim3(threads), lds, st,
-                               table, ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
-        else
-            hipLaunchKernelGGL((gather_sum_kernel<V, L, false, true>), dim3((unsigned)blocks), dim3(threads), lds, st,
-                               table, ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
+#define TIPK_GS_LAUNCH(W, G, S, GRID, BLOCK, LDS)                                                             \
+        hipLaunchKernelGGL((gather_sum_kernel<V, L, W, G, S>), dim3((unsigned)(GRID)), dim3(BLOCK), LDS, st, table, \
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d)
+        if (edge_w) { if (small) TIPK_GS_LAUNCH(true, true, true, blocks, threads, lds); else TIPK_GS_LAUNCH(true, true, false, blocks, threads, lds); }
+        else { if (small) TIPK_GS_LAUNCH(false, true, true, blocks, threads, lds); else TIPK_GS_LAUNCH(false, true, false, blocks, threads, lds); }
         TIPK_RETURN_LAUNCH();
     }
     const int64_t waves = tipk_ceil_div(n_items, SLOTS);
     const int64_t blocks = tipk_ceil_div(waves, 4);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
-    if (edge_w)
-        hipLaunchKernelGGL((gather_sum_kernel<V, L, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, table,
-                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
-    else
-        hipLaunchKernelGGL((gather_sum_kernel<V, L, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, table,
-                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d);
+    if (edge_w) { if (small) TIPK_GS_LAUNCH(true, false, true, blocks, 256, 0); else TIPK_GS_LAUNCH(true, false, false, blocks, 256, 0); }
+    else { if (small) TIPK_GS_LAUNCH(false, false, true, blocks, 256, 0); else TIPK_GS_LAUNCH(false, false, false, blocks, 256, 0); }
+#undef TIPK_GS_LAUNCH
     TIPK_RETURN_LAUNCH();
 }
 
@@ -275,7 +286,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, const int32_t* row_id,
+extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
                                const float* edge_w, const int32_t* items, int64_t n_items, float* out,
                                int64_t ld_out, float* partial, const float* row_scale, const float* bias,
                                int relu, int d, int group_slots, tipk_stream_t stream) {
@@ -285,11 +296,12 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, const int32
     if (!aligned16(items)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Epilogue ep{row_scale, bias, relu};
+    const bool small = n_table > 0 && ld_table > 0 && n_table * ld_table * 4 < (1LL << 32);   // 32-bit row offsets
     const bool vec = d % 4 == 0 && ld_table % 4 == 0 && ld_out % 4 == 0 && aligned16(table) && aligned16(out) &&
                      (!partial || aligned16(partial)) && (!bias || aligned16(bias));
 #define TIPK_GS(V, L) \
     return launch_gather<V, L>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, partial, ep, d, \
-                               group_slots, st)
+                               group_slots, small, st)
     if (vec) {
         if (d > 256) return TIPK_EUNSUPPORTED;
         switch (pow2_at_least(d / 4)) {
@@ -350,6 +362,15 @@ extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* row
 
 namespace {
 
+// 16-byte store that does NOT stay in the XCD's L2 (`sc1`, MI355X_MICROARCH.md "stores of each flavour"):
+// the output of the transposed pass is a 10 GB write-once stream in config 5; kept in L2 it evicts the
+// 5 MB table every gathered row comes from.
+typedef float tipk_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+    tipk_f4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(q) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // CSR rows: out[r] = sum_{e in [row_ptr[r], row_ptr[r+1])} table[row_id[e]] for EVERY row r, rows short
 // (include/tipk.h section 1c).  The transposed D-D pass of a large graph writes R*N rows of ~2.5 edges
@@ -375,6 +396,8 @@ __global__ __launch_bounds__(256) void gather_rows_csr_kernel(const float* __res
     const int nr = (int)(n_out - r0 < rp ? n_out - r0 : rp);
     const int col = sub * 4;
     const bool col_ok = col < d;
+    const float* table_c = table + (col_ok ? col : 0);
+    const unsigned ldb = (unsigned)ld_table * 4u;
     // lane k of the slot holds row_ptr[r0 + k] (k <= nr <= L - 1): one coalesced load for the whole task
     const int pk = sub <= nr ? sub : nr;
     const int myptr = row_ptr[r0 + pk];
@@ -396,18 +419,21 @@ __global__ __launch_bounds__(256) void gather_rows_csr_kernel(const float* __res
             const int ej = e0 + U + (sub & (U - 1));
             idn = row_id[ej < e_end ? ej : e_end - 1];                        // clamped, unconditional
         }
+        // all ids first (U shuffles, one wait), then all rows; lanes beyond d read column 0 and are masked
+        // at the store; a row address = scalar table base + 32-bit byte offset (host checks the table size)
+        int ids[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) ids[j] = __shfl(idv, j, L);
         float4 v[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int id = __shfl(idv, j, L);
-            v[j] = col_ok ? tipk_ld4(table + (int64_t)id * ld_table + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < U; ++j)
+            v[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(table_c) + (unsigned)ids[j] * ldb);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int e = e0 + j;
             if (e < e_end) {
                 while (e >= next) {                        // rows that end before this edge (also empty ones)
-                    if (col_ok) tipk_st4(o + (int64_t)row * ld_out, acc);
+                    if (col_ok) st4_stream(o + (int64_t)row * ld_out, acc);
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     ++row;
                     next = __shfl(myptr, row + 1 < nr ? row + 1 : nr, L);
@@ -417,7 +443,7 @@ __global__ __launch_bounds__(256) void gather_rows_csr_kernel(const float* __res
         }
     }
     for (; row < nr; ++row) {                              // the last row with edges and any empty rows behind it
-        if (col_ok) tipk_st4(o + (int64_t)row * ld_out, acc);
+        if (col_ok) st4_stream(o + (int64_t)row * ld_out, acc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
@@ -437,9 +463,11 @@ int launch_rows_csr(const float* table, int64_t ld_table, const int32_t* row_ptr
 
 }  // namespace
 
-extern "C" int tipk_gather_rows_csr(const float* table, int64_t ld_table, const int32_t* row_ptr, const int32_t* row_id,
-                                    int64_t n_out, float* out, int64_t ld_out, int d, tipk_stream_t stream) {
+extern "C" int tipk_gather_rows_csr(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_ptr,
+                                    const int32_t* row_id, int64_t n_out, float* out, int64_t ld_out, int d,
+                                    tipk_stream_t stream) {
     if (n_out < 0 || d < 8 || d > 256 || d % 4 != 0) return n_out < 0 || d <= 0 ? TIPK_EINVAL : TIPK_EUNSUPPORTED;
+    if (n_table <= 0 || n_table * ld_table * 4 >= (1LL << 32)) return TIPK_EUNSUPPORTED;   // 32-bit row offsets
     if (n_out == 0) return TIPK_OK;
     if (!table || !row_ptr || !out || ld_table % 4 != 0 || ld_out % 4 != 0 ||      // row_id may be NULL for E = 0
         (reinterpret_cast<uintptr_t>(table) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))

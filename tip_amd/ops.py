@@ -119,7 +119,7 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
     st = stream_ptr(table.device)
     L = lib()
     with _timed('gather_sum[%s,d=%d]' % (plan.tag, d)):
-        check(L.tipk_gather_sum(ptr(table), table.stride(0), ptr(plan.row_id), ptr(plan.edge_w), ptr(plan.items),
+        check(L.tipk_gather_sum(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_id), ptr(plan.edge_w), ptr(plan.items),
                                 plan.items.shape[0], ptr(out), out.stride(0), ptr(partial), ptr(row_scale),
                                 ptr(bias), int(relu), d, plan.group_slots, st), 'tipk_gather_sum')
     if plan.n_slots:
@@ -137,7 +137,7 @@ def gather_rows_csr(plan, table):
     assert table.shape[0] == plan.n_table, (table.shape, plan.n_table)
     out = torch.empty((plan.n_out, d), dtype=torch.float32, device=table.device)
     with _timed('gather_rows_csr[%s,d=%d]' % (plan.tag, d)):
-        check(lib().tipk_gather_rows_csr(ptr(table), table.stride(0), ptr(plan.row_ptr), ptr(plan.row_id), plan.n_out,
+        check(lib().tipk_gather_rows_csr(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_ptr), ptr(plan.row_id), plan.n_out,
                                          ptr(out), out.stride(0), d, stream_ptr(table.device)), 'tipk_gather_rows_csr')
     return out
 
@@ -613,8 +613,23 @@ def distmult_bwd(g_score, score, z, weight, edge_index, edge_type, sigmoid=True)
     return g_z, g_w
 
 
+_DET_WS = {}
+
+
+def _det_workspace(device, n_nodes, k, n_rel):
+    """Zeroed fixed-point workspace of the deterministic objective (one per device and shape; every
+    call leaves it zeroed again, so it is allocated and cleared exactly once)."""
+    key = (str(device), int(n_nodes), int(k), int(n_rel))
+    ws = _DET_WS.get(key)
+    if ws is None:
+        n = int(lib().tipk_distmult_workspace_bytes(n_nodes, k, n_rel)) // 8
+        ws = _DET_WS[key] = torch.zeros(n, dtype=torch.int64, device=device)
+    return ws
+
+
 def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
-    """(loss [1], g_z, g_w) of the fused TIP objective (include/tipk.h section 4)."""
+    """(loss [1], g_z, g_w) of the fused TIP objective (include/tipk.h section 4); bitwise reproducible
+    (fixed-point cross-workgroup sums) unless TIPK_FLOAT_ATOMICS=1."""
     z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
     require_device(z, weight, pos_index, neg_index, edge_type)
     validate_triples(pos_index, edge_type, z.shape[0], weight.shape[0])
@@ -628,10 +643,12 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     g_z = torch.zeros_like(z) if need_grad else None
     g_w = torch.zeros_like(weight) if need_grad else None
     tasks = relation_tasks(et, pos_index)
+    ws = None if (tasks is None or os.environ.get('TIPK_FLOAT_ATOMICS')) else \
+        _det_workspace(z.device, z.shape[0], z.shape[1], weight.shape[0])
     check(lib().tipk_distmult_loss(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pu), ptr(pv),
                                    ptr(nu), ptr(nv), _idx_bytes(pu), ptr(et), _idx_bytes(et), pu.numel(),
                                    ptr(tasks), 0 if tasks is None else tasks.shape[0],
-                                   ptr(loss), ptr(g_z), ptr(g_w), stream_ptr(z.device)), 'tipk_distmult_loss')
+                                   ptr(loss), ptr(g_z), ptr(g_w), ptr(ws), stream_ptr(z.device)), 'tipk_distmult_loss')
     return loss, g_z, g_w
 
 
