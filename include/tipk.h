@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 8
+#define TIPK_ABI_VERSION 7
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -134,12 +134,9 @@ int tipk_gather_rows_csr(const float* table, int64_t ld_table, int64_t n_table /
  *     list of n_units WORK UNITS: a unit is one relation, or -- for relations much larger than the
  *     per-workgroup average, which would otherwise set the length of the launch -- every k-th output
  *     position of one relation:
- *     The arrays below are copied into LDS verbatim by LDS-DMA, hence 16-byte aligned and, per unit,
- *     np = n_nodes rounded up to a multiple of 8 entries long:
- *       node_at[n_units][np]    uint16: output node at position p of the unit; positions are
+ *       node_at[n_units][n_nodes] uint16: output node at position p of the unit; positions are
  *                               ordered by decreasing run length
- *       runs[n_units][np]       uint32 per position: (begin / 8) | (padded length / 8) << 16, begin relative
- *                               to the unit's first id (both are multiples of 8; a unit has < 2^19 ids)
+ *       runs[n_units][n_nodes][2] (begin relative to the unit's first id, padded length) per position
  *       idx[..]                 uint16 table node of each edge TIMES idx_unit (16-byte aligned array;
  *                               idx_unit = 1, or a power of two up to the bytes of one column-block
  *                               row with n_nodes * idx_unit <= 65535: then a row's LDS address is
@@ -166,12 +163,12 @@ int tipk_rel_gather_supported(int64_t n_nodes, int d, int backward);
  * two 1024-thread workgroups share a CU (8 waves per SIMD hide the kernel's LDS round trips); the host
  * builds the plan for  occupancy * CUs / column-blocks  workgroups.  Option "rg_occupancy" (1 | 2). */
 int tipk_rel_gather_occupancy(int64_t n_nodes, int d, int backward);
-/* ids per LDS chunk buffer for this shape (a multiple of 1024 in [4096, 16384], what the LDS leaves after
- * the double-buffered per-unit arrays): a unit with more ids is walked in several stages. */
+/* ids staged into LDS per pass for this shape (8192 or 16384): a forward work unit with more ids than
+ * this reloads its id chunk synchronously, so the host cuts forward units at this size. */
 int tipk_rel_gather_chunk(int64_t n_nodes, int d, int backward);
 int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t n_nodes, int d,
                     int64_t n_wg, const int32_t* wg_unit_ptr, const int32_t* unit_meta,
-                    const uint16_t* idx, int idx_unit, const uint32_t* runs, const uint16_t* node_at,
+                    const uint16_t* idx, int idx_unit, const int32_t* runs, const uint16_t* node_at,
                     const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

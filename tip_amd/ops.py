@@ -198,7 +198,7 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
         out = torch.empty((rp.n_wg, n, d), dtype=torch.float32, device=table.device)
     with _timed('rel_gather[%s,d=%d]' % ('dd.bwd' if backward else 'dd.fwd', d)):
         check(lib().tipk_rel_gather(int(backward), ptr(table), table.stride(0), n, d, rp.n_wg, ptr(rp.wg_rel_ptr),
-                                    ptr(rp.unit_meta), ptr(rp.idx), rp.idx_unit, ptr(rp.runs_packed), ptr(rp.node_pad),
+                                    ptr(rp.unit_meta), ptr(rp.idx), rp.idx_unit, ptr(rp.runs), ptr(rp.node_at),
                                     ptr(row_scale) if backward else None, ptr(out), d, stream_ptr(table.device)),
               'tipk_rel_gather')
     if backward or not reduce:

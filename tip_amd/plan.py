@@ -357,21 +357,9 @@ class RelPlan(object):
     wg_rel_ptr = range of every workgroup in unit_meta, wg_rels = the same order as unit ids."""
 
     def __init__(self, n_nodes, n_rel, n_wg, node_at, rel_idx_off, rel_len, idx, runs, wg_rel_ptr, wg_rels,
-                 unit_rel, unit_npos, unit_meta=None, idx_unit=1, runs_packed=None, node_pad=None):
+                 unit_rel, unit_npos, unit_meta=None, idx_unit=1):
         self.n_nodes, self.n_rel, self.n_wg = int(n_nodes), int(n_rel), int(n_wg)
         self.idx_unit = int(idx_unit)             # idx holds node * idx_unit (pre-scaled LDS row offsets)
-        # what the kernel copies into LDS verbatim (LDS-DMA): per unit `np` = n_nodes rounded up to 8 entries of
-        # runs_packed uint32 = (begin / 8) | (length / 8) << 16 (stored as int32) and node_pad uint16
-        if runs_packed is None:
-            npad = (self.n_nodes + 7) // 8 * 8
-            U = int(unit_rel.numel())
-            rp = torch.zeros((U, npad), dtype=torch.int64, device=runs.device)
-            rp[:, :self.n_nodes] = (runs[:, :, 0].long() >> 3) | ((runs[:, :, 1].long() >> 3) << 16)
-            runs_packed = torch.where(rp >= 2 ** 31, rp - 2 ** 32, rp).to(torch.int32).contiguous()
-            nd = torch.zeros((U, npad), dtype=torch.int32, device=runs.device)
-            nd[:, :self.n_nodes] = node_at.to(torch.int32)
-            node_pad = nd.to(torch.uint16).contiguous()
-        self.runs_packed, self.node_pad = runs_packed, node_pad
         self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs = node_at, rel_idx_off, rel_len, idx, runs
         self.wg_rel_ptr, self.wg_rels = wg_rel_ptr, wg_rels
         self.unit_rel, self.unit_npos = unit_rel, unit_npos
@@ -388,8 +376,7 @@ class RelPlan(object):
     def to(self, device):
         return RelPlan(self.n_nodes, self.n_rel, self.n_wg, *[t.to(device) for t in (
             self.node_at, self.rel_idx_off, self.rel_len, self.idx, self.runs, self.wg_rel_ptr, self.wg_rels,
-            self.unit_rel, self.unit_npos, self.unit_meta)], idx_unit=self.idx_unit,
-            runs_packed=self.runs_packed.to(device), node_pad=self.node_pad.to(device))
+            self.unit_rel, self.unit_npos, self.unit_meta)], idx_unit=self.idx_unit)
 
 
 def assign_relations(sizes, n_wg, fixed_cost=0):

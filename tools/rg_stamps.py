@@ -25,13 +25,18 @@ for d in (32, 16):
         split = ops.rel_gather_split(N, d, bwd)
         n = rp.n_wg * split
         a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 16, 8)[:n].astype(np.float64)
-        tot, loop, wait, first, epi, issue, stages = a[..., 0], a[..., 1], a[..., 3], a[..., 4], a[..., 5], a[..., 6], a[..., 7]
-        print('d=%d %s  workgroups %d x 16 waves, %.1f stages per workgroup' % (d, 'bwd' if bwd else 'fwd', n, stages.mean()))
-        pc = lambda x: '%8.0f (%2.0f %%)' % (x.mean(), 100 * x.mean() / tot.mean())
-        print('   wave lifetime        %8.0f cycles (max %.0f)' % (tot.mean(), tot.max()))
-        print('   position loops     ', pc(loop), '  per-WG max/mean over waves %.2f' % (loop.max(1) / loop.mean(1)).mean())
-        print('   stage barrier      ', pc(wait), '  (wait for the slowest wave + DMA drain)')
-        print('   issuing DMA        ', pc(issue))
-        print('   start -> 1st stage ', pc(first))
-        print('   epilogue           ', pc(epi))
-        print('   other               %.0f %%' % (100 * (1 - (loop + wait + issue + first + epi).mean() / tot.mean())))
+        tot, loop, commit, wait = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+        print('d=%d %s  workgroups %d x 16 waves' % (d, 'bwd' if bwd else 'fwd', n))
+        print('   wave lifetime      mean %8.0f  max %8.0f cycles (100 MHz ticks x?)' % (tot.mean(), tot.max()))
+        print('   position loops     mean %8.0f  (%.0f %%)   per-WG max/mean over waves %.2f' % (
+            loop.mean(), 100 * loop.mean() / tot.mean(), (loop.max(1) / loop.mean(1)).mean()))
+        print('   commit             mean %8.0f  (%.0f %%)' % (commit.mean(), 100 * commit.mean() / tot.mean()))
+        print('   wait at barrier    mean %8.0f  (%.0f %%)' % (wait.mean(), 100 * wait.mean() / tot.mean()))
+        pro, epi = a[..., 4], a[..., 5]
+        print('   start -> 1st unit  mean %8.0f  (%.0f %%)' % (pro.mean(), 100 * pro.mean() / tot.mean()))
+        print('   epilogue           mean %8.0f  (%.0f %%)' % (epi.mean(), 100 * epi.mean() / tot.mean()))
+        pref, rel_ = a[..., 6], a[..., 7]
+        print('   prefetch issue     mean %8.0f  (%.0f %%)' % (pref.mean(), 100 * pref.mean() / tot.mean()))
+        print('   id chunk reloads   mean %8.0f  (%.0f %%)' % (rel_.mean(), 100 * rel_.mean() / tot.mean()))
+        print('   other              %.0f %%' % (100 * (1 - (loop + commit + wait + pro + epi + pref + rel_).mean() / tot.mean())))
+        print('   per-WG lifetime (max wave): min %8.0f  mean %8.0f  max %8.0f' % (tot.max(1).min(), tot.max(1).mean(), tot.max(1).max()))
