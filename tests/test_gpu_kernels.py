@@ -294,6 +294,27 @@ def test_gemm_group_bit_identical_to_single_launches(ops):
     assert ops.gemm_group([]) == []
 
 
+def test_grouped_slab_sum_vector_path_bit_identical(ops):
+    """The grouped slab sum takes a 16-byte path for 4-lane sums of aligned operands (one thread = 4 elements
+    x all four slab lanes): same order of additions as the dword kernel, for every slab count and epilogue."""
+    g = torch.Generator().manual_seed(8)
+    for n_slabs in (1, 2, 3, 4, 6, 8, 9, 17, 31, 40):
+        for rows, cols in ((645, 32), (2048, 4), (1030, 12)):
+            part = torch.randn(n_slabs, rows, cols, generator=g).to(DEV)
+            scale = torch.rand(rows, generator=g).to(DEV)
+            add = torch.randn(rows, cols, generator=g).to(DEV)
+            gate = torch.randn(rows, cols, generator=g).to(DEV)
+            base = torch.randn(rows, cols, generator=g).to(DEV)
+            jobs = [ops.slab_job(part), ops.slab_job(part, alpha=0.25, row_scale=scale, addend=add, relu=True),
+                    ops.slab_job(part, out=base.clone(), accumulate=True, gate=gate)]
+            ops.gemm_group([], jobs)
+            assert torch.equal(jobs[0].out, ops.sum_slabs(part))
+            assert torch.equal(jobs[1].out, ops.sum_slabs(part, alpha=0.25, row_scale=scale, addend=add, relu=True))
+            want = ops.sum_slabs(part, out=base.clone(), accumulate=True)
+            assert torch.equal(jobs[2].out, torch.where(gate > 0, want, torch.zeros_like(want)))
+            torch.testing.assert_close(jobs[0].out.cpu(), part.double().sum(0).float().cpu(), rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------ row-wise glue
 def test_rowwise_ops(ops):
     g = torch.Generator().manual_seed(2)

@@ -1040,16 +1040,18 @@ class _GCNConv(torch.autograd.Function):
             if j_b is not None:
                 gemm_group([j_b])
             return None, g_w, (j_b.out.view(-1) if j_b else None), None, None
+        # d W in the parameter's own memory layout (tip_amd.layers._Lin keeps [in, out] storage behind the [out, in]
+        # shape): autograd's AccumulateGrad otherwise re-lays the gradient out with a copy kernel of its own
+        w_t = weight.t().is_contiguous() and not weight.is_contiguous()
+        j_w = gemm_job(x.t(), g_table) if w_t else gemm_job(g_table.t(), x)
+        g_w = j_w.out.t() if w_t else j_w.out
+        j_x = gemm_job(g_table, weight) if ctx.needs_input_grad[0] else None
         if bias_parts is not None:                                      # rides in the grouped slab sum below
             s_b = slab_job(bias_parts)
-            j_w = gemm_job(g_table.t(), x)
-            j_x = gemm_job(g_table, weight) if ctx.needs_input_grad[0] else None
             gemm_group([j for j in (j_w, j_x) if j is not None], [s_b])
-            return (j_x.out if j_x else None), j_w.out, s_b.out.view(-1), None, None
-        j_w = gemm_job(g_table.t(), x)
-        j_x = gemm_job(g_table, weight) if ctx.needs_input_grad[0] else None
+            return (j_x.out if j_x else None), g_w, s_b.out.view(-1), None, None
         gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
-        return (j_x.out if j_x else None), j_w.out, (j_b.out.view(-1) if j_b else None), None, None
+        return (j_x.out if j_x else None), g_w, (j_b.out.view(-1) if j_b else None), None, None
 
 
 def gcn_conv(x, weight, bias, graph, relu=False):
