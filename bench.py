@@ -204,7 +204,14 @@ def dd_aggregation_launches(enc, dev):
         g = torch.randn(n, d, device=dev)
         for bwd in (False, True):
             rp = graph.rl_bwd if bwd else graph.rl_fwd
-            if ops.rel_gather_usable(rp, n, d, bwd):
+            rs = graph.rs_bwd if bwd else None
+            if rs is not None and ops.rel_stream_split(n, d):
+                split = ops.rel_stream_split(n, d)
+                key = 'rel_stream_bwd_kernel<%d' % (d // split // 4)
+                grid = '%dx%dx1' % (rs.n_wg * 1024, split)
+                out.append(('rel_stream[dd.bwd,d=%d]' % d, key, grid, d, 'lds',
+                            lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale)))
+            elif ops.rel_gather_usable(rp, n, d, bwd):
                 split = ops.rel_gather_split(n, d, bwd)
                 key = 'rel_gather_kernel<%d, %s' % (d // split // 4, 'true' if bwd else 'false')
                 grid = '%dx%dx1' % (rp.n_wg * 1024, split)

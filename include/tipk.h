@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 7
+#define TIPK_ABI_VERSION 8
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -172,6 +172,35 @@ int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t 
                     const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 1d. Wave-stream gather -- the TRANSPOSED D-D pass (autograd of src/layers.py:159-180) when g' fits in LDS:
+ *
+ *       out[row] = sum_{e: row(e) = row} g'[tab(e)],   row = relation * n_nodes + source node  (every row written)
+ *
+ *     the sums of tipk_rel_gather(backward = 1), without work units: after g' is staged (one barrier) every
+ *     wavefront streams through its own list of fixed-size records and never meets the others
+ *     (tip_amd/csrc/tipk_rel_stream.hip explains why).  L = (d / column blocks) / 4 lanes form a slot,
+ *     S = 64 / L slots a wavefront, P = tipk_rel_stream_piece() steps of 8 ids a cell.  Plan
+ *     (tip_amd/plan.py `build_stream_plan`), all device arrays:
+ *       wave_ptr[n_wg * 16 + 1]  int32: range of bands of every wavefront (wavefront = workgroup * 16 + wave)
+ *       cells[n_bands][S]        uint32: row (24 bits) | steps << 24 (0 .. P) | first << 28 | last << 29.  A slot
+ *                                adds the steps' rows to a register sum that is cleared on `first` and written
+ *                                to out[row] on `last`: a run longer than P steps continues in the SAME slot of
+ *                                the wavefront's next band; 0 = idle cell
+ *       ids[n_bands][P][S][8]    uint16: table node * idx_unit of the edges (see 1b), runs padded to 8 with the
+ *                                sentinel n_nodes * idx_unit (a zero row); steps beyond a cell's count are not read
+ *       zero_ptr[n_wg * 16 + 1], zero_rows[]  int32: the rows without edges, dealt to the wavefronts; zero_ptr
+ *                                = NULL: those rows are left untouched (the consumer masks them: section 2b row_used)
+ *     n_rel * n_nodes < 2^24.  row_scale (nullable): g' = row_scale[node] * table[node] while staging.
+ */
+/* column blocks of the launch (grid = n_wg x blocks); 0 = g' does not fit (use tipk_gather_rows_csr) */
+int tipk_rel_stream_supported(int64_t n_nodes, int d);
+int tipk_rel_stream_piece(void);
+int tipk_rel_stream_bwd(const float* table, int64_t ld_table, int64_t n_nodes, int d, int64_t n_wg,
+                        const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
+                        const int32_t* zero_ptr, const int32_t* zero_rows, const float* row_scale,
+                        float* out, int64_t ld_out, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
  *
  *   C[z] = relu?( alpha * sum_{q<kbatch} A[z,q] (m x k) . B[z,q] (k x n) + C_in[z] ),  z < batch
@@ -242,10 +271,16 @@ int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, in
  *        datt_slabs [col_slabs][n_rel x n_bases]    one per chunk of 512 columns
  *     `tipk_rgcn_dy_products_plan` returns the slab counts (both 0: shape not supported -- n_bases > 32;
  *     use two tipk_gemm_f32 then).  The datt slabs are n_bases / 512 of the size of dY.
+ *     row_used (nullable; then n_nodes = n_cols / columns per node): uint32 [ceil(n_rel / 32)][n_nodes], bit
+ *     (r & 31) of word (r >> 5, node) = "relation r has an edge leaving node" = row (r, node) of dY holds data.
+ *     More than half of the (relation, source) rows of BioSNAP have no edge: with the mask the transposed
+ *     gather (section 1d, zero_ptr = NULL) does not write their zeros -- 48 of 91 MB at layer 1 -- and
+ *     whatever the buffer holds there is cleared bitwise after it is loaded.
  */
 int tipk_rgcn_dy_products_plan(int64_t n_rel, int64_t n_cols, int n_bases, int* col_slabs, int* row_slabs);
 int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int64_t ld_att,
                           const float* xb, int64_t ld_xb, int64_t n_rel, int64_t n_cols, int n_bases,
+                          const uint32_t* row_used, int64_t n_nodes,
                           float* dxb_slabs, float* datt_slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

@@ -239,6 +239,43 @@ def test_dy_products_fused(ops, r, nc, nb, monkeypatch):
     assert torch.equal(e_att.cpu(), gi @ xi.t()) and torch.equal(e_xb.cpu(), ai.t() @ gi)
 
 
+@pytest.mark.parametrize('R,N,d', [(70, 645, 32), (33, 100, 16), (1097, 37, 8)])
+def test_unwritten_rows_masked_end_to_end(ops, R, N, d):
+    """Rows (relation, node) without edges: the wave-stream gather with write_zeros=False leaves them untouched
+    and `dy_products(row_used=...)` clears whatever the buffer holds there (NaN bit patterns included): same
+    d att / d XB, bit for bit, as the zero-filled run."""
+    from tip_amd.plan import build_stream_plan
+    g = torch.Generator().manual_seed(R + N)
+    E = 40 * R
+    rel = torch.randint(0, R, (E,), generator=g)
+    src = torch.randint(0, max(1, N // 3), (E,), generator=g)              # two thirds of the nodes never a source
+    dst = torch.randint(0, N, (E,), generator=g)
+    split = ops.rel_stream_split(N, d)
+    sp = build_stream_plan(src, dst, rel, N, R, 16, d // split // 4, ops.rel_stream_piece()).to(DEV)
+    cnt = torch.bincount(rel * N + src, minlength=R * N).view(R, N)
+    bits = sp.row_used.cpu().long() & 0xffffffff
+    for r in (0, R // 2, R - 1):
+        assert torch.equal(((bits[r >> 5] >> (r & 31)) & 1).bool(), cnt[r] > 0)
+    gp = torch.randn(N, d, generator=g).to(DEV)
+    full = ops.rel_stream_bwd(sp, gp)
+    # poison the allocation the next call will get, then gather without the zero rows
+    poison = torch.full((R * N, d), float('nan'), device=DEV)
+    ptr = poison.data_ptr()
+    del poison
+    part = ops.rel_stream_bwd(sp, gp, write_zeros=False)
+    if part.data_ptr() == ptr:                                             # the caching allocator handed the block back
+        assert bool(torch.isnan(part).any()) and bool(torch.isnan(part.view(R, N, d)[cnt.to(DEV) == 0]).all())
+    assert torch.equal(part.view(R, N, d)[cnt.to(DEV) > 0], full.view(R, N, d)[cnt.to(DEV) > 0])
+    nb = 32
+    att = torch.randn(R, nb, generator=g).to(DEV)
+    xb = torch.randn(nb, N * d, generator=g).to(DEV)
+    assert ops.dy_products_fused(R, N * d, nb)
+    want = ops.dy_products(full.view(R, N * d), att, xb)
+    got = ops.dy_products(part.view(R, N * d), att, xb, sp.row_used, N)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert not bool(torch.isnan(got[0]).any()) and not bool(torch.isnan(got[1]).any())
+
+
 def test_gemm_output_beyond_4GB(ops):
     """Y of the synthetic config is 10 GB: rows past the 4 GB mark must land where they belong
     (32-bit offsets are tile-local only)."""
@@ -590,6 +627,36 @@ def test_rel_gather_other_node_counts(ops, N, d):
     planb = build_rel_plan(src, dst, rel, N, R, n_wg=256, backward=True).to(DEV)
     close(ops.rel_gather(planb, gp.to(DEV), backward=True, row_scale=scale.to(DEV)),
           O.gather_sum(gp.double() * scale.double().unsqueeze(1), dst, rel * N + src, R * N))
+
+
+@pytest.mark.parametrize('N,d', [(645, 32), (645, 16), (645, 4), (645, 128), (1000, 32), (1024, 8), (300, 64), (17, 128), (2000, 16)])
+def test_rel_stream_bwd(ops, N, d):
+    """Wave-stream transposed pass (include/tipk.h section 1d): every (relation, source) row, hub runs that
+    span many bands of one slot, relations without edges, strided table, row scale, few workgroups."""
+    from tip_amd.plan import build_stream_plan
+    g = torch.Generator().manual_seed(N + d)
+    R = 9
+    sizes = torch.tensor([40000, 1, 0, 3000, 17000, 250, 5, 9000, 700])
+    E = int(sizes.sum())
+    rel = torch.repeat_interleave(torch.arange(R), sizes)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, max(1, N - 7), (E,), generator=g)
+    src[:9000] = 11                                                            # hub: one output row with 9 000 edges
+    split = ops.rel_stream_split(N, d)
+    assert split >= 1
+    lanes = d // split // 4
+    gp = torch.randn(N, d, generator=g)
+    scale = torch.rand(N, generator=g) + 0.5
+    want = O.gather_sum(gp.double() * scale.double().unsqueeze(1), dst, rel * N + src, R * N)
+    for n_wg in (256, 3):
+        sp = build_stream_plan(src, dst, rel, N, R, n_wg, lanes, ops.rel_stream_piece()).to(DEV)
+        got = ops.rel_stream_bwd(sp, gp.to(DEV), row_scale=scale.to(DEV))
+        close(got, want)
+        assert torch.equal(got, ops.rel_stream_bwd(sp, gp.to(DEV), row_scale=scale.to(DEV)))     # bitwise reproducible
+    wide = torch.randn(N, d + 8, generator=g).to(DEV)
+    close(ops.rel_stream_bwd(sp, wide[:, 4:4 + d]), O.gather_sum(wide[:, 4:4 + d].cpu().double(), dst, rel * N + src, R * N))
+    from tip_amd import _lib
+    assert _lib.lib().tipk_rel_stream_supported(10000, 32) == 0 and _lib.lib().tipk_rel_stream_supported(645, 24) == 0
 
 
 def test_rel_gather_unsupported_shapes():

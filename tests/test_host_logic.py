@@ -271,6 +271,17 @@ def test_rel_plan_semantics():
             slot = p % 256                                              # band 0 of a 256-slot workgroup (N < 256 positions)
             key = (run % n_cls - rot[slot % 16]) % n_cls
             assert bool((key[1:] >= key[:-1]).all())
+    # wave-stream plan of the transposed pass: every row exactly once, runs continue in their slot, balanced streams
+    from tip_amd.plan import build_stream_plan, execute_stream_plan_reference
+    for lanes in (1, 2, 4, 8, 16):
+        sp = build_stream_plan(src, dst, rel, N, R, 2, lanes, piece=4)
+        torch.testing.assert_close(execute_stream_plan_reference(sp, gp), wantb)
+        assert sp.cells.shape[1] == 64 // lanes and sp.ids.numel() == sp.n_bands * 4 * (64 // lanes) * 8
+        assert int(sp.ids.to(torch.int32).max()) <= N * sp.idx_unit <= 65535
+        per_wave = (sp.wave_ptr[1:] - sp.wave_ptr[:-1])
+        assert int(per_wave.sum()) == sp.n_bands and int(per_wave.max()) - int(per_wave.min()) <= max(4, sp.n_bands // 8)
+    sp1 = build_stream_plan(src, dst, rel, N, R, 1, 4, piece=2)                 # shorter cells: more continuation bands
+    torch.testing.assert_close(execute_stream_plan_reference(sp1, gp), wantb)
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
     loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]
     assert sorted(loads) == [14, 14]

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class TipkError(RuntimeError):
@@ -62,12 +62,15 @@ SIGNATURES = {
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
+    'tipk_rel_stream_supported': (_I, [_L, _I]),
+    'tipk_rel_stream_piece': (_I, []),
+    'tipk_rel_stream_bwd': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),
     'tipk_sum_slabs_group': (_I, [C.POINTER(SlabSumDesc), C.c_int32, _P]),
     'tipk_rgcn_dy_products_plan': (_I, [_L, _L, _I, C.POINTER(_I), C.POINTER(_I)]),
-    'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _P, _P]),
+    'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _P, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

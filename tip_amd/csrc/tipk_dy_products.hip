@@ -30,6 +30,9 @@ struct DpArgs {
     int R, NC, NB;
     int64_t ld_dy, ld_att, ld_xb;
     float* dxb; float* datt;                            // slabs: [s_r][NB x NC], [s_c][R x NB]
+    const uint32_t* used; int cols_per_node, n_nodes;   // nullable: bit (r & 31) of used[(r >> 5) * n_nodes + c / cols_per_node]
+                                                        // = row r of dY holds data in the columns of that node; rows whose
+                                                        // bit is clear are NOT read as data (the producer never wrote them)
     int rows_per_range;                                 // multiple of 32
     int dbg;                                            // TIPK_DP_DEBUG: 1 no loads after the first tile, 2 no 2nd product, 4 no 1st
 };
@@ -39,6 +42,7 @@ __device__ __forceinline__ float ldg(const float* base, u32 byte_off) {
 }
 __device__ __forceinline__ float and_mask(float v, u32 mask) { return __uint_as_float(__float_as_uint(v) & mask); }
 
+template <bool MASKED>
 __global__ __launch_bounds__(1024) void dy_products_kernel(DpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -72,21 +76,45 @@ __global__ __launch_bounds__(1024) void dy_products_kernel(DpArgs a) {
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
 
     float dyv[16], atv[16];
+    // Row mask (a.used): rows (relation, node) without edges are never written by the transposed gather.  Their
+    // loads are REDIRECTED to a row of the same tile and column that does hold data (a line this lane fetches
+    // anyway: no extra traffic, and no exec-masked loads, which hipcc serialises), and the value is cleared
+    // bitwise afterwards.  The mask word of a tile is requested one tile ahead of the addresses it steers.
+    uint32_t uw_cur = 0xffffffffu, uw_nxt = 0xffffffffu;     // this lane's rows: bit j = row 2 j + kh ... after the shift below
+    const u32 used_b = MASKED ? (u32)((col < NC ? col : NC - 1) / a.cols_per_node) * 4u : 0u;
+    const int last_word = (r_hi - 1) >> 5;
+    auto mask_word = [&](int r0) {
+        const int wd = (r0 >> 5) < last_word ? (r0 >> 5) : last_word;
+        return __float_as_uint(ldg(reinterpret_cast<const float*>(a.used + (int64_t)wd * a.n_nodes), used_b));
+    };
     auto load_tile = [&](int r0) {                      // dY tile in B-operand layout + att^T in A-operand layout
         // 64-bit (wave-uniform) address of the tile's first row + 32-bit offsets inside the 32 rows:
         // dY may be far larger than 4 GB (synthetic config: 10 GB)
         const float* dy_t = a.dy + (int64_t)r0 * a.ld_dy;
         const float* att_t = a.att + (int64_t)r0 * a.ld_att;
+        u32 safe_off = 0;
+        if (MASKED) safe_off = (uw_cur ? (u32)__builtin_ctz(uw_cur) : 0u) * ld_dy + col_b;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int r = r0 + 2 * kk + kh;
             const u32 rl = (u32)((r < r_hi ? r : r_hi - 1) - r0);
-            dyv[kk] = ldg(dy_t, rl * ld_dy + col_b);
+            u32 off = rl * ld_dy + col_b;
+            if (MASKED) off = ((uw_cur >> (2 * kk + kh)) & 1u) ? off : safe_off;      // bits beyond r_hi are clear
+            dyv[kk] = ldg(dy_t, off);
             atv[kk] = ldg(att_t, rl * ld_att + (u32)(row < NB ? row : NB - 1) * 4u);
         }
     };
-    if (r_lo < r_hi) load_tile(r_lo);
+    if (r_lo < r_hi) {
+        if (MASKED) { uw_cur = mask_word(r_lo); uw_nxt = mask_word(r_lo + 32); }
+        load_tile(r_lo);
+    }
     for (int r0 = r_lo; r0 < r_hi; r0 += 32) {
+        if (MASKED) {
+            const int uwl = (int)(uw_cur >> kh);                      // bit 2 kk = this lane's row of step kk
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)                           // one signed 1-bit field extract = 0 / ~0
+                dyv[kk] = and_mask(dyv[kk], (u32)__builtin_amdgcn_sbfe(uwl, 2 * kk, 1));
+        }
         // (1) dXB += att^T . dY : rows beyond r_hi (and bases beyond NB) are zeroed in the A operand
         if (!TIPK_DBG(a.dbg & 4))
 #pragma unroll
@@ -98,7 +126,10 @@ __global__ __launch_bounds__(1024) void dy_products_kernel(DpArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) tile[row * DP_TLD + 2 * kk + kh] = dyv[kk];
         __builtin_amdgcn_sched_barrier(0);
-        if (r0 + 32 < r_hi && !TIPK_DBG(a.dbg & 1)) load_tile(r0 + 32);   // next tile in flight during the second product
+        if (r0 + 32 < r_hi && !TIPK_DBG(a.dbg & 1)) {                       // next tile in flight during the second product
+            if (MASKED) { uw_cur = uw_nxt; uw_nxt = mask_word(r0 + 64); }
+            load_tile(r0 + 32);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (TIPK_DBG(a.dbg & 2)) continue;
         // (2) datt tile = dY . XB^T : A operand lane = row r, k = column c
@@ -157,8 +188,8 @@ extern "C" int tipk_rgcn_dy_products_plan(int64_t n_rel, int64_t n_cols, int n_b
 }
 
 extern "C" int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int64_t ld_att, const float* xb,
-                                     int64_t ld_xb, int64_t n_rel, int64_t n_cols, int n_bases, float* dxb_slabs,
-                                     float* datt_slabs, tipk_stream_t stream) {
+                                     int64_t ld_xb, int64_t n_rel, int64_t n_cols, int n_bases, const uint32_t* row_used,
+                                     int64_t n_nodes, float* dxb_slabs, float* datt_slabs, tipk_stream_t stream) {
     int s_c = 0, s_r = 0;
     const int rc = tipk_rgcn_dy_products_plan(n_rel, n_cols, n_bases, &s_c, &s_r);
     if (rc != TIPK_OK) return rc;
@@ -171,10 +202,16 @@ extern "C" int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float
     a.R = (int)n_rel; a.NC = (int)n_cols; a.NB = n_bases;
     a.ld_dy = ld_dy; a.ld_att = ld_att; a.ld_xb = ld_xb;
     a.dxb = dxb_slabs; a.datt = datt_slabs;
+    a.used = row_used; a.n_nodes = (int)n_nodes; a.cols_per_node = 1;
+    if (row_used) {
+        if (n_nodes <= 0 || n_cols % n_nodes != 0) return TIPK_EINVAL;
+        a.cols_per_node = (int)(n_cols / n_nodes);
+    }
     a.rows_per_range = (int)(tipk_ceil_div(tipk_ceil_div(n_rel, s_r), 32) * 32);
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
-    hipError_t e = hipFuncSetAttribute((const void*)dy_products_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS);
+    auto kern = row_used ? dy_products_kernel<true> : dy_products_kernel<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS);
     if (e != hipSuccess) return tipk_hip_status(e);
-    hipLaunchKernelGGL(dy_products_kernel, dim3((unsigned)s_c, (unsigned)s_r), dim3(1024), DP_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)s_c, (unsigned)s_r), dim3(1024), DP_LDS, (hipStream_t)stream, a);
     TIPK_RETURN_LAUNCH();
 }

@@ -1,0 +1,197 @@
+// Wave-stream gather: the TRANSPOSED D-D pass (dY_r = A_r^T g', include/tipk.h section 1d) when the
+// table g' fits in LDS -- the same sums as tipk_rel_gather(backward = 1), organised so that the 16
+// wavefronts of a workgroup never meet after the table is staged.
+//
+// tipk_rel_gather walks work UNITS (relations): per unit the workgroup stages ids and run tables together
+// and meets at two barriers.  In-kernel stamps (tools/rg_stamps.py) put 14-19 % of a wave's life into
+// waiting at those barriers (the unit lasts as long as its hub node's run), 9-12 % into the staging between
+// them and 3-5 % into id-chunk reloads, while the LDS pipe -- the resource that bounds the row reads -- idles.
+// In the transposed pass nothing forces that structure: g' is the SAME table for every relation and every
+// output row (relation, source node) is an independent sum.  So the plan (tip_amd/plan.py
+// `build_stream_plan`) cuts the whole pass into per-WAVEFRONT streams of fixed-size records:
+//
+//   band  = one cell per slot (a slot = L lanes = one output row at a time, 64 / L slots per wavefront)
+//   cell  = up to RS_PIECE steps of 8 edge ids of ONE output row: (row | steps << 24 | first << 28 | last << 29);
+//           a longer run continues in the same slot of the next band, its sum stays in registers
+//   ids   = [band][step][slot][8] uint16, pre-scaled row offsets: one 16-byte load per slot and step, the
+//           slots of a wavefront read one contiguous block per step
+//
+// Runs are sorted by length before they are dealt, so the slots of a band hold equally long pieces (no
+// idle lanes behind a hub run), rows of bands are dealt to the wavefronts by longest-processing-time, and
+// a wavefront just streams: next band's cell + ids are in flight (registers) while the current band is
+// gathered from LDS; no LDS id buffers, no run tables, no barriers.  Rows without edges are written as
+// zeros from a per-wavefront list.  Fixed order everywhere: bitwise reproducible.
+#include <stdlib.h>
+#include "tipk_common.h"
+
+namespace {
+
+constexpr int RS_PIECE = 4;            // steps (8 ids each) per cell
+constexpr int RS_DEPTH = 3;            // band records in flight per wavefront
+constexpr int64_t RS_LDS_LIMIT = 158 * 1024;
+
+struct RsArgs {
+    const float* table; int64_t ld_t;
+    int n_nodes, dc;                   // dc = columns of one column block
+    const int32_t* wave_ptr;           // [n_waves + 1] band range of every wavefront
+    const uint32_t* cells;             // [n_bands][64 / L]
+    const uint16_t* ids;               // [n_bands][RS_PIECE][64 / L][8]
+    const int32_t* zero_ptr;           // [n_waves + 1] range in zero_rows
+    const int32_t* zero_rows;          // output rows without edges
+    float* out; int64_t ld_out;
+    const float* row_scale;            // g' = row_scale[node] * table[node], applied while staging (nullable)
+    int idx_mul;                       // byte offset of a table row = id * idx_mul
+};
+
+template <int L, bool UNIT>
+__global__ __launch_bounds__(1024) void rel_stream_bwd_kernel(RsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];        // [n_nodes + 1][dc], last row = 0 (the pad id's row)
+    constexpr int SPW = 64 / L;
+    constexpr int q4 = L;
+    const int t = threadIdx.x, lane = t & 63;
+    const int n_nodes = a.n_nodes, dc = a.dc;
+    const int slot = lane / L, c0 = (lane & (L - 1)) * 4;
+    const int col0 = blockIdx.y * dc;
+    const float* table = a.table + col0;
+    float* out = a.out + col0;
+    const int total4 = n_nodes * q4;
+    if (t < dc) tab[(int64_t)n_nodes * dc + t] = 0.f;
+    for (int base = 0; base < total4; base += 4096) {
+        float4 gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int i = base + u * 1024 + t;
+            i = i < total4 ? i : total4 - 1;
+            const int r = i / q4, c = (i - r * q4) * 4;
+            gv[u] = tipk_ld4(table + (int64_t)r * a.ld_t + c);
+            if (a.row_scale) { const float sc = a.row_scale[r]; gv[u].x *= sc; gv[u].y *= sc; gv[u].z *= sc; gv[u].w *= sc; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 1024 + t;
+            if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * dc + c, gv[u]); }
+        }
+    }
+    __syncthreads();                                   // the only barrier of the launch
+
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 16 + (t >> 6));
+    int b = __builtin_amdgcn_readfirstlane(a.wave_ptr[gw]);
+    const int b1 = __builtin_amdgcn_readfirstlane(a.wave_ptr[gw + 1]);
+    const char* tabb = reinterpret_cast<const char*>(tab + c0);
+    const unsigned ldt4 = (unsigned)a.idx_mul;
+
+    // A band is walked in about a microsecond; its record (cell word + ids) comes from HBM and takes two under
+    // load.  RS_DEPTH records are therefore in flight per wavefront (registers, requested RS_DEPTH bands ahead;
+    // loads are unconditional: the band index is clamped to the wavefront's last band).  With one record in
+    // flight the launch ran at 31 us alone (records in L2) but 42 us inside the step (records in HBM).
+    uint32_t cell_q[RS_DEPTH];
+    uint4 id_q[RS_DEPTH][RS_PIECE];
+    auto fetch = [&](int band, uint32_t& cw, uint4 (&iw)[RS_PIECE]) {
+        band = band < b1 ? band : b1 - 1;
+        cw = a.cells[(int64_t)band * SPW + slot];
+        const uint4* p = reinterpret_cast<const uint4*>(a.ids) + ((int64_t)band * (RS_PIECE * SPW) + slot);
+#pragma unroll
+        for (int k = 0; k < RS_PIECE; ++k) iw[k] = p[k * SPW];
+    };
+    if (b < b1) {
+#pragma unroll
+        for (int q = 0; q < RS_DEPTH; ++q) fetch(b + q, cell_q[q], id_q[q]);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // RS_DEPTH bands per iteration, every record in its own registers (rotating the records through one set of
+    // names would copy registers whose loads are still in flight: hipcc then waits for all of them)
+    for (; b < b1; b += RS_DEPTH) {
+#pragma unroll
+        for (int q = 0; q < RS_DEPTH; ++q) {
+            const uint32_t cell = b + q < b1 ? cell_q[q] : 0u;                 // past the end: an idle cell
+            uint4 idv[RS_PIECE];
+#pragma unroll
+            for (int k = 0; k < RS_PIECE; ++k) idv[k] = id_q[q][k];
+            fetch(b + q + RS_DEPTH, cell_q[q], id_q[q]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int len = (int)((cell >> 24) & 15u);
+            if (cell & (1u << 28)) acc = make_float4(0.f, 0.f, 0.f, 0.f);      // first piece of its row
+#pragma unroll
+            for (int k = 0; k < RS_PIECE; ++k) {
+                if (k < len) {
+                    // one step: 8 pre-scaled ids -> 8 row addresses (SDWA adds) -> 8 ds_read_b128 -> one wait, rows
+                    // added last to first (the last row's arrival implies the others: LDS returns in order)
+                    const unsigned w4[4] = {idv[k].x, idv[k].y, idv[k].z, idv[k].w};
+                    const char* ad[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
+                        ad[jj] = UNIT ? tabb + idj : tabb + __umul24(idj, ldt4);
+                    }
+                    float4 v[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const float4*>(ad[jj]);
+#pragma unroll
+                    for (int jj = 7; jj >= 0; --jj) { acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w; }
+                }
+            }
+            if (cell & (1u << 29))                                               // last piece: the row is complete
+                tipk_st4(out + (int64_t)(cell & 0xffffffu) * a.ld_out + c0, acc);
+        }
+    }
+    // rows (relation, node) without edges
+    if (!a.zero_ptr) return;                           // the consumer masks those rows (tipk_rgcn_dy_products row_used)
+    const int z0 = __builtin_amdgcn_readfirstlane(a.zero_ptr[gw]), z1 = __builtin_amdgcn_readfirstlane(a.zero_ptr[gw + 1]);
+    for (int z = z0 + slot; z < z1; z += SPW)
+        tipk_st4(out + (int64_t)a.zero_rows[z] * a.ld_out + c0, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+// column blocks of the launch (grid.y): the table of one block must fit in LDS; 0 = not supported
+inline int rel_stream_split(int64_t n_nodes, int d) {
+    if (n_nodes <= 0 || n_nodes > 65535 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
+    for (int split = 1; split <= 4 && d / split >= 4; split *= 2) {      // every column block walks all the ids again
+        const int dc = d / split;
+        if (dc > 64) continue;
+        if ((n_nodes + 1) * dc * 4 <= RS_LDS_LIMIT) return split;
+    }
+    return 0;
+}
+
+template <int L>
+int launch_rs(const RsArgs& a, int n_wg, int split, hipStream_t st) {
+    const size_t lds = (size_t)(a.n_nodes + 1) * a.dc * 4;
+    auto kern = a.idx_mul == 1 ? rel_stream_bwd_kernel<L, true> : rel_stream_bwd_kernel<L, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return tipk_hip_status(e);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)split), dim3(1024), lds, st, a);
+    TIPK_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int tipk_rel_stream_supported(int64_t n_nodes, int d) { return rel_stream_split(n_nodes, d); }
+
+extern "C" int tipk_rel_stream_piece(void) { return RS_PIECE; }
+
+extern "C" int tipk_rel_stream_bwd(const float* table, int64_t ld_table, int64_t n_nodes, int d, int64_t n_wg,
+                                   const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
+                                   const int32_t* zero_ptr, const int32_t* zero_rows, const float* row_scale,
+                                   float* out, int64_t ld_out, tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table || !wave_ptr || !cells || !ids || (zero_ptr && !zero_rows) || !out ||
+        (reinterpret_cast<uintptr_t>(ids) & 15))
+        return TIPK_EINVAL;
+    const int split = rel_stream_split(n_nodes, d);
+    if (split == 0) return TIPK_EUNSUPPORTED;
+    if (ld_table % 4 != 0 || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(table) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & 15))
+        return TIPK_EINVAL;
+    RsArgs a;
+    a.table = table; a.ld_t = ld_table; a.n_nodes = (int)n_nodes; a.dc = d / split;
+    a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
+    a.out = out; a.ld_out = ld_out; a.row_scale = row_scale;
+    if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || (int64_t)n_nodes * idx_unit > 65535) return TIPK_EINVAL;
+    a.idx_mul = a.dc * 4 / idx_unit;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.dc / 4) {
+        case 1: return launch_rs<1>(a, (int)n_wg, split, st);
+        case 2: return launch_rs<2>(a, (int)n_wg, split, st);
+        case 4: return launch_rs<4>(a, (int)n_wg, split, st);
+        case 8: return launch_rs<8>(a, (int)n_wg, split, st);
+        default: return launch_rs<16>(a, (int)n_wg, split, st);
+    }
+}

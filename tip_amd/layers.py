@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_csr_plan, group_slots_for,
+from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_csr_plan, group_slots_for,
                    relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
@@ -310,7 +310,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     else:
         assert in_degree.numel() == n_nodes
         deg = in_degree.to(src.device).to(torch.float32).clamp_(min=1)
-    rl_fwd = rl_bwd = None
+    rl_fwd = rl_bwd = rs_bwd = None
     if n_nodes <= 1024 and n_rel > 0 and src.numel() > 0:
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
@@ -328,7 +328,12 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             lanes_f = lanes_b = None
         cap_f = None           # (cutting forward units to the id chunk was measured slower: smaller units fill fewer bands)
         rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
-        rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
+        # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
+        split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
+        if split_s:
+            rs_bwd = build_stream_plan(src, dst, rel, n_nodes, n_rel, n_cu, (d_out // split_s) // 4, ops.rel_stream_piece())
+        else:
+            rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
     def fwd_plan():
         # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by
         # relation block, so that a row of Y gathered by several edges crosses the fabric once
@@ -343,7 +348,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     return ops.AggGraph(fwd_plan,
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd,
-                        csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'))
+                        csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'), rs_bwd=rs_bwd)
 
 
 class _RGCNBase(nn.Module):

@@ -206,6 +206,46 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
     return sum_slabs(out)
 
 
+def rel_stream_split(n_nodes, d):
+    """column blocks `tipk_rel_stream_bwd` would use for this shape; 0 = the table does not fit in LDS."""
+    if os.environ.get('TIPK_NO_RELSTREAM') or os.environ.get('TIPK_NO_RELLOCAL'):
+        return 0
+    return int(lib().tipk_rel_stream_supported(n_nodes, d))
+
+
+def rel_stream_piece():
+    return int(lib().tipk_rel_stream_piece())
+
+
+def dy_products_fused(r, nc, nb):
+    """True when `dy_products` takes the fused one-pass kernel for this shape (it alone honours `row_used`)."""
+    import ctypes as C
+    s_c, s_r = C.c_int(0), C.c_int(0)
+    if os.environ.get('TIPK_NO_DY_FUSED'):
+        return False
+    check(lib().tipk_rgcn_dy_products_plan(r, nc, nb, C.byref(s_c), C.byref(s_r)), 'tipk_rgcn_dy_products_plan')
+    return s_c.value != 0
+
+
+def rel_stream_bwd(sp, table, row_scale=None, write_zeros=True):
+    """Transposed D-D pass on a wave-stream plan (include/tipk.h section 1d): table = g [N, d] (scaled per
+    row while staged) -> dY [R * N, d].  write_zeros=False leaves the rows without edges UNTOUCHED (garbage):
+    only for a consumer that masks them with `sp.row_used` (`dy_products`)."""
+    table = _f32c(table)
+    require_device(table, sp.ids)
+    d = table.shape[1]
+    n, r = sp.n_nodes, sp.n_rel
+    split = rel_stream_split(n, d)
+    assert split and (d // split) // 4 == sp.lanes, 'plan was built for another launch shape'
+    out = torch.empty((r * n, d), dtype=torch.float32, device=table.device)
+    with _timed('rel_stream[dd.bwd,d=%d]' % d):
+        check(lib().tipk_rel_stream_bwd(ptr(table), table.stride(0), n, d, sp.n_wg, ptr(sp.wave_ptr), ptr(sp.cells),
+                                        ptr(sp.ids), sp.idx_unit, ptr(sp.zero_ptr) if write_zeros else None,
+                                        ptr(sp.zero_rows), ptr(row_scale),
+                                        ptr(out), d, stream_ptr(table.device)), 'tipk_rel_stream_bwd')
+    return out
+
+
 def _strides3(t):
     """(batch stride, row stride, col stride) of a 2-D (batch stride 0) or 3-D tensor."""
     if t.dim() == 2:
@@ -329,7 +369,7 @@ def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, k
     return job.out
 
 
-def dy_products(g_y, att, xb2):
+def dy_products(g_y, att, xb2, row_used=None, n_nodes=0):
     """(d att, d XB) = (g_y @ xb2^T, att^T @ g_y) in ONE pass over g_y [R, N*out] (include/tipk.h
     section 2b); falls back to two grouped GEMMs for shapes the fused kernel does not take."""
     import ctypes as C
@@ -339,6 +379,7 @@ def dy_products(g_y, att, xb2):
     if not os.environ.get('TIPK_NO_DY_FUSED') and g_y.stride(1) == 1 and att.stride(1) == 1 and xb2.stride(1) == 1:
         check(lib().tipk_rgcn_dy_products_plan(r, nc, nb, C.byref(s_c), C.byref(s_r)), 'tipk_rgcn_dy_products_plan')
     if s_c.value == 0:
+        assert row_used is None, 'the two-GEMM path reads every row of dY'
         g_att, g_xb = gemm_group([gemm_job(g_y, xb2.t()), gemm_job(att.t(), g_y)])
         return g_att, g_xb
     dev = g_y.device
@@ -346,7 +387,7 @@ def dy_products(g_y, att, xb2):
     datt_slabs = torch.empty((s_c.value, r, nb), dtype=torch.float32, device=dev)
     with _timed('dy_products[%dx%dx%d]' % (r, nc, nb)):
         check(lib().tipk_rgcn_dy_products(ptr(g_y), g_y.stride(0), ptr(att), att.stride(0), ptr(xb2), xb2.stride(0),
-                                          r, nc, nb, ptr(dxb_slabs), ptr(datt_slabs), stream_ptr(dev)),
+                                          r, nc, nb, ptr(row_used), n_nodes, ptr(dxb_slabs), ptr(datt_slabs), stream_ptr(dev)),
               'tipk_rgcn_dy_products')
     j_att = slab_job(datt_slabs)
     if s_r.value == 1:                                   # one row range: the slab IS d XB
@@ -678,13 +719,14 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
-    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None):
+    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
         generic D-D plans are only needed where the relation-local kernel does not apply).
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
         self._fwd, self._bwd, self.scale = fwd, bwd, scale
         self._csr_bwd = csr_bwd
         self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
+        self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
 
     @property
@@ -863,7 +905,15 @@ class _RGCN(torch.autograd.Function):
         r = att.shape[0]
         xb2 = xb.view(nb, n * d_out)
         if r > 0:
-            if rel_gather_usable(graph.rl_bwd, n, d_out, True):          # dY_r = A_r^T (D^-1 g), 1/deg fused
+            rs = graph.rs_bwd
+            used = None
+            if rs is not None and rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes:
+                # dY_r = A_r^T (D^-1 g), 1/deg fused.  Rows (relation, node) without edges -- half of them -- are
+                # neither written here nor read as data by the fused products (row mask)
+                masked = dy_products_fused(r, n * d_out, nb) and xb.stride(-1) == 1 and not os.environ.get('TIPK_DY_ZEROS')
+                g_y = rel_stream_bwd(rs, g, row_scale=graph.scale, write_zeros=not masked).view(r, n * d_out)
+                used = rs.row_used if masked else None
+            elif rel_gather_usable(graph.rl_bwd, n, d_out, True):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
@@ -873,7 +923,7 @@ class _RGCN(torch.autograd.Function):
                 else:
                     g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
             # both consumers of dY in one pass over it (+ one grouped slab sum)
-            g_att, g_xb = dy_products(g_y, att, xb2)
+            g_att, g_xb = dy_products(g_y, att, xb2, used, n)
             g_xb = g_xb.view(nb, n, d_out)
         else:
             g_att = torch.zeros((0, nb), dtype=torch.float32, device=x.device)

@@ -523,6 +523,166 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
                    npos.to(torch.int32).contiguous(), idx_unit=idx_unit)
 
 
+class StreamPlan(object):
+    """Device arrays of `tipk_rel_stream_bwd` (layout: include/tipk.h section 1d)."""
+
+    def __init__(self, n_nodes, n_rel, n_wg, lanes, piece, wave_ptr, cells, ids, zero_ptr, zero_rows, row_used, idx_unit):
+        self.n_nodes, self.n_rel, self.n_wg, self.lanes, self.piece = int(n_nodes), int(n_rel), int(n_wg), int(lanes), int(piece)
+        self.wave_ptr, self.cells, self.ids, self.zero_ptr, self.zero_rows = wave_ptr, cells, ids, zero_ptr, zero_rows
+        self.row_used = row_used                  # int32 [ceil(R / 32), N] bit mask of the rows with edges (tipk.h section 2b)
+        self.idx_unit = int(idx_unit)
+        self.n_bands = int(cells.shape[0])
+
+    def to(self, device):
+        return StreamPlan(self.n_nodes, self.n_rel, self.n_wg, self.lanes, self.piece, *[t.to(device) for t in (
+            self.wave_ptr, self.cells, self.ids, self.zero_ptr, self.zero_rows, self.row_used)], idx_unit=self.idx_unit)
+
+
+STREAM_BAND_OVERHEAD = 2.0     # what a band costs besides its steps (record fetch, row store), in steps
+
+
+def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4):
+    """Wave-stream plan for  out[r * N + o] = sum_{e in r: out_node[e] = o} table[tab_node[e]]  (every row).
+
+    The runs (one per output row with edges) are sorted by decreasing length and taken SPW = 64 / lanes at
+    a time: such a GROUP is what the slots of one wavefront walk side by side, so its runs should be
+    equally long (no lanes idling behind a hub run) -- after the sort they are.  A group whose longest run
+    has s steps of 8 ids occupies ceil(s / piece) consecutive BANDS of its wavefront (a run continues in
+    the same slot, its sum stays in registers).  Groups are dealt to the n_wg * 16 wavefronts by the
+    longest-processing-time rule on  steps + STREAM_BAND_OVERHEAD * bands; rows without edges are dealt
+    evenly.  Inside a run the ids are ordered for conflict-free LDS reads (`bank_rotation`) and pre-scaled
+    (idx_unit) exactly as in `build_rel_plan`."""
+    import heapq
+    dev = out_node.device
+    N, S, W = int(n_nodes), 64 // int(lanes), int(n_wg) * 16
+    assert N <= 65535 and n_rel * N < 2 ** 24, 'cells hold the output row in 24 bits'
+    E = int(out_node.numel())
+    key = rel * N + out_node
+    cnt_rows = torch.bincount(key, minlength=n_rel * N)
+    zero_rows = torch.nonzero(cnt_rows == 0).flatten()
+    run_row = torch.nonzero(cnt_rows > 0).flatten()
+    run_cnt = cnt_rows[run_row]
+    # by decreasing STEPS (8 ids each), rows ascending inside a class: equal work per slot of a group, and the
+    # rows a wavefront writes together are neighbours in dY more often than not
+    order = torch.sort((run_cnt + 7) // 8, descending=True, stable=True).indices
+    run_row, run_cnt = run_row[order], run_cnt[order]
+    n_runs = int(run_row.numel())
+    G = -(-n_runs // S)
+    steps = torch.zeros(G * S, dtype=torch.int64, device=dev)
+    steps[:n_runs] = (run_cnt + 7) // 8
+    rows_p = torch.zeros(G * S, dtype=torch.int64, device=dev)
+    rows_p[:n_runs] = run_row
+    steps, rows_p = steps.view(G, S), rows_p.view(G, S)
+    g_steps = steps.max(1).values if G else steps.new_zeros(0)            # longest run of the group
+    g_bands = torch.clamp((g_steps + piece - 1) // piece, min=1)
+    cost = (g_steps.double() + STREAM_BAND_OVERHEAD * g_bands.double()).cpu().tolist()
+    # longest-processing-time deal (groups come in decreasing cost)
+    # (giving every wavefront a contiguous range of output rows instead -- length-sorted only inside windows of
+    # 645 ... 32 768 rows, so that its writes sweep dY front to back -- measured no faster inside the step)
+    heap = [(0.0, w) for w in range(W)]
+    wave_of = [0] * G
+    for g in range(G):
+        load, w = heapq.heappop(heap)
+        wave_of[g] = w
+        heapq.heappush(heap, (load + cost[g], w))
+    wave_of = torch.tensor(wave_of, dtype=torch.int64, device=dev)
+    g_order = torch.sort(wave_of, stable=True).indices                   # layout order: wavefront by wavefront
+    bands_l = g_bands[g_order]
+    band0_l = torch.cumsum(bands_l, 0) - bands_l
+    n_bands = int(bands_l.sum()) if G else 0
+    g_band0 = torch.empty(G, dtype=torch.int64, device=dev)
+    g_band0[g_order] = band0_l
+    per_wave = torch.zeros(W, dtype=torch.int64, device=dev).index_add_(0, wave_of, g_bands)
+    wave_ptr = torch.cat([per_wave.new_zeros(1), torch.cumsum(per_wave, 0)])
+    # cells
+    grp = torch.repeat_interleave(g_order, bands_l)                       # group of every band
+    k = torch.arange(n_bands, device=dev) - torch.repeat_interleave(band0_l, bands_l)
+    st = steps[grp]                                                       # [n_bands, S]
+    nb_run = (st + piece - 1) // piece
+    length = torch.clamp(st - k.unsqueeze(1) * piece, min=0, max=piece)
+    first = (st > 0) & (k.unsqueeze(1) == 0)
+    last = (st > 0) & (k.unsqueeze(1) == nb_run - 1)
+    active = (st > 0) & (k.unsqueeze(1) < nb_run)
+    cells = torch.where(active, rows_p[grp] | (length << 24) | (first.long() << 28) | (last.long() << 29),
+                        torch.zeros_like(st))
+    # ids
+    idx_unit = 1
+    row_bytes = lanes * 16
+    while idx_unit * 2 <= row_bytes and N * idx_unit * 2 <= 65535:
+        idx_unit *= 2
+    run_of_row = torch.full((n_rel * N,), -1, dtype=torch.int64, device=dev)
+    run_of_row[run_row] = torch.arange(n_runs, device=dev)
+    ri = run_of_row[key]                                                  # run of every edge
+    n_cls, rot = bank_rotation(lanes)
+    cls = (tab_node % n_cls - torch.tensor(rot, device=dev)[ri % S]) % n_cls
+    e_order = torch.sort(ri * n_cls + cls, stable=True).indices
+    ri_s = ri[e_order]
+    run_first = torch.cumsum(run_cnt, 0) - run_cnt
+    j = torch.arange(E, device=dev) - run_first[ri_s]                     # rank inside the run
+    step = j // 8
+    band = g_band0[ri_s // S] + step // piece
+    dest = ((band * piece + step % piece) * S + ri_s % S) * 8 + j % 8
+    ids32 = torch.full((max(n_bands, 1) * piece * S * 8,), N * idx_unit, dtype=torch.int32, device=dev)
+    ids32[dest] = (tab_node[e_order] * idx_unit).to(torch.int32)
+    nz = int(zero_rows.numel())
+    zero_ptr = (torch.arange(W + 1, device=dev) * nz) // W
+    cells_u = torch.where(cells >= 2 ** 31, cells - 2 ** 32, cells).to(torch.int32)
+    if zero_rows.numel() == 0:
+        zero_rows = torch.zeros(1, dtype=torch.int64, device=dev)
+    # bit (r & 31) of row_used[r >> 5, node] = row (r, node) has edges
+    rt = -(-n_rel // 32)
+    has = torch.zeros(rt * 32, N, dtype=torch.int64, device=dev)
+    has[:n_rel] = (cnt_rows.view(n_rel, N) > 0).long()
+    word = (has.view(rt, 32, N) << torch.arange(32, device=dev).view(1, 32, 1)).sum(1)
+    row_used = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32).contiguous()
+    return StreamPlan(N, n_rel, n_wg, lanes, piece, wave_ptr.to(torch.int32).contiguous(),
+                      cells_u.view(n_bands, S).contiguous() if n_bands else cells_u.new_zeros((0, S)),
+                      ids32.to(torch.uint16).contiguous(), zero_ptr.to(torch.int32).contiguous(),
+                      zero_rows.to(torch.int32).contiguous(), row_used, idx_unit)
+
+
+def execute_stream_plan_reference(plan, table):
+    """Pure-torch interpretation of a wave-stream plan (CPU unit tests only): what every slot of every
+    wavefront does, in order; checks that every output row is written exactly once."""
+    N, R, S, P = plan.n_nodes, plan.n_rel, 64 // plan.lanes, plan.piece
+    d = table.shape[1]
+    ids = plan.ids.to(torch.int64)
+    assert bool((ids % plan.idx_unit == 0).all())
+    ids = (ids // plan.idx_unit).view(-1, P, S, 8)
+    cells = plan.cells.to(torch.int64) & 0xffffffff
+    out = torch.zeros((R * N, d), dtype=table.dtype)
+    written = torch.zeros(R * N, dtype=torch.long)
+    wp, zp = plan.wave_ptr.tolist(), plan.zero_ptr.tolist()
+    assert len(wp) == plan.n_wg * 16 + 1 and wp[0] == 0 and wp[-1] == plan.n_bands
+    for w in range(plan.n_wg * 16):
+        acc = torch.zeros((S, d), dtype=table.dtype)
+        open_row = [-1] * S
+        for b in range(wp[w], wp[w + 1]):
+            for s_ in range(S):
+                c = int(cells[b, s_])
+                row, ln, first, last = c & 0xffffff, (c >> 24) & 15, (c >> 28) & 1, (c >> 29) & 1
+                if c == 0:
+                    continue
+                assert 1 <= ln <= P
+                if first:
+                    assert open_row[s_] == -1
+                    acc[s_] = 0
+                    open_row[s_] = row
+                assert open_row[s_] == row, 'a run continues in the same slot of the next band'
+                nodes = ids[b, :ln, s_].reshape(-1)
+                nodes = nodes[nodes < N]
+                acc[s_] += table[nodes].sum(0)
+                if last:
+                    out[row] = acc[s_]
+                    written[row] += 1
+                    open_row[s_] = -1
+        assert all(r == -1 for r in open_row)
+        for z in range(zp[w], zp[w + 1]):
+            written[int(plan.zero_rows[z])] += 1
+    assert bool((written == 1).all()), 'every (relation, node) row is written exactly once'
+    return out
+
+
 def execute_rel_plan_reference(plan, table, backward):
     """Pure-torch interpretation of a relation-local plan (CPU unit tests only)."""
     n, R = plan.n_nodes, plan.n_rel

@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tip_amd import ops, _lib
 from tip_amd.data import build_data_dict
 from tip_amd.layers import rgcn_graph
+import os as _os
+_os.environ['TIPK_NO_RELSTREAM'] = '1'            # the stamps live in the relation-local kernel: build ITS backward plan
 dd = build_data_dict(); dev = 'cuda:0'
 ei = dd['dd_train_idx'].to(dev); rg = dd['dd_train_range']; R = dd['n_dd_et']; N = 645
 rel = torch.repeat_interleave(torch.arange(R), rg[:, 1] - rg[:, 0]).to(dev)

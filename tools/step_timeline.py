@@ -4,7 +4,7 @@ import csv, glob, os, sys
 root = sys.argv[1]
 f = sorted(glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-fw = [i for i, r in enumerate(rows) if 'rel_gather_kernel' in r['Kernel_Name'] and r['Grid_Size_Y'] == '2']
+fw = [i for i, r in enumerate(rows) if 'rel_gather_kernel' in r['Kernel_Name'] and r['Grid_Size_Y'] == '2']   # the layer-1 forward launch
 steps = [(a, b) for a, b in zip(fw, fw[1:]) if b - a > 10]          # skip the back-to-back launch timing loops
 i0, i1 = steps[len(steps) // 2]
 t0 = int(rows[i0]['Start_Timestamp'])
@@ -16,7 +16,7 @@ for r in rows[i0:i1]:
     dur = (e - s) / 1e3
     print('%8.1f  dur %6.1f  gap %5.1f  %-46s %sx%s' % ((s - t0) / 1e3, dur, ((s - prev) / 1e3 if prev else 0), name,
                                                      r['Grid_Size_X'], r['Grid_Size_Y']))
-    if dur < 16.5 and 'rel_gather' not in name and 'dy_products' not in name and 'gemm_stream' not in name:
+    if dur < 16.5 and 'rel_gather' not in name and 'rel_stream' not in name and 'dy_products' not in name and 'gemm_stream' not in name:
         small += dur
     else:
         big += dur
