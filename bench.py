@@ -202,12 +202,25 @@ def dd_aggregation_launches(enc, dev):
             continue
         y = torch.randn(r * n, d, device=dev)
         g = torch.randn(n, d, device=dev)
+        nb = layer.num_bases
         for bwd in (False, True):
             rp = graph.rl_bwd if bwd else graph.rl_fwd
             rs = graph.rs_bwd if bwd else None
-            if rs is not None and ops.rel_stream_split(n, d):
+            pair = None if bwd or os.environ.get('TIPK_NO_PAIR_FWD') else graph.pair_fwd
+            if pair is not None and pair.n_table == r and ops.stream_gather_split(r, nb):
+                # forward in pair form: per edge one id + one att row (nb floats) from LDS; the dense product that
+                # follows is a separate launch (gemm[...] in kernels_eager_ms)
+                split = ops.stream_gather_split(r, nb)
+                key = 'stream_gather_kernel<%d, %s, 1' % (nb // split // 4, 'true' if pair.idx_unit == nb // split * 4 else 'false')
+                grid = '%dx%dx1' % (pair.n_wg * 1024, split)
+                att = torch.randn(r, nb, device=dev)
+                cells = graph.pair_cells(n, nb, dev)
+                out.append(('pair_cells[dd.fwd,d=%d]' % d, key, grid, nb, 'lds',
+                            lambda pair=pair, att=att, cells=cells, nb=nb: ops.stream_gather(
+                                pair, att, write_zeros=False, out=cells.view(n * n, nb), kind=1)))
+            elif rs is not None and ops.rel_stream_split(n, d):
                 split = ops.rel_stream_split(n, d)
-                key = 'rel_stream_bwd_kernel<%d' % (d // split // 4)
+                key = 'stream_gather_kernel<%d, %s, 0' % (d // split // 4, 'true' if rs.idx_unit == d // split * 4 else 'false')
                 grid = '%dx%dx1' % (rs.n_wg * 1024, split)
                 out.append(('rel_stream[dd.bwd,d=%d]' % d, key, grid, d, 'lds',
                             lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale)))

@@ -172,33 +172,38 @@ int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t 
                     const float* row_scale, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
- * 1d. Wave-stream gather -- the TRANSPOSED D-D pass (autograd of src/layers.py:159-180) when g' fits in LDS:
- *
- *       out[row] = sum_{e: row(e) = row} g'[tab(e)],   row = relation * n_nodes + source node  (every row written)
- *
- *     the sums of tipk_rel_gather(backward = 1), without work units: after g' is staged (one barrier) every
+ * 1d. Wave-stream gather:   out[row] = sum_{e: row(e) = row} table[tab(e)]   for a table [n_table x d] that fits in LDS
+ *     (one column block of it: `tipk_stream_gather_supported`).  After the table is staged (one barrier) every
  *     wavefront streams through its own list of fixed-size records and never meets the others
- *     (tip_amd/csrc/tipk_rel_stream.hip explains why).  L = (d / column blocks) / 4 lanes form a slot,
- *     S = 64 / L slots a wavefront, P = tipk_rel_stream_piece() steps of 8 ids a cell.  Plan
- *     (tip_amd/plan.py `build_stream_plan`), all device arrays:
+ *     (tip_amd/csrc/tipk_rel_stream.hip explains why).  Two uses on the TIP path:
+ *       - the TRANSPOSED D-D pass (autograd of src/layers.py:159-180): table = g' [nodes x out], row = relation *
+ *         nodes + source node -- the sums of tipk_rel_gather(backward = 1), without its work units;
+ *       - the FORWARD D-D pass (src/layers.py:159-180) in pair form: table = att [relations x bases], row =
+ *         destination * nodes + source: cell (v, u) = sum of att[r, :] over the relations r that link u -> v
+ *         (a drug pair of BioSNAP is linked by 66 relations on average), followed by ONE dense product with
+ *         X . basis (tip_amd/ops.py `_RGCN.forward`): Y = att . XB is never formed.
+ *     L = (d / column blocks) / 4 lanes form a slot, S = 64 / L slots a wavefront, P = tipk_stream_gather_piece()
+ *     steps of 8 ids a cell.  Plan (tip_amd/plan.py `build_stream_plan_rows`), all device arrays:
  *       wave_ptr[n_wg * 16 + 1]  int32: range of bands of every wavefront (wavefront = workgroup * 16 + wave)
  *       cells[n_bands][S]        uint32: row (24 bits) | steps << 24 (0 .. P) | first << 28 | last << 29.  A slot
  *                                adds the steps' rows to a register sum that is cleared on `first` and written
  *                                to out[row] on `last`: a run longer than P steps continues in the SAME slot of
  *                                the wavefront's next band; 0 = idle cell
- *       ids[n_bands][P][S][8]    uint16: table node * idx_unit of the edges (see 1b), runs padded to 8 with the
- *                                sentinel n_nodes * idx_unit (a zero row); steps beyond a cell's count are not read
+ *       ids[n_bands][P][S][8]    uint16: table row * idx_unit of the edges (see 1b), runs padded to 8 with the
+ *                                sentinel n_table * idx_unit (a zero row); steps beyond a cell's count are not read
  *       zero_ptr[n_wg * 16 + 1], zero_rows[]  int32: the rows without edges, dealt to the wavefronts; zero_ptr
- *                                = NULL: those rows are left untouched (the consumer masks them: section 2b row_used)
- *     n_rel * n_nodes < 2^24.  row_scale (nullable): g' = row_scale[node] * table[node] while staging.
+ *                                = NULL: those rows are left untouched (the consumer masks them -- section 2b
+ *                                row_used -- or they live in a buffer that was zeroed once)
+ *     rows < 2^24.  row_scale (nullable): row_scale[i] * table[i] is what is staged.
  */
-/* column blocks of the launch (grid = n_wg x blocks); 0 = g' does not fit (use tipk_gather_rows_csr) */
-int tipk_rel_stream_supported(int64_t n_nodes, int d);
-int tipk_rel_stream_piece(void);
-int tipk_rel_stream_bwd(const float* table, int64_t ld_table, int64_t n_nodes, int d, int64_t n_wg,
+/* column blocks of the launch (grid = n_wg x blocks); 0 = the table does not fit in LDS */
+int tipk_stream_gather_supported(int64_t n_table, int d);
+int tipk_stream_gather_piece(void);
+int tipk_stream_gather(const float* table, int64_t ld_table, int64_t n_table, int d, int64_t n_wg,
                         const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
                         const int32_t* zero_ptr, const int32_t* zero_rows, const float* row_scale,
-                        float* out, int64_t ld_out, tipk_stream_t stream);
+                        float* out, int64_t ld_out, int kind /* 0 | 1: names the kernel instance in profiles, nothing else */,
+                        tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).

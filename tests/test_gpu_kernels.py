@@ -656,7 +656,29 @@ def test_rel_stream_bwd(ops, N, d):
     wide = torch.randn(N, d + 8, generator=g).to(DEV)
     close(ops.rel_stream_bwd(sp, wide[:, 4:4 + d]), O.gather_sum(wide[:, 4:4 + d].cpu().double(), dst, rel * N + src, R * N))
     from tip_amd import _lib
-    assert _lib.lib().tipk_rel_stream_supported(10000, 32) == 0 and _lib.lib().tipk_rel_stream_supported(645, 24) == 0
+    assert _lib.lib().tipk_stream_gather_supported(10000, 32) == 0 and _lib.lib().tipk_stream_gather_supported(645, 24) == 0
+
+
+@pytest.mark.parametrize('N,R,nb', [(645, 1097, 32), (200, 50, 32), (100, 1500, 16), (64, 9, 8)])
+def test_stream_gather_pair_form(ops, N, R, nb):
+    """The forward pass in pair form: cell (v, u) = sum of att[r] over the relations linking u -> v, written into a
+    buffer that was zeroed once (cells of unlinked pairs are never touched); table = att stays in LDS."""
+    from tip_amd.plan import build_stream_plan_rows
+    g = torch.Generator().manual_seed(N + R)
+    E = 60000
+    rel = torch.randint(0, R, (E,), generator=g)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = (src + 1 + torch.randint(0, max(1, N // 4), (E,), generator=g)) % N      # pairs repeat: ~E / (N * N / 4) relations each
+    split = ops.stream_gather_split(R, nb)
+    assert split >= 1
+    sp = build_stream_plan_rows(dst * N + src, rel, N * N, R, 64, nb // split // 4, ops.rel_stream_piece()).to(DEV)
+    att = torch.randn(R, nb, generator=g)
+    cells = torch.zeros(N * N, nb, device=DEV)
+    for _ in range(2):                                                             # second call rewrites the same cells
+        ops.stream_gather(sp, att.to(DEV), write_zeros=False, out=cells, kind=1)
+    want = torch.zeros(N * N, nb, dtype=torch.float64).index_add_(0, dst * N + src, att.double()[rel])
+    close(cells, want)
+    assert int((cells.abs().sum(1) > 0).sum()) == int(torch.unique(dst * N + src).numel())
 
 
 def test_rel_gather_unsupported_shapes():

@@ -62,9 +62,9 @@ SIGNATURES = {
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
-    'tipk_rel_stream_supported': (_I, [_L, _I]),
-    'tipk_rel_stream_piece': (_I, []),
-    'tipk_rel_stream_bwd': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
+    'tipk_stream_gather_supported': (_I, [_L, _I]),
+    'tipk_stream_gather_piece': (_I, []),
+    'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),

@@ -1,6 +1,8 @@
-// Wave-stream gather: the TRANSPOSED D-D pass (dY_r = A_r^T g', include/tipk.h section 1d) when the
-// table g' fits in LDS -- the same sums as tipk_rel_gather(backward = 1), organised so that the 16
-// wavefronts of a workgroup never meet after the table is staged.
+// Wave-stream gather (include/tipk.h section 1d):  out[row] = sum_{e: row(e) = row} table[tab(e)]  for a table
+// that fits in LDS, organised so that the 16 wavefronts of a workgroup never meet after the table is staged.
+// Two uses on the TIP path: the TRANSPOSED D-D pass (dY_r = A_r^T g': table = g', rows = (relation, source)
+// -- the sums of tipk_rel_gather(backward = 1)) and the forward D-D pass in its pair form (table = att, rows =
+// (destination, source) drug pairs: tip_amd/ops.py `_RGCN.forward`).
 //
 // tipk_rel_gather walks work UNITS (relations): per unit the workgroup stages ids and run tables together
 // and meets at two barriers.  In-kernel stamps (tools/rg_stamps.py) put 14-19 % of a wave's life into
@@ -27,7 +29,7 @@
 namespace {
 
 constexpr int RS_PIECE = 4;            // steps (8 ids each) per cell
-constexpr int RS_DEPTH = 3;            // band records in flight per wavefront
+constexpr int RS_DEPTH = 2;            // bands a record is requested ahead of its use
 constexpr int64_t RS_LDS_LIMIT = 158 * 1024;
 
 struct RsArgs {
@@ -43,8 +45,9 @@ struct RsArgs {
     int idx_mul;                       // byte offset of a table row = id * idx_mul
 };
 
-template <int L, bool UNIT>
-__global__ __launch_bounds__(1024) void rel_stream_bwd_kernel(RsArgs a) {
+// KIND only names the launch in profiles (0: rows = (relation, node), the transposed pass; 1: rows = node pairs)
+template <int L, bool UNIT, int KIND>
+__global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];        // [n_nodes + 1][dc], last row = 0 (the pad id's row)
     constexpr int SPW = 64 / L;
     constexpr int q4 = L;
@@ -81,11 +84,14 @@ __global__ __launch_bounds__(1024) void rel_stream_bwd_kernel(RsArgs a) {
     const unsigned ldt4 = (unsigned)a.idx_mul;
 
     // A band is walked in about a microsecond; its record (cell word + ids) comes from HBM and takes two under
-    // load.  RS_DEPTH records are therefore in flight per wavefront (registers, requested RS_DEPTH bands ahead;
-    // loads are unconditional: the band index is clamped to the wavefront's last band).  With one record in
-    // flight the launch ran at 31 us alone (records in L2) but 42 us inside the step (records in HBM).
-    uint32_t cell_q[RS_DEPTH];
-    uint4 id_q[RS_DEPTH][RS_PIECE];
+    // load, so records are requested RS_DEPTH bands ahead (loads are unconditional: the band index is clamped
+    // to the wavefront's last band).  Registers: 2 x RS_DEPTH record sets used round robin -- band j is walked
+    // out of set j mod 4 while band j + 2 lands in set (j + 2) mod 4 -- so a record is never copied: rotating
+    // the records through one set of names makes hipcc move registers whose loads are still in flight, i.e.
+    // drain the whole queue once per trip (measured: 42 us inside the step with one record in flight, 31 alone).
+    static_assert(RS_DEPTH == 2, "four record sets below");
+    uint32_t c0q = 0, c1q = 0, c2q = 0, c3q = 0;
+    uint4 i0q[RS_PIECE], i1q[RS_PIECE], i2q[RS_PIECE], i3q[RS_PIECE];
     auto fetch = [&](int band, uint32_t& cw, uint4 (&iw)[RS_PIECE]) {
         band = band < b1 ? band : b1 - 1;
         cw = a.cells[(int64_t)band * SPW + slot];
@@ -93,46 +99,45 @@ __global__ __launch_bounds__(1024) void rel_stream_bwd_kernel(RsArgs a) {
 #pragma unroll
         for (int k = 0; k < RS_PIECE; ++k) iw[k] = p[k * SPW];
     };
-    if (b < b1) {
-#pragma unroll
-        for (int q = 0; q < RS_DEPTH; ++q) fetch(b + q, cell_q[q], id_q[q]);
-    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // RS_DEPTH bands per iteration, every record in its own registers (rotating the records through one set of
-    // names would copy registers whose loads are still in flight: hipcc then waits for all of them)
-    for (; b < b1; b += RS_DEPTH) {
+    // walk band `band` out of (cw, iw) and request band + RS_DEPTH into (nw, niw)
+    auto walk = [&](int band, const uint32_t& cw, const uint4 (&iw)[RS_PIECE], uint32_t& nw, uint4 (&niw)[RS_PIECE]) {
+        const uint32_t cell = band < b1 ? cw : 0u;                             // past the end: an idle cell
+        fetch(band + RS_DEPTH, nw, niw);
+        __builtin_amdgcn_sched_barrier(0);
+        const int len = (int)((cell >> 24) & 15u);
+        if (cell & (1u << 28)) acc = make_float4(0.f, 0.f, 0.f, 0.f);          // first piece of its row
 #pragma unroll
-        for (int q = 0; q < RS_DEPTH; ++q) {
-            const uint32_t cell = b + q < b1 ? cell_q[q] : 0u;                 // past the end: an idle cell
-            uint4 idv[RS_PIECE];
+        for (int k = 0; k < RS_PIECE; ++k) {
+            if (k < len) {
+                // one step: 8 pre-scaled ids -> 8 row addresses (SDWA adds) -> 8 ds_read_b128 -> one wait, rows
+                // added last to first (the last row's arrival implies the others: LDS returns in order)
+                const unsigned w4[4] = {iw[k].x, iw[k].y, iw[k].z, iw[k].w};
+                const char* ad[8];
 #pragma unroll
-            for (int k = 0; k < RS_PIECE; ++k) idv[k] = id_q[q][k];
-            fetch(b + q + RS_DEPTH, cell_q[q], id_q[q]);
-            __builtin_amdgcn_sched_barrier(0);
-            const int len = (int)((cell >> 24) & 15u);
-            if (cell & (1u << 28)) acc = make_float4(0.f, 0.f, 0.f, 0.f);      // first piece of its row
-#pragma unroll
-            for (int k = 0; k < RS_PIECE; ++k) {
-                if (k < len) {
-                    // one step: 8 pre-scaled ids -> 8 row addresses (SDWA adds) -> 8 ds_read_b128 -> one wait, rows
-                    // added last to first (the last row's arrival implies the others: LDS returns in order)
-                    const unsigned w4[4] = {idv[k].x, idv[k].y, idv[k].z, idv[k].w};
-                    const char* ad[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
-                        ad[jj] = UNIT ? tabb + idj : tabb + __umul24(idj, ldt4);
-                    }
-                    float4 v[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const float4*>(ad[jj]);
-#pragma unroll
-                    for (int jj = 7; jj >= 0; --jj) { acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w; }
+                for (int jj = 0; jj < 8; ++jj) {
+                    const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
+                    ad[jj] = UNIT ? tabb + idj : tabb + __umul24(idj, ldt4);
                 }
+                float4 v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const float4*>(ad[jj]);
+#pragma unroll
+                for (int jj = 7; jj >= 0; --jj) { acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w; }
             }
-            if (cell & (1u << 29))                                               // last piece: the row is complete
-                tipk_st4(out + (int64_t)(cell & 0xffffffu) * a.ld_out + c0, acc);
         }
+        if (cell & (1u << 29))                                                   // last piece: the row is complete
+            tipk_st4(out + (int64_t)(cell & 0xffffffu) * a.ld_out + c0, acc);
+    };
+    if (b < b1) {
+        fetch(b, c0q, i0q);
+        fetch(b + 1, c1q, i1q);
+    }
+    for (; b < b1; b += 4) {
+        walk(b, c0q, i0q, c2q, i2q);
+        walk(b + 1, c1q, i1q, c3q, i3q);
+        walk(b + 2, c2q, i2q, c0q, i0q);
+        walk(b + 3, c3q, i3q, c1q, i1q);
     }
     // rows (relation, node) without edges
     if (!a.zero_ptr) return;                           // the consumer masks those rows (tipk_rgcn_dy_products row_used)
@@ -153,9 +158,10 @@ inline int rel_stream_split(int64_t n_nodes, int d) {
 }
 
 template <int L>
-int launch_rs(const RsArgs& a, int n_wg, int split, hipStream_t st) {
+int launch_rs(const RsArgs& a, int n_wg, int split, int kind, hipStream_t st) {
     const size_t lds = (size_t)(a.n_nodes + 1) * a.dc * 4;
-    auto kern = a.idx_mul == 1 ? rel_stream_bwd_kernel<L, true> : rel_stream_bwd_kernel<L, false>;
+    auto kern = kind ? (a.idx_mul == 1 ? stream_gather_kernel<L, true, 1> : stream_gather_kernel<L, false, 1>)
+                     : (a.idx_mul == 1 ? stream_gather_kernel<L, true, 0> : stream_gather_kernel<L, false, 0>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return tipk_hip_status(e);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)split), dim3(1024), lds, st, a);
@@ -164,14 +170,14 @@ int launch_rs(const RsArgs& a, int n_wg, int split, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int tipk_rel_stream_supported(int64_t n_nodes, int d) { return rel_stream_split(n_nodes, d); }
+extern "C" int tipk_stream_gather_supported(int64_t n_table, int d) { return rel_stream_split(n_table, d); }
 
-extern "C" int tipk_rel_stream_piece(void) { return RS_PIECE; }
+extern "C" int tipk_stream_gather_piece(void) { return RS_PIECE; }
 
-extern "C" int tipk_rel_stream_bwd(const float* table, int64_t ld_table, int64_t n_nodes, int d, int64_t n_wg,
+extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t n_nodes, int d, int64_t n_wg,
                                    const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
                                    const int32_t* zero_ptr, const int32_t* zero_rows, const float* row_scale,
-                                   float* out, int64_t ld_out, tipk_stream_t stream) {
+                                   float* out, int64_t ld_out, int kind, tipk_stream_t stream) {
     if (n_wg <= 0 || n_wg > 65535 || !table || !wave_ptr || !cells || !ids || (zero_ptr && !zero_rows) || !out ||
         (reinterpret_cast<uintptr_t>(ids) & 15))
         return TIPK_EINVAL;
@@ -188,10 +194,10 @@ extern "C" int tipk_rel_stream_bwd(const float* table, int64_t ld_table, int64_t
     a.idx_mul = a.dc * 4 / idx_unit;
     hipStream_t st = (hipStream_t)stream;
     switch (a.dc / 4) {
-        case 1: return launch_rs<1>(a, (int)n_wg, split, st);
-        case 2: return launch_rs<2>(a, (int)n_wg, split, st);
-        case 4: return launch_rs<4>(a, (int)n_wg, split, st);
-        case 8: return launch_rs<8>(a, (int)n_wg, split, st);
-        default: return launch_rs<16>(a, (int)n_wg, split, st);
+        case 1: return launch_rs<1>(a, (int)n_wg, split, kind != 0, st);
+        case 2: return launch_rs<2>(a, (int)n_wg, split, kind != 0, st);
+        case 4: return launch_rs<4>(a, (int)n_wg, split, kind != 0, st);
+        case 8: return launch_rs<8>(a, (int)n_wg, split, kind != 0, st);
+        default: return launch_rs<16>(a, (int)n_wg, split, kind != 0, st);
     }
 }

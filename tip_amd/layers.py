@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_csr_plan, group_slots_for,
+from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
                    relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
@@ -296,7 +296,7 @@ def relation_of_edges(range_list, n_edges, device):
     return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
 
 
-def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None):
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
     scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `in_degree`: [N]
     in-degree of the WHOLE graph when `edge_index` is only one rank's shard (tip_amd/dist.py)."""
@@ -310,7 +310,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     else:
         assert in_degree.numel() == n_nodes
         deg = in_degree.to(src.device).to(torch.float32).clamp_(min=1)
-    rl_fwd = rl_bwd = rs_bwd = None
+    rl_fwd = rl_bwd = rs_bwd = pair_fwd = None
     if n_nodes <= 1024 and n_rel > 0 and src.numel() > 0:
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
@@ -328,6 +328,11 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             lanes_f = lanes_b = None
         cap_f = None           # (cutting forward units to the id chunk was measured slower: smaller units fill fewer bands)
         rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
+        # forward pass in pair form: cells (destination, source) <- sums of att rows (LDS-resident att table)
+        split_p = ops.stream_gather_split(n_rel, n_bases) if on_dev and n_bases and n_nodes * n_nodes < 2 ** 24 else 0
+        if split_p:
+            pair_fwd = build_stream_plan_rows(dst * n_nodes + src, rel, n_nodes * n_nodes, n_rel, n_cu,
+                                              (n_bases // split_p) // 4, ops.rel_stream_piece())
         # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
         split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
         if split_s:
@@ -348,7 +353,8 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     return ops.AggGraph(fwd_plan,
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd,
-                        csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'), rs_bwd=rs_bwd)
+                        csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'), rs_bwd=rs_bwd,
+                        pair_fwd=pair_fwd)
 
 
 class _RGCNBase(nn.Module):
@@ -406,7 +412,7 @@ class MyRGCNConv2(_RGCNBase):
         def build():
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
             return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
-                              d_out=self.out_channels)
+                              d_out=self.out_channels, n_bases=self.num_bases)
         graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
         return self._run(x, graph, fuse_relu, gate_input)
 
@@ -419,7 +425,8 @@ class MyRGCNConv(_RGCNBase):
         n = x.shape[0]
         graph = self._cache.get((edge_index, edge_type),
                                 lambda: rgcn_graph(edge_index, edge_type, n, self.num_relations, self.chunk,
-                                                   in_degree=self._global_degree(), d_out=self.out_channels))
+                                                   in_degree=self._global_degree(), d_out=self.out_channels,
+                                                   n_bases=self.num_bases))
         return self._run(x, graph)
 
 

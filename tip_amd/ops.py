@@ -206,15 +206,18 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
     return sum_slabs(out)
 
 
-def rel_stream_split(n_nodes, d):
-    """column blocks `tipk_rel_stream_bwd` would use for this shape; 0 = the table does not fit in LDS."""
+def stream_gather_split(n_table, d):
+    """column blocks `tipk_stream_gather` would use for a table [n_table, d]; 0 = it does not fit in LDS."""
     if os.environ.get('TIPK_NO_RELSTREAM') or os.environ.get('TIPK_NO_RELLOCAL'):
         return 0
-    return int(lib().tipk_rel_stream_supported(n_nodes, d))
+    return int(lib().tipk_stream_gather_supported(n_table, d))
+
+
+rel_stream_split = stream_gather_split
 
 
 def rel_stream_piece():
-    return int(lib().tipk_rel_stream_piece())
+    return int(lib().tipk_stream_gather_piece())
 
 
 def dy_products_fused(r, nc, nb):
@@ -227,23 +230,29 @@ def dy_products_fused(r, nc, nb):
     return s_c.value != 0
 
 
-def rel_stream_bwd(sp, table, row_scale=None, write_zeros=True):
-    """Transposed D-D pass on a wave-stream plan (include/tipk.h section 1d): table = g [N, d] (scaled per
-    row while staged) -> dY [R * N, d].  write_zeros=False leaves the rows without edges UNTOUCHED (garbage):
-    only for a consumer that masks them with `sp.row_used` (`dy_products`)."""
+def stream_gather(sp, table, row_scale=None, write_zeros=True, out=None, label='stream_gather', kind=0):
+    """out[row] = sum of table rows on a wave-stream plan (include/tipk.h section 1d), table [n_table, d] staged
+    in LDS (scaled per row while staged).  write_zeros=False leaves the rows without edges UNTOUCHED: only for
+    a consumer that masks them (`dy_products(row_used=...)`) or an `out` buffer that was zeroed once."""
     table = _f32c(table)
     require_device(table, sp.ids)
     d = table.shape[1]
-    n, r = sp.n_nodes, sp.n_rel
-    split = rel_stream_split(n, d)
-    assert split and (d // split) // 4 == sp.lanes, 'plan was built for another launch shape'
-    out = torch.empty((r * n, d), dtype=torch.float32, device=table.device)
-    with _timed('rel_stream[dd.bwd,d=%d]' % d):
-        check(lib().tipk_rel_stream_bwd(ptr(table), table.stride(0), n, d, sp.n_wg, ptr(sp.wave_ptr), ptr(sp.cells),
-                                        ptr(sp.ids), sp.idx_unit, ptr(sp.zero_ptr) if write_zeros else None,
-                                        ptr(sp.zero_rows), ptr(row_scale),
-                                        ptr(out), d, stream_ptr(table.device)), 'tipk_rel_stream_bwd')
+    split = stream_gather_split(sp.n_table, d)
+    assert table.shape[0] == sp.n_table and split and (d // split) // 4 == sp.lanes, 'plan was built for another launch shape'
+    if out is None:
+        out = torch.empty((sp.n_rows, d), dtype=torch.float32, device=table.device)
+    assert out.shape == (sp.n_rows, d) and out.is_contiguous()
+    with _timed('%s[d=%d]' % (label, d)):
+        check(lib().tipk_stream_gather(ptr(table), table.stride(0), sp.n_table, d, sp.n_wg, ptr(sp.wave_ptr), ptr(sp.cells),
+                                       ptr(sp.ids), sp.idx_unit, ptr(sp.zero_ptr) if write_zeros else None,
+                                       ptr(sp.zero_rows), ptr(row_scale), ptr(out), d, kind, stream_ptr(table.device)),
+              'tipk_stream_gather')
     return out
+
+
+def rel_stream_bwd(sp, table, row_scale=None, write_zeros=True):
+    """Transposed D-D pass: table = g [N, d] -> dY [R * N, d] (plan of `build_stream_plan`)."""
+    return stream_gather(sp, table, row_scale, write_zeros, label='rel_stream[dd.bwd]')
 
 
 def _strides3(t):
@@ -719,7 +728,8 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
-    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None):
+    def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None,
+                 pair_fwd=None):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
         generic D-D plans are only needed where the relation-local kernel does not apply).
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
@@ -727,6 +737,8 @@ class AggGraph(object):
         self._csr_bwd = csr_bwd
         self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
         self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
+        self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
+        self._pair_cells = {}                              # persistent [N, N * bases] cell buffers, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
 
     @property
@@ -740,6 +752,16 @@ class AggGraph(object):
         if callable(self._bwd):
             self._bwd = self._bwd()
         return self._bwd
+
+    def pair_cells(self, n, nb, device):
+        """The dense cell matrix A[v, u, b] of the pair-form forward.  Allocated and zeroed ONCE: the stream
+        gather rewrites the cells of the drug pairs that are linked on every call and nothing ever touches
+        the others."""
+        key = (int(n), int(nb), str(device))
+        buf = self._pair_cells.get(key)
+        if buf is None:
+            buf = self._pair_cells[key] = torch.zeros((n, n * nb), dtype=torch.float32, device=device)
+        return buf
 
     @property
     def csr_bwd(self):
@@ -867,6 +889,35 @@ class _RGCN(torch.autograd.Function):
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
         elif r > 0:
             assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
+        pair = graph.pair_fwd if r > 0 else None
+        if pair is not None and not (pair.n_table == r and pair.n_rows == n * n and stream_gather_split(r, nb)
+                                     and (nb // stream_gather_split(r, nb)) // 4 == pair.lanes
+                                     and not os.environ.get('TIPK_NO_PAIR_FWD')):
+            pair = None
+        if pair is not None:
+            # PAIR FORM.  sum_r A_r X W_r = sum_{(u -> v)} sum_b C[v, u, b] XB_b[u],  C[v, u, :] = sum of att[r, :] over
+            # the relations r that link u -> v.  A BioSNAP drug pair is linked by 66 relations on average, so the
+            # per-EDGE work shrinks to adding one att row (LDS-resident for the whole launch: a wave-stream gather
+            # like the transposed pass) and the per-PAIR work is one dense product -- Y = att . XB [R N, out]
+            # (91 MB written and gathered back at layer 1) is never formed.
+            xb_nb = torch.empty((n, nb, d_out), dtype=torch.float32, device=x.device)       # XB as [(u, b), out]: the product's B operand
+            xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb.permute(1, 0, 2)), gemm_job(x, root)])
+            cells = graph.pair_cells(n, nb, x.device)
+            stream_gather(pair, att, write_zeros=False, out=cells.view(n * n, nb), label='pair_cells[dd.fwd]', kind=1)
+            job = gemm_job(cells, xb_nb.view(n * nb, d_out))
+            st = stream_ptr(x.device)
+            with _timed('gemm[%s]' % job.label):
+                check(lib().tipk_gemm_f32(job.desc, st), 'tipk_gemm_f32')
+            slabs = job.slabs if job.slabs is not None else job.out.view(1, n, d_out)
+            if shard is None:
+                out = sum_slabs(slabs.view(-1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
+            else:
+                agg = sum_slabs(slabs.view(-1, n, d_out))
+                shard.all_reduce(agg)
+                out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
+            ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
+            ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
+            return out
         xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
         y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out) if r > 0 else None     # [R N, out]
         if shard is None:

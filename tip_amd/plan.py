@@ -524,25 +524,30 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
 
 
 class StreamPlan(object):
-    """Device arrays of `tipk_rel_stream_bwd` (layout: include/tipk.h section 1d)."""
+    """Device arrays of `tipk_stream_gather` (layout: include/tipk.h section 1d): out rows <- sums of table rows."""
 
-    def __init__(self, n_nodes, n_rel, n_wg, lanes, piece, wave_ptr, cells, ids, zero_ptr, zero_rows, row_used, idx_unit):
-        self.n_nodes, self.n_rel, self.n_wg, self.lanes, self.piece = int(n_nodes), int(n_rel), int(n_wg), int(lanes), int(piece)
+    def __init__(self, n_rows, n_table, n_wg, lanes, piece, wave_ptr, cells, ids, zero_ptr, zero_rows, idx_unit,
+                 row_used=None, n_nodes=None, n_rel=None):
+        self.n_rows, self.n_table, self.n_wg, self.lanes, self.piece = int(n_rows), int(n_table), int(n_wg), int(lanes), int(piece)
         self.wave_ptr, self.cells, self.ids, self.zero_ptr, self.zero_rows = wave_ptr, cells, ids, zero_ptr, zero_rows
-        self.row_used = row_used                  # int32 [ceil(R / 32), N] bit mask of the rows with edges (tipk.h section 2b)
         self.idx_unit = int(idx_unit)
         self.n_bands = int(cells.shape[0])
+        # the (relation, node) form of `build_stream_plan`: rows = relation * n_nodes + node
+        self.row_used = row_used                  # int32 [ceil(R / 32), N] bit mask of the rows with edges (tipk.h section 2b)
+        self.n_nodes, self.n_rel = n_nodes, n_rel
 
     def to(self, device):
-        return StreamPlan(self.n_nodes, self.n_rel, self.n_wg, self.lanes, self.piece, *[t.to(device) for t in (
-            self.wave_ptr, self.cells, self.ids, self.zero_ptr, self.zero_rows, self.row_used)], idx_unit=self.idx_unit)
+        mv = lambda t: None if t is None else t.to(device)
+        return StreamPlan(self.n_rows, self.n_table, self.n_wg, self.lanes, self.piece, mv(self.wave_ptr), mv(self.cells),
+                          mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
+                          self.n_nodes, self.n_rel)
 
 
 STREAM_BAND_OVERHEAD = 2.0     # what a band costs besides its steps (record fetch, row store), in steps
 
 
-def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4):
-    """Wave-stream plan for  out[r * N + o] = sum_{e in r: out_node[e] = o} table[tab_node[e]]  (every row).
+def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece=4):
+    """Wave-stream plan for  out[o] = sum_{e: out_row[e] = o} table[tab_row[e]],  o < n_rows, table rows < n_table.
 
     The runs (one per output row with edges) are sorted by decreasing length and taken SPW = 64 / lanes at
     a time: such a GROUP is what the slots of one wavefront walk side by side, so its runs should be
@@ -553,17 +558,27 @@ def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piec
     evenly.  Inside a run the ids are ordered for conflict-free LDS reads (`bank_rotation`) and pre-scaled
     (idx_unit) exactly as in `build_rel_plan`."""
     import heapq
-    dev = out_node.device
-    N, S, W = int(n_nodes), 64 // int(lanes), int(n_wg) * 16
-    assert N <= 65535 and n_rel * N < 2 ** 24, 'cells hold the output row in 24 bits'
-    E = int(out_node.numel())
-    key = rel * N + out_node
-    cnt_rows = torch.bincount(key, minlength=n_rel * N)
+    dev = out_row.device
+    T, S, W = int(n_table), 64 // int(lanes), int(n_wg) * 16
+    assert T <= 65535 and n_rows < 2 ** 24, 'cells hold the output row in 24 bits, ids are 16-bit'
+    E = int(out_row.numel())
+    key = out_row
+    if os.environ.get('TIPK_RS_CAP_EXPERIMENT'):      # TIMING EXPERIMENT ONLY (wrong sums): drop the edges of a run beyond the cap
+        cap = int(os.environ['TIPK_RS_CAP_EXPERIMENT']) * 8
+        o = torch.sort(key, stable=True).indices
+        ks = key[o]
+        first = torch.cat([ks.new_ones(1, dtype=torch.bool), ks[1:] != ks[:-1]])
+        start = torch.cummax(torch.where(first, torch.arange(E, device=dev), torch.zeros(E, dtype=torch.long, device=dev)), 0).values
+        keep = o[(torch.arange(E, device=dev) - start) < cap]
+        out_row, tab_row = out_row[keep], tab_row[keep]
+        key = out_row
+        E = int(out_row.numel())
+    cnt_rows = torch.bincount(key, minlength=n_rows)
     zero_rows = torch.nonzero(cnt_rows == 0).flatten()
     run_row = torch.nonzero(cnt_rows > 0).flatten()
     run_cnt = cnt_rows[run_row]
     # by decreasing STEPS (8 ids each), rows ascending inside a class: equal work per slot of a group, and the
-    # rows a wavefront writes together are neighbours in dY more often than not
+    # rows a wavefront writes together are neighbours in the output more often than not
     order = torch.sort((run_cnt + 7) // 8, descending=True, stable=True).indices
     run_row, run_cnt = run_row[order], run_cnt[order]
     n_runs = int(run_row.numel())
@@ -578,7 +593,7 @@ def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piec
     cost = (g_steps.double() + STREAM_BAND_OVERHEAD * g_bands.double()).cpu().tolist()
     # longest-processing-time deal (groups come in decreasing cost)
     # (giving every wavefront a contiguous range of output rows instead -- length-sorted only inside windows of
-    # 645 ... 32 768 rows, so that its writes sweep dY front to back -- measured no faster inside the step)
+    # 645 ... 32 768 rows, so that its writes sweep the output front to back -- measured no faster inside the step)
     heap = [(0.0, w) for w in range(W)]
     wave_of = [0] * G
     for g in range(G):
@@ -608,13 +623,13 @@ def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piec
     # ids
     idx_unit = 1
     row_bytes = lanes * 16
-    while idx_unit * 2 <= row_bytes and N * idx_unit * 2 <= 65535:
+    while idx_unit * 2 <= row_bytes and T * idx_unit * 2 <= 65535:
         idx_unit *= 2
-    run_of_row = torch.full((n_rel * N,), -1, dtype=torch.int64, device=dev)
+    run_of_row = torch.full((n_rows,), -1, dtype=torch.int64, device=dev)
     run_of_row[run_row] = torch.arange(n_runs, device=dev)
     ri = run_of_row[key]                                                  # run of every edge
     n_cls, rot = bank_rotation(lanes)
-    cls = (tab_node % n_cls - torch.tensor(rot, device=dev)[ri % S]) % n_cls
+    cls = (tab_row % n_cls - torch.tensor(rot, device=dev)[ri % S]) % n_cls
     e_order = torch.sort(ri * n_cls + cls, stable=True).indices
     ri_s = ri[e_order]
     run_first = torch.cumsum(run_cnt, 0) - run_cnt
@@ -622,36 +637,47 @@ def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piec
     step = j // 8
     band = g_band0[ri_s // S] + step // piece
     dest = ((band * piece + step % piece) * S + ri_s % S) * 8 + j % 8
-    ids32 = torch.full((max(n_bands, 1) * piece * S * 8,), N * idx_unit, dtype=torch.int32, device=dev)
-    ids32[dest] = (tab_node[e_order] * idx_unit).to(torch.int32)
+    ids32 = torch.full((max(n_bands, 1) * piece * S * 8,), T * idx_unit, dtype=torch.int32, device=dev)
+    ids32[dest] = (tab_row[e_order] * idx_unit).to(torch.int32)
     nz = int(zero_rows.numel())
     zero_ptr = (torch.arange(W + 1, device=dev) * nz) // W
     cells_u = torch.where(cells >= 2 ** 31, cells - 2 ** 32, cells).to(torch.int32)
     if zero_rows.numel() == 0:
         zero_rows = torch.zeros(1, dtype=torch.int64, device=dev)
+    return StreamPlan(n_rows, T, n_wg, lanes, piece, wave_ptr.to(torch.int32).contiguous(),
+                      cells_u.view(n_bands, S).contiguous() if n_bands else cells_u.new_zeros((0, S)),
+                      ids32.to(torch.uint16).contiguous(), zero_ptr.to(torch.int32).contiguous(),
+                      zero_rows.to(torch.int32).contiguous(), idx_unit)
+
+
+def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4):
+    """The (relation, node) form: out[r * N + o] = sum_{e in r: out_node[e] = o} table[tab_node[e]], table =
+    [N, d] -- the transposed D-D pass.  Adds `row_used`, the bit mask of the rows with edges."""
+    N = int(n_nodes)
+    sp = build_stream_plan_rows(rel * N + out_node, tab_node, n_rel * N, N, n_wg, lanes, piece)
+    dev = out_node.device
+    cnt_rows = torch.bincount(rel * N + out_node, minlength=n_rel * N)
     # bit (r & 31) of row_used[r >> 5, node] = row (r, node) has edges
     rt = -(-n_rel // 32)
     has = torch.zeros(rt * 32, N, dtype=torch.int64, device=dev)
     has[:n_rel] = (cnt_rows.view(n_rel, N) > 0).long()
     word = (has.view(rt, 32, N) << torch.arange(32, device=dev).view(1, 32, 1)).sum(1)
-    row_used = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32).contiguous()
-    return StreamPlan(N, n_rel, n_wg, lanes, piece, wave_ptr.to(torch.int32).contiguous(),
-                      cells_u.view(n_bands, S).contiguous() if n_bands else cells_u.new_zeros((0, S)),
-                      ids32.to(torch.uint16).contiguous(), zero_ptr.to(torch.int32).contiguous(),
-                      zero_rows.to(torch.int32).contiguous(), row_used, idx_unit)
+    sp.row_used = torch.where(word >= 2 ** 31, word - 2 ** 32, word).to(torch.int32).contiguous()
+    sp.n_nodes, sp.n_rel = N, int(n_rel)
+    return sp
 
 
 def execute_stream_plan_reference(plan, table):
     """Pure-torch interpretation of a wave-stream plan (CPU unit tests only): what every slot of every
     wavefront does, in order; checks that every output row is written exactly once."""
-    N, R, S, P = plan.n_nodes, plan.n_rel, 64 // plan.lanes, plan.piece
+    T, S, P = plan.n_table, 64 // plan.lanes, plan.piece
     d = table.shape[1]
     ids = plan.ids.to(torch.int64)
     assert bool((ids % plan.idx_unit == 0).all())
     ids = (ids // plan.idx_unit).view(-1, P, S, 8)
     cells = plan.cells.to(torch.int64) & 0xffffffff
-    out = torch.zeros((R * N, d), dtype=table.dtype)
-    written = torch.zeros(R * N, dtype=torch.long)
+    out = torch.zeros((plan.n_rows, d), dtype=table.dtype)
+    written = torch.zeros(plan.n_rows, dtype=torch.long)
     wp, zp = plan.wave_ptr.tolist(), plan.zero_ptr.tolist()
     assert len(wp) == plan.n_wg * 16 + 1 and wp[0] == 0 and wp[-1] == plan.n_bands
     for w in range(plan.n_wg * 16):
@@ -670,7 +696,7 @@ def execute_stream_plan_reference(plan, table):
                     open_row[s_] = row
                 assert open_row[s_] == row, 'a run continues in the same slot of the next band'
                 nodes = ids[b, :ln, s_].reshape(-1)
-                nodes = nodes[nodes < N]
+                nodes = nodes[nodes < T]
                 acc[s_] += table[nodes].sum(0)
                 if last:
                     out[row] = acc[s_]
@@ -679,7 +705,7 @@ def execute_stream_plan_reference(plan, table):
         assert all(r == -1 for r in open_row)
         for z in range(zp[w], zp[w + 1]):
             written[int(plan.zero_rows[z])] += 1
-    assert bool((written == 1).all()), 'every (relation, node) row is written exactly once'
+    assert bool((written == 1).all()), 'every output row is written exactly once'
     return out
 
 
