@@ -214,10 +214,10 @@ def dd_aggregation_launches(enc, dev):
                 key = 'stream_gather_kernel<%d, %s, 1' % (nb // split // 4, 'true' if pair.idx_unit == nb // split * 4 else 'false')
                 grid = '%dx%dx1' % (pair.n_wg * 1024, split)
                 att = torch.randn(r, nb, device=dev)
-                cells = graph.pair_cells(n, nb, dev)
+                cells = graph.pair_buffers(n, nb, d, dev)[0]
                 out.append(('pair_cells[dd.fwd,d=%d]' % d, key, grid, nb, 'lds',
                             lambda pair=pair, att=att, cells=cells, nb=nb: ops.stream_gather(
-                                pair, att, write_zeros=False, out=cells.view(n * n, nb), kind=1)))
+                                pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1)))
             elif rs is not None and ops.rel_stream_split(n, d):
                 split = ops.rel_stream_split(n, d)
                 key = 'stream_gather_kernel<%d, %s, 0' % (d // split // 4, 'true' if rs.idx_unit == d // split * 4 else 'false')

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 8
+#define TIPK_ABI_VERSION 9
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -185,10 +185,15 @@ int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t 
  *     L = (d / column blocks) / 4 lanes form a slot, S = 64 / L slots a wavefront, P = tipk_stream_gather_piece()
  *     steps of 8 ids a cell.  Plan (tip_amd/plan.py `build_stream_plan_rows`), all device arrays:
  *       wave_ptr[n_wg * 16 + 1]  int32: range of bands of every wavefront (wavefront = workgroup * 16 + wave)
- *       cells[n_bands][S]        uint32: row (24 bits) | steps << 24 (0 .. P) | first << 28 | last << 29.  A slot
- *                                adds the steps' rows to a register sum that is cleared on `first` and written
- *                                to out[row] on `last`: a run longer than P steps continues in the SAME slot of
- *                                the wavefront's next band; 0 = idle cell
+ *       cells[n_bands][S]        uint32: row (24 bits) | steps << 24 (0 .. P) | first << 28 | last << 29 | log2 k << 30.
+ *                                A slot adds the steps' rows to a register sum that is cleared on `first` and
+ *                                written to out[row] on `last`: a run longer than P steps continues in the SAME
+ *                                slot of the wavefront's next band; 0 = idle cell.  log2 k > 0 (on the last band
+ *                                of a WIDE run, in all its slots): the run was cut into k = 2, 4 or 8 sub-runs in
+ *                                adjacent slots s0 .. s0 + k - 1 (s0 a multiple of k); their sums are added in
+ *                                the fixed order  s <- s + 2^j,  j = 0, 1, ..,  and slot s0 (the one with `last`)
+ *                                writes the row -- a slot's run is a chain of dependent steps, and the longest
+ *                                run of the graph would otherwise set the length of the launch
  *       ids[n_bands][P][S][8]    uint16: table row * idx_unit of the edges (see 1b), runs padded to 8 with the
  *                                sentinel n_table * idx_unit (a zero row); steps beyond a cell's count are not read
  *       zero_ptr[n_wg * 16 + 1], zero_rows[]  int32: the rows without edges, dealt to the wavefronts; zero_ptr
@@ -264,6 +269,23 @@ typedef struct tipk_slab_sum_desc {
     float* out;
 } tipk_slab_sum_desc;
 int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, int32_t count, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 2c. The dense half of the pair-form D-D forward pass (src/layers.py:159-180; tip_amd/ops.py `_RGCN.forward`):
+ *
+ *        slabs[g][v, c] = sum_{u in group g} sum_b cells[u][v][b] * xb[u][b][c]        g < n_src / group
+ *
+ *     cells [n_src][n_dst][n_bases] = the pair cells written by tipk_stream_gather (table = att), xb
+ *     [n_src][n_bases][d] = X . basis per source node; n_src is the node count rounded up to a multiple of
+ *     `group` with blocks that stay zero.  slabs [n_src / group][n_dst][d] are added in order by
+ *     tipk_sum_slabs_ex (which also applies 1 / deg, + X root and the ReLU).  n_bases in {8, 16, 32}, d <= 32
+ *     (`tipk_pair_product_supported`; otherwise tipk_gemm_f32 with kbatch = group does the same sums).
+ *     symmetric != 0: every relation links u -> v iff it links v -> u (BioSNAP), so cells[u][v] == cells[v][u]
+ *     and the gather only built the cells with u <= v (half the edges); cell (u, v) with v < u is read at (v, u).
+ */
+int tipk_pair_product_supported(int n_bases, int d);
+int tipk_pair_product(const float* cells, const float* xb, int64_t n_src, int64_t n_dst, int n_bases, int d,
+                      int group, int symmetric, float* slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2b. Both consumers of dY (the gradient of Y = att . XB, src/layers.py:163-172 under autograd) in

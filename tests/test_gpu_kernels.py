@@ -331,6 +331,52 @@ def test_gemm_group_bit_identical_to_single_launches(ops):
     assert ops.gemm_group([]) == []
 
 
+def test_gemm_reduce_batch_in_groups(ops):
+    """sum_z a[z] @ b[z] with the terms summed in groups of `kgroup` (one slab per group): the pair-form D-D product."""
+    g = torch.Generator().manual_seed(12)
+    for z, m, k, n, kg in ((648, 645, 32, 32, 8), (24, 100, 16, 16, 4), (16, 33, 32, 8, 16)):
+        a = torch.randn(z, m, k, generator=g).to(DEV)
+        b = torch.randn(z, k, n, generator=g).to(DEV)
+        job = ops.gemm_job(a, b, reduce_batch=True, kgroup=kg)
+        assert job.slabs.shape == (z // kg, m, n)
+        out = ops.gemm_group([job])[0]
+        want = torch.einsum('zmk,zkn->mn', a.double().cpu(), b.double().cpu())
+        close(out, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+        per_group = torch.einsum('gzmk,gzkn->gmn', a.double().cpu().view(z // kg, kg, m, k), b.double().cpu().view(z // kg, kg, k, n))
+        close(job.slabs, per_group, rtol=2e-5, atol=2e-5 * float(per_group.abs().max()))
+
+
+@pytest.mark.parametrize('n,nb,d', [(645, 32, 32), (645, 32, 16), (100, 16, 8), (37, 8, 32), (70, 32, 5)])
+def test_pair_product(ops, n, nb, d, monkeypatch):
+    """tipk_pair_product (section 2c): slabs of sum_u cells[u] @ xb[u] per group of source nodes; the tiled GEMM
+    with kbatch = group is the cross-check."""
+    g = torch.Generator().manual_seed(n + nb + d)
+    n_pad = -(-n // ops.PAIR_KGROUP) * ops.PAIR_KGROUP
+    cells = torch.zeros(n_pad, n, nb)
+    cells[:n] = torch.randn(n, n, nb, generator=g) * (torch.rand(n, n, 1, generator=g) < 0.3)
+    xb = torch.zeros(n_pad, nb, d)
+    xb[:n] = torch.randn(n, nb, d, generator=g)
+    slabs = ops.pair_product(cells.to(DEV), xb.to(DEV))
+    assert slabs.shape == (n_pad // ops.PAIR_KGROUP, n, d)
+    want = torch.einsum('guvb,gubc->gvc', cells.double().view(-1, ops.PAIR_KGROUP, n, nb), xb.double().view(-1, ops.PAIR_KGROUP, nb, d))
+    close(slabs, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+    assert torch.equal(slabs, ops.pair_product(cells.to(DEV), xb.to(DEV)))
+    monkeypatch.setenv('TIPK_NO_PAIR_PRODUCT', '1')
+    close(ops.pair_product(cells.to(DEV), xb.to(DEV)), want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+    monkeypatch.delenv('TIPK_NO_PAIR_PRODUCT')
+    # symmetric cells: only the half with source <= destination is stored, the other half may hold anything
+    sym = cells.clone()
+    sym[:n] = torch.triu(cells[:n].permute(2, 0, 1)).permute(1, 2, 0)                 # keep u <= v
+    full = sym.clone()
+    full[:n] = sym[:n] + torch.triu(sym[:n].permute(2, 0, 1), 1).permute(2, 1, 0)      # mirror: C[v][u] = C[u][v]
+    want_s = torch.einsum('guvb,gubc->gvc', full.double().view(-1, ops.PAIR_KGROUP, n, nb), xb.double().view(-1, ops.PAIR_KGROUP, nb, d))
+    junk = sym.clone()
+    lower = torch.tril(torch.ones(n, n), -1).bool()
+    junk[:n][lower] = float('nan')
+    got_s = ops.pair_product(junk.to(DEV), xb.to(DEV), symmetric=True)
+    close(got_s, want_s, rtol=2e-5, atol=2e-5 * float(want_s.abs().max()))
+
+
 def test_grouped_slab_sum_vector_path_bit_identical(ops):
     """The grouped slab sum takes a 16-byte path for 4-lane sums of aligned operands (one thread = 4 elements
     x all four slab lanes): same order of additions as the dword kernel, for every slab count and epilogue."""

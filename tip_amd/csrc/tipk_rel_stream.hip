@@ -13,7 +13,7 @@
 // `build_stream_plan`) cuts the whole pass into per-WAVEFRONT streams of fixed-size records:
 //
 //   band  = one cell per slot (a slot = L lanes = one output row at a time, 64 / L slots per wavefront)
-//   cell  = up to RS_PIECE steps of 8 edge ids of ONE output row: (row | steps << 24 | first << 28 | last << 29);
+//   cell  = up to RS_PIECE steps of 8 edge ids of ONE output row: (row | steps << 24 | first << 28 | last << 29 | log2 k << 30);
 //           a longer run continues in the same slot of the next band, its sum stays in registers
 //   ids   = [band][step][slot][8] uint16, pre-scaled row offsets: one 16-byte load per slot and step, the
 //           slots of a wavefront read one contiguous block per step
@@ -126,7 +126,23 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
                 for (int jj = 7; jj >= 0; --jj) { acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w; }
             }
         }
-        if (cell & (1u << 29))                                                   // last piece: the row is complete
+        // a WIDE run was cut into 2^klog sub-runs in adjacent (aligned) slots: on its last band the partial sums are
+        // added in a fixed tree order, slot s <- slot s + 2^j, and the set's first slot holds the row
+        const unsigned klog = cell >> 30;
+        if (__builtin_amdgcn_ballot_w64(klog != 0u) != 0ull) {                   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                constexpr int LL = L;
+                const int delta = LL << j;
+                if (delta < 64) {
+                    float4 o;
+                    o.x = __shfl_down(acc.x, delta, 64); o.y = __shfl_down(acc.y, delta, 64);
+                    o.z = __shfl_down(acc.z, delta, 64); o.w = __shfl_down(acc.w, delta, 64);
+                    if ((int)klog > j && (slot & ((2 << j) - 1)) == 0) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+                }
+            }
+        }
+        if (cell & (1u << 29))                                                   // the row is complete
             tipk_st4(out + (int64_t)(cell & 0xffffffu) * a.ld_out + c0, acc);
     };
     if (b < b1) {

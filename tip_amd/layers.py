@@ -328,11 +328,19 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             lanes_f = lanes_b = None
         cap_f = None           # (cutting forward units to the id chunk was measured slower: smaller units fill fewer bands)
         rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
-        # forward pass in pair form: cells (destination, source) <- sums of att rows (LDS-resident att table)
+        # forward pass in pair form: cells (source, destination) <- sums of att rows (LDS-resident att table)
         split_p = ops.stream_gather_split(n_rel, n_bases) if on_dev and n_bases and n_nodes * n_nodes < 2 ** 24 else 0
         if split_p:
-            pair_fwd = build_stream_plan_rows(dst * n_nodes + src, rel, n_nodes * n_nodes, n_rel, n_cu,
+            # every relation symmetric (u -> v iff v -> u: BioSNAP) => cell (u, v) == cell (v, u): build the cells
+            # with u <= v only, from half the edges; the product reads the mirrored ones at their transposed place
+            k_fw = torch.sort((rel * n_nodes + src) * n_nodes + dst).values
+            k_bw = torch.sort((rel * n_nodes + dst) * n_nodes + src).values
+            symmetric = bool(torch.equal(k_fw, k_bw)) and bool(ops.lib().tipk_pair_product_supported(n_bases, d_out)) \
+                and not os.environ.get('TIPK_NO_PAIR_SYMMETRY')
+            keep = src <= dst if symmetric else torch.ones_like(src, dtype=torch.bool)
+            pair_fwd = build_stream_plan_rows(src[keep] * n_nodes + dst[keep], rel[keep], n_nodes * n_nodes, n_rel, n_cu,
                                               (n_bases // split_p) // 4, ops.rel_stream_piece())
+            pair_fwd.symmetric = symmetric
         # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
         split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
         if split_s:

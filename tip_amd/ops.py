@@ -278,7 +278,7 @@ class GemmJob(object):
     __slots__ = ('desc', 'label', 'slabs', 'n_slabs', 'per', 'alpha', 'accumulate', 'out', 'keep', 'gate')
 
 
-def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
+def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None, kgroup=None):
     """Prepare out = relu?(alpha * a @ b + c_in) on the matrix cores (include/tipk.h section 2).
 
     a: [M,K] or [Z,M,K]; b: [K,N] or [Z,K,N] -- arbitrary strides (transposed views are free).
@@ -287,6 +287,9 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     (dW = g^T h over 19 081 proteins, X^T g over 645 drugs, att^T dY over 1 097 relations) would
     run as a handful of serial workgroups; they are cut into slabs that fill the chip and the
     slabs are added in order by `tipk_sum_slabs` (deterministic, no atomics).
+    kgroup (with reduce_batch): the Z batch terms are summed in groups of `kgroup` consecutive terms, one
+    slab per group -- sum_z a[z] @ b[z] with Z in the hundreds (the pair-form D-D product: one term per
+    source node), where one slab per term would be as large as the operands.
     """
     require_device(a, b)
     if a.dtype != torch.float32 or b.dtype != torch.float32:
@@ -310,9 +313,12 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     bm, bn = _tile_shape(m, n)
     tiles = -(-m // bm) * -(-n // bn) * (1 if reduce_batch else z)
     plain = relu is False and (c_in is None or c_in.data_ptr() == out.data_ptr()) and out.is_contiguous()
-    slab_mode = None                       # None | 'k' (split the k range) | 'q' (one slab per batch term)
+    slab_mode = None                       # None | 'k' (split the k range) | 'q' (one slab per batch term) | 'g' (per group of terms)
     n_slabs = 0
-    if reduce_batch and plain and tiles * 2 <= 256 and z > 1:
+    if kgroup:
+        assert reduce_batch and plain and c_in is None and z % kgroup == 0 and a.dim() == 3 and b.dim() == 3
+        slab_mode, n_slabs = 'g', z // kgroup
+    elif reduce_batch and plain and tiles * 2 <= 256 and z > 1:
         slab_mode, n_slabs = 'q', z
     elif ksplit is None:
         # a workgroup's K loop is a chain of dependent ~1.5 us load round trips: small products are cut
@@ -332,7 +338,10 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     g.a, g.b = a.data_ptr(), b.data_ptr()
     g.a_sm, g.a_sk, g.b_sk, g.b_sn = a_sm, a_sk, b_sk, b_sn
     g.ksplit = n_slabs if slab_mode == 'k' else 1
-    if reduce_batch and slab_mode != 'q':
+    if slab_mode == 'g':
+        g.batch, g.kbatch = n_slabs, kgroup
+        g.a_sq, g.b_sq, g.a_sz, g.b_sz = a_sz, b_sz, a_sz * kgroup, b_sz * kgroup
+    elif reduce_batch and slab_mode != 'q':
         g.batch, g.kbatch = 1, z
         g.a_sq, g.b_sq, g.a_sz, g.b_sz = a_sz, b_sz, 0, 0
     else:
@@ -343,8 +352,8 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     if slab_mode == 'k':
         slabs = torch.empty((n_slabs,) + oshape, dtype=torch.float32, device=dev)
         g.c, g.c_sm, g.c_sz, g.c_ss = slabs.data_ptr(), n, m * n, per
-    elif slab_mode == 'q':
-        slabs = torch.empty((z, m, n), dtype=torch.float32, device=dev)
+    elif slab_mode in ('q', 'g'):
+        slabs = torch.empty((n_slabs, m, n), dtype=torch.float32, device=dev)
         g.c, g.c_sm, g.c_sz, g.c_ss = slabs.data_ptr(), n, m * n, 0
     else:
         g.c, g.c_sm = out.data_ptr(), out.stride(-2)
@@ -725,6 +734,27 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 # ---------------------------------------------------------------------------------------------
 # static graph containers (plans in both directions + normalisers)
 # ---------------------------------------------------------------------------------------------
+PAIR_KGROUP = 8          # source nodes whose products are summed inside one wavefront of the pair-form product
+
+
+def pair_product(cells, xb_nb, symmetric=False):
+    """slabs[g] = sum_{u in group g} cells[u] (N x bases) @ xb_nb[u] (bases x out)  (include/tipk.h section 2c):
+    cells [N_pad, N, bases], xb_nb [N_pad, bases, out] -> [N_pad / PAIR_KGROUP, N, out]."""
+    n_pad, n, nb = cells.shape
+    d = xb_nb.shape[2]
+    assert cells.is_contiguous() and xb_nb.is_contiguous() and xb_nb.shape[:2] == (n_pad, nb) and n_pad % PAIR_KGROUP == 0
+    if (not lib().tipk_pair_product_supported(nb, d) or os.environ.get('TIPK_NO_PAIR_PRODUCT')) and not symmetric:
+        job = gemm_job(cells, xb_nb, reduce_batch=True, kgroup=PAIR_KGROUP)      # same sums on the tiled GEMM
+        with _timed('gemm[%s]' % job.label):
+            check(lib().tipk_gemm_f32(job.desc, stream_ptr(cells.device)), 'tipk_gemm_f32')
+        return job.slabs
+    slabs = torch.empty((n_pad // PAIR_KGROUP, n, d), dtype=torch.float32, device=cells.device)
+    with _timed('pair_product[%dx%dx%dx%d]' % (n_pad, n, nb, d)):
+        check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(slabs),
+                                      stream_ptr(cells.device)), 'tipk_pair_product')
+    return slabs
+
+
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
@@ -738,7 +768,7 @@ class AggGraph(object):
         self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
         self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
-        self._pair_cells = {}                              # persistent [N, N * bases] cell buffers, zeroed once
+        self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
 
     @property
@@ -753,14 +783,16 @@ class AggGraph(object):
             self._bwd = self._bwd()
         return self._bwd
 
-    def pair_cells(self, n, nb, device):
-        """The dense cell matrix A[v, u, b] of the pair-form forward.  Allocated and zeroed ONCE: the stream
-        gather rewrites the cells of the drug pairs that are linked on every call and nothing ever touches
-        the others."""
-        key = (int(n), int(nb), str(device))
+    def pair_buffers(self, n, nb, d_out, device):
+        """(cells C[u, v, b] as [N_pad, N, bases], XB as [N_pad, bases, out]) of the pair-form forward, N_pad = N
+        rounded up to PAIR_KGROUP.  Allocated and zeroed ONCE: every call rewrites the cells of the linked drug
+        pairs and the first N blocks of XB; nothing ever touches the rest."""
+        key = (int(n), int(nb), int(d_out), str(device))
         buf = self._pair_cells.get(key)
         if buf is None:
-            buf = self._pair_cells[key] = torch.zeros((n, n * nb), dtype=torch.float32, device=device)
+            n_pad = -(-n // PAIR_KGROUP) * PAIR_KGROUP
+            buf = self._pair_cells[key] = (torch.zeros((n_pad, n, nb), dtype=torch.float32, device=device),
+                                           torch.zeros((n_pad, nb, d_out), dtype=torch.float32, device=device))
         return buf
 
     @property
@@ -890,6 +922,8 @@ class _RGCN(torch.autograd.Function):
         elif r > 0:
             assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         pair = graph.pair_fwd if r > 0 else None
+        if pair is not None and pair.symmetric and not lib().tipk_pair_product_supported(nb, d_out):
+            pair = None                                      # only the dedicated product kernel reads mirrored cells
         if pair is not None and not (pair.n_table == r and pair.n_rows == n * n and stream_gather_split(r, nb)
                                      and (nb // stream_gather_split(r, nb)) // 4 == pair.lanes
                                      and not os.environ.get('TIPK_NO_PAIR_FWD')):
@@ -900,15 +934,13 @@ class _RGCN(torch.autograd.Function):
             # per-EDGE work shrinks to adding one att row (LDS-resident for the whole launch: a wave-stream gather
             # like the transposed pass) and the per-PAIR work is one dense product -- Y = att . XB [R N, out]
             # (91 MB written and gathered back at layer 1) is never formed.
-            xb_nb = torch.empty((n, nb, d_out), dtype=torch.float32, device=x.device)       # XB as [(u, b), out]: the product's B operand
-            xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb.permute(1, 0, 2)), gemm_job(x, root)])
-            cells = graph.pair_cells(n, nb, x.device)
-            stream_gather(pair, att, write_zeros=False, out=cells.view(n * n, nb), label='pair_cells[dd.fwd]', kind=1)
-            job = gemm_job(cells, xb_nb.view(n * nb, d_out))
-            st = stream_ptr(x.device)
-            with _timed('gemm[%s]' % job.label):
-                check(lib().tipk_gemm_f32(job.desc, st), 'tipk_gemm_f32')
-            slabs = job.slabs if job.slabs is not None else job.out.view(1, n, d_out)
+            # cells are kept SOURCE-major, C[u, v, :]: the product  sum_u C[u] (N x bases) . XB[u] (bases x out)  then reads
+            # 16 KB contiguous per operand tile (destination-major cells made every tile 128 separate 128-byte rows:
+            # 2.5 TB/s); the u range is padded to a multiple of PAIR_KGROUP with cells / XB rows that stay zero
+            cells, xb_nb = graph.pair_buffers(n, nb, d_out, x.device)
+            xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+            stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
+            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric)
             if shard is None:
                 out = sum_slabs(slabs.view(-1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
             else:

@@ -534,19 +534,25 @@ class StreamPlan(object):
         self.n_bands = int(cells.shape[0])
         # the (relation, node) form of `build_stream_plan`: rows = relation * n_nodes + node
         self.row_used = row_used                  # int32 [ceil(R / 32), N] bit mask of the rows with edges (tipk.h section 2b)
+        self.symmetric = False                    # pair-form plans: built from the edges with source <= destination only
         self.n_nodes, self.n_rel = n_nodes, n_rel
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
-        return StreamPlan(self.n_rows, self.n_table, self.n_wg, self.lanes, self.piece, mv(self.wave_ptr), mv(self.cells),
-                          mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
-                          self.n_nodes, self.n_rel)
+        sp = StreamPlan(self.n_rows, self.n_table, self.n_wg, self.lanes, self.piece, mv(self.wave_ptr), mv(self.cells),
+                        mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
+                        self.n_nodes, self.n_rel)
+        sp.symmetric = self.symmetric
+        return sp
 
 
 STREAM_BAND_OVERHEAD = 2.0     # what a band costs besides its steps (record fetch, row store), in steps
 
 
-def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece=4):
+STREAM_WIDE_STEPS = 16        # a run with more steps than this is cut into 2, 4 or 8 sub-runs walked side by side
+
+
+def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece=4, wide_steps=None):
     """Wave-stream plan for  out[o] = sum_{e: out_row[e] = o} table[tab_row[e]],  o < n_rows, table rows < n_table.
 
     The runs (one per output row with edges) are sorted by decreasing length and taken SPW = 64 / lanes at
@@ -556,47 +562,81 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     the same slot, its sum stays in registers).  Groups are dealt to the n_wg * 16 wavefronts by the
     longest-processing-time rule on  steps + STREAM_BAND_OVERHEAD * bands; rows without edges are dealt
     evenly.  Inside a run the ids are ordered for conflict-free LDS reads (`bank_rotation`) and pre-scaled
-    (idx_unit) exactly as in `build_rel_plan`."""
+    (idx_unit) exactly as in `build_rel_plan`.
+
+    WIDE runs: a slot walks its run as a chain of dependent steps, so the longest run of the graph (BioSNAP:
+    a drug pair linked by 475 relations = 60 steps) set the length of the launch once everything else was
+    balanced (measured: capping runs at 24 steps, 4 % of the work, took the pair gather from 21.5 to 15.2 us).
+    A run with more than `wide_steps` steps is therefore cut into k = 2, 4 or 8 sub-runs that sit in k
+    adjacent, k-aligned slots of ONE group; their partial sums are added in a fixed tree order by the kernel
+    (cell bits 30-31 = log2 k on the set's last band) and the first slot writes the row."""
     import heapq
     dev = out_row.device
     T, S, W = int(n_table), 64 // int(lanes), int(n_wg) * 16
     assert T <= 65535 and n_rows < 2 ** 24, 'cells hold the output row in 24 bits, ids are 16-bit'
+    if wide_steps is None:
+        wide_steps = int(os.environ.get('TIPK_RS_WIDE_STEPS', '0')) or STREAM_WIDE_STEPS
     E = int(out_row.numel())
-    key = out_row
-    if os.environ.get('TIPK_RS_CAP_EXPERIMENT'):      # TIMING EXPERIMENT ONLY (wrong sums): drop the edges of a run beyond the cap
-        cap = int(os.environ['TIPK_RS_CAP_EXPERIMENT']) * 8
-        o = torch.sort(key, stable=True).indices
-        ks = key[o]
-        first = torch.cat([ks.new_ones(1, dtype=torch.bool), ks[1:] != ks[:-1]])
-        start = torch.cummax(torch.where(first, torch.arange(E, device=dev), torch.zeros(E, dtype=torch.long, device=dev)), 0).values
-        keep = o[(torch.arange(E, device=dev) - start) < cap]
-        out_row, tab_row = out_row[keep], tab_row[keep]
-        key = out_row
-        E = int(out_row.numel())
-    cnt_rows = torch.bincount(key, minlength=n_rows)
+    cnt_rows = torch.bincount(out_row, minlength=n_rows)
     zero_rows = torch.nonzero(cnt_rows == 0).flatten()
-    run_row = torch.nonzero(cnt_rows > 0).flatten()
+    run_row = torch.nonzero(cnt_rows > 0).flatten()                        # runs in row order
     run_cnt = cnt_rows[run_row]
-    # by decreasing STEPS (8 ids each), rows ascending inside a class: equal work per slot of a group, and the
-    # rows a wavefront writes together are neighbours in the output more often than not
-    order = torch.sort((run_cnt + 7) // 8, descending=True, stable=True).indices
-    run_row, run_cnt = run_row[order], run_cnt[order]
     n_runs = int(run_row.numel())
-    G = -(-n_runs // S)
-    steps = torch.zeros(G * S, dtype=torch.int64, device=dev)
-    steps[:n_runs] = (run_cnt + 7) // 8
-    rows_p = torch.zeros(G * S, dtype=torch.int64, device=dev)
-    rows_p[:n_runs] = run_row
-    steps, rows_p = steps.view(G, S), rows_p.view(G, S)
-    g_steps = steps.max(1).values if G else steps.new_zeros(0)            # longest run of the group
+    run_steps = (run_cnt + 7) // 8
+    # sub-runs per run (1 = plain) and steps per sub-run
+    kmax = min(S, 8)
+    need = (run_steps + wide_steps - 1) // wide_steps
+    k_run = torch.ones_like(run_steps)
+    for kk in (2, 4, 8):
+        if kk <= kmax:
+            k_run = torch.where(need > kk // 2, torch.full_like(k_run, kk), k_run)
+    q_run = (run_steps + k_run - 1) // k_run                               # steps of the (largest) sub-runs
+    # ---- the slot list ("virtual runs") in layout order: wide sets first (largest k first, k-aligned inside groups
+    # of S slots), then the plain runs by decreasing steps (rows ascending inside a class: the rows a wavefront
+    # writes together are neighbours in the output more often than not)
+    v_run, v_pos = [], []                                                   # per virtual run: original run (-1 = idle slot), position in its set
+    for kk in (8, 4, 2):
+        sel = torch.nonzero(k_run == kk).flatten()
+        if sel.numel() == 0:
+            continue
+        sel = sel[torch.sort(q_run[sel], descending=True, stable=True).indices]
+        v_run.append(torch.repeat_interleave(sel, kk))
+        v_pos.append(torch.arange(kk, device=dev).repeat(sel.numel()))
+        pad = (-int(sel.numel()) * kk) % S
+        v_run.append(torch.full((pad,), -1, dtype=torch.int64, device=dev))
+        v_pos.append(torch.zeros(pad, dtype=torch.int64, device=dev))
+    plain = torch.nonzero(k_run == 1).flatten()
+    plain = plain[torch.sort(run_steps[plain], descending=True, stable=True).indices]
+    v_run.append(plain)
+    v_pos.append(torch.zeros(plain.numel(), dtype=torch.int64, device=dev))
+    pad = (-sum(int(t.numel()) for t in v_run)) % S
+    v_run.append(torch.full((pad,), -1, dtype=torch.int64, device=dev))
+    v_pos.append(torch.zeros(pad, dtype=torch.int64, device=dev))
+    v_run, v_pos = torch.cat(v_run), torch.cat(v_pos)
+    V = int(v_run.numel())
+    G = V // S
+    real = v_run >= 0
+    vr = torch.clamp(v_run, min=0)
+    v_k = torch.where(real, k_run[vr], torch.ones_like(vr)) if n_runs else torch.ones_like(vr)
+    v_q = torch.where(real, q_run[vr], torch.zeros_like(vr)) if n_runs else torch.zeros_like(vr)
+    v_tot = torch.where(real, run_steps[vr], torch.zeros_like(vr)) if n_runs else torch.zeros_like(vr)
+    v_steps = torch.clamp(v_tot - v_pos * v_q, min=0)
+    v_steps = torch.minimum(v_steps, v_q)                                   # steps of this sub-run
+    v_nb = torch.where(real, torch.clamp((v_q + piece - 1) // piece, min=1), torch.zeros_like(v_q))   # bands of its set
+    v_klog = torch.where(v_k >= 8, 3, torch.where(v_k >= 4, 2, torch.where(v_k >= 2, 1, 0)))
+    v_rowid = torch.where(real, run_row[vr], torch.zeros_like(vr)) if n_runs else torch.zeros_like(vr)
+    # ---- groups -> wavefronts
+    g_steps = v_q.view(G, S).max(1).values if G else v_q.new_zeros(0)
     g_bands = torch.clamp((g_steps + piece - 1) // piece, min=1)
-    cost = (g_steps.double() + STREAM_BAND_OVERHEAD * g_bands.double()).cpu().tolist()
-    # longest-processing-time deal (groups come in decreasing cost)
+    cost_t = g_steps.double() + STREAM_BAND_OVERHEAD * g_bands.double()
+    by_cost = torch.sort(cost_t, descending=True, stable=True).indices.cpu().tolist()
+    cost = cost_t.cpu().tolist()
+    # longest-processing-time deal
     # (giving every wavefront a contiguous range of output rows instead -- length-sorted only inside windows of
     # 645 ... 32 768 rows, so that its writes sweep the output front to back -- measured no faster inside the step)
     heap = [(0.0, w) for w in range(W)]
     wave_of = [0] * G
-    for g in range(G):
+    for g in by_cost:
         load, w = heapq.heappop(heap)
         wave_of[g] = w
         heapq.heappush(heap, (load + cost[g], w))
@@ -609,36 +649,48 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     g_band0[g_order] = band0_l
     per_wave = torch.zeros(W, dtype=torch.int64, device=dev).index_add_(0, wave_of, g_bands)
     wave_ptr = torch.cat([per_wave.new_zeros(1), torch.cumsum(per_wave, 0)])
-    # cells
+    # ---- cells
     grp = torch.repeat_interleave(g_order, bands_l)                       # group of every band
-    k = torch.arange(n_bands, device=dev) - torch.repeat_interleave(band0_l, bands_l)
-    st = steps[grp]                                                       # [n_bands, S]
-    nb_run = (st + piece - 1) // piece
-    length = torch.clamp(st - k.unsqueeze(1) * piece, min=0, max=piece)
-    first = (st > 0) & (k.unsqueeze(1) == 0)
-    last = (st > 0) & (k.unsqueeze(1) == nb_run - 1)
-    active = (st > 0) & (k.unsqueeze(1) < nb_run)
-    cells = torch.where(active, rows_p[grp] | (length << 24) | (first.long() << 28) | (last.long() << 29),
-                        torch.zeros_like(st))
-    # ids
+    k = (torch.arange(n_bands, device=dev) - torch.repeat_interleave(band0_l, bands_l)).unsqueeze(1)
+    pick = lambda t: t.view(G, S)[grp]                                    # [n_bands, S]
+    st, nb_set, pos, klog, rid, rl = pick(v_steps), pick(v_nb), pick(v_pos), pick(v_klog), pick(v_rowid), pick(real)
+    length = torch.clamp(st - k * piece, min=0, max=piece)
+    final = k == nb_set - 1
+    first = rl & (k == 0)
+    last = rl & final & (pos == 0)
+    active = rl & (k < nb_set)
+    cells = torch.where(active, rid | (length << 24) | (first.long() << 28) | (last.long() << 29)
+                        | (torch.where(final, klog, torch.zeros_like(klog)) << 30), torch.zeros_like(st))
+    # ---- ids
     idx_unit = 1
     row_bytes = lanes * 16
     while idx_unit * 2 <= row_bytes and T * idx_unit * 2 <= 65535:
         idx_unit *= 2
+    v_first = torch.full((max(n_runs, 1),), -1, dtype=torch.int64, device=dev)      # virtual index of a run's first sub-run
+    head = real & (v_pos == 0)
+    v_first[v_run[head]] = torch.nonzero(head).flatten()
     run_of_row = torch.full((n_rows,), -1, dtype=torch.int64, device=dev)
     run_of_row[run_row] = torch.arange(n_runs, device=dev)
-    ri = run_of_row[key]                                                  # run of every edge
-    n_cls, rot = bank_rotation(lanes)
-    cls = (tab_row % n_cls - torch.tensor(rot, device=dev)[ri % S]) % n_cls
-    e_order = torch.sort(ri * n_cls + cls, stable=True).indices
-    ri_s = ri[e_order]
+    ri = run_of_row[out_row]                                              # run of every edge
+    o1 = torch.sort(ri, stable=True).indices
+    ri1 = ri[o1]
     run_first = torch.cumsum(run_cnt, 0) - run_cnt
-    j = torch.arange(E, device=dev) - run_first[ri_s]                     # rank inside the run
-    step = j // 8
-    band = g_band0[ri_s // S] + step // piece
-    dest = ((band * piece + step % piece) * S + ri_s % S) * 8 + j % 8
+    j1 = torch.arange(E, device=dev) - run_first[ri1]                     # rank inside the run (edge order)
+    q8 = q_run[ri1] * 8
+    ve = v_first[ri1] + j1 // q8                                          # virtual run of every edge
+    n_cls, rot = bank_rotation(lanes)
+    tab1 = tab_row[o1]
+    cls = (tab1 % n_cls - torch.tensor(rot, device=dev)[ve % S]) % n_cls
+    o2 = torch.sort(ve * n_cls + cls, stable=True).indices
+    ve2 = ve[o2]
+    v_cnt = torch.bincount(ve2, minlength=V) if E else torch.zeros(V, dtype=torch.int64, device=dev)
+    v_start = torch.cumsum(v_cnt, 0) - v_cnt
+    jr = torch.arange(E, device=dev) - v_start[ve2]                       # rank inside the sub-run (bank order)
+    step = jr // 8
+    band = g_band0[ve2 // S] + step // piece
+    dest = ((band * piece + step % piece) * S + ve2 % S) * 8 + jr % 8
     ids32 = torch.full((max(n_bands, 1) * piece * S * 8,), T * idx_unit, dtype=torch.int32, device=dev)
-    ids32[dest] = (tab_row[e_order] * idx_unit).to(torch.int32)
+    ids32[dest] = (tab1[o2] * idx_unit).to(torch.int32)
     nz = int(zero_rows.numel())
     zero_ptr = (torch.arange(W + 1, device=dev) * nz) // W
     cells_u = torch.where(cells >= 2 ** 31, cells - 2 ** 32, cells).to(torch.int32)
@@ -682,27 +734,31 @@ def execute_stream_plan_reference(plan, table):
     assert len(wp) == plan.n_wg * 16 + 1 and wp[0] == 0 and wp[-1] == plan.n_bands
     for w in range(plan.n_wg * 16):
         acc = torch.zeros((S, d), dtype=table.dtype)
-        open_row = [-1] * S
         for b in range(wp[w], wp[w + 1]):
+            klogs = [0] * S
+            lasts = []
             for s_ in range(S):
                 c = int(cells[b, s_])
-                row, ln, first, last = c & 0xffffff, (c >> 24) & 15, (c >> 28) & 1, (c >> 29) & 1
                 if c == 0:
                     continue
-                assert 1 <= ln <= P
+                row, ln, first, last, klogs[s_] = c & 0xffffff, (c >> 24) & 15, (c >> 28) & 1, (c >> 29) & 1, (c >> 30) & 3
+                assert 0 <= ln <= P
                 if first:
-                    assert open_row[s_] == -1
                     acc[s_] = 0
-                    open_row[s_] = row
-                assert open_row[s_] == row, 'a run continues in the same slot of the next band'
                 nodes = ids[b, :ln, s_].reshape(-1)
                 nodes = nodes[nodes < T]
                 acc[s_] += table[nodes].sum(0)
                 if last:
-                    out[row] = acc[s_]
-                    written[row] += 1
-                    open_row[s_] = -1
-        assert all(r == -1 for r in open_row)
+                    lasts.append((s_, row))
+            if any(klogs):                                  # the kernel's tree: slot s receives slot s + 2^j when its set allows
+                for jj in range(3):
+                    for s_ in range(S):
+                        if klogs[s_] > jj and s_ % (2 << jj) == 0 and s_ + (1 << jj) < S:
+                            assert klogs[s_ + (1 << jj)] == klogs[s_], 'a set occupies aligned adjacent slots'
+                            acc[s_] = acc[s_] + acc[s_ + (1 << jj)]
+            for s_, row in lasts:
+                out[row] = acc[s_]
+                written[row] += 1
         for z in range(zp[w], zp[w + 1]):
             written[int(plan.zero_rows[z])] += 1
     assert bool((written == 1).all()), 'every output row is written exactly once'
