@@ -63,6 +63,8 @@ def parse():
     ap.add_argument('--oversubscribe', action='store_true',
                     help='allow more ranks than GPUs (ranks share devices, gloo collectives): functional check only')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the eager per-kernel event pass')
+    ap.add_argument('--step-only', action='store_true',
+                    help='run nothing but the warm-up and timed steps (PMC passes: bytes / (steps + warmup) = bytes per step)')
     return ap.parse_args()
 
 
@@ -217,20 +219,20 @@ def dd_aggregation_launches(enc, dev):
                 cells = graph.pair_buffers(n, nb, d, dev)[0]
                 out.append(('pair_cells[dd.fwd,d=%d]' % d, key, grid, nb, 'lds',
                             lambda pair=pair, att=att, cells=cells, nb=nb: ops.stream_gather(
-                                pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1)))
+                                pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1), pair.n_edges))
             elif rs is not None and ops.rel_stream_split(n, d):
                 split = ops.rel_stream_split(n, d)
                 key = 'stream_gather_kernel<%d, %s, 0' % (d // split // 4, 'true' if rs.idx_unit == d // split * 4 else 'false')
                 grid = '%dx%dx1' % (rs.n_wg * 1024, split)
                 out.append(('rel_stream[dd.bwd,d=%d]' % d, key, grid, d, 'lds',
-                            lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale)))
+                            lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale), rs.n_edges))
             elif ops.rel_gather_usable(rp, n, d, bwd):
                 split = ops.rel_gather_split(n, d, bwd)
                 key = 'rel_gather_kernel<%d, %s' % (d // split // 4, 'true' if bwd else 'false')
                 grid = '%dx%dx1' % (rp.n_wg * 1024, split)
                 fn = (lambda rp=rp, g=g: ops.rel_gather(rp, g, True, row_scale=graph.scale)) if bwd else \
                      (lambda rp=rp, y=y: ops.rel_gather(rp, y, False, reduce=False))
-                out.append(('rel_gather[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'lds', fn))
+                out.append(('rel_gather[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'lds', fn, None))
             else:
                 lanes = 1
                 while lanes < d // 4:
@@ -244,14 +246,14 @@ def dd_aggregation_launches(enc, dev):
                     key = 'gather_rows_csr_kernel<%d' % lanes
                     grid = '%dx1x1' % (-(-waves // 4) * 256)
                     out.append(('gather_rows_csr[dd.bwd,d=%d]' % d, key, grid, d, 'hbm',
-                                lambda csr=csr, g=g: ops.gather_rows_csr(csr, g)))
+                                lambda csr=csr, g=g: ops.gather_rows_csr(csr, g), None))
                     continue
                 plan = graph.bwd if bwd else graph.fwd
                 waves = -(-plan.items.shape[0] // (64 // lanes))
                 key = 'gather_sum_kernel<4, %d' % lanes
                 grid = '%dx1x1' % (-(-waves // 4) * 256)
                 fn = (lambda plan=plan, g=g: ops.gather_sum(plan, g)) if bwd else (lambda plan=plan, y=y: ops.gather_sum(plan, y))
-                out.append(('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'hbm', fn))
+                out.append(('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'hbm', fn, None))
     return out
 
 
@@ -303,6 +305,20 @@ def pmc_traffic(key_prefix, grid):
     except Exception:
         pass
     return traffic, trace_us, src
+
+
+def step_hbm_bytes():
+    """(HBM bytes of ONE step, file) from the newest committed PMC summary that has the total
+    (tools/summarize_prof.py: all libtipk launches of `bench.py --step-only` / (steps + warmup))."""
+    import glob
+    try:
+        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+            v = json.load(open(fn)).get('step_hbm_bytes')
+            if v:
+                return float(v), os.path.basename(fn)
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -435,11 +451,11 @@ def main():
 
     # the D-D aggregation launches alone (roofline), then an eager per-kernel table of the whole step
     agg_us = {}
-    launches = dd_aggregation_launches(enc, dev)
-    for label, key, grid, d_row, bound, fn in launches:
+    launches = [] if args.step_only else dd_aggregation_launches(enc, dev)
+    for label, key, grid, d_row, bound, fn, n_e in launches:
         agg_us[label] = time_launch_us(fn)
     kern = {}
-    if not args.no_kernel_table:
+    if not args.no_kernel_table and not args.step_only:
         ops.timing_start()
         for _ in range(max(3, min(args.steps, 10))):
             step()
@@ -470,8 +486,9 @@ def main():
         # dominant kernel = the D-D aggregation launch with the longest duration
         if agg_us:
             dom = max(agg_us, key=agg_us.get)
-            label, key, grid, d_row, bound, _ = [l for l in launches if l[0] == dom][0]
-            n_edges = int(dd_rank['dd_train_idx'].shape[1])        # rank 0's share when sharded
+            label, key, grid, d_row, bound, _, n_launch = [l for l in launches if l[0] == dom][0]
+            # edges the launch walks: rank 0's share when sharded; a pair-form launch of a symmetric graph half of them
+            n_edges = int(n_launch) if n_launch is not None else int(dd_rank['dd_train_idx'].shape[1])
             # one id + one d-wide fp32 row per edge and pass (ids are 4 B in the generic
             # plans, 2 B in the relation-local ones; the figure keeps 4 B so runs stay comparable)
             alg_bytes = n_edges * (4 + 4 * d_row)
@@ -482,28 +499,37 @@ def main():
             roof = {'bound': bound, 'kernel': dom, 'grid': grid, 'achieved': achieved, 'peak': peak, 'unit': 'GB/s',
                     'frac': achieved / peak, 'traffic': traffic, 'launch_us': us,
                     'timing': 'HIP events on the launch stream around a hipGraph of 20 back-to-back launches',
-                    'algorithmic_bytes_per_launch': alg_bytes}
+                    'algorithmic_bytes_per_launch': alg_bytes, 'edges_per_launch': n_edges, 'row_floats': d_row}
             if traffic is not None:
                 roof['hbm_traffic_frac'] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 roof['traffic_source'] = 'profiles/' + src
             if trace_us is not None:
                 roof['rocprof_trace_us'] = trace_us
             if bound == 'lds':
-                roof['note'] = ('rows are gathered from LDS (relation-local kernel): the bound is the ds_read_b128 rate, '
-                                'HBM only carries the ids and one coalesced read of Y (fwd) / write of dY (bwd)')
+                roof['note'] = ('rows are gathered from LDS (wave-stream / relation-local kernel): the bound is the ds_read_b128 '
+                                'rate; HBM only carries the ids and the output rows')
             out['roofline'] = roof
             out['dd_aggregations_us'] = {k: round(v, 2) for k, v in agg_us.items()}
         per_edge = sum(2 * (8 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2'))     # 416 / 2080 B per edge
         out['whole_step'] = {'alg_bytes': E * per_edge, 'bytes_per_edge': per_edge,
                              'GBps': E * per_edge / (ms * 1e-3) / 1e9,
-                             'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'note': 'SURVEY 8(d) prices one id + one d-wide row per edge and pass from HBM; this build serves the '
+                                     'rows from LDS and, in the pair-form forward, adds one att row per edge of HALF the '
+                                     '(symmetric) graph, so the figure can exceed 1: it compares against the survey '
+                                     'yardstick, it is not an HBM utilisation'}
+        hb = step_hbm_bytes()
+        if hb is not None and args.workload.startswith('biosnap') and world == 1:
+            out['whole_step']['hbm_bytes_measured'] = hb[0]
+            out['whole_step']['hbm_frac_measured'] = hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out['whole_step']['hbm_source'] = 'profiles/' + hb[1]
         if kern:
             out['kernels_eager_ms'] = {
                 'note': 'one HIP event pair per EAGER launch: includes ~5-8 us of event/launch overhead each; '
                         'kernel-only times: profiles/*_kernel_by_grid.csv',
                 'table': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
                           for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.step_only:
             out['cpu_baseline'] = cpu_baseline(dd, dims, args.mod, args.cpu_seconds)
     if dist.is_initialized():
         dist.barrier()

@@ -535,6 +535,7 @@ class StreamPlan(object):
         # the (relation, node) form of `build_stream_plan`: rows = relation * n_nodes + node
         self.row_used = row_used                  # int32 [ceil(R / 32), N] bit mask of the rows with edges (tipk.h section 2b)
         self.symmetric = False                    # pair-form plans: built from the edges with source <= destination only
+        self.n_edges = 0                          # edges the plan walks
         self.n_nodes, self.n_rel = n_nodes, n_rel
 
     def to(self, device):
@@ -542,7 +543,7 @@ class StreamPlan(object):
         sp = StreamPlan(self.n_rows, self.n_table, self.n_wg, self.lanes, self.piece, mv(self.wave_ptr), mv(self.cells),
                         mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
                         self.n_nodes, self.n_rel)
-        sp.symmetric = self.symmetric
+        sp.symmetric, sp.n_edges = self.symmetric, self.n_edges
         return sp
 
 
@@ -696,10 +697,12 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     cells_u = torch.where(cells >= 2 ** 31, cells - 2 ** 32, cells).to(torch.int32)
     if zero_rows.numel() == 0:
         zero_rows = torch.zeros(1, dtype=torch.int64, device=dev)
-    return StreamPlan(n_rows, T, n_wg, lanes, piece, wave_ptr.to(torch.int32).contiguous(),
-                      cells_u.view(n_bands, S).contiguous() if n_bands else cells_u.new_zeros((0, S)),
-                      ids32.to(torch.uint16).contiguous(), zero_ptr.to(torch.int32).contiguous(),
-                      zero_rows.to(torch.int32).contiguous(), idx_unit)
+    sp = StreamPlan(n_rows, T, n_wg, lanes, piece, wave_ptr.to(torch.int32).contiguous(),
+                    cells_u.view(n_bands, S).contiguous() if n_bands else cells_u.new_zeros((0, S)),
+                    ids32.to(torch.uint16).contiguous(), zero_ptr.to(torch.int32).contiguous(),
+                    zero_rows.to(torch.int32).contiguous(), idx_unit)
+    sp.n_edges = E
+    return sp
 
 
 def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4):

@@ -1,18 +1,25 @@
-"""A few rel_gather launches on the BioSNAP D-D graph for PMC collection."""
+"""The D-D aggregation launches of one BioSNAP step (+ the pair-form product), a few times each, for PMC collection
+(tools/profile_gpu.sh: SQ / LDS counter passes).  Plans and shapes are the step's own (bench.dd_aggregation_launches)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
 from tip_amd import ops
 from tip_amd.data import build_data_dict
-from tip_amd.plan import build_rel_plan
-dd = build_data_dict(); dev = 'cuda:0'
-ei = dd['dd_train_idx'].to(dev); rg = dd['dd_train_range']; R = dd['n_dd_et']; N = 645
-rel = torch.repeat_interleave(torch.arange(R), rg[:, 1] - rg[:, 0]).to(dev)
-for d in (32, 16):
-    split = ops.rel_gather_split(N, d, False)
-    pf = build_rel_plan(ei[1], ei[0], rel, N, R, 256 // split)
-    pb = build_rel_plan(ei[0], ei[1], rel, N, R, 256, backward=True)
-    y = torch.randn(R * N, d, device=dev); g = torch.randn(N, d, device=dev)
+from tip_amd.layers import TIP, Setting
+dev = torch.device('cuda:0')
+dd = build_data_dict()
+model = TIP(Setting(), dev, data=dd)
+enc, data = model.encoder, model.data
+z = enc(data.d_feat, data.dd_train_idx, data.dd_train_et, data.dd_train_range, data.d_norm, data.p_feat,
+        data.pp_train_indices, data.dp_edge_index, data.dp_range_list)          # builds the plans
+for label, key, grid, d_row, bound, fn, n_e in bench.dd_aggregation_launches(enc, dev):
     for _ in range(3):
-        ops.rel_gather(pf, y, False, reduce=False)
-        ops.rel_gather(pb, g, True)
+        fn()
+n, nb = 645, 32
+for layer in (enc.rgcn1, enc.rgcn2):
+    graph = layer._cache.value
+    cells, xb_nb = graph.pair_buffers(n, layer.num_bases, layer.out_channels, dev)
+    for _ in range(3):
+        ops.pair_product(cells, xb_nb, symmetric=graph.pair_fwd.symmetric)
 torch.cuda.synchronize()

@@ -14,8 +14,8 @@ mkdir -p $OUT
 # 1. per-kernel time of the default bench command (hipGraph replay of the step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 # 2./3. HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC has 4 slots: 3 + 2)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --launch eager --no-kernel-table $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --launch eager --no-kernel-table $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --launch eager --step-only $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --launch eager --step-only $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err
 # 4. SQ / LDS counters of the D-D aggregation kernels (own passes, --kernel-trace only besides --pmc)
 if [ -z "$ARGS" ]; then
 i=0

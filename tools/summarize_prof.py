@@ -99,18 +99,33 @@ for n, d in pmc.items():
     f_kb, w_kb = d.get('FETCH_SIZE_KB_avg', 0.0), d.get('WRITE_SIZE_KB_avg', 0.0)
     d['hbm_bytes_per_launch'] = (2.0 * f_kb + w_kb) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 of wide reads
     d['hbm_bytes_per_launch_uncorrected'] = (f_kb + w_kb) * 1024.0
+step_bytes = None
+if pmc:
+    # bytes of ONE step: every libtipk launch of the PMC passes (bench.py --step-only runs nothing but steps) / steps run
+    try:
+        line = [l for l in open(os.path.join(src, 'bench_fetch.json')) if l.startswith('{')][-1]
+        meta = json.loads(line)
+        n_steps = int(meta['steps']) + int(meta['warmup'])
+        tot = sum(d['hbm_bytes_per_launch'] * max(d.get('launches_FETCH_SIZE', 0), d.get('launches_WRITE_SIZE', 0))
+                  for k, d in pmc.items() if not (k.startswith('at::') or k.startswith('rocprim') or 'elementwise' in k
+                                                  or k.startswith('__amd_rocclr')))          # setup copies / fills
+        step_bytes = tot / n_steps
+    except Exception as exc:
+        print('no per-step total:', exc)
 if pmc:
     keep = {k: v for k, v in pmc.items() if not (k.startswith('at::') or k.startswith('rocprim'))}
     top = dict(sorted(keep.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:48])
     json.dump({'note': 'FETCH_SIZE/WRITE_SIZE in KB per launch (separate rocprofv3 --pmc passes of bench.py --launch eager); '
                        'hbm_bytes = (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md HBM section; keys = kernel + full grid XxYxZ '
-                       '(joined from the kernel trace of the same pass by Dispatch_Id)', 'kernels': top},
+                       '(joined from the kernel trace of the same pass by Dispatch_Id); step_hbm_bytes = all libtipk launches '
+                       'of the pass / (steps + warmup) of `bench.py --launch eager --step-only`',
+               'step_hbm_bytes': step_bytes, 'kernels': top},
               open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 
 lds = {}
 for sub in sorted(glob.glob(os.path.join(src, 'pmc_sq*'))):
     for key, cs in counters_by_launch(os.path.basename(sub)).items():
-        if 'rel_gather' not in key and 'gather_sum' not in key and 'dy_products' not in key and 'rgcn_' not in key:
+        if not any(t in key for t in ('rel_gather', 'stream_gather', 'pair_product', 'gather_sum', 'dy_products', 'rgcn_')):
             continue
         for c, v in cs.items():
             lds.setdefault(key, {})[c] = sum(v) / len(v)
