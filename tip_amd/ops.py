@@ -734,6 +734,7 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 # ---------------------------------------------------------------------------------------------
 # static graph containers (plans in both directions + normalisers)
 # ---------------------------------------------------------------------------------------------
+PAIR_FWD_MAX_WORLD = 4   # relation-sharded runs with this many ranks or more use the Y route (see _RGCN.forward)
 PAIR_KGROUP = 8          # source nodes whose products are summed inside one wavefront of the pair-form product
 
 
@@ -922,6 +923,10 @@ class _RGCN(torch.autograd.Function):
         elif r > 0:
             assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         pair = graph.pair_fwd if r > 0 else None
+        if shard is not None and shard.world >= PAIR_FWD_MAX_WORLD:
+            # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (20 us at BioSNAP, whatever
+            # the rank's share of the relations); the Y route scales with the share: (25 + 48) us / world per layer
+            pair = None
         if pair is not None and pair.symmetric and not lib().tipk_pair_product_supported(nb, d_out):
             pair = None                                      # only the dedicated product kernel reads mirrored cells
         if pair is not None and not (pair.n_table == r and pair.n_rows == n * n and stream_gather_split(r, nb)
