@@ -26,9 +26,16 @@
 #include <stdlib.h>
 #include "tipk_common.h"
 
+#ifdef TIPK_DEBUG
+// debug builds only: per-wave cycle stamps of the last stream-gather launch (tools/rs_stamps.py):
+// [wave][4] = { total, table staging + barrier, band loop, bands walked }
+__device__ unsigned long long tipk_rs_stamps[4096 * 4];
+#endif
+
 namespace {
 
 constexpr int RS_PIECE = 4;            // steps (8 ids each) per cell
+constexpr int RS_STAGE = 10;           // float4 per thread requested at once while the table is staged
 constexpr int RS_DEPTH = 2;            // bands a record is requested ahead of its use
 constexpr int64_t RS_LDS_LIMIT = 158 * 1024;
 
@@ -52,33 +59,19 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     constexpr int SPW = 64 / L;
     constexpr int q4 = L;
     const int t = threadIdx.x, lane = t & 63;
+#ifdef TIPK_DEBUG
+    const unsigned long long st0 = __builtin_readcyclecounter();
+#endif
     const int n_nodes = a.n_nodes, dc = a.dc;
     const int slot = lane / L, c0 = (lane & (L - 1)) * 4;
     const int col0 = blockIdx.y * dc;
     const float* table = a.table + col0;
     float* out = a.out + col0;
-    const int total4 = n_nodes * q4;
-    if (t < dc) tab[(int64_t)n_nodes * dc + t] = 0.f;
-    for (int base = 0; base < total4; base += 4096) {
-        float4 gv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int i = base + u * 1024 + t;
-            i = i < total4 ? i : total4 - 1;
-            const int r = i / q4, c = (i - r * q4) * 4;
-            gv[u] = tipk_ld4(table + (int64_t)r * a.ld_t + c);
-            if (a.row_scale) { const float sc = a.row_scale[r]; gv[u].x *= sc; gv[u].y *= sc; gv[u].z *= sc; gv[u].w *= sc; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = base + u * 1024 + t;
-            if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * dc + c, gv[u]); }
-        }
-    }
-    __syncthreads();                                   // the only barrier of the launch
-
     const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 16 + (t >> 6));
     int b = __builtin_amdgcn_readfirstlane(a.wave_ptr[gw]);
+#ifdef TIPK_DEBUG
+    const int b_first = b;
+#endif
     const int b1 = __builtin_amdgcn_readfirstlane(a.wave_ptr[gw + 1]);
     const char* tabb = reinterpret_cast<const char*>(tab + c0);
     const unsigned ldt4 = (unsigned)a.idx_mul;
@@ -99,6 +92,43 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
 #pragma unroll
         for (int k = 0; k < RS_PIECE; ++k) iw[k] = p[k * SPW];
     };
+    // the first two records travel while the table is staged
+    if (b < b1) {
+        fetch(b, c0q, i0q);
+        fetch(b + 1, c1q, i1q);
+    }
+    const int total4 = n_nodes * q4;
+    if (t < dc) tab[(int64_t)n_nodes * dc + t] = 0.f;
+    // the whole table in ONE round trip: up to RS_STAGE float4 per thread are requested before the first is stored
+    // (the LDS holds at most 10 112 float4; a loop of 4-deep batches cost a dependent round trip per 64 KB)
+    for (int base = 0; base < total4; base += 1024 * RS_STAGE) {
+        float4 gv[RS_STAGE];
+#pragma unroll
+        for (int u = 0; u < RS_STAGE; ++u) {
+            int i = base + u * 1024 + t;
+            i = i < total4 ? i : total4 - 1;
+            const int r = i / q4, c = (i - r * q4) * 4;
+            gv[u] = tipk_ld4(table + (int64_t)r * a.ld_t + c);
+        }
+        if (a.row_scale) {
+#pragma unroll
+            for (int u = 0; u < RS_STAGE; ++u) {
+                int i = base + u * 1024 + t;
+                i = i < total4 ? i : total4 - 1;
+                const float sc = a.row_scale[i / q4];
+                gv[u].x *= sc; gv[u].y *= sc; gv[u].z *= sc; gv[u].w *= sc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RS_STAGE; ++u) {
+            const int i = base + u * 1024 + t;
+            if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * dc + c, gv[u]); }
+        }
+    }
+    __syncthreads();                                   // the only barrier of the launch
+#ifdef TIPK_DEBUG
+    const unsigned long long st1 = __builtin_readcyclecounter();
+#endif
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     // walk band `band` out of (cw, iw) and request band + RS_DEPTH into (nw, niw)
     auto walk = [&](int band, const uint32_t& cw, const uint4 (&iw)[RS_PIECE], uint32_t& nw, uint4 (&niw)[RS_PIECE]) {
@@ -145,16 +175,21 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
         if (cell & (1u << 29))                                                   // the row is complete
             tipk_st4(out + (int64_t)(cell & 0xffffffu) * a.ld_out + c0, acc);
     };
-    if (b < b1) {
-        fetch(b, c0q, i0q);
-        fetch(b + 1, c1q, i1q);
-    }
     for (; b < b1; b += 4) {
         walk(b, c0q, i0q, c2q, i2q);
         walk(b + 1, c1q, i1q, c3q, i3q);
         walk(b + 2, c2q, i2q, c0q, i0q);
         walk(b + 3, c3q, i3q, c1q, i1q);
     }
+#ifdef TIPK_DEBUG
+    if (lane == 0 && blockIdx.y == 0 && gw < 4096) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        tipk_rs_stamps[gw * 4 + 0] = now - st0;
+        tipk_rs_stamps[gw * 4 + 1] = st1 - st0;
+        tipk_rs_stamps[gw * 4 + 2] = now - st1;
+        tipk_rs_stamps[gw * 4 + 3] = (unsigned long long)(b1 - b_first);
+    }
+#endif
     // rows (relation, node) without edges
     if (!a.zero_ptr) return;                           // the consumer masks those rows (tipk_rgcn_dy_products row_used)
     const int z0 = __builtin_amdgcn_readfirstlane(a.zero_ptr[gw]), z1 = __builtin_amdgcn_readfirstlane(a.zero_ptr[gw + 1]);
@@ -185,6 +220,12 @@ int launch_rs(const RsArgs& a, int n_wg, int split, int kind, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef TIPK_DEBUG
+extern "C" int tipk_debug_rs_stamps(unsigned long long* host_out /* [4096 * 4] */) {
+    return tipk_hip_status(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tipk_rs_stamps), sizeof(unsigned long long) * 4096 * 4));
+}
+#endif
 
 extern "C" int tipk_stream_gather_supported(int64_t n_table, int d) { return rel_stream_split(n_table, d); }
 
