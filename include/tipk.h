@@ -276,7 +276,7 @@ int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, in
  *        slabs[g][v, c] = sum_{u in group g} sum_b cells[u][v][b] * xb[u][b][c]        g < n_src / group
  *
  *     cells [n_src][n_dst][n_bases] = the pair cells written by tipk_stream_gather (table = att), xb
- *     [n_src][n_bases][d] = X . basis per source node; n_src is the node count rounded up to a multiple of
+ *     [n_src][n_bases][32] = X . basis per source node, rows PADDED to 32 columns with zeros beyond d; n_src is the node count rounded up to a multiple of
  *     `group` with blocks that stay zero.  slabs [n_src / group][n_dst][d] are added in order by
  *     tipk_sum_slabs_ex (which also applies 1 / deg, + X root and the ReLU).  n_bases in {8, 16, 32}, d <= 32
  *     (`tipk_pair_product_supported`; otherwise tipk_gemm_f32 with kbatch = group does the same sums).

@@ -356,6 +356,17 @@ def test_pair_product(ops, n, nb, d, monkeypatch):
     cells[:n] = torch.randn(n, n, nb, generator=g) * (torch.rand(n, n, 1, generator=g) < 0.3)
     xb = torch.zeros(n_pad, nb, d)
     xb[:n] = torch.randn(n, nb, d, generator=g)
+    xb_host = xb
+    xb_pad = torch.zeros(n_pad, nb, 32, device=DEV)                        # the kernel's layout: rows padded to 32 columns
+    xb_pad[:, :, :d] = xb.to(DEV)
+
+    class _Padded(object):                                                 # `xb.to(DEV)` below -> the padded device view
+        def to(self, _):
+            return xb_pad[:, :, :d]
+
+        def double(self):
+            return xb_host.double()
+    xb = _Padded()
     slabs = ops.pair_product(cells.to(DEV), xb.to(DEV))
     assert slabs.shape == (n_pad // ops.PAIR_KGROUP, n, d)
     want = torch.einsum('guvb,gubc->gvc', cells.double().view(-1, ops.PAIR_KGROUP, n, nb), xb.double().view(-1, ops.PAIR_KGROUP, nb, d))

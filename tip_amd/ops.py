@@ -740,15 +740,18 @@ PAIR_KGROUP = 8          # source nodes whose products are summed inside one wav
 
 def pair_product(cells, xb_nb, symmetric=False):
     """slabs[g] = sum_{u in group g} cells[u] (N x bases) @ xb_nb[u] (bases x out)  (include/tipk.h section 2c):
-    cells [N_pad, N, bases], xb_nb [N_pad, bases, out] -> [N_pad / PAIR_KGROUP, N, out]."""
+    cells [N_pad, N, bases], xb_nb [N_pad, bases, out] -- or a column slice [..., :out] of a buffer whose rows are
+    padded to 32 columns with zeros (what the dedicated kernel reads) -> [N_pad / PAIR_KGROUP, N, out]."""
     n_pad, n, nb = cells.shape
     d = xb_nb.shape[2]
-    assert cells.is_contiguous() and xb_nb.is_contiguous() and xb_nb.shape[:2] == (n_pad, nb) and n_pad % PAIR_KGROUP == 0
-    if (not lib().tipk_pair_product_supported(nb, d) or os.environ.get('TIPK_NO_PAIR_PRODUCT')) and not symmetric:
+    assert cells.is_contiguous() and xb_nb.shape[:2] == (n_pad, nb) and n_pad % PAIR_KGROUP == 0
+    padded = xb_nb.stride() == (nb * 32, 32, 1) and d <= 32
+    if (not lib().tipk_pair_product_supported(nb, d) or os.environ.get('TIPK_NO_PAIR_PRODUCT') or not padded) and not symmetric:
         job = gemm_job(cells, xb_nb, reduce_batch=True, kgroup=PAIR_KGROUP)      # same sums on the tiled GEMM
         with _timed('gemm[%s]' % job.label):
             check(lib().tipk_gemm_f32(job.desc, stream_ptr(cells.device)), 'tipk_gemm_f32')
         return job.slabs
+    assert padded, 'tipk_pair_product reads XB rows padded to 32 columns (AggGraph.pair_buffers)'
     slabs = torch.empty((n_pad // PAIR_KGROUP, n, d), dtype=torch.float32, device=cells.device)
     with _timed('pair_product[%dx%dx%dx%d]' % (n_pad, n, nb, d)):
         check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(slabs),
@@ -785,15 +788,17 @@ class AggGraph(object):
         return self._bwd
 
     def pair_buffers(self, n, nb, d_out, device):
-        """(cells C[u, v, b] as [N_pad, N, bases], XB as [N_pad, bases, out]) of the pair-form forward, N_pad = N
+        """(cells C[u, v, b] as [N_pad, N, bases], XB as [N_pad, bases, out] -- a column slice of rows padded to 32)
+        of the pair-form forward, N_pad = N
         rounded up to PAIR_KGROUP.  Allocated and zeroed ONCE: every call rewrites the cells of the linked drug
         pairs and the first N blocks of XB; nothing ever touches the rest."""
         key = (int(n), int(nb), int(d_out), str(device))
         buf = self._pair_cells.get(key)
         if buf is None:
             n_pad = -(-n // PAIR_KGROUP) * PAIR_KGROUP
+            xb_pad = torch.zeros((n_pad, nb, 32 if d_out <= 32 else d_out), dtype=torch.float32, device=device)
             buf = self._pair_cells[key] = (torch.zeros((n_pad, n, nb), dtype=torch.float32, device=device),
-                                           torch.zeros((n_pad, nb, d_out), dtype=torch.float32, device=device))
+                                           xb_pad[:, :, :d_out])           # rows padded to 32 columns: the product kernel's layout
         return buf
 
     @property
