@@ -280,6 +280,18 @@ def test_rel_plan_semantics():
         assert int(sp.ids.to(torch.int32).max()) <= N * sp.idx_unit <= 65535
         per_wave = (sp.wave_ptr[1:] - sp.wave_ptr[:-1])
         assert int(per_wave.sum()) == sp.n_bands and int(per_wave.max()) - int(per_wave.min()) <= max(4, sp.n_bands // 8)
+    # pair form of the forward pass: rows = (source, destination) cells, table = att; a symmetric graph builds the
+    # cells with source <= destination from half the edges and mirrors them
+    from tip_amd.plan import build_stream_plan_rows
+    att = torch.randn(R, 32, generator=g, dtype=torch.float64)
+    s2, d2, r2 = torch.cat([src, dst]), torch.cat([dst, src]), torch.cat([rel, rel])      # every relation symmetric
+    full = torch.zeros(N * N, 32, dtype=torch.float64).index_add_(0, s2 * N + d2, att[r2])
+    keep = s2 <= d2
+    half = build_stream_plan_rows(s2[keep] * N + d2[keep], r2[keep], N * N, R, 2, 8, piece=4)
+    assert half.n_edges == int(keep.sum()) and half.n_table == R
+    c = execute_stream_plan_reference(half, att).view(N, N, 32)
+    mirrored = c + torch.triu(c.permute(2, 0, 1), 1).permute(2, 1, 0)
+    torch.testing.assert_close(mirrored.view(N * N, 32), full)
     sp1 = build_stream_plan(src, dst, rel, N, R, 1, 4, piece=2)                 # shorter cells: more continuation bands
     torch.testing.assert_close(execute_stream_plan_reference(sp1, gp), wantb)
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
