@@ -206,7 +206,6 @@ def dd_aggregation_launches(enc, dev):
         g = torch.randn(n, d, device=dev)
         nb = layer.num_bases
         for bwd in (False, True):
-            rp = graph.rl_bwd if bwd else graph.rl_fwd
             rs = graph.rs_bwd if bwd else None
             pair = None if bwd or os.environ.get('TIPK_NO_PAIR_FWD') else graph.pair_fwd
             if pair is not None and pair.n_table == r and ops.stream_gather_split(r, nb):
@@ -226,7 +225,8 @@ def dd_aggregation_launches(enc, dev):
                 grid = '%dx%dx1' % (rs.n_wg * 1024, split)
                 out.append(('rel_stream[dd.bwd,d=%d]' % d, key, grid, d, 'lds',
                             lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale), rs.n_edges))
-            elif ops.rel_gather_usable(rp, n, d, bwd):
+            elif ops.rel_gather_usable(graph.rl_bwd if bwd else graph.rl_fwd, n, d, bwd):
+                rp = graph.rl_bwd if bwd else graph.rl_fwd
                 split = ops.rel_gather_split(n, d, bwd)
                 key = 'rel_gather_kernel<%d, %s' % (d // split // 4, 'true' if bwd else 'false')
                 grid = '%dx%dx1' % (rp.n_wg * 1024, split)

@@ -327,7 +327,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         if os.environ.get('TIPK_RG_PLAIN_ORDER'):
             lanes_f = lanes_b = None
         cap_f = None           # (cutting forward units to the id chunk was measured slower: smaller units fill fewer bands)
-        rl_fwd = build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
+        rl_fwd = lambda: build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
         # forward pass in pair form: cells (source, destination) <- sums of att rows (LDS-resident att table)
         split_p = ops.stream_gather_split(n_rel, n_bases) if on_dev and n_bases and n_nodes * n_nodes < 2 ** 24 else 0
         if split_p:
@@ -346,7 +346,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         if split_s:
             rs_bwd = build_stream_plan(src, dst, rel, n_nodes, n_rel, n_cu, (d_out // split_s) // 4, ops.rel_stream_piece())
         else:
-            rl_bwd = build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
+            rl_bwd = lambda: build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
     def fwd_plan():
         # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by
         # relation block, so that a row of Y gathered by several edges crosses the fabric once

@@ -769,11 +769,24 @@ class AggGraph(object):
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
         self._fwd, self._bwd, self.scale = fwd, bwd, scale
         self._csr_bwd = csr_bwd
-        self.rl_fwd, self.rl_bwd = rl_fwd, rl_bwd          # relation-local (LDS) plans of a D-D graph
+        self._rl_fwd, self._rl_bwd = rl_fwd, rl_bwd        # relation-local (LDS) plans of a D-D graph: plans, or callables
+                                                           # that build them on first use (fallback routes only)
         self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
+
+    @property
+    def rl_fwd(self):
+        if callable(self._rl_fwd):
+            self._rl_fwd = self._rl_fwd()
+        return self._rl_fwd
+
+    @property
+    def rl_bwd(self):
+        if callable(self._rl_bwd):
+            self._rl_bwd = self._rl_bwd()
+        return self._rl_bwd
 
     @property
     def fwd(self):
@@ -922,11 +935,6 @@ class _RGCN(torch.autograd.Function):
         n, d_in = x.shape
         nb, _, d_out = basis.shape
         r = att.shape[0]
-        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)
-        if use_rl:
-            assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
-        elif r > 0:
-            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         pair = graph.pair_fwd if r > 0 else None
         if shard is not None and shard.world >= PAIR_FWD_MAX_WORLD:
             # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (20 us at BioSNAP, whatever
@@ -960,6 +968,11 @@ class _RGCN(torch.autograd.Function):
             ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
             ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
             return out
+        use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)   # (the unit plan is built here, on first use)
+        if use_rl:
+            assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
+        elif r > 0:
+            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
         y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out) if r > 0 else None     # [R N, out]
         if shard is None:
