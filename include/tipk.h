@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 9
+#define TIPK_ABI_VERSION 10
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -309,6 +309,31 @@ int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int6
                           const float* xb, int64_t ld_xb, int64_t n_rel, int64_t n_cols, int n_bases,
                           const uint32_t* row_used, int64_t n_nodes,
                           float* dxb_slabs, float* datt_slabs, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 2d. The same two products as 2b on the COMPACT, node-major form of dY (autograd of src/layers.py:163-172 and of
+ *     the scatter-mean at :159-180, for graphs whose transposed pass runs as tipk_stream_gather):
+ *
+ *        dXB [b, u, c] = sum_{r leaves u} att[r, b] * dY[(u, r), c]      datt[r, b] = sum_u sum_c dY[(u, r), c] * XB[b, u, c]
+ *
+ *     dyc [n_rows + 1][d]: one row per (source node u, relation r) pair that has an edge (BioSNAP: 47 % of the
+ *       R x N pairs), grouped by node, ascending relation inside a node -- the row numbers are what the plan of the
+ *       transposed gather (section 1d) writes into its cells, so the gather produces this layout directly; row
+ *       n_rows must hold zeros (pairs without an edge read it).
+ *     node_desc [n_nodes][4]  { node u, first row, end row, 0 } of the nodes by DECREASING row count (launch order of
+ *       the per-node workgroups; 16-byte aligned);   row_rel [n_rows]  relation of a row;
+ *     pos [n_nodes][ceil(n_rel / 64) * 64]  row of (u, r), or n_rows when the pair has no edge / r >= n_rel.
+ *     xb element (b, u, c) at xb[b * xb_sb + u * xb_su + c] (strides multiples of 4 floats), dxb likewise: written
+ *     COMPLETE (no slabs); datt_slabs [att_slabs][n_rel][n_bases] are added in order by tipk_sum_slabs(_group).
+ *     d in {16, 32, 64, 128}, n_bases <= 32 (`tipk_rgcn_node_products_plan` returns att_slabs = 0 otherwise: use the
+ *     dense form 2b).  All sums in fixed order: bitwise reproducible.
+ */
+int tipk_rgcn_node_products_plan(int64_t n_nodes, int d, int64_t n_rel, int n_bases, int* att_slabs);
+int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32_t* node_desc, const int32_t* row_rel,
+                            const int32_t* pos, int64_t n_nodes, int64_t n_rel,
+                            const float* att, int64_t ld_att, int n_bases,
+                            const float* xb, int64_t xb_sb, int64_t xb_su,
+                            float* dxb, int64_t dxb_sb, int64_t dxb_su, float* datt_slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).

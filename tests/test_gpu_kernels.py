@@ -239,6 +239,54 @@ def test_dy_products_fused(ops, r, nc, nb, monkeypatch):
     assert torch.equal(e_att.cpu(), gi @ xi.t()) and torch.equal(e_xb.cpu(), ai.t() @ gi)
 
 
+@pytest.mark.parametrize('R,N,d,nb', [(1097, 645, 32, 32), (1097, 645, 16, 32), (70, 100, 64, 7), (33, 129, 16, 32), (5, 31, 128, 1),
+                                      (200, 77, 32, 20)])
+def test_node_products_compact(ops, R, N, d, nb):
+    """tipk_rgcn_node_products (tipk.h section 2d): the transposed gather writes dY compact and node-major, both
+    products run on that form: == the dense products of the full dY (fp64), complete d XB (nodes without edges: zero
+    blocks), reproducible, exact on integers; sources concentrated on a third of the nodes, relations without edges."""
+    from tip_amd.plan import build_stream_plan
+    g = torch.Generator().manual_seed(R + N + d)
+    E = 30 * R
+    rel = torch.randint(0, R, (E,), generator=g)
+    rel[rel == R // 2] = 0                                                 # a relation without edges
+    src = torch.randint(0, max(1, N // 3), (E,), generator=g)
+    src[:E // 10] = torch.randint(0, N, (E // 10,), generator=g)
+    dst = torch.randint(0, N, (E,), generator=g)
+    split = ops.rel_stream_split(N, d)
+    assert ops.node_products_slabs(N, d, R, nb) > 0
+    sp = build_stream_plan(src, dst, rel, N, R, 16, d // split // 4, ops.rel_stream_piece(), compact=True).to(DEV)
+    cr = sp.compact
+    gp = torch.randn(N, d, generator=g)
+    scale = torch.rand(N, generator=g) + 0.5
+    att = torch.randn(R, nb, generator=g)
+    xb = torch.randn(nb, N, d, generator=g)
+    dy = O.gather_sum(gp.double() * scale.double().unsqueeze(1), dst, rel * N + src, R * N).view(R, N * d)
+    want_att = dy @ xb.double().view(nb, N * d).t()
+    want_xb = (att.double().t() @ dy).view(nb, N, d)
+    dyc = ops.rel_stream_bwd(sp, gp.to(DEV), row_scale=scale.to(DEV))
+    assert dyc.shape == (cr.n_rows + 1, d) and not bool(dyc[-1].any())
+    rows = (cr.pos.long()[:, :R].t().reshape(-1))                          # (r, u) -> compact row | n_rows
+    close(dyc[rows.to(DEV)].view(R, N * d), dy)
+    job, g_xb = ops.node_products(dyc, cr, att.to(DEV), xb.to(DEV))
+    ops.gemm_group([], [job])
+    close(job.out, want_att, rtol=2e-5, atol=2e-5 * float(want_att.abs().max()))
+    close(g_xb, want_xb, rtol=2e-5, atol=2e-5 * float(want_xb.abs().max()))
+    job2, g_xb2 = ops.node_products(dyc, cr, att.to(DEV), xb.to(DEV))
+    ops.gemm_group([], [job2])
+    assert torch.equal(job2.out, job.out) and torch.equal(g_xb2, g_xb)
+    # exact on integers
+    gi = torch.randint(-3, 4, (N, d), generator=g).float()
+    ai = torch.randint(-3, 4, (R, nb), generator=g).float()
+    xi = torch.randint(-3, 4, (nb, N, d), generator=g).float()
+    dyi = O.gather_sum(gi.double(), dst, rel * N + src, R * N).view(R, N * d)
+    dyc = ops.rel_stream_bwd(sp, gi.to(DEV))
+    job, g_xb = ops.node_products(dyc, cr, ai.to(DEV), xi.to(DEV))
+    ops.gemm_group([], [job])
+    assert torch.equal(job.out.cpu().double(), dyi @ xi.double().view(nb, N * d).t())
+    assert torch.equal(g_xb.cpu().double(), (ai.double().t() @ dyi).view(nb, N, d))
+
+
 @pytest.mark.parametrize('R,N,d', [(70, 645, 32), (33, 100, 16), (1097, 37, 8)])
 def test_unwritten_rows_masked_end_to_end(ops, R, N, d):
     """Rows (relation, node) without edges: the wave-stream gather with write_zeros=False leaves them untouched

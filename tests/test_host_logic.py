@@ -294,6 +294,24 @@ def test_rel_plan_semantics():
     torch.testing.assert_close(mirrored.view(N * N, 32), full)
     sp1 = build_stream_plan(src, dst, rel, N, R, 1, 4, piece=2)                 # shorter cells: more continuation bands
     torch.testing.assert_close(execute_stream_plan_reference(sp1, gp), wantb)
+    # compact node-major rows (tipk.h section 2d): only the (node, relation) pairs with edges, grouped by node
+    spc = build_stream_plan(src, dst, rel, N, R, 2, 8, piece=4, compact=True)
+    cr = spc.compact
+    got = execute_stream_plan_reference(spc, gp)                                # asserts: every compact row written exactly once
+    cnt = torch.bincount(rel * N + src, minlength=R * N).view(R, N)
+    assert cr.n_rows == int((cnt > 0).sum()) == got.shape[0] and cr.pos.shape == (N, -(-R // 64) * 64)
+    pos = cr.pos.long()
+    wb = wantb.view(R, N, -1)
+    for u in range(N):
+        rows = torch.arange(int(cr.node_ptr[u]), int(cr.node_ptr[u + 1]))
+        rels = cr.row_rel[rows].long()
+        assert bool((rels[1:] > rels[:-1]).all()) and torch.equal(rels, torch.nonzero(cnt[:, u] > 0).flatten())
+        assert torch.equal(pos[u, rels], rows)
+        torch.testing.assert_close(got[rows], wb[rels, u])
+    assert int((pos == cr.n_rows).sum()) == N * pos.shape[1] - cr.n_rows
+    nd = cr.node_desc.long()
+    assert sorted(nd[:, 0].tolist()) == list(range(N)) and bool(((nd[1:, 2] - nd[1:, 1]) <= (nd[:-1, 2] - nd[:-1, 1])).all())
+    assert torch.equal(nd[:, 1], cr.node_ptr.long()[nd[:, 0]]) and torch.equal(nd[:, 2], cr.node_ptr.long()[nd[:, 0] + 1])
     ptr, rels = assign_relations([10, 1, 7, 7, 3], 2, fixed_cost=0)
     loads = [sum([10, 1, 7, 7, 3][r] for r in rels[ptr[i]:ptr[i + 1]].tolist()) for i in range(2)]
     assert sorted(loads) == [14, 14]

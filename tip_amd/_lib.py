@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class TipkError(RuntimeError):
@@ -73,6 +73,8 @@ SIGNATURES = {
     'tipk_sum_slabs_group': (_I, [C.POINTER(SlabSumDesc), C.c_int32, _P]),
     'tipk_rgcn_dy_products_plan': (_I, [_L, _L, _I, C.POINTER(_I), C.POINTER(_I)]),
     'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _P, _P]),
+    'tipk_rgcn_node_products_plan': (_I, [_L, _I, _L, _I, C.POINTER(_I)]),
+    'tipk_rgcn_node_products': (_I, [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _I, _P, _L, _L, _P, _L, _L, _P, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

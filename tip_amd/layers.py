@@ -344,7 +344,10 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
         split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
         if split_s:
-            rs_bwd = build_stream_plan(src, dst, rel, n_nodes, n_rel, n_cu, (d_out // split_s) // 4, ops.rel_stream_piece())
+            # compact node-major rows when the products of dY can run on them (tipk_rgcn_node_products)
+            compact = bool(n_bases) and ops.node_products_slabs(n_nodes, d_out, n_rel, n_bases) > 0
+            rs_bwd = build_stream_plan(src, dst, rel, n_nodes, n_rel, n_cu, (d_out // split_s) // 4, ops.rel_stream_piece(),
+                                       compact=compact)
         else:
             rl_bwd = lambda: build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
     def fwd_plan():

@@ -250,9 +250,25 @@ def stream_gather(sp, table, row_scale=None, write_zeros=True, out=None, label='
     return out
 
 
+_DYC = {}
+
+
 def rel_stream_bwd(sp, table, row_scale=None, write_zeros=True):
-    """Transposed D-D pass: table = g [N, d] -> dY [R * N, d] (plan of `build_stream_plan`)."""
-    return stream_gather(sp, table, row_scale, write_zeros, label='rel_stream[dd.bwd]')
+    """Transposed D-D pass: table = g [N, d] -> dY (plan of `build_stream_plan`): [R * N, d], or -- compact plans --
+    [n_rows + 1, d] node-major with a trailing zero row (a buffer kept per plan and width: the zero row is written
+    once, every call rewrites all the other rows)."""
+    if sp.compact is None:
+        return stream_gather(sp, table, row_scale, write_zeros, label='rel_stream[dd.bwd]')
+    d = table.shape[1]
+    key = (id(sp), d, str(table.device))
+    hit = _DYC.get(key)
+    if hit is None:
+        if len(_DYC) > 16:
+            _DYC.clear()
+        hit = _DYC[key] = (torch.zeros((sp.n_rows + 1, d), dtype=torch.float32, device=table.device), sp)   # pins the plan: ids stay unique
+    buf = hit[0]
+    stream_gather(sp, table, row_scale, write_zeros=False, out=buf[:sp.n_rows], label='rel_stream[dd.bwd]')
+    return buf
 
 
 def _strides3(t):
@@ -414,6 +430,37 @@ def dy_products(g_y, att, xb2, row_used=None, n_nodes=0):
     j_xb = slab_job(dxb_slabs)
     gemm_group([], [j_xb, j_att])
     return j_att.out, j_xb.out
+
+
+def node_products_slabs(n_nodes, d, n_rel, nb):
+    """d att slabs `node_products` produces for this shape; 0 = shape not supported (dense `dy_products` then)."""
+    import ctypes as C
+    g = C.c_int(0)
+    if os.environ.get('TIPK_NO_NODE_PRODUCTS'):
+        return 0
+    check(lib().tipk_rgcn_node_products_plan(n_nodes, d, n_rel, nb, C.byref(g)), 'tipk_rgcn_node_products_plan')
+    return g.value
+
+
+def node_products(dyc, cr, att, xb):
+    """(pending slab sum of d att, d XB [bases, N, d]) from the COMPACT node-major dY (include/tipk.h section 2d):
+    dyc [n_rows + 1, d] as written by `stream_gather` on a compact plan (last row zero), cr = plan.compact,
+    xb [bases, N, d].  d XB is complete; the d att slabs are summed by the caller's next grouped slab sum."""
+    n_rows, d = dyc.shape[0] - 1, dyc.shape[1]
+    nb, n = xb.shape[0], xb.shape[1]
+    r = att.shape[0]
+    assert cr.n_rows == n_rows and xb.shape[2] == d and xb.stride(2) == 1 and att.stride(1) == 1 and dyc.is_contiguous()
+    g = node_products_slabs(n, d, r, nb)
+    assert g > 0
+    dev = dyc.device
+    dxb = torch.empty((nb, n, d), dtype=torch.float32, device=dev)
+    datt_slabs = torch.empty((g, r, nb), dtype=torch.float32, device=dev)
+    with _timed('node_products[%dx%dx%d,rows=%d]' % (r, n * d, nb, n_rows)):
+        check(lib().tipk_rgcn_node_products(ptr(dyc), n_rows, d, ptr(cr.node_desc), ptr(cr.row_rel), ptr(cr.pos),
+                                            n, r, ptr(att), att.stride(0), nb, ptr(xb), xb.stride(0),
+                                            xb.stride(1), ptr(dxb), dxb.stride(0), dxb.stride(1), ptr(datt_slabs),
+                                            stream_ptr(dev)), 'tipk_rgcn_node_products')
+    return slab_job(datt_slabs), dxb
 
 
 class SlabJob(object):
@@ -1013,7 +1060,14 @@ class _RGCN(torch.autograd.Function):
         if r > 0:
             rs = graph.rs_bwd
             used = None
-            if rs is not None and rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes:
+            j_att = None
+            if rs is not None and rs.compact is not None:
+                assert rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes and rs.n_rel == r
+                # dY_r = A_r^T (D^-1 g) in COMPACT node-major form: only the (relation, source) rows that have an edge
+                # exist; both products of dY run on that form (d XB complete, d att as a few small slabs)
+                dyc = rel_stream_bwd(rs, g, row_scale=graph.scale)
+                j_att, g_xb = node_products(dyc, rs.compact, att, xb)
+            elif rs is not None and rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes:
                 # dY_r = A_r^T (D^-1 g), 1/deg fused.  Rows (relation, node) without edges -- half of them -- are
                 # neither written here nor read as data by the fused products (row mask)
                 masked = dy_products_fused(r, n * d_out, nb) and xb.stride(-1) == 1 and not os.environ.get('TIPK_DY_ZEROS')
@@ -1028,12 +1082,17 @@ class _RGCN(torch.autograd.Function):
                     g_y = gather_rows_csr(csr, gs).view(r, n * d_out)
                 else:
                     g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
-            # both consumers of dY in one pass over it (+ one grouped slab sum)
-            g_att, g_xb = dy_products(g_y, att, xb2, used, n)
-            g_xb = g_xb.view(nb, n, d_out)
+            if j_att is None:
+                # both consumers of dY in one pass over it (+ one grouped slab sum)
+                g_att, g_xb = dy_products(g_y, att, xb2, used, n)
+                g_xb = g_xb.view(nb, n, d_out)
         else:
+            j_att = None
             g_att = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
             g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
+        extra = [] if j_att is None else [j_att]                         # the d att slabs ride in this layer's grouped slab sum
+        if j_att is not None:
+            g_att = j_att.out
         # d basis, d root and both halves of dX are independent given dXB and g: one grouped launch
         j_root = gemm_job(x.t(), g)
         if shard is None:
@@ -1044,9 +1103,9 @@ class _RGCN(torch.autograd.Function):
             if j_xq.slabs is not None:                                   # summed on top of g root^T afterwards
                 if ctx.gate_input:
                     j_xq.gate = x                                        # ... and masked with (x > 0) in the same pass
-                gemm_group([j_basis, j_root, j_xr, j_xq])
+                gemm_group([j_basis, j_root, j_xr, j_xq], extra)
             else:                                                        # reads g_x while accumulating
-                gemm_group([j_basis, j_root, j_xr])
+                gemm_group([j_basis, j_root, j_xr], extra)
                 gemm_group([j_xq])
                 if ctx.gate_input:
                     g_x = rows_affine(g_x, gate=x)
@@ -1060,7 +1119,7 @@ class _RGCN(torch.autograd.Function):
             g_basis = flat[n * d_in:].view(nb, d_in, d_out)
             j_basis = gemm_job(x.t(), g_xb, out=g_basis)
             j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, reduce_batch=True)   # partial over this shard
-            gemm_group([j_basis, j_root, j_xq])
+            gemm_group([j_basis, j_root, j_xq], extra)
             g_root = j_root.out
             shard.all_reduce(flat)
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once

@@ -537,6 +537,7 @@ class StreamPlan(object):
         self.symmetric = False                    # pair-form plans: built from the edges with source <= destination only
         self.n_edges = 0                          # edges the plan walks
         self.n_nodes, self.n_rel = n_nodes, n_rel
+        self.compact = None                       # CompactRows: the rows are the node-major compact numbering (tipk.h section 2d)
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
@@ -544,6 +545,7 @@ class StreamPlan(object):
                         mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
                         self.n_nodes, self.n_rel)
         sp.symmetric, sp.n_edges = self.symmetric, self.n_edges
+        sp.compact = None if self.compact is None else self.compact.to(device)
         return sp
 
 
@@ -705,12 +707,56 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     return sp
 
 
-def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4):
-    """The (relation, node) form: out[r * N + o] = sum_{e in r: out_node[e] = o} table[tab_node[e]], table =
-    [N, d] -- the transposed D-D pass.  Adds `row_used`, the bit mask of the rows with edges."""
-    N = int(n_nodes)
-    sp = build_stream_plan_rows(rel * N + out_node, tab_node, n_rel * N, N, n_wg, lanes, piece)
+class CompactRows(object):
+    """Node-major compact numbering of the (node, relation) pairs that have an edge (include/tipk.h section 2d):
+    node_ptr [N + 1], row_rel [n_rows], pos [N, ceil(R / 64) * 64] (n_rows where a pair has no edge),
+    node_desc [N, 4] = (node, first row, end row, 0) of the nodes by decreasing row count -- all int32 on the plan's device."""
+
+    def __init__(self, n_rows, node_ptr, row_rel, pos, node_desc):
+        self.n_rows, self.node_ptr, self.row_rel, self.pos, self.node_desc = int(n_rows), node_ptr, row_rel, pos, node_desc
+
+    def to(self, device):
+        return CompactRows(self.n_rows, self.node_ptr.to(device), self.row_rel.to(device), self.pos.to(device),
+                           self.node_desc.to(device))
+
+
+def compact_rows(out_node, rel, n_nodes, n_rel):
+    """-> (CompactRows, row index of every edge).  Row of (node u, relation r) = node_ptr[u] + rank of r among the
+    relations that have an edge at u (ascending)."""
     dev = out_node.device
+    N, R = int(n_nodes), int(n_rel)
+    r_pad = -(-R // 64) * 64
+    has = torch.zeros(N * r_pad, dtype=torch.bool, device=dev)
+    key = out_node * r_pad + rel
+    has[key] = True
+    used = torch.nonzero(has).flatten()                                    # ascending (node, relation)
+    n_rows = int(used.numel())
+    pos = torch.full((N * r_pad,), n_rows, dtype=torch.int64, device=dev)
+    pos[used] = torch.arange(n_rows, device=dev)
+    per_node = torch.bincount(used // r_pad, minlength=N)
+    node_ptr = torch.cat([per_node.new_zeros(1), torch.cumsum(per_node, 0)])
+    order = torch.sort(per_node, descending=True, stable=True).indices
+    node_desc = torch.stack([order, node_ptr[order], node_ptr[order + 1], torch.zeros_like(order)], dim=1)
+    cr = CompactRows(n_rows, node_ptr.to(torch.int32).contiguous(), (used % r_pad).to(torch.int32).contiguous(),
+                     pos.view(N, r_pad).to(torch.int32).contiguous(), node_desc.to(torch.int32).contiguous())
+    return cr, pos[key]
+
+
+def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4, compact=False):
+    """The (relation, node) form: out[row(r, o)] = sum_{e in r: out_node[e] = o} table[tab_node[e]], table =
+    [N, d] -- the transposed D-D pass.
+    compact = False: row(r, o) = r * N + o, all R N rows (those without edges through the zero-row list or `row_used`,
+    the bit mask of the rows with edges); compact = True: only the rows WITH edges exist, numbered node-major
+    (`compact_rows`; plan.compact holds the tables of tipk_rgcn_node_products)."""
+    N = int(n_nodes)
+    dev = out_node.device
+    if compact:
+        cr, row = compact_rows(out_node, rel, N, n_rel)
+        sp = build_stream_plan_rows(row, tab_node, cr.n_rows, N, n_wg, lanes, piece)
+        sp.compact = cr
+        sp.n_nodes, sp.n_rel = N, int(n_rel)
+        return sp
+    sp = build_stream_plan_rows(rel * N + out_node, tab_node, n_rel * N, N, n_wg, lanes, piece)
     cnt_rows = torch.bincount(rel * N + out_node, minlength=n_rel * N)
     # bit (r & 31) of row_used[r >> 5, node] = row (r, node) has edges
     rt = -(-n_rel // 32)

@@ -4,8 +4,14 @@ import csv, glob, os, sys
 root = sys.argv[1]
 f = sorted(glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-fw = [i for i, r in enumerate(rows) if 'rel_gather_kernel' in r['Kernel_Name'] and r['Grid_Size_Y'] == '2']   # the layer-1 forward launch
+ANCHOR = sys.argv[2] if len(sys.argv) > 2 else 'gate_colsum_kernel'   # a kernel that is launched once per step
+fw = [i for i, r in enumerate(rows) if ANCHOR in r['Kernel_Name']]
 steps = [(a, b) for a, b in zip(fw, fw[1:]) if b - a > 10]          # skip the back-to-back launch timing loops
+per = {}
+for a, b in steps:
+    per[b - a] = per.get(b - a, 0) + 1
+period = max(per, key=per.get)                                      # the replayed step (most frequent distance)
+steps = [(a, b) for a, b in steps if b - a == period]
 i0, i1 = steps[len(steps) // 2]
 t0 = int(rows[i0]['Start_Timestamp'])
 prev = None
