@@ -28,8 +28,16 @@ Objects on the JSON line besides the contract's fields:
                 "hbm" otherwise.  traffic = HBM bytes per launch from the committed PMC summary of
                 this command (profiles/*_pmc_traffic.json, keyed by kernel and full grid x*y*z);
                 hbm_traffic_frac = traffic / duration / 8 TB/s.
-  whole_step    algorithmic bytes of the whole step (416 B/edge BioSNAP, 2080 B/edge synthetic) over
-                the measured step time, as a fraction of the 8 TB/s HBM spec.
+                The object describes the LONGEST kernel of the step (today the two products of dY,
+                bound "mfma"); `roofline_aggregation` keeps the slowest D-D aggregation launch.
+  step_floor    sum over the step's launches of what bounds each one (LDS time of the gathers, MFMA time
+                of the products, HBM time of the streaming kernels, 2 us for everything else = the measured
+                hand-over of a launch inside a replayed graph) and floor / ms_per_step.
+  parity_in_bench  the replayed graph's z and two gradients against the oracle pass of the cpu_baseline
+                leg, which is handed the benched encoder's own weights (non-zero exit code on failure).
+  other_configs / train_step  the other BASELINE configurations (TIP-add, the paper's 963 relations,
+                config 5 on one GPU) and the whole graphed training epoch (tip.py:24-30), each timed by
+                this process after the headline measurement (fewer steps; --no-extras skips them).
   cpu_baseline  the oracle's CPU port on the host cores (rank 0, N = 1 only), bounded sample.
 """
 import argparse
@@ -45,6 +53,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 LDS_PEAK_GBS = 256 * 256 * 2.4   # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 286 GB/s
+L2_GATHER_GBS = 18800.0          # MI355X_MICROARCH.md gather table: rows of a table every workgroup shares out of the XCD's L2: 16.8-18.8 TB/s
 
 
 def parse():
@@ -63,6 +72,7 @@ def parse():
     ap.add_argument('--oversubscribe', action='store_true',
                     help='allow more ranks than GPUs (ranks share devices, gloo collectives): functional check only')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the eager per-kernel event pass')
+    ap.add_argument('--no-extras', action='store_true', help='skip other_configs / train_step')
     ap.add_argument('--step-only', action='store_true',
                     help='run nothing but the warm-up and timed steps (PMC passes: bytes / (steps + warmup) = bytes per step)')
     return ap.parse_args()
@@ -81,6 +91,8 @@ def free_port():
 
 def launch_ranks(args):
     import torch                                   # device_count() does not initialise the GPU on this image
+    from tip_amd import _lib
+    _lib.ensure_built()                            # ONE build, here: N children racing `make` would corrupt the tree
     have = torch.cuda.device_count()
     if have < args.gpus and not args.oversubscribe:
         sys.stderr.write('bench.py: --gpus %d but this box has %d GPU(s); pass --oversubscribe to run %d ranks on '
@@ -124,26 +136,25 @@ def make_workload(args):
     return dd, dims, name
 
 
-def cpu_baseline(dd, dims, mod, budget_s):
+def cpu_baseline(dd, dims, mod, budget_s, weights, up):
     """The oracle (CPU port of the same algorithm: transform-then-gather with explicit backward)
     on this host's cores, plus the reference-shaped op sequence (PyG-CPU path: lift E x in,
-    per-relation slice+mm, cat, scatter-mean, autograd backward) on a bounded relation sample."""
+    per-relation slice+mm, cat, scatter-mean, autograd backward) on a bounded relation sample.
+    weights: the benched encoder's own parameters (state_dict names, CPU) -- the oracle computes with them, so
+    its first pass is also the checker of `parity_in_bench`.  -> (record, z, gradients) of that pass."""
     import torch
     from oracle import tip_oracle as O
     E = dd['dd_train_idx'].shape[1]
     R = dd['n_dd_et']
-    p = O.init_params(dd['n_drug'], dd['n_prot'], R, mod=mod, seed=1111, prot_drug_dim=dims['prot_drug_dim'],
-                      n_embed=dims['n_embed'], n_hid1=dims['n_hid1'], n_hid2=dims['n_hid2'],
-                      num_base=dims['num_base'])
-    up = torch.randn(dd['n_drug'], dims['n_hid2'], generator=torch.Generator().manual_seed(0))
+    p = weights
     # torch's default (= all hardware threads) oversubscribes these small ops on big hosts
     threads = max(1, min(16, os.cpu_count() or 1))
     torch.set_num_threads(threads)
 
     def step():
         z, saved = O.fm_encoder_fwd(p, dd, mod)
-        O.fm_encoder_bwd(up, p, dd, saved, mod)
-    step()                                                    # warm-up (page-in, thread pool)
+        return z, O.fm_encoder_bwd(up, p, dd, saved, mod)
+    zo, go = step()                                           # warm-up (page-in, thread pool) = the parity reference
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -180,18 +191,42 @@ def cpu_baseline(dd, dims, mod, budget_s):
                                        'probe of the literal reference measured 0.020 M edges/s on 8 cores)'}
     except Exception as exc:                                   # never let the side leg kill the bench
         out['reference_shaped'] = {'error': repr(exc)}
-    return out
+    return out, zo, go
+
+
+def parity_check(z_dev, grads, zo, go):
+    """max |got - want| / max |want| of the replayed graph's z and two gradients against the oracle pass."""
+    import torch
+    rec, ok = {}, True
+    for name, got, want, tol in (('z', z_dev, zo, 1e-3), ('grad rgcn1.att', grads['rgcn1.att'], go['rgcn1.att'], 2e-3),
+                                 ('grad pp_encoder.conv1.lin.weight', grads['pp_encoder.conv1.lin.weight'],
+                                  go['pp_encoder.conv1.lin.weight'], 2e-3)):
+        got, want = got.detach().cpu().double(), want.double()
+        err = float((got - want).abs().max()) / max(1e-30, float(want.abs().max()))
+        rec[name] = {'max_rel_err': err, 'tol': tol}
+        ok = ok and bool(torch.isfinite(got).all()) and err <= tol
+    rec['ok'] = ok
+    rec['checker'] = 'oracle/tip_oracle.py (CPU, fp32) on the benched encoder\'s own weights and upstream gradient'
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------
-# the D-D aggregation launches of the step, timed alone (roofline object)
+# the large launches of the step, timed alone (roofline objects)
 # ---------------------------------------------------------------------------------------------
-def dd_aggregation_launches(enc, dev):
-    """[(label, kernel key for profiles/, grid 'XxYxZ', d, callable)] for the four D-D aggregations
-    of one step, on the step's own plans with random tables of the step's shapes."""
+def dd_launches(enc, dev):
+    """[dict(label, key, grid, bound, work, unit_work, fn, ...)] for the D-D launches of one step -- the four
+    aggregations, the dense halves of the pair form and the products of dY -- on the step's own plans with random
+    tables of the step's shapes.  work = ALGORITHMIC bytes (gathers: (4 + 4 d) B per edge walked) or
+    flops (products: 2 flops per multiply-add of the sums the math needs -- rows of dY without an edge are not
+    counted, although the d att half of the kernel multiplies their zeros)."""
     import torch
     from tip_amd import ops
     out = []
+
+    def add(label, key, grid, bound, work, fn, **extra):
+        rec = {'label': label, 'key': key, 'grid': grid, 'bound': bound, 'work': float(work), 'fn': fn}
+        rec.update(extra)
+        out.append(rec)
     for layer in (enc.rgcn1, enc.rgcn2):
         graph = layer._cache.value
         if graph is None:
@@ -202,58 +237,80 @@ def dd_aggregation_launches(enc, dev):
         r = layer.num_relations if shard is None else int(shard.rel_ids.numel())
         if r == 0:
             continue
-        y = torch.randn(r * n, d, device=dev)
+        n_edges_all = None
+        y = None
         g = torch.randn(n, d, device=dev)
         nb = layer.num_bases
         for bwd in (False, True):
             rs = graph.rs_bwd if bwd else None
             pair = None if bwd or os.environ.get('TIPK_NO_PAIR_FWD') else graph.pair_fwd
             if pair is not None and pair.n_table == r and ops.stream_gather_split(r, nb):
-                # forward in pair form: per edge one id + one att row (nb floats) from LDS; the dense product that
-                # follows is a separate launch (gemm[...] in kernels_eager_ms)
+                # forward in pair form: per edge one id + one att row (nb floats) from LDS, then the dense product
                 split = ops.stream_gather_split(r, nb)
                 key = 'stream_gather_kernel<%d, %s, 1' % (nb // split // 4, 'true' if pair.idx_unit == nb // split * 4 else 'false')
-                grid = '%dx%dx1' % (pair.n_wg * 1024, split)
                 att = torch.randn(r, nb, device=dev)
-                cells = graph.pair_buffers(n, nb, d, dev)[0]
-                out.append(('pair_cells[dd.fwd,d=%d]' % d, key, grid, nb, 'lds',
-                            lambda pair=pair, att=att, cells=cells, nb=nb: ops.stream_gather(
-                                pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1), pair.n_edges))
+                cells, xb_nb = graph.pair_buffers(n, nb, d, dev)
+                add('pair_cells[dd.fwd,d=%d]' % d, key, '%dx%dx1' % (pair.n_wg * 1024, split), 'lds', pair.n_edges * (4 + 4 * nb),
+                    lambda pair=pair, att=att, cells=cells, nb=nb, n=n: ops.stream_gather(
+                        pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1),
+                    edges=pair.n_edges, row_floats=nb, aggregation=True)
+                add('pair_product[dd.fwd,d=%d]' % d, 'pair_product_kernel', None, 'mfma', 2.0 * n * n * nb * d,
+                    lambda cells=cells, xb_nb=xb_nb, pair=pair: ops.pair_product(cells, xb_nb, symmetric=pair.symmetric),
+                    hbm_bytes=cells.numel() * 4.0 / (2 if pair.symmetric else 1))
             elif rs is not None and ops.rel_stream_split(n, d):
                 split = ops.rel_stream_split(n, d)
                 key = 'stream_gather_kernel<%d, %s, 0' % (d // split // 4, 'true' if rs.idx_unit == d // split * 4 else 'false')
-                grid = '%dx%dx1' % (rs.n_wg * 1024, split)
-                out.append(('rel_stream[dd.bwd,d=%d]' % d, key, grid, d, 'lds',
-                            lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale), rs.n_edges))
+                add('rel_stream[dd.bwd,d=%d]' % d, key, '%dx%dx1' % (rs.n_wg * 1024, split), 'lds', rs.n_edges * (4 + 4 * d),
+                    lambda rs=rs, g=g: ops.rel_stream_bwd(rs, g, row_scale=graph.scale), edges=rs.n_edges, row_floats=d,
+                    aggregation=True)
+                if rs.compact is not None:
+                    att = torch.randn(r, nb, device=dev)
+                    xb = torch.randn(nb, n, d, device=dev)
+                    dyc = ops.rel_stream_bwd(rs, g, row_scale=graph.scale)
+                    rows = rs.compact.n_rows
+                    add('node_products[dd.bwd,d=%d]' % d, 'node_products_kernel', None, 'mfma', 2 * 2.0 * rows * d * nb,
+                        lambda dyc=dyc, cr=rs.compact, att=att, xb=xb: ops.node_products(dyc, cr, att, xb),
+                        rows=rows, flops_dense_form=2 * 2.0 * r * n * d * nb)
             elif ops.rel_gather_usable(graph.rl_bwd if bwd else graph.rl_fwd, n, d, bwd):
                 rp = graph.rl_bwd if bwd else graph.rl_fwd
                 split = ops.rel_gather_split(n, d, bwd)
                 key = 'rel_gather_kernel<%d, %s' % (d // split // 4, 'true' if bwd else 'false')
-                grid = '%dx%dx1' % (rp.n_wg * 1024, split)
+                if y is None:
+                    y = torch.randn(r * n, d, device=dev)
                 fn = (lambda rp=rp, g=g: ops.rel_gather(rp, g, True, row_scale=graph.scale)) if bwd else \
                      (lambda rp=rp, y=y: ops.rel_gather(rp, y, False, reduce=False))
-                out.append(('rel_gather[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'lds', fn, None))
+                add('rel_gather[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, '%dx%dx1' % (rp.n_wg * 1024, split), 'lds',
+                    None, fn, row_floats=d, aggregation=True)
             else:
                 lanes = 1
                 while lanes < d // 4:
                     lanes *= 2
+                if y is None and not bwd:
+                    y = torch.randn(r * n, d, device=dev)
                 if bwd and d % 4 == 0 and 8 <= d <= 256 and not os.environ.get('TIPK_NO_CSR'):
                     csr = graph.csr_bwd                        # the path _RGCN.backward takes on large graphs
                     lanes = max(lanes, 2)
                     rp = lanes - 1 if lanes <= 16 else 16
                     tasks = -(-csr.n_out // rp)
                     waves = -(-tasks // (64 // lanes))
-                    key = 'gather_rows_csr_kernel<%d' % lanes
-                    grid = '%dx1x1' % (-(-waves // 4) * 256)
-                    out.append(('gather_rows_csr[dd.bwd,d=%d]' % d, key, grid, d, 'hbm',
-                                lambda csr=csr, g=g: ops.gather_rows_csr(csr, g), None))
+                    add('gather_rows_csr[dd.bwd,d=%d]' % d, 'gather_rows_csr_kernel<%d' % lanes, '%dx1x1' % (-(-waves // 4) * 256),
+                        'hbm', csr.n_edges * (4 + 4 * d), lambda csr=csr, g=g: ops.gather_rows_csr(csr, g),
+                        edges=csr.n_edges, row_floats=d, aggregation=True)
                     continue
                 plan = graph.bwd if bwd else graph.fwd
                 waves = -(-plan.items.shape[0] // (64 // lanes))
-                key = 'gather_sum_kernel<4, %d' % lanes
-                grid = '%dx1x1' % (-(-waves // 4) * 256)
                 fn = (lambda plan=plan, g=g: ops.gather_sum(plan, g)) if bwd else (lambda plan=plan, y=y: ops.gather_sum(plan, y))
-                out.append(('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), key, grid, d, 'hbm', fn, None))
+                add('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), 'gather_sum_kernel<4, %d' % lanes,
+                    '%dx1x1' % (-(-waves // 4) * 256), 'hbm', plan.n_edges * (4 + 4 * d), fn, edges=plan.n_edges, row_floats=d,
+                    aggregation=True)
+        rs = graph.rs_bwd
+        if (rs is None or rs.compact is None) and ops.dy_products_fused(r, n * d, nb):
+            g_y = torch.randn(r, n * d, device=dev)
+            att = torch.randn(r, nb, device=dev)
+            xb2 = torch.randn(nb, n * d, device=dev)
+            add('dy_products[dd.bwd,d=%d]' % d, 'dy_products_kernel', None, 'mfma', 2 * 2.0 * r * n * d * nb,
+                lambda g_y=g_y, att=att, xb2=xb2: ops.dy_products(g_y, att, xb2))
+        del y
     return out
 
 
@@ -280,45 +337,281 @@ def time_launch_us(fn, reps=20, replays=5):
     return a.elapsed_time(b) * 1e3 / (reps * replays)
 
 
-def pmc_traffic(key_prefix, grid):
+def pmc_traffic(key_prefix, grid, build_id):
     """(HBM bytes per launch, trace us, source file) of a kernel from the newest committed summaries
     (profiles/*_pmc_traffic.json / *_kernel_by_grid.csv: separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes and the --kernel-trace of this command; bytes corrected as
-    MI355X_MICROARCH.md prescribes).  Entries are keyed by kernel name and the FULL grid XxYxZ."""
+    MI355X_MICROARCH.md prescribes).  Entries are keyed by kernel name and the FULL grid XxYxZ (grid None: any).
+    A summary is only used when it was profiled on THIS build of the library (its `build_id` stamp): numbers of
+    other kernels would go stale silently."""
     import csv
     import glob
     traffic = trace_us = src = None
+
+    def match(name):
+        return name.startswith(key_prefix) and (grid is None or name.endswith('grid=' + grid))
     try:
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
-            for name, k in json.load(open(fn))['kernels'].items():
-                if name.startswith(key_prefix) and name.endswith('grid=' + grid):
+            doc = json.load(open(fn))
+            if doc.get('build_id') != build_id:
+                continue
+            for name, k in doc['kernels'].items():
+                if match(name):
                     traffic, src = k['hbm_bytes_per_launch'], os.path.basename(fn)
                     break
+            tr = fn.replace('_pmc_traffic.json', '_kernel_by_grid.csv')
+            if traffic is not None and os.path.exists(tr):
+                rows = [r for r in csv.reader(l for l in open(tr) if not l.startswith('#'))][1:]
+                hit = [r for r in rows if match(r[0])]
+                if hit:
+                    trace_us = float(hit[0][2]) / 1e3
             if traffic is not None:
-                break
-        for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_by_grid.csv')), reverse=True):
-            rows = [r for r in csv.reader(l for l in open(fn) if not l.startswith('#'))][1:]
-            hit = [r for r in rows if r[0].startswith(key_prefix) and r[0].endswith('grid=' + grid)]
-            if hit:
-                trace_us = float(hit[0][2]) / 1e3
                 break
     except Exception:
         pass
     return traffic, trace_us, src
 
 
-def step_hbm_bytes():
-    """(HBM bytes of ONE step, file) from the newest committed PMC summary that has the total
+def step_hbm_bytes(build_id):
+    """(HBM bytes of ONE step, file) from the newest committed PMC summary of THIS build that has the total
     (tools/summarize_prof.py: all libtipk launches of `bench.py --step-only` / (steps + warmup))."""
     import glob
     try:
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
-            v = json.load(open(fn)).get('step_hbm_bytes')
-            if v:
-                return float(v), os.path.basename(fn)
+            doc = json.load(open(fn))
+            if doc.get('build_id') == build_id and doc.get('step_hbm_bytes'):
+                return float(doc['step_hbm_bytes']), os.path.basename(fn)
     except Exception:
         pass
     return None
+
+
+MFMA_F32_PEAK = 157.3e12          # MI355X_MICROARCH.md: dense fp32 matrix rate
+LAUNCH_FLOOR_US = 2.0             # hand-over of a small launch inside a replayed graph (tools/microbench/launch_floor.hip: 1.6 empty, 2.5 at the margin)
+
+
+def roofline_of(rec, us, build_id):
+    """The contract's roofline object of one launch record of `dd_launches` timed at `us`."""
+    if rec['bound'] == 'mfma':
+        achieved = rec['work'] / (us * 1e-6) / 1e12
+        roof = {'bound': 'mfma', 'kernel': rec['label'], 'achieved': achieved, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': achieved * 1e12 / MFMA_F32_PEAK, 'launch_us': us, 'algorithmic_flops_per_launch': rec['work']}
+        if rec.get('flops_dense_form'):
+            roof['frac_dense_form'] = rec['flops_dense_form'] / (us * 1e-6) / MFMA_F32_PEAK
+            roof['note'] = ('algorithmic flops = both products of dY over the %d (relation, source) rows that have an edge; '
+                            'frac_dense_form prices all R x N rows (the figure quoted for the dense kernel of round 2)' % rec['rows'])
+    else:
+        peak = LDS_PEAK_GBS if rec['bound'] == 'lds' else HBM_PEAK_GBS
+        achieved = rec['work'] / (us * 1e-6) / 1e9
+        roof = {'bound': rec['bound'], 'kernel': rec['label'], 'achieved': achieved, 'peak': peak, 'unit': 'GB/s',
+                'frac': achieved / peak, 'launch_us': us, 'algorithmic_bytes_per_launch': rec['work'],
+                'edges_per_launch': rec.get('edges'), 'row_floats': rec.get('row_floats')}
+        if rec['bound'] == 'lds':
+            roof['note'] = ('rows are gathered from LDS (wave-stream / relation-local kernel): the bound is the ds_read_b128 '
+                            'rate; HBM only carries the ids and the output rows')
+    roof['grid'] = rec['grid']
+    roof['timing'] = 'HIP events on the launch stream around a hipGraph of 20 back-to-back launches'
+    traffic, trace_us, src = pmc_traffic(rec['key'], rec['grid'], build_id)
+    roof['traffic'] = traffic
+    if traffic is not None:
+        roof['hbm_traffic_frac'] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        roof['traffic_source'] = 'profiles/' + src + ' (same build id)'
+    if trace_us is not None:
+        roof['rocprof_trace_us'] = trace_us
+    return roof
+
+
+def step_floor(launch_us, launches, kern, pp_edges, dims):
+    """What the step's own kernels' bounds allow: sum over its launches of the larger of the kernel's roofline time
+    and the launch floor.  launches: records of `dd_launches` (modelled); kern: the eager per-kernel table
+    (label -> (launches per pass ..)) -- every launch that is not modelled counts LAUNCH_FLOOR_US, the four P-P
+    gathers their L2 gather time."""
+    parts = {}
+    for rec in launches:
+        if rec['work'] is None:
+            continue
+        if rec['bound'] == 'mfma':
+            t = rec['work'] / MFMA_F32_PEAK * 1e6
+            if rec.get('hbm_bytes'):
+                t = max(t, rec['hbm_bytes'] / (HBM_PEAK_GBS * 1e9) * 1e6)
+        else:
+            t = rec['work'] / ((LDS_PEAK_GBS if rec['bound'] == 'lds' else HBM_PEAK_GBS) * 1e9) * 1e6
+        parts[rec['label']] = max(t, LAUNCH_FLOOR_US)
+    modelled = len(parts)
+    n_launches = None
+    if kern:
+        passes = max(v[0] for v in kern.values())
+        passes = min(v[0] for v in kern.values()) if passes else 1
+        n_launches = int(round(sum(v[0] for v in kern.values()) / max(1, passes)))
+        pp = 0
+        for label in kern:
+            if label.startswith('gather_sum[pp.'):
+                dcol = int(label.split('d=')[1].rstrip(']'))
+                t = pp_edges * (4 + 4 * dcol) / (L2_GATHER_GBS * 1e9) * 1e6         # the 2.4 MB table is L2-resident
+                parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
+                pp += kern[label][0] // passes
+        rest = max(0, n_launches - modelled - pp)
+        parts['%d other launches x %.1f us' % (rest, LAUNCH_FLOOR_US)] = rest * LAUNCH_FLOOR_US
+    return {'us': sum(parts.values()), 'launches_per_step': n_launches, 'parts_us': {k: round(v, 2) for k, v in parts.items()},
+            'note': 'sum over the launches of one step of max(kernel roofline time, %.1f us launch floor): D-D gathers at the LDS '
+                    'ds_read_b128 peak, products at the fp32 MFMA peak (pair product: or its one pass over the cell matrix at 8 TB/s), '
+                    'P-P gathers at the L2 gather rate (18.8 TB/s: their table is L2-resident), every other launch at the floor' % LAUNCH_FLOOR_US}
+
+
+# ---------------------------------------------------------------------------------------------
+# one configuration: build, capture, time
+# ---------------------------------------------------------------------------------------------
+class Bench(object):
+    """Encoder forward + backward of one workload on this rank: build -> capture -> timed replays."""
+
+    def __init__(self, dd, dims, mod, dev, shard=None):
+        import torch
+        from tip_amd.data import Data
+        from tip_amd.layers import FMEncoder
+        self.dd, self.dims, self.mod, self.dev = dd, dims, mod, dev
+        torch.manual_seed(1111)
+        n_rel = dd['n_dd_et']
+        self.enc = FMEncoder(dev, dd['n_drug_feat'], n_rel, dd['n_prot'], dd['n_prot'], dd['n_drug'], mod=mod, **dims).to(dev)
+        self.d = Data.from_dict({k: v for k, v in dd.items() if k != 'dd_edge_index'}).to(dev)
+        self.g_up_cpu = torch.randn(dd['n_drug'], dims['n_hid2'], generator=torch.Generator().manual_seed(0))
+        self.g_up = self.g_up_cpu.to(dev)
+        self.z = None
+        self.graph = None
+        self.static_z, self.static_grads = None, None
+
+    def step(self):
+        enc, d = self.enc, self.d
+        for prm in enc.parameters():
+            prm.grad = None
+        z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat,
+                d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
+        z.backward(self.g_up)
+        self.z = z.detach()            # the buffer, not the autograd graph: a graph kept alive across steps breaks capture
+
+    def prepare(self):
+        """first step: builds + caches all gather plans.  -> seconds"""
+        import torch
+        t0 = time.perf_counter()
+        self.step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def capture(self, thread_local=False):
+        """The whole step (about 30 kernels, plus the RCCL all-reduces when sharded) becomes one hipGraph: replay
+        removes the per-launch host cost, which is larger than the kernels themselves at BioSNAP scale."""
+        import torch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        # with a process group alive the RCCL watchdog thread makes HIP calls of its own: only this
+        # thread's calls may invalidate the capture
+        mode = {'capture_error_mode': 'thread_local'} if thread_local else {}
+        with torch.cuda.graph(graph, **mode):
+            self.step()
+        self.graph = graph
+        # the graph's own output buffers (later eager steps re-bind .grad and self.z to fresh tensors)
+        self.static_z = self.z
+        self.static_grads = {k: prm.grad for k, prm in self.enc.named_parameters()}
+        return graph.replay
+
+    def outputs(self):
+        """(z, {name: gradient}) of the most recent step: the replayed graph's buffers, or the eager tensors."""
+        if self.graph is not None:
+            return self.static_z, self.static_grads
+        return self.z, {k: prm.grad for k, prm in self.enc.named_parameters()}
+
+    def weights_cpu(self):
+        return {k: v.detach().cpu().contiguous() for k, v in self.enc.state_dict().items()}
+
+
+def timed(run, steps, warmup, fence):
+    for _ in range(warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    fence()
+    return time.perf_counter() - t0
+
+
+def release(*objs):
+    import gc
+    import torch
+    from tip_amd import ops
+    ops._DYC.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def measure_config(workload, mod, dev, steps=20, warmup=5):
+    """ms/step, edges/s and the longest D-D kernel of another configuration (single GPU, hipGraph replay)."""
+    import torch
+    from tip_amd import _lib
+    a = argparse.Namespace(workload=workload, mod=mod)
+    t0 = time.perf_counter()
+    dd, dims, name = make_workload(a)
+    gen_s = time.perf_counter() - t0
+    b = Bench(dd, dims, mod, dev)
+    pre = b.prepare()
+    run = b.capture()
+    el = timed(run, steps, warmup, torch.cuda.synchronize)
+    E = int(dd['dd_train_idx'].shape[1])
+    ms = el / steps * 1e3
+    rec = {'workload': name, 'mod': mod, 'directed_dd_edges': E, 'relations': dd['n_dd_et'], 'steps': steps, 'warmup': warmup,
+           'ms_per_step': ms, 'value': E * steps / el, 'unit': 'edges/s', 'preprocess_s': pre, 'generate_s': gen_s}
+    launches = dd_launches(b.enc, dev)
+    us = {l['label']: time_launch_us(l['fn'], reps=10 if workload == 'synthetic' else 20, replays=3) for l in launches
+          if l['work'] is not None}
+    if us:
+        dom = max(us, key=us.get)
+        roof = roofline_of([l for l in launches if l['label'] == dom][0], us[dom], _lib.build_id())
+        rec['dominant_kernel'] = {k: roof[k] for k in ('kernel', 'bound', 'launch_us', 'achieved', 'peak', 'unit', 'frac')}
+        rec['dd_launches_us'] = {k: round(v, 2) for k, v in us.items()}
+    per_edge = sum(2 * (8 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2'))
+    if workload.startswith('synthetic'):
+        # config 5: rows of Y / dY are gathered from HBM-resident tables -- SURVEY 8(d)'s HBM yardstick applies;
+        # next to it the dense side (Y = att . XB, both products of dY, XB / dX / d basis products)
+        rec['hbm_roofline_frac'] = E * per_edge / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+        n, r, nb = dd['n_drug'], dd['n_dd_et'], dims['num_base']
+        flops = sum(3 * 2.0 * r * n * dims[k] * nb for k in ('n_hid1', 'n_hid2'))
+        rec['mfma_side'] = {'flops_per_step': flops, 'ms_at_fp32_mfma_peak': flops / MFMA_F32_PEAK * 1e3,
+                            'note': 'Y = att . XB forward and the two products of dY backward, per layer; the HBM side prices '
+                                    '%d B per edge' % per_edge}
+    del launches, run, b
+    release()
+    return rec
+
+
+def train_step_record(dev, epochs=20):
+    """The whole graphed training epoch of tip.py:24-30 (sampler + encoder + fused objective + backward + fused Adam)
+    on BASELINE config 2: ms per epoch."""
+    import torch
+    from tip_amd.layers import TIP, Setting
+    from tip_amd.train import GraphedTrainStep
+    torch.manual_seed(1111)
+    model = TIP(Setting(), dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=True)
+    step = GraphedTrainStep(model, opt)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / epochs * 1e3
+    E = int(model.data.dd_train_idx.shape[1])
+    loss = float(step())
+    rec = {'ms_per_epoch': ms, 'edges_per_s': E / (ms * 1e-3), 'epochs_timed': epochs, 'loss_after': loss,
+           'what': 'hipGraph replay of zero_grad + typed negative sampling + encoder + fused DistMult objective + backward + '
+                   'fused Adam (tip_amd/train.py), TIP-cat BioSNAP R=%d' % model.data.n_dd_et}
+    del step, opt, model
+    release()
+    return rec
 
 
 def main():
@@ -328,10 +621,14 @@ def main():
 
     import torch
     from tip_amd import _lib
-    _lib.ensure_built()                            # child `make` if the .so is missing / stale (before GPU use)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import fcntl
+    with open(os.path.join(ROOT, 'tip_amd', '.build.lock'), 'w') as lk:    # ranks started by a launcher: ONE `make` at a time
+        fcntl.flock(lk, fcntl.LOCK_EX)                                     # (the first builds, the others find it fresh)
+        _lib.ensure_built()                        # child `make` if the .so is missing / stale (before GPU use)
+        fcntl.flock(lk, fcntl.LOCK_UN)
     args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
     n_dev = torch.cuda.device_count()
@@ -359,8 +656,6 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from tip_amd import ops
-    from tip_amd.data import Data
-    from tip_amd.layers import FMEncoder
     if args.chunk:
         os.environ['TIPK_CHUNK'] = str(args.chunk)
     launch = args.launch or ('eager' if shared else 'graph')
@@ -380,9 +675,8 @@ def main():
         dd_rank = shard_data_dict(dd, shard)                   # this rank's relations' edges only
     else:
         dd_rank = dd
-    torch.manual_seed(1111)
-    enc = FMEncoder(dev, dd['n_drug_feat'], dd_rank['n_dd_et'], dd['n_prot'], dd['n_prot'], dd['n_drug'],
-                    mod=args.mod, **dims).to(dev)
+    b = Bench(dd_rank, dims, args.mod, dev, shard)
+    enc = b.enc
     if sharded:
         for name, prm in enc.named_parameters():               # identical replicas (att rows are shard-local)
             if not name.endswith('.att'):
@@ -390,15 +684,6 @@ def main():
                 dist.broadcast(buf, 0)
                 prm.data.copy_(buf)
         attach_shard(enc, shard)
-    d = Data.from_dict({k: v for k, v in dd_rank.items() if k != 'dd_edge_index'}).to(dev)
-    g_up = torch.randn(dd['n_drug'], dims['n_hid2'], generator=torch.Generator().manual_seed(0)).to(dev)
-
-    def step():
-        for prm in enc.parameters():
-            prm.grad = None
-        z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat,
-                d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
-        z.backward(g_up)
 
     def fence():
         torch.cuda.synchronize()
@@ -406,59 +691,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    t0 = time.perf_counter()
-    step()                                                     # builds + caches all gather plans
-    torch.cuda.synchronize()
-    preprocess_s = time.perf_counter() - t0
-    run = step
+    preprocess_s = b.prepare()
+    run = b.step
     if launch == 'graph':
-        # the whole step (about 36 kernels, plus the RCCL all-reduces when sharded) becomes one
-        # hipGraph: replay removes the per-launch host cost, which is larger than the kernels
-        # themselves at BioSNAP scale.  If capture fails (e.g. a collective that cannot be captured on
-        # this RCCL build) every rank falls back to eager launches together.
+        # If capture fails (e.g. a collective that cannot be captured on this RCCL build) every rank falls back to
+        # eager launches together.
         ok = torch.ones(1, device=dev)
-        graph = None
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            # with a process group alive the RCCL watchdog thread makes HIP calls of its own: only this
-            # thread's calls may invalidate the capture
-            mode = {'capture_error_mode': 'thread_local'} if dist.is_initialized() else {}
-            with torch.cuda.graph(graph, **mode):
-                step()
+            run = b.capture(thread_local=dist.is_initialized())
         except Exception as exc:                               # noqa: BLE001
             sys.stderr.write('graph capture failed on rank %d (%r): eager launches\n' % (rank, exc))
             ok.zero_()
             torch.cuda.synchronize()
         if dist.is_initialized() and world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) > 0:
-            run = graph.replay
-        else:
-            launch = 'eager'
-    for _ in range(args.warmup):
-        run()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
+        if float(ok.item()) <= 0:
+            run, launch = b.step, 'eager'
+    elapsed = timed(run, args.steps, args.warmup, fence)
 
-    # the D-D aggregation launches alone (roofline), then an eager per-kernel table of the whole step
-    agg_us = {}
-    launches = [] if args.step_only else dd_aggregation_launches(enc, dev)
-    for label, key, grid, d_row, bound, fn, n_e in launches:
-        agg_us[label] = time_launch_us(fn)
+    # the large D-D launches alone (roofline objects), then an eager per-kernel table of the whole step
+    launches = [] if args.step_only else dd_launches(enc, dev)
+    launch_us = {l['label']: time_launch_us(l['fn']) for l in launches if l['work'] is not None}
     kern = {}
     if not args.no_kernel_table and not args.step_only:
         ops.timing_start()
         for _ in range(max(3, min(args.steps, 10))):
-            step()
+            b.step()
         fence()
         kern = ops.timing_stop()
     if world > 1:
@@ -466,8 +724,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    rc = 0
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        bid = _lib.build_id()
         out = {
             'metric': 'D-D edges aggregated/sec (encoder fwd+bwd)',
             'value': E * args.steps / elapsed, 'unit': 'edges/s',
@@ -481,48 +741,30 @@ def main():
                        'launch': 'hipGraph replay of the captured step' if launch == 'graph'
                        else 'eager (one ctypes call per kernel)'},
             'preprocess_s': preprocess_s,
-            'build_id': _lib.build_id(),
+            'build_id': bid,
         }
-        # dominant kernel = the D-D aggregation launch with the longest duration
-        if agg_us:
-            dom = max(agg_us, key=agg_us.get)
-            label, key, grid, d_row, bound, _, n_launch = [l for l in launches if l[0] == dom][0]
-            # edges the launch walks: rank 0's share when sharded; a pair-form launch of a symmetric graph half of them
-            n_edges = int(n_launch) if n_launch is not None else int(dd_rank['dd_train_idx'].shape[1])
-            # one id + one d-wide fp32 row per edge and pass (ids are 4 B in the generic
-            # plans, 2 B in the relation-local ones; the figure keeps 4 B so runs stay comparable)
-            alg_bytes = n_edges * (4 + 4 * d_row)
-            us = agg_us[dom]
-            achieved = alg_bytes / (us * 1e-6) / 1e9
-            peak = LDS_PEAK_GBS if bound == 'lds' else HBM_PEAK_GBS
-            traffic, trace_us, src = pmc_traffic(key, grid)
-            roof = {'bound': bound, 'kernel': dom, 'grid': grid, 'achieved': achieved, 'peak': peak, 'unit': 'GB/s',
-                    'frac': achieved / peak, 'traffic': traffic, 'launch_us': us,
-                    'timing': 'HIP events on the launch stream around a hipGraph of 20 back-to-back launches',
-                    'algorithmic_bytes_per_launch': alg_bytes, 'edges_per_launch': n_edges, 'row_floats': d_row}
-            if traffic is not None:
-                roof['hbm_traffic_frac'] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-                roof['traffic_source'] = 'profiles/' + src
-            if trace_us is not None:
-                roof['rocprof_trace_us'] = trace_us
-            if bound == 'lds':
-                roof['note'] = ('rows are gathered from LDS (wave-stream / relation-local kernel): the bound is the ds_read_b128 '
-                                'rate; HBM only carries the ids and the output rows')
-            out['roofline'] = roof
-            out['dd_aggregations_us'] = {k: round(v, 2) for k, v in agg_us.items()}
+        if launch_us:
+            by = {l['label']: l for l in launches}
+            dom = max(launch_us, key=launch_us.get)                               # the longest kernel of the step
+            out['roofline'] = roofline_of(by[dom], launch_us[dom], bid)
+            aggs = {k: v for k, v in launch_us.items() if by[k].get('aggregation')}
+            if aggs:
+                dom_a = max(aggs, key=aggs.get)
+                out['roofline_aggregation'] = roofline_of(by[dom_a], aggs[dom_a], bid)
+            out['dd_launches_us'] = {k: round(v, 2) for k, v in launch_us.items()}
         per_edge = sum(2 * (8 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2'))     # 416 / 2080 B per edge
-        out['whole_step'] = {'alg_bytes': E * per_edge, 'bytes_per_edge': per_edge,
-                             'GBps': E * per_edge / (ms * 1e-3) / 1e9,
-                             'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             'note': 'SURVEY 8(d) prices one id + one d-wide row per edge and pass from HBM; this build serves the '
-                                     'rows from LDS and, in the pair-form forward, adds one att row per edge of HALF the '
-                                     '(symmetric) graph, so the figure can exceed 1: it compares against the survey '
-                                     'yardstick, it is not an HBM utilisation'}
-        hb = step_hbm_bytes()
-        if hb is not None and args.workload.startswith('biosnap') and world == 1:
-            out['whole_step']['hbm_bytes_measured'] = hb[0]
-            out['whole_step']['hbm_frac_measured'] = hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            out['whole_step']['hbm_source'] = 'profiles/' + hb[1]
+        if args.workload.startswith('synthetic'):
+            out['whole_step'] = {'alg_bytes': E * per_edge, 'bytes_per_edge': per_edge, 'GBps': E * per_edge / (ms * 1e-3) / 1e9,
+                                 'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        elif launch_us and world == 1:
+            pp_edges = int(dd['pp_train_indices'].shape[1]) + dd['n_prot']
+            fl = step_floor(launch_us, launches, kern, pp_edges, dims)
+            fl['frac'] = fl['us'] / (ms * 1e3)
+            out['step_floor'] = fl
+            hb = step_hbm_bytes(bid)
+            if hb is not None:
+                out['step_hbm'] = {'bytes_measured': hb[0], 'frac_of_8TBps': hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   'source': 'profiles/' + hb[1] + ' (same build id)'}
         if kern:
             out['kernels_eager_ms'] = {
                 'note': 'one HIP event pair per EAGER launch: includes ~5-8 us of event/launch overhead each; '
@@ -530,7 +772,33 @@ def main():
                 'table': {k: {'launches': v[0], 'mean_ms': round(v[1], 5)}
                           for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}
         if world == 1 and not args.no_cpu_baseline and not args.step_only:
-            out['cpu_baseline'] = cpu_baseline(dd, dims, args.mod, args.cpu_seconds)
+            if launch == 'graph':
+                b.graph.replay()                                   # the timed object itself: one more replay of the captured step
+                torch.cuda.synchronize()
+            z_dev, grads = b.outputs()
+            out['cpu_baseline'], zo, go = cpu_baseline(dd, dims, args.mod, args.cpu_seconds, b.weights_cpu(), b.g_up_cpu)
+            out['parity_in_bench'] = parity_check(z_dev, grads, zo, go)
+            out['parity_in_bench']['what'] = 'outputs of %s' % ('a replay of the timed hipGraph' if launch == 'graph' else 'an eager step')
+            if not out['parity_in_bench']['ok']:
+                rc = 1
+        extras = (world == 1 and not args.no_extras and not args.step_only and not args.no_cpu_baseline
+                  and args.workload == 'biosnap' and args.mod == 'cat')
+        if extras:
+            del launches, run
+            b.graph = None
+            del b, enc
+            release()
+            out['other_configs'] = {}
+            for key, (wl, mod) in (('tip_add', ('biosnap', 'add')), ('biosnap963', ('biosnap963', 'cat')), ('synthetic', ('synthetic', 'cat'))):
+                try:
+                    out['other_configs'][key] = measure_config(wl, mod, dev)
+                except Exception as exc:                           # noqa: BLE001 -- never lose the headline line
+                    out['other_configs'][key] = {'error': repr(exc)}
+                    release()
+            try:
+                out['train_step'] = train_step_record(dev)
+            except Exception as exc:                               # noqa: BLE001
+                out['train_step'] = {'error': repr(exc)}
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -542,6 +810,7 @@ def main():
         os.close(stdout_fd)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    sys.exit(rc)
 
 
 if __name__ == '__main__':

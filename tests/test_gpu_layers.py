@@ -308,6 +308,45 @@ def test_full_biosnap_encoder_vs_oracle(biosnap_full, mod, generic, monkeypatch)
         close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
 
 
+def test_paper_configuration_963_relations_encoder_and_objective_vs_oracle():
+    """The paper's configuration (BASELINE config 2 "~960 relations": the 963 side effects with >= 500 drug pairs,
+    reference analysis/evaluation.ipynb) at full size: z, every encoder gradient, the fused objective and
+    d decoder.weight against the CPU oracle -- `bench.py --workload biosnap963` times exactly this graph."""
+    from tip_amd.data import build_data_dict, Data
+    from tip_amd.layers import FMEncoder, MultiInnerProductDecoder
+    from tip_amd.neg_sampling import typed_negative_sampling
+    dd = build_data_dict(min_pairs=500)
+    R = dd['n_dd_et']
+    assert R == 963
+    dims = dict(prot_drug_dim=16, n_embed=48)
+    p = O.init_params(dd['n_drug'], dd['n_prot'], R, mod='cat', seed=1111, **dims)
+    enc = FMEncoder(DEV, dd['n_drug'], R, dd['n_prot'], dd['n_prot'], dd['n_drug'], num_base=32, n_hid1=32,
+                    n_hid2=16, mod='cat', **dims)
+    enc = load_params(enc, p)
+    dec = MultiInnerProductDecoder(16, R)
+    dec.weight.data = p['decoder.weight'].clone()
+    dec = dec.to(DEV)
+    d = Data.from_dict(dd).to(DEV)
+    z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices,
+            d.dp_edge_index, d.dp_range_list)
+    neg = typed_negative_sampling(d.dd_train_idx, d.n_drug, d.dd_train_range, seed=11)
+    loss = dec.objective(z, d.dd_train_idx, neg, d.dd_train_et)
+    loss.backward()
+    zo, saved = O.fm_encoder_fwd(p, dd, 'cat')
+    negc = neg.cpu()
+    ps = O.distmult_fwd(zo, dd['dd_train_idx'], dd['dd_train_et'], p['decoder.weight'])
+    ns = O.distmult_fwd(zo, negc, dd['dd_train_et'], p['decoder.weight'])
+    gp, gn = O.tip_loss_bwd(ps, ns)
+    gz1, gw1 = O.distmult_bwd(gp, zo, dd['dd_train_idx'], dd['dd_train_et'], p['decoder.weight'])
+    gz2, gw2 = O.distmult_bwd(gn, zo, negc, dd['dd_train_et'], p['decoder.weight'])
+    go = O.fm_encoder_bwd(gz1 + gz2, p, dd, saved, 'cat')
+    close(z, zo, rtol=1e-3)
+    close(loss, O.tip_loss(ps, ns), rtol=1e-4, atol=1e-6)
+    close(dec.weight.grad, gw1 + gw2, rtol=2e-3, atol=1e-4 * float((gw1 + gw2).abs().max()))
+    for k, prm in enc.named_parameters():
+        close(prm.grad, go[k], rtol=5e-3, atol=2e-5 * max(1e-6, float(go[k].abs().max())))
+
+
 def test_full_biosnap_size_independent_properties(biosnap_full):
     """Linearity and symmetry of the D-D aggregation at full size (no oracle needed):
     rgcn(a x1 + b x2) = a rgcn(x1) + b rgcn(x2);  <A x, y> = <x, A^T y> via autograd."""

@@ -1,5 +1,5 @@
 """The D-D aggregation launches of one BioSNAP step (+ the pair-form product), a few times each, for PMC collection
-(tools/profile_gpu.sh: SQ / LDS counter passes).  Plans and shapes are the step's own (bench.dd_aggregation_launches)."""
+(tools/profile_gpu.sh: SQ / LDS counter passes).  Plans and shapes are the step's own (bench.dd_launches)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,9 +13,9 @@ model = TIP(Setting(), dev, data=dd)
 enc, data = model.encoder, model.data
 z = enc(data.d_feat, data.dd_train_idx, data.dd_train_et, data.dd_train_range, data.d_norm, data.p_feat,
         data.pp_train_indices, data.dp_edge_index, data.dp_range_list)          # builds the plans
-for label, key, grid, d_row, bound, fn, n_e in bench.dd_aggregation_launches(enc, dev):
+for rec in bench.dd_launches(enc, dev):
     for _ in range(3):
-        fn()
+        rec['fn']()
 n, nb = 645, 32
 for layer in (enc.rgcn1, enc.rgcn2):
     graph = layer._cache.value

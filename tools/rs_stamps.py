@@ -14,9 +14,12 @@ enc, d = model.encoder, model.data
 enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
 L = _lib.lib()
 buf = (C.c_ulonglong * (4096 * 4))()
-for label, key, grid, d_row, bound, fn, n_e in bench.dd_aggregation_launches(enc, dev):
+for rec in bench.dd_launches(enc, dev):
+    if not rec.get('aggregation'):
+        continue
+    label = rec['label']
     for _ in range(3):
-        fn()
+        rec['fn']()
     torch.cuda.synchronize()
     assert L.tipk_debug_rs_stamps(buf) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 4).astype(np.float64)

@@ -100,6 +100,11 @@ for n, d in pmc.items():
     d['hbm_bytes_per_launch'] = (2.0 * f_kb + w_kb) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 of wide reads
     d['hbm_bytes_per_launch_uncorrected'] = (f_kb + w_kb) * 1024.0
 step_bytes = None
+build_id = None
+try:                                                 # the build the counters were collected on (bench.py drops stale summaries)
+    build_id = json.loads([l for l in open(os.path.join(src, 'bench_fetch.json')) if l.startswith('{')][-1]).get('build_id')
+except Exception as exc:
+    print('no build id:', exc)
 if pmc:
     # bytes of ONE step: every libtipk launch of the PMC passes (bench.py --step-only runs nothing but steps) / steps run
     try:
@@ -119,13 +124,13 @@ if pmc:
                        'hbm_bytes = (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md HBM section; keys = kernel + full grid XxYxZ '
                        '(joined from the kernel trace of the same pass by Dispatch_Id); step_hbm_bytes = all libtipk launches '
                        'of the pass / (steps + warmup) of `bench.py --launch eager --step-only`',
-               'step_hbm_bytes': step_bytes, 'kernels': top},
+               'build_id': build_id, 'step_hbm_bytes': step_bytes, 'kernels': top},
               open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 
 lds = {}
 for sub in sorted(glob.glob(os.path.join(src, 'pmc_sq*'))):
     for key, cs in counters_by_launch(os.path.basename(sub)).items():
-        if not any(t in key for t in ('rel_gather', 'stream_gather', 'pair_product', 'gather_sum', 'dy_products', 'rgcn_')):
+        if not any(t in key for t in ('rel_gather', 'stream_gather', 'pair_product', 'gather_sum', 'dy_products', 'node_products', 'rgcn_')):
             continue
         for c, v in cs.items():
             lds.setdefault(key, {})[c] = sum(v) / len(v)
