@@ -47,7 +47,8 @@ const char* tipk_build_id(void);
  *      "gemm_thin_k_narrow"  1 = dword body of the Y = att.XB streaming kernel
  *      "gemm_stream_kk"      1 = lane-per-row streaming body for d att
  *      "rg_occupancy"        workgroups per CU tipk_rel_gather aims for: 1, 2 (0 = library default)
- *      "rg_debug", "dp_debug"  bit masks that SKIP parts of tipk_rel_gather / tipk_rgcn_dy_products
+ *      "dm_task_kernel"      1 = fused objective through the k/4-lanes-per-position task kernel (the round-2 kernel; A/B runs)
+ *      "rg_debug", "dp_debug", "dm_debug"  bit masks that SKIP parts of tipk_rel_gather / tipk_rgcn_dy_products / the decoder kernels
  *                            (timing decompositions): accepted by -DTIPK_DEBUG builds only; a release
  *                            library returns TIPK_EUNSUPPORTED for a non-zero value and its kernels
  *                            contain no skip code.
@@ -402,7 +403,12 @@ int tipk_distmult_bwd(const float* g_score, const float* score,
  * the call leaves it zeroed): with it -- and a task table, i.e. on the LDS-resident fast kernel -- the sums across
  * workgroups of loss, d z and d w are 64-bit fixed-point integer atomics (exact, order-independent) converted by
  * a finalize launch: the objective and its gradients are BITWISE REPRODUCIBLE from run to run (the float
- * atomics of the default path differ at the 1e-7 level with the arrival order of 256 workgroups). */
+ * atomics of the default path differ at the 1e-7 level with the arrival order of 256 workgroups).
+ * With k in {4, 8, 16} this path runs distmult_objective_kernel: one lane evaluates a position (ids straight from global
+ * memory, sigma / log / quotient on the hardware transcendental units), the gradient terms are scattered with k lanes per
+ * row of the LDS image, and every term is converted to fixed point with a PER-TERM scale (|term| <= 4 zmax wmax / n:
+ * one multiply, one round, one 32-bit convert instead of a double-precision sequence); option "dm_task_kernel" = 1
+ * keeps the k/4-lanes-per-position kernel of round 2 for A/B runs. */
 int64_t tipk_distmult_workspace_bytes(int64_t n_nodes, int k, int64_t n_rel);
 int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                        const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,

@@ -19,9 +19,9 @@ static const char tipk_build_marker[] = "TIPK_BUILD_ID=" TIPK_BUILD_ID;
 #endif
 extern "C" const char* tipk_build_id(void) { return tipk_build_marker + 14; }
 
-static int g_options[TIPK_OPT_COUNT] = {0, 0, 0, 0, 0, 0};
+static int g_options[TIPK_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 static const char* const g_option_names[TIPK_OPT_COUNT] = {"gemm_no_stream", "gemm_thin_k_narrow", "gemm_stream_kk",
-                                                            "rg_debug", "dp_debug", "rg_occupancy"};
+                                                            "rg_debug", "dp_debug", "rg_occupancy", "dm_debug", "dm_task_kernel"};
 
 int tipk_option(int id) { return (id >= 0 && id < TIPK_OPT_COUNT) ? g_options[id] : 0; }
 
@@ -30,7 +30,7 @@ extern "C" int tipk_set_option(const char* name, int value) {
     for (int i = 0; i < TIPK_OPT_COUNT; ++i) {
         if (strcmp(name, g_option_names[i]) != 0) continue;
 #ifndef TIPK_DEBUG
-        if ((i == TIPK_OPT_RG_DEBUG || i == TIPK_OPT_DP_DEBUG) && value != 0) return TIPK_EUNSUPPORTED;
+        if ((i == TIPK_OPT_RG_DEBUG || i == TIPK_OPT_DP_DEBUG || i == TIPK_OPT_DM_DEBUG) && value != 0) return TIPK_EUNSUPPORTED;
 #endif
         g_options[i] = value;
         return TIPK_OK;

@@ -30,7 +30,9 @@ enum {
     TIPK_OPT_RG_DEBUG = 3,            // debug builds only
     TIPK_OPT_DP_DEBUG = 4,            // debug builds only
     TIPK_OPT_RG_OCCUPANCY = 5,        // tipk_rel_gather: workgroups per CU to aim for (0 = default, 1, 2)
-    TIPK_OPT_COUNT = 6
+    TIPK_OPT_DM_DEBUG = 6,            // debug builds only (decoder kernels)
+    TIPK_OPT_DM_TASK_KERNEL = 7,      // fused objective through distmult_task_kernel (k / 4 lanes per position) -- A/B runs
+    TIPK_OPT_COUNT = 8
 };
 int tipk_option(int id);
 #ifdef TIPK_DEBUG

@@ -7,6 +7,7 @@
 // per-workgroup LDS image with ds_add_f32 and flushed once; d w[r] is reduced across the wave with
 // shuffles whenever the wave's triples share one relation (triples arrive grouped by relation,
 // src/utils.py:57-63), so global float atomics are per wave, not per triple (Guideline 12).
+#include <type_traits>
 #include "tipk_common.h"
 
 namespace {
@@ -189,6 +190,21 @@ __device__ __forceinline__ void fx_add(unsigned long long* p, float c, double sc
     atomicAdd(p, (unsigned long long)(long long)((double)c * scale));      // ds_add_u64
 }
 
+// The fused objective's fixed point (MODE 1 with a workspace): every term added to d z is bounded INDIVIDUALLY --
+// |q| <= 2 / n (weight-2 positives), |z w| <= zmax wmax -- so the scale is chosen per TERM: scaled terms stay below 2^30
+// in magnitude, one fp32 multiply by a power of two, a round to nearest and a 32-bit convert give the integer (the eight
+// double-precision instructions `(long long)(double)` expands to -- v_cvt_f64_f32, v_mul_f64, v_trunc / ldexp / floor /
+// fmac _f64, two converts back -- were a third of the kernel: tools/bench_decoder.py), and the 64-bit accumulators
+// hold up to 2^33 such terms.  Resolution: 2^-30 of the largest possible term, rounding unbiased.
+__device__ __forceinline__ void fx_add_term(unsigned long long* p, float c, float scale_f) {
+    const int v = (int)rintf(c * scale_f);                                 // |c * scale| < 2^30 by construction
+    atomicAdd(p, (unsigned long long)(long long)v);                        // ds_add_u64
+}
+
+// sigma, log and the quotient of the objective on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32,
+// ~1 ulp each) instead of the IEEE-accurate library sequences: the objective is compared at 2e-5, its gradient at 2e-6
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 constexpr int TASK_MAX = 2048;          // positions per task (ids staged in LDS: 4 x 2048 x 2 B)
 
 template <typename IT, int MODE>
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
     const IT* __restrict__ nu, const IT* __restrict__ nv, const float* __restrict__ g_score, int sig,
     int64_t n_total, float* __restrict__ loss_out, float* __restrict__ g_z, float* __restrict__ g_w,
-    unsigned long long* __restrict__ ws) {
+    unsigned long long* __restrict__ ws, int dbg) {
     // ws != NULL (fused objective only): the cross-workgroup sums of loss, d z and d w go through 64-bit FIXED-POINT
     // integer atomics into `ws` (exact, order-independent) and det_finalize_kernel converts them: the training
     // objective and its gradients are then bitwise reproducible; with float atomics they differ at ~1e-7.
@@ -236,6 +252,12 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         int ex = 60;
         if (bound > 0.f && bound < 3.0e38f) ex = 60 - (ilogbf(bound) + 1);
         ex = ex > 180 ? 180 : ex;
+        if (MODE == 1 && ws) {                                  // per-TERM scale (fx_add_term): a term is <= bound / n
+            const float tb = bound / (float)n_total;
+            ex = 100;
+            if (tb > 0.f && tb < 3.0e38f) ex = 30 - (ilogbf(tb) + 1);
+            ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);     // (the scale also has to fit a float)
+        }
         scale = ldexp(1.0, ex);
     }
     // fixed-point scales of the deterministic path: identical in every workgroup (they depend on z and w only)
@@ -254,6 +276,13 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         }
     }
     __syncthreads();
+    const bool per_term = MODE == 1 && ws != nullptr;
+    const float scale_f = (float)scale;
+    float dbg_sink = 0.f;
+    auto fxa = [&](unsigned long long* p, float c) {
+        if (TIPK_DBG(dbg & 1)) { dbg_sink += c; return; }                 // debug builds: no conversion, no atomic
+        if (per_term) fx_add_term(p, c, scale_f); else fx_add(p, c, scale);
+    };
     const int KL = k >> 2;                                    // lanes per position (power of two <= 16)
     const int sub = t & (KL - 1);
     const int slot = t / KL;
@@ -329,20 +358,20 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 // executes one transcendental sequence per step instead of two
                 const bool neg_lane = KL > 1 && sub == 1;
                 const float x = neg_lane ? d1 : d0;
-                const float sg = sigmoidf(x);
+                const float sg = fast_sigmoid(x);
                 const float val = neg_lane ? 1.f - sg : sg;
-                const float lg = logf(val + TIP_EPS);
-                const float qq = inv_n * sg * (1.f - sg) / (val + TIP_EPS);
+                const float lg = __logf(val + TIP_EPS);
+                const float qq = inv_n * sg * (1.f - sg) * __builtin_amdgcn_rcpf(val + TIP_EPS);
                 const float pw = (float)pos_w;
                 if (KL > 1) {
                     if (valid && sub < 2) loss -= neg_lane ? lg : pw * lg;
                     q0 = -pw * __shfl(qq, 0, KL);
                     q1 = __shfl(qq, 1, KL);
                 } else {                                   // k = 4: one lane per position does both
-                    const float sn = sigmoidf(d1);
-                    if (valid) loss -= pw * lg + logf(1.f - sn + TIP_EPS);
+                    const float sn = fast_sigmoid(d1);
+                    if (valid) loss -= pw * lg + __logf(1.f - sn + TIP_EPS);
                     q0 = -pw * qq;
-                    q1 = inv_n * sn * (1.f - sn) / (1.f - sn + TIP_EPS);
+                    q1 = inv_n * sn * (1.f - sn) * __builtin_amdgcn_rcpf(1.f - sn + TIP_EPS);
                 }
                 if (!valid) { q0 = 0.f; q1 = 0.f; }
             } else if (valid) {
@@ -353,20 +382,20 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
                 if (pos_w != 0) {
                     unsigned long long* gu = gzl + cu0 * lg + c0;
                     unsigned long long* gv = gzl + cv0 * lg + c0;
-                    fx_add(gu + 0, q0 * b0.x * wr.x, scale); fx_add(gu + 1, q0 * b0.y * wr.y, scale);
-                    fx_add(gu + 2, q0 * b0.z * wr.z, scale); fx_add(gu + 3, q0 * b0.w * wr.w, scale);
-                    fx_add(gv + 0, q0 * a0.x * wr.x, scale); fx_add(gv + 1, q0 * a0.y * wr.y, scale);
-                    fx_add(gv + 2, q0 * a0.z * wr.z, scale); fx_add(gv + 3, q0 * a0.w * wr.w, scale);
+                    fxa(gu + 0, q0 * b0.x * wr.x); fxa(gu + 1, q0 * b0.y * wr.y);
+                    fxa(gu + 2, q0 * b0.z * wr.z); fxa(gu + 3, q0 * b0.w * wr.w);
+                    fxa(gv + 0, q0 * a0.x * wr.x); fxa(gv + 1, q0 * a0.y * wr.y);
+                    fxa(gv + 2, q0 * a0.z * wr.z); fxa(gv + 3, q0 * a0.w * wr.w);
                     gw.x = fmaf(q0, a0.x * b0.x, gw.x); gw.y = fmaf(q0, a0.y * b0.y, gw.y);
                     gw.z = fmaf(q0, a0.z * b0.z, gw.z); gw.w = fmaf(q0, a0.w * b0.w, gw.w);
                 }
                 if (MODE == 1) {
                     unsigned long long* hu = gzl + cu1 * lg + c0;
                     unsigned long long* hv = gzl + cv1 * lg + c0;
-                    fx_add(hu + 0, q1 * b1.x * wr.x, scale); fx_add(hu + 1, q1 * b1.y * wr.y, scale);
-                    fx_add(hu + 2, q1 * b1.z * wr.z, scale); fx_add(hu + 3, q1 * b1.w * wr.w, scale);
-                    fx_add(hv + 0, q1 * a1.x * wr.x, scale); fx_add(hv + 1, q1 * a1.y * wr.y, scale);
-                    fx_add(hv + 2, q1 * a1.z * wr.z, scale); fx_add(hv + 3, q1 * a1.w * wr.w, scale);
+                    fxa(hu + 0, q1 * b1.x * wr.x); fxa(hu + 1, q1 * b1.y * wr.y);
+                    fxa(hu + 2, q1 * b1.z * wr.z); fxa(hu + 3, q1 * b1.w * wr.w);
+                    fxa(hv + 0, q1 * a1.x * wr.x); fxa(hv + 1, q1 * a1.y * wr.y);
+                    fxa(hv + 2, q1 * a1.z * wr.z); fxa(hv + 3, q1 * a1.w * wr.w);
                     gw.x = fmaf(q1, a1.x * b1.x, gw.x); gw.y = fmaf(q1, a1.y * b1.y, gw.y);
                     gw.z = fmaf(q1, a1.z * b1.z, gw.z); gw.w = fmaf(q1, a1.w * b1.w, gw.w);
                 }
@@ -391,6 +420,7 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
             __syncthreads();
         }
     }
+    if (TIPK_DBG(dbg) && dbg_sink == 12345.f) loss += 1.f;
     if (MODE == 1) {
         loss = wave_sum(loss);
         if (tipk_lane() == 0) red[16 * k + (t >> 6)] = loss;
@@ -408,8 +438,199 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
         for (int i = t; i < n_nodes * k; i += 1024) {
             const int r = i / k, c = i - r * k;
             const long long a = (long long)gzl[r * lg + c];
+            if (TIPK_DBG(dbg & 4)) continue;                           // debug builds: no flush of the d z image
             if (ws && MODE == 1) { if (a != 0) atomicAdd(ws + i, (unsigned long long)a); }
             else if (a != 0) atomicAdd(g_z + i, (float)((double)a * inv_scale));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fused objective, one LANE per position (deterministic path: tasks + workspace; k in {4, 8, 16}).
+//
+// distmult_task_kernel gives a position to k / 4 lanes: every lane of the group executes the position's
+// transcendentals, the dot product ends in shuffles, and the task's ids are staged through LDS behind a barrier -- a
+// load phase nothing overlaps.  Measured at BioSNAP size (tools/bench_decoder.py, rocprofv3): 280 us for the objective
+// alone (no gradients), against 88 us per 8.3 M scores for the plain one-thread-per-triple score kernel.  Here a lane
+// owns a position outright for the EVALUATION: its four ids come straight from global memory (coalesced across the
+// wave, the next task's ids requested before the current one is evaluated), the rows of z from the LDS image as b128
+// reads, the dot products, sigma / log / quotient once.  The gradient terms are then scattered with k LANES PER ROW
+// (phase 2 below: ids and coefficients travel by wave shuffles), so that one LDS atomic instruction touches 64 / k
+// rows of the fixed-point d z image as contiguous pieces; d w[r] is summed per task: a column per lane -> the
+// wave's groups by shuffles -> 16 waves through LDS -> one fixed-point add per column.
+template <int I>
+__device__ __forceinline__ int pr_row_bcast(int x) {      // lane I of every 16-lane DPP row, broadcast to its row
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + (I & 15), 0xf, 0xf, false);
+}
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void pr_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pr_static_for<N, I + 1>(f);
+    }
+}
+
+template <typename IT, int K>
+__global__ __launch_bounds__(1024) void distmult_objective_kernel(
+    const float* __restrict__ z, int n_nodes, const float* __restrict__ w, int n_rel,
+    const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
+    const IT* __restrict__ nu, const IT* __restrict__ nv, int64_t n_total, int want_grad,
+    unsigned long long* __restrict__ ws, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+    const int t = threadIdx.x;
+    constexpr int ld = K + 4, lg = K + 1;
+    unsigned long long* gzl = lds64;                                      // [n_nodes][K + 1] fixed point
+    float* zl = (float*)(gzl + (int64_t)n_nodes * lg);                    // [n_nodes][K + 4]
+    float* red = zl + (((int64_t)n_nodes * ld + 3) & ~3LL);               // [16 waves][K] + [16]
+    float zmax = 0.f, wmax = 0.f;
+    for (int i = t; i < n_nodes * K; i += 1024) {
+        const int r = i / K, c = i - r * K;
+        const float v = z[i];
+        zl[r * ld + c] = v;
+        zmax = fmaxf(zmax, fabsf(v));
+    }
+    for (int i = t; i < n_nodes * lg; i += 1024) gzl[i] = 0ull;
+    for (int i = t; i < n_rel * K; i += 1024) wmax = fmaxf(wmax, fabsf(w[i]));
+    zmax = block_max_1024(zmax, red, t);
+    wmax = block_max_1024(wmax, red, t);
+    // scales: identical in every workgroup (they depend on z and w only); per-TERM scale for d z (fx_add_term)
+    double scale, scale_w;
+    {
+        const float tb = 4.f * zmax * wmax / (float)n_total;
+        int ex = 100;
+        if (tb > 0.f && tb < 3.0e38f) ex = 30 - (ilogbf(tb) + 1);
+        scale = ldexp(1.0, ex > 100 ? 100 : (ex < -100 ? -100 : ex));
+        const float bw = 4.f * zmax * zmax;
+        ex = 60;
+        if (bw > 0.f && bw < 3.0e38f) ex = 60 - (ilogbf(bw) + 1);
+        scale_w = ldexp(1.0, ex > 180 ? 180 : ex);
+    }
+    const double scale_l = 1125899906842624.0;                            // 2^50: the objective is < 2^7
+    if (blockIdx.x == 0 && t == 0) {                                      // the finalize kernel divides by them
+        const int64_t base = (int64_t)n_nodes * K + (int64_t)n_rel * K + 1;
+        reinterpret_cast<double*>(ws)[base] = scale;
+        reinterpret_cast<double*>(ws)[base + 1] = scale_w;
+        reinterpret_cast<double*>(ws)[base + 2] = scale_l;
+    }
+    __syncthreads();
+    const float scale_f = (float)scale;
+    const float inv_n = 1.f / (float)n_total;
+    float loss = 0.f;
+
+    // ids of (task, half h) for this lane: positions tb + h * 1024 + t (clamped; `valid` says whether it exists)
+    struct Ids { int pu, pv, nu, nv; };
+    auto fetch = [&](int task, int h, Ids& o) {
+        task = task < n_tasks ? task : n_tasks - 1;
+        const int tb = tasks[4 * task + 1], te = tasks[4 * task + 2];
+        int64_t q = (int64_t)tb + h * 1024 + t;
+        q = q < te ? q : (int64_t)te - 1;
+        o.pu = (int)pu[q]; o.pv = (int)pv[q]; o.nu = (int)nu[q]; o.nv = (int)nv[q];
+    };
+    Ids cur0, cur1, nx0, nx1;
+    fetch(blockIdx.x, 0, cur0);
+    fetch(blockIdx.x, 1, cur1);
+    for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int rel = tasks[4 * task], tb = tasks[4 * task + 1], te = tasks[4 * task + 2];
+        const int pos_w = tasks[4 * task + 3];
+        const float pw = (float)pos_w;
+        fetch(task + gridDim.x, 0, nx0);                                  // the next task's ids travel during this one
+        fetch(task + gridDim.x, 1, nx1);
+        float wr[K];
+#pragma unroll
+        for (int j = 0; j < K; j += 4) {
+            const float4 v = tipk_ld4(w + (int64_t)rel * K + j);
+            wr[j] = v.x; wr[j + 1] = v.y; wr[j + 2] = v.z; wr[j + 3] = v.w;
+        }
+        constexpr int G = 64 / K;                                         // positions one scatter instruction covers
+        const int col = t & (K - 1), grp = (t & 63) / K;
+        const float wcol = w[(int64_t)rel * K + col];
+        float gwc = 0.f;                                                  // this lane's column of d w[rel]
+        // PHASE 1, one lane per position: score and the coefficient q of its gradient terms (0: nothing to add)
+        auto triple = [&](int u, int v, bool negative, float weight) -> float {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; j += 4) {
+                const float4 x = tipk_ld4(zl + u * ld + j), y = tipk_ld4(zl + v * ld + j);
+                d = fmaf(x.x * y.x, wr[j], d); d = fmaf(x.y * y.y, wr[j + 1], d);
+                d = fmaf(x.z * y.z, wr[j + 2], d); d = fmaf(x.w * y.w, wr[j + 3], d);
+            }
+            const float sg = fast_sigmoid(d);
+            const float val = negative ? 1.f - sg : sg;
+            loss -= weight * __logf(val + TIP_EPS);
+            const float q = weight * inv_n * sg * (1.f - sg) * __builtin_amdgcn_rcpf(val + TIP_EPS);
+            return negative ? q : -q;
+        };
+        // PHASE 2, K lanes per row: the wave's 64 positions are revisited G at a time; lane `col` of group `grp` adds
+        // column `col` of both gradient terms of position i * G + grp -- one scatter instruction touches G rows of the
+        // d z image, each as one contiguous 8 K-byte piece (a lane per position made every instruction touch 64 rows:
+        // twice the time, tools/bench_decoder.py) -- and keeps its column of d w
+        auto scatter = [&](float q_mine, int u_mine, int v_mine) {
+            pr_static_for<64 / G>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float q;
+                int u, v;
+                if constexpr (K == 16) {
+                    // group = one DPP row of 16 lanes: lane i of every row is broadcast to its row (row_newbcast:i,
+                    // a full-rate VALU move) -- group g revisits the positions of lanes 16 g .. 16 g + 15
+                    q = __int_as_float(pr_row_bcast<i>(__float_as_int(q_mine)));
+                    u = pr_row_bcast<i>(u_mine);
+                    v = pr_row_bcast<i>(v_mine);
+                } else {
+                    const int src = i * G + grp;
+                    q = __shfl(q_mine, src, 64);
+                    u = __shfl(u_mine, src, 64);
+                    v = __shfl(v_mine, src, 64);
+                }
+                const float ua = zl[u * ld + col], vb = zl[v * ld + col];
+                const float qw = q * wcol;
+                if (q != 0.f && !TIPK_DBG(dbg & 1)) {
+                    fx_add_term(gzl + u * lg + col, qw * vb, scale_f);
+                    fx_add_term(gzl + v * lg + col, qw * ua, scale_f);
+                }
+                gwc = fmaf(q, ua * vb, gwc);
+            });
+        };
+        const int cnt = te - tb;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Ids& id = h ? cur1 : cur0;
+            const bool valid = t + h * 1024 < cnt;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;     // wave-uniform
+            float qp = 0.f, qn = 0.f;
+            if (valid) {
+                if (pos_w != 0) qp = triple(id.pu, id.pv, false, pw);
+                qn = triple(id.nu, id.nv, true, 1.f);
+            }
+            if (want_grad) {
+                if (pos_w != 0) scatter(qp, id.pu, id.pv);
+                scatter(qn, id.nu, id.nv);
+            }
+        }
+        cur0 = nx0;
+        cur1 = nx1;
+        if (want_grad) {                                                  // d w[rel]: the wave's G groups, then 16 waves via LDS
+#pragma unroll
+            for (int o = K; o < 64; o <<= 1) gwc += __shfl_xor(gwc, o, 64);
+            __syncthreads();                                              // red is free (previous task has been summed)
+            if (tipk_lane() < K) red[(t >> 6) * K + col] = gwc;
+            __syncthreads();
+            if (t < K) {
+                float tot = 0.f;
+                for (int wv = 0; wv < 16; ++wv) tot += red[wv * K + t];
+                atomicAdd(ws + (int64_t)n_nodes * K + (int64_t)rel * K + t, (unsigned long long)(long long)((double)tot * scale_w));
+            }
+        }
+    }
+    loss = block_sum_1024(loss, red, t);
+    if (t == 0)
+        atomicAdd(ws + (int64_t)n_nodes * K + (int64_t)n_rel * K, (unsigned long long)(long long)((double)(loss * inv_n) * scale_l));
+    if (want_grad) {
+        __syncthreads();
+        // (one slab per workgroup summed by the finalize kernel instead of these atomics: measured 20 us SLOWER)
+        for (int i = t; i < n_nodes * K; i += 1024) {
+            const int r = i / K, c = i - r * K;
+            const unsigned long long a = gzl[r * lg + c];
+            if (a != 0ull) atomicAdd(ws + i, a);
         }
     }
 }
@@ -440,6 +661,15 @@ __global__ __launch_bounds__(256) void det_finalize_kernel(unsigned long long* w
     }
 }
 
+int launch_finalize(int64_t n_nodes, int k, int64_t n_rel, float* loss_out, float* g_z, float* g_w, unsigned long long* ws,
+                    hipStream_t st) {
+    const int64_t n_z = n_nodes * k, n_w = n_rel * k;
+    const int64_t blocks = tipk_ceil_div(n_z + n_w + 1, 256);
+    hipLaunchKernelGGL(det_finalize_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, ws, n_z,
+                       n_w, loss_out, g_z, g_w);
+    TIPK_RETURN_LAUNCH();
+}
+
 template <typename IT, int MODE>
 int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, int64_t n_rel, const int32_t* tasks,
                  int64_t n_tasks, const void* pu, const void* pv, const void* nu, const void* nv,
@@ -451,14 +681,32 @@ int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, int64_t
     int64_t grid = n_tasks < 256 ? n_tasks : 256;              // one persistent workgroup per CU
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), (size_t)lds_bytes, st, z, (int)n_nodes, k, w, (int)n_rel,
                        tasks, (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, g_score, sig,
-                       n_total, loss_out, g_z, g_w, MODE == 1 ? ws : nullptr);
-    if (ws && MODE == 1) {
-        const int64_t n_z = n_nodes * k, n_w = n_rel * k;
-        const int64_t blocks = tipk_ceil_div(n_z + n_w + 1, 256);
-        hipLaunchKernelGGL(det_finalize_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, ws, n_z,
-                           n_w, loss_out, g_z, g_w);
-    }
+                       n_total, loss_out, g_z, g_w, MODE == 1 ? ws : nullptr, TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG)));
+    if (ws && MODE == 1) return launch_finalize(n_nodes, k, n_rel, loss_out, g_z, g_w, ws, st);
     TIPK_RETURN_LAUNCH();
+}
+
+int launch_objective(const float* z, int64_t n_nodes, int k, const float* w, int64_t n_rel, const int32_t* tasks,
+                     int64_t n_tasks, const void* pu, const void* pv, const void* nu, const void* nv, int idx_bytes,
+                     int64_t n_total, float* loss_out, float* g_z, float* g_w, unsigned long long* ws, hipStream_t st) {
+    const size_t lds = (size_t)(n_nodes * (k + 1) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * 4);
+    const int64_t grid = n_tasks < 256 ? n_tasks : 256;              // one persistent workgroup per CU
+    const int dbg = TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG));
+#define OBJ(IT, KK)                                                                                                      \
+    {                                                                                                                    \
+        auto kern = distmult_objective_kernel<IT, KK>;                                                                   \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        if (e != hipSuccess) return tipk_hip_status(e);                                                                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, st, z, (int)n_nodes, w, (int)n_rel, tasks,      \
+                           (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, n_total,           \
+                           g_z != nullptr ? 1 : 0, ws, dbg);                                                             \
+    }
+    if (idx_bytes == 8) { if (k == 4) OBJ(int64_t, 4) else if (k == 8) OBJ(int64_t, 8) else OBJ(int64_t, 16) }
+    else { if (k == 4) OBJ(int32_t, 4) else if (k == 8) OBJ(int32_t, 8) else OBJ(int32_t, 16) }
+#undef OBJ
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return tipk_hip_status(le);
+    return launch_finalize(n_nodes, k, n_rel, loss_out, g_z, g_w, ws, st);
 }
 
 constexpr int64_t LDS_GZ_LIMIT = 96 * 1024;
@@ -580,6 +828,10 @@ extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const 
     const bool vec = vec_ok(z, rel_w, k);
     int64_t lds_bytes = 0;
     if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
+        if (ws && (k == 4 || k == 8 || k == 16) && (idx_bytes == 8 || idx_bytes == 4) && n_nodes <= 0x7fffffffLL &&
+            !tipk_option(TIPK_OPT_DM_TASK_KERNEL))
+            return launch_objective(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, idx_bytes,
+                                    n_triples, loss_out, g_z, g_w, ws, st);
         if (idx_bytes == 8)
             return launch_tasks<int64_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
                                             1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws);

@@ -19,3 +19,15 @@ print('fwd score ms', t(lambda: ops.distmult_fwd(z, w, pos, et)))
 pos32, neg32, et32 = pos.int(), neg.int(), et.int()
 ops.relation_tasks(et32)
 print('loss+grad int32 ms', t(lambda: ops.distmult_loss(z, w, pos32, neg32, et32)))
+
+from tip_amd import _lib
+_lib.set_option('dm_task_kernel', 1)
+print('task kernel (k/4 lanes per position): loss+grad ms %.3f   loss only ms %.3f' % (
+    t(lambda: ops.distmult_loss(z, w, pos, neg, et)), t(lambda: ops.distmult_loss(z, w, pos, neg, et, need_grad=False))))
+_lib.set_option('dm_task_kernel', 0)
+if '+debug' in _lib.build_id():                               # TIPK_LIB=tip_amd/libtipk_debug.so
+    _lib.set_option('dm_debug', 1)
+    print('no fixed-point adds at all: loss+grad ms %.3f' % t(lambda: ops.distmult_loss(z, w, pos, neg, et)))
+    _lib.set_option('dm_debug', 4)
+    print('no flush of the d z image:  loss+grad ms %.3f' % t(lambda: ops.distmult_loss(z, w, pos, neg, et)))
+    _lib.set_option('dm_debug', 0)
