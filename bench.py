@@ -298,6 +298,8 @@ def dd_launches(enc, dev):
                         edges=csr.n_edges, row_floats=d, aggregation=True)
                     continue
                 plan = graph.bwd if bwd else graph.fwd
+                if getattr(plan, 'block_width', 0):            # blockwise forward (TIPK_BLOCKWISE_Y): ~100 small launches, not timed alone
+                    continue
                 waves = -(-plan.items.shape[0] // (64 // lanes))
                 fn = (lambda plan=plan, g=g: ops.gather_sum(plan, g)) if bwd else (lambda plan=plan, y=y: ops.gather_sum(plan, y))
                 add('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), 'gather_sum_kernel<4, %d' % lanes,

@@ -362,6 +362,13 @@ int tipk_gate_colsum(const float* in, int64_t ld_in, const float* gate, int64_t 
                      float* out, int64_t ld_out, int64_t rows, int64_t cols, float* scratch,
                      tipk_stream_t stream);
 
+/* The drug feature mix of FMEncoder in one forward launch (src/layers.py:526-539 with the dense map of
+ * MyHierarchyConv, :239):   x0 = cat(xd / d_norm, mean W)  (cat != 0)   or   x0 = xd / d_norm + mean W  (q == ne).
+ * xd [rows x ne], mean [rows x p], W [p x q] row-major contiguous, p, q <= 64; d_norm nullable (= 1). */
+int tipk_drug_mix_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* mean, int64_t ld_mean,
+                      const float* w, int p, int q, int64_t rows, int ne, int cat, float* out, int64_t ld_out,
+                      tipk_stream_t stream);
+
 /* out[c] = sum_r in[r, c]  (bias gradients of GCNConv).  `scratch` holds >= 256*cols floats. */
 int tipk_col_sum(const float* in, int64_t ld_in, int64_t rows, int64_t cols,
                  float* scratch, float* out, tipk_stream_t stream);
@@ -450,11 +457,15 @@ int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
  * argument is ignored -- a captured hipGraph draws new negatives on every replay
  * (`tipk_counter_advance` on state[0] is the next node), and re-seeding after capture (a device-side
  * write of the two words) takes effect in the replays.
+ * pos_offset (nullable, int64 [n_rel]): the Philox counter of position e of relation r is e + pos_offset[r] -- a rank
+ * of a relation-sharded run passes (start of r's block in the WHOLE triple list) - rel_ptr[r], so that its negatives
+ * are exactly the negatives the unsharded run draws for those relations, whatever the number of ranks.
  */
 int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
                                  const uint64_t* call_counter /* nullable device uint64[2], see above */,
                                  const int32_t* wg_rel_ptr /* nullable */, const int32_t* wg_rels, int64_t n_wg,
+                                 const int64_t* pos_offset /* nullable */,
                                  void* out_u, void* out_v, int idx_bytes,
                                  int64_t n_positions /* = rel_ptr[n_rel], host copy */,
                                  tipk_stream_t stream);

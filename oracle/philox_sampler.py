@@ -55,8 +55,9 @@ def _mulhi64(a, b):
     return a_hi * b_hi + (mid1 >> np.uint64(32)) + (mid2 >> np.uint64(32))
 
 
-def typed_negative_sampling_spec(pos_edge_index, num_nodes, rel_ptr, seed):
-    """pos_edge_index: int64 [2, E] numpy; rel_ptr: [R+1]; returns int64 [2, E]."""
+def typed_negative_sampling_spec(pos_edge_index, num_nodes, rel_ptr, seed, pos_offset=None):
+    """pos_edge_index: int64 [2, E] numpy; rel_ptr: [R+1]; returns int64 [2, E].
+    pos_offset (optional, [R]): the Philox counter of position e of relation r is e + pos_offset[r]."""
     pos = np.asarray(pos_edge_index, dtype=np.int64)
     rel_ptr = np.asarray(rel_ptr, dtype=np.int64)
     n = int(num_nodes)
@@ -69,8 +70,10 @@ def typed_negative_sampling_spec(pos_edge_index, num_nodes, rel_ptr, seed):
             continue
         keys = np.unique(pos[0, a:b] * n + pos[1, a:b]).astype(np.uint64)
         todo = np.arange(a, b, dtype=np.uint64)
+        off = np.uint64(0 if pos_offset is None else int(pos_offset[r]))
         for attempt in range(MAX_ATTEMPTS):
-            x0, x1, _, _ = philox4x32_10(todo & MASK32, todo >> np.uint64(32), np.full(todo.size, attempt), 0, k0, k1)
+            ctr = todo + off
+            x0, x1, _, _ = philox4x32_10(ctr & MASK32, ctr >> np.uint64(32), np.full(todo.size, attempt), 0, k0, k1)
             cand = _mulhi64(x0 | (x1 << np.uint64(32)), n * n)
             out[todo.astype(np.int64)] = cand
             bad = np.isin(cand, keys)

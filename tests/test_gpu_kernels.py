@@ -622,6 +622,17 @@ def test_negative_sampler_bit_exact_vs_spec_and_properties():
     assert torch.equal(a1, b1) and not torch.equal(a1, a2)
     assert np.array_equal(a1.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(7, 0)))
     assert np.array_equal(a2.cpu().numpy(), typed_negative_sampling_spec(pos, n, rel_ptr, call_key(7, 1)))
+    # relation-sharded runs: a rank that holds relations (3, 1) and passes their global offsets draws exactly the
+    # unsharded run's negatives for them (Philox counters run over GLOBAL positions), on both kernels and in the spec
+    keep = [1, 3]
+    loc = np.concatenate([pos[:, rel_ptr[r]:rel_ptr[r + 1]] for r in keep], axis=1)
+    loc_ptr = np.r_[0, np.cumsum([sizes[r] for r in keep])]
+    off = torch.tensor([rel_ptr[r] - loc_ptr[i] for i, r in enumerate(keep)])
+    rg_l = torch.tensor(np.stack([loc_ptr[:-1], loc_ptr[1:]], 1))
+    want_l = np.concatenate([want[:, rel_ptr[r]:rel_ptr[r + 1]] for r in keep], axis=1)
+    got_l = NS.typed_negative_sampling(torch.from_numpy(loc).to(DEV), n, rg_l, seed=0x1234567887654321, pos_offset=off)
+    assert np.array_equal(got_l.cpu().numpy(), want_l)
+    assert np.array_equal(typed_negative_sampling_spec(loc, n, loc_ptr, 0x1234567887654321, pos_offset=off.numpy()), want_l)
     assert call_key(7, 1) == NS.call_key(7, 1)
     # the stream's seed lives on the device next to its position: a captured sampler call keeps
     # advancing on replay, and RE-SEEDING AFTER CAPTURE takes effect in the replays

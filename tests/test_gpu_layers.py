@@ -246,9 +246,13 @@ def test_encoder_other_dimensions_vs_oracle(dims):
         close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
 
 
-def test_synthetic_encoder_large_node_set_vs_oracle():
+@pytest.mark.parametrize('blockwise', [False, True])
+def test_synthetic_encoder_large_node_set_vs_oracle(blockwise, monkeypatch):
     """More drugs than the LDS-resident kernel takes (N > 1024): the fabric-gather path, its finalize
-    launch, dy_products with hundreds of column chunks -- the route BASELINE config 5 takes -- vs the oracle."""
+    launch, dy_products with hundreds of column chunks -- the route BASELINE config 5 takes -- vs the oracle.
+    blockwise: the opt-in forward pass that produces Y per block of source nodes (TIPK_BLOCKWISE_Y = block bytes)."""
+    if blockwise:
+        monkeypatch.setenv('TIPK_BLOCKWISE_Y', '400000')
     from tip_amd.data import synthetic_data_dict, Data
     from tip_amd.layers import FMEncoder
     from tip_amd import ops
@@ -271,6 +275,7 @@ def test_synthetic_encoder_large_node_set_vs_oracle():
     close(z, zo, rtol=1e-3)
     for k, prm in enc.named_parameters():
         close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+    assert bool(enc.rgcn1._cache.value.fwd.block_width) == blockwise
 
 
 @pytest.fixture(scope='module')
@@ -392,12 +397,17 @@ def _shard_worker(rank, world, port, ret, max_relations=12):
         dd = build_data_dict(max_relations=max_relations)
         R = dd['n_dd_et']
         st = Setting()
+        from tip_amd import neg_sampling as NS
         torch.manual_seed(3)
+        NS.manual_seed(77)
         ref = TIP(st, torch.device(DEV), data=dd)                          # unsharded
         full_sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
         shard = make_shard(dd['dd_train_range'], rank, world)
         assert 0 < shard.rel_ids.numel() < R
+        NS.manual_seed(77)
         model = TIP(st, torch.device(DEV), data=dd, shard=shard)           # this rank's relations only
+        # the sampler's counters run over GLOBAL positions: a rank draws the unsharded run's negatives of its relations
+        assert torch.equal(model.test_neg_index, shard_edges(ref.test_neg_index, dd['dd_test_range'], shard.rel_ids)[0])
         assert model.data.dd_train_idx.shape[1] == shard.n_train_local < shard.n_train_total
         assert model.decoder.weight.shape[0] == model.encoder.rgcn1.att.shape[0] == shard.rel_ids.numel()
         model.load_state_dict(shard_state_dict(full_sd, shard))

@@ -403,7 +403,13 @@ def test_triple_validation_is_cached_and_raises():
     ei = torch.tensor([[0, 1, 2], [2, 1, 0]])
     et = torch.tensor([0, 0, 1])
     ops.validate_triples(ei, et, 3, 2)
-    assert any(k[0] == ei.data_ptr() for k in ops._VALID)
+    assert ei._tipk_range_ok == (ei._version, 3) and et._tipk_range_ok == (et._version, 2)     # the verdict lives ON the tensor:
+    assert not hasattr(ops, '_VALID')                                                          # no global cache pins index tensors
+    ei[0, 0] = 1                                                       # modified in place: checked again
+    assert ei._tipk_range_ok != (ei._version, 3)
+    ops.validate_triples(ei, et, 3, 2)
+    with pytest.raises(ValueError):
+        ops.validate_triples(ei, et[:2], 3, 2)                         # one relation id per triple
     with pytest.raises(IndexError):
         ops.validate_triples(ei, et, 2, 2)                             # node id 2 of 2 nodes
     with pytest.raises(IndexError):

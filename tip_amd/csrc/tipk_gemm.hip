@@ -486,7 +486,7 @@ inline int stream_kind(const GemmArgs& g, int64_t batch) {
     if (g.a_sm < 0 || g.a_sk < 0 || g.b_sk < 0 || g.b_sn < 0 || g.m > lim || g.n > lim || g.k > lim) return STREAM_NONE;
     if ((g.m - 1) * g.a_sm + (g.k - 1) * g.a_sk >= lim || (g.k - 1) * g.b_sk + (g.n - 1) * g.b_sn >= lim) return STREAM_NONE;
     if (g.c_sm < 0 || g.cin_sm < 0 || 32 * g.c_sm >= lim || 32 * g.cin_sm >= lim) return STREAM_NONE;   // tile-local C offsets
-    if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && g.m >= 256 && g.n >= 1024)
+    if (g.k <= 32 && g.ksplit == 1 && g.b_sn == 1 && (g.m >= 256 || (g.m >= 8 && g.n >= (1 << 16))) && g.n >= 1024)
         return (thin_k_wide_ok(g, batch) && !tipk_option(TIPK_OPT_GEMM_THIN_K_NARROW)) ? STREAM_THIN_K4 : STREAM_THIN_K;
     if (g.m <= 32 && g.b_sn == 1 && g.n >= 1024 && g.k >= 256) return STREAM_THIN_M;
     // lane-per-row dwordx4 loads keep the texture addresser 70 % busy (PMC) and the LDS-tiled kernel is as

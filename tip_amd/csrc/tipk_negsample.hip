@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
                                                          const int64_t* __restrict__ rel_ptr, int64_t n_rel,
                                                          int64_t n_nodes, uint64_t seed,
                                                          const uint64_t* __restrict__ call_counter,
+                                                         const int64_t* __restrict__ pos_offset,
                                                          OT* __restrict__ out_u, OT* __restrict__ out_v) {
     const uint64_t key = call_counter ? call_key(call_counter[1], call_counter[0]) : seed;
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
@@ -55,9 +56,10 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
     }
     const int64_t a = rel_ptr[lo], b = rel_ptr[lo + 1];
     const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
+    const uint64_t ctr = (uint64_t)(e + (pos_offset ? pos_offset[lo] : 0));      // the position's number in the WHOLE triple list
     uint64_t cand = 0;
     for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
-        cand = __umul64hi(philox64((uint64_t)e, (uint32_t)attempt, k0, k1), nn);
+        cand = __umul64hi(philox64(ctr, (uint32_t)attempt, k0, k1), nn);
         int64_t l = a, h = b;                       // lower_bound(keys[a:b], cand)
         while (l < h) {
             const int64_t mid = (l + h) >> 1;
@@ -78,7 +80,7 @@ template <typename OT>
 __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_rel_ptr,
     const int32_t* __restrict__ wg_rels, int64_t n_nodes, uint64_t seed, const uint64_t* __restrict__ call_counter,
-    OT* __restrict__ out_u, OT* __restrict__ out_v) {
+    const int64_t* __restrict__ pos_offset, OT* __restrict__ out_u, OT* __restrict__ out_v) {
     extern __shared__ unsigned bm[];
     const uint64_t key = call_counter ? call_key(call_counter[1], call_counter[0]) : seed;
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     for (int ri = wg_rel_ptr[blockIdx.x]; ri < wg_rel_ptr[blockIdx.x + 1]; ++ri) {
         const int rel = wg_rels[ri];
         const int64_t a = rel_ptr[rel], b = rel_ptr[rel + 1];
+        const int64_t off = pos_offset ? pos_offset[rel] : 0;
         __syncthreads();                                   // the previous relation's tests are done
         for (int i = t; i < words; i += 1024) bm[i] = 0u;
         __syncthreads();
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
         for (int64_t e = a + t; e < b; e += 1024) {
             uint64_t cand = 0;
             for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
-                cand = __umul64hi(philox64((uint64_t)e, (uint32_t)attempt, k0, k1), nn);
+                cand = __umul64hi(philox64((uint64_t)(e + off), (uint32_t)attempt, k0, k1), nn);
                 if (!((bm[cand >> 5] >> (cand & 31)) & 1u)) break;
             }
             out_u[e] = (OT)(cand / (uint64_t)n_nodes);
@@ -119,6 +122,7 @@ extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
 extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
                                             int64_t n_nodes, uint64_t seed, const uint64_t* call_counter,
                                             const int32_t* wg_rel_ptr, const int32_t* wg_rels, int64_t n_wg,
+                                            const int64_t* pos_offset,
                                             void* out_u, void* out_v, int idx_bytes, int64_t n_positions,
                                             tipk_stream_t stream) {
     if (n_rel < 0 || n_nodes <= 0 || n_positions < 0 || n_nodes > 0xffffffffLL) return TIPK_EINVAL;
@@ -134,13 +138,13 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, (int64_t*)out_u, (int64_t*)out_v);
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
         } else if (idx_bytes == 4) {
             auto kern = neg_sample_bitmap_kernel<int32_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, (int32_t*)out_u, (int32_t*)out_v);
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
         } else {
             return TIPK_EINVAL;
         }
@@ -148,10 +152,10 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
     }
     if (idx_bytes == 8)
         hipLaunchKernelGGL(neg_sample_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
-                           rel_ptr, n_rel, n_nodes, seed, call_counter, (int64_t*)out_u, (int64_t*)out_v);
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
     else if (idx_bytes == 4)
         hipLaunchKernelGGL(neg_sample_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
-                           rel_ptr, n_rel, n_nodes, seed, call_counter, (int32_t*)out_u, (int32_t*)out_v);
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
     else
         return TIPK_EINVAL;
     TIPK_RETURN_LAUNCH();

@@ -94,6 +94,43 @@ __global__ __launch_bounds__(256) void gate_colsum_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The drug feature mix of FMEncoder (src/layers.py:526-539) in ONE forward launch:
+//     x0 = cat(xd / d_norm, mean W)    or    x0 = xd / d_norm + mean W        (mean [N x p], W [p x q], p, q <= 64)
+// The dense map of MyHierarchyConv (src/layers.py:239) is 645 x 16 x 16 at BioSNAP size: as a GEMM launch plus a
+// row-scaling launch the arithmetic is nothing and the second hand-over is 5 us.  One thread per output element; W in LDS.
+// (The backward pass keeps its grouped split-K product + ordered slab sum: d W = mean^T g_pd is a reduction over all
+// rows, and ONE workgroup doing it -- rows straight from global memory, 128-row LDS tiles, or all rows in one LDS
+// tile -- took 22 ... 30 us inside the step against 17 us for the three launches it replaced.)
+constexpr int DM_MAX = 64;
+
+__global__ __launch_bounds__(256) void drug_mix_fwd_kernel(const float* __restrict__ xd, int64_t ld_xd,
+                                                           const float* __restrict__ d_norm,
+                                                           const float* __restrict__ mean, int64_t ld_mean,
+                                                           const float* __restrict__ w, int p, int q, int ne, int cat,
+                                                           float* __restrict__ out, int64_t ld_out, int64_t rows) {
+    __shared__ float wl[DM_MAX * DM_MAX];
+    for (int i = threadIdx.x; i < p * q; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int cols = cat ? ne + q : ne;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    float v = 0.f;
+    if (c < ne) {
+        v = xd[r * ld_xd + c];
+        if (d_norm) v /= d_norm[r];
+    }
+    const int j = cat ? c - ne : c;
+    if (j >= 0 && j < q) {
+        float s = 0.f;
+        for (int k = 0; k < p; ++k) s = fmaf(mean[r * ld_mean + k], wl[k * q + j], s);
+        v += s;
+    }
+    out[r * ld_out + c] = v;
+}
+
 }  // namespace
 
 extern "C" int tipk_gate_colsum_groups(int64_t rows, int64_t cols) {
@@ -157,4 +194,18 @@ extern "C" int tipk_col_sum(const float* in, int64_t ld_in, int64_t rows, int64_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tipk_hip_status(e);
     return tipk_sum_slabs(scratch, groups, cols, cols, 1.0f, 0, out, stream);
+}
+
+extern "C" int tipk_drug_mix_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* mean, int64_t ld_mean,
+                                 const float* w, int p, int q, int64_t rows, int ne, int cat, float* out, int64_t ld_out,
+                                 tipk_stream_t stream) {
+    if (rows < 0 || ne < 0 || p <= 0 || q <= 0 || p > DM_MAX || q > DM_MAX || (!cat && q != ne)) return TIPK_EINVAL;
+    if (rows == 0) return TIPK_OK;
+    if (!xd || !mean || !w || !out) return TIPK_EINVAL;
+    const int64_t cols = cat ? ne + q : ne;
+    const int64_t blocks = tipk_ceil_div(rows * cols, 256);
+    if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    hipLaunchKernelGGL(drug_mix_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xd, ld_xd, d_norm, mean,
+                       ld_mean, w, p, q, ne, cat, out, ld_out, rows);
+    TIPK_RETURN_LAUNCH();
 }

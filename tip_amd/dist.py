@@ -118,6 +118,10 @@ def shard_data_dict(dd, shard):
             continue
         ei, rel = shard_edges(dd[idx_k], dd[rg_k], ids)
         out[idx_k], out['dd_%s_et' % split], out[rg_k] = ei.contiguous(), rel, _local_ranges(dd[rg_k], ids)
+        # position of a relation's block in the WHOLE list minus its position in the local one: the sampler's Philox
+        # counter runs over global positions, so the negatives do not depend on the number of ranks
+        rg_all = torch.as_tensor(dd[rg_k]).to(torch.int64).cpu()
+        out['dd_%s_pos_offset' % split] = (rg_all[ids, 0] - out[rg_k][:, 0]) if len(ids) else torch.zeros(0, dtype=torch.int64)
     shard.n_train_local = int(out['dd_train_idx'].shape[1])
     out['n_dd_et'] = len(ids)
     out['dd_rel_ids'] = shard.rel_ids.clone()

@@ -23,7 +23,7 @@ from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
 from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
-                   relations_per_segment, DEFAULT_CHUNK)
+                   relations_per_segment, source_block_width, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
 EPS = 1e-13                    # src/layers.py:15
@@ -355,9 +355,18 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         # relation block, so that a row of Y gathered by several edges crosses the fabric once
         y_bytes = n_rel * n_nodes * (d_out or 0) * 4
         ordered = rel.numel() < 2 or bool((rel[1:] >= rel[:-1]).all())
+        bw = int(os.environ.get('TIPK_BLOCKWISE_Y', '0') or 0)            # 1 = default block budget, > 1 = the budget in bytes
+        if bw and y_bytes > 2 * (bw if bw > 1 else (96 << 20)):
+            # segments = blocks of SOURCE nodes; table rows are local to the block (relation * width + source - first):
+            # Y is produced block by block (all relations x the block's sources) and gathered out of the Infinity Cache
+            width = source_block_width(n_nodes, n_rel, d_out, bw if bw > 1 else (96 << 20))
+            plan = build_gather_plan_segmented(dst, rel * width + src % width, src // width, n_nodes, n_rel * width, chunk,
+                                               'dd.fwd', any_order=True)
+            plan.seg_rows, plan.block_width = n_rel * width, width
+            return plan
         if y_bytes > (192 << 20) and ordered and not os.environ.get('TIPK_NO_SEGMENTS'):
-            seg = rel // relations_per_segment(n_nodes, d_out)
-            return build_gather_plan_segmented(dst, yrow, seg, n_nodes, n_rel * n_nodes, chunk, 'dd.fwd')
+            per = relations_per_segment(n_nodes, d_out)
+            return build_gather_plan_segmented(dst, yrow, rel // per, n_nodes, n_rel * n_nodes, chunk, 'dd.fwd')
         return build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd')
 
     # the generic plans are built on first use: with the relation-local kernels they are never needed
@@ -620,7 +629,8 @@ class TIP(nn.Module):
 
     def __prepare_model(self):
         d, s = self.data, self.settings
-        self.test_neg_index = typed_negative_sampling(d.dd_test_idx, d.n_drug, d.dd_test_range)   # :293
+        self.test_neg_index = typed_negative_sampling(d.dd_test_idx, d.n_drug, d.dd_test_range,    # :293
+                                                      pos_offset=getattr(d, 'dd_test_pos_offset', None))
         self.encoder = FMEncoder(self.device, d.n_drug_feat, d.n_dd_et, d.n_prot, d.n_prot, d.n_drug,
                                  s.prot_drug_dim, s.num_base, s.n_embed, s.n_hid1, s.n_hid2,
                                  mod=self.mod).to(self.device)
@@ -638,7 +648,8 @@ class TIP(nn.Module):
         self.embeddings = self.__encode()
         pos_index = d.dd_train_idx
         if neg_index is None:
-            neg_index = typed_negative_sampling(d.dd_train_idx, d.n_drug, d.dd_train_range)
+            neg_index = typed_negative_sampling(d.dd_train_idx, d.n_drug, d.dd_train_range,
+                                                pos_offset=getattr(d, 'dd_train_pos_offset', None))
         neg_index = neg_index.type_as(pos_index)
         if self.shard is not None:
             return self.__sharded_objective(pos_index, neg_index)

@@ -110,17 +110,22 @@ def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
     return hit
 
 
-def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _range_ident=None):
+def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _range_ident=None, pos_offset=None):
     """Drop-in for `src/neg_sampling.py:22-26`.  `seed` (optional) pins the Philox key of this
-    call; by default consecutive calls use consecutive keys of the `manual_seed` stream."""
+    call; by default consecutive calls use consecutive keys of the `manual_seed` stream.
+    pos_offset (extension, int64 [R]): what to add to a position of relation r to get its number in the WHOLE triple
+    list of a relation-sharded run (tip_amd/dist.py) -- the rank then draws exactly the unsharded run's negatives."""
     num_nodes = int(num_nodes)
     keys, rel_ptr, n_rel, wg, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
+    if pos_offset is not None:
+        pos_offset = pos_offset.to(pos_edge_index.device, torch.int64).contiguous()
+        assert pos_offset.numel() == n_rel
     if seed is not None:                                     # explicit Philox key for this call
         return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
-                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg)
+                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg, pos_offset=pos_offset)
     return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, _state['seed'],
                                               pos_edge_index.shape[1], dtype=torch.int64,
-                                              call_counter=_counter(pos_edge_index.device), wg=wg)
+                                              call_counter=_counter(pos_edge_index.device), wg=wg, pos_offset=pos_offset)
 
 
 def negative_sampling(pos_edge_index, num_nodes, seed=None):

@@ -122,11 +122,34 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
         check(L.tipk_gather_sum(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_id), ptr(plan.edge_w), ptr(plan.items),
                                 plan.items.shape[0], ptr(out), out.stride(0), ptr(partial), ptr(row_scale),
                                 ptr(bias), int(relu), d, plan.group_slots, st), 'tipk_gather_sum')
-    if plan.n_slots:
-        check(L.tipk_gather_sum_finalize(ptr(partial), ptr(plan.split_rows), plan.split_rows.shape[0], ptr(out),
-                                         out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, plan.max_slots, st),
-              'tipk_gather_sum_finalize')
+    gather_sum_finish(plan, partial, out, row_scale, bias, relu)
     return out
+
+
+def gather_sum_finish(plan, partial, out, row_scale=None, bias=None, relu=False):
+    """Adds the pieces of the rows that a plan cut into several work items (slot order: deterministic)."""
+    if plan.n_slots:
+        d = out.shape[1]
+        check(lib().tipk_gather_sum_finalize(ptr(partial), ptr(plan.split_rows), plan.split_rows.shape[0], ptr(out),
+                                             out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, plan.max_slots,
+                                             stream_ptr(out.device)), 'tipk_gather_sum_finalize')
+
+
+def gather_sum_segment(plan, seg, table_block, out, partial, row_scale=None):
+    """The work items of segment `seg` of a blockwise plan over `table_block` [plan.seg_rows, d] (the plan's row ids are
+    local to the block).  Rows a single item completes are written to `out` (scaled), pieces to `partial`;
+    `gather_sum_finish` ends the pass."""
+    d = table_block.shape[1]
+    lo, hi = plan.seg_item_ptr[seg], plan.seg_item_ptr[seg + 1]
+    if hi == lo:
+        return
+    assert table_block.is_contiguous() and table_block.shape[0] == plan.seg_rows
+    import ctypes as C
+    items = C.c_void_p(plan.items.data_ptr() + lo * 16)
+    with _timed('gather_sum[%s.block,d=%d]' % (plan.tag, d)):
+        check(lib().tipk_gather_sum(ptr(table_block), d, plan.seg_rows, ptr(plan.row_id), None, items, hi - lo, ptr(out),
+                                    out.stride(0), ptr(partial), ptr(row_scale), None, 0, d, 0, stream_ptr(out.device)),
+              'tipk_gather_sum')
 
 
 def gather_rows_csr(plan, table):
@@ -603,35 +626,37 @@ def _uv(edge_index):
     return ei[0], ei[1]
 
 
-_VALID = {}
+def _range_checked(t, limit, what):
+    """Raise IndexError unless every entry of the index tensor `t` lies in [0, limit).  The verdict is remembered ON
+    the tensor (attribute keyed by its version counter and the limit): no global cache pins index tensors, a tensor
+    that was modified in place is checked again, and a fresh tensor costs ONE fused device reduction and one sync."""
+    tag = getattr(t, '_tipk_range_ok', None)
+    if tag == (t._version, int(limit)):
+        return
+    if t.numel():
+        lo, hi = torch.stack([t.min(), t.max()]).tolist()
+        if lo < 0 or hi >= limit:
+            raise IndexError('%s id out of range: [%d, %d] for %d' % (what, lo, hi, limit))
+    try:
+        t._tipk_range_ok = (t._version, int(limit))
+    except Exception:
+        pass
 
 
 def validate_triples(edge_index, edge_type, n_nodes, n_rel):
-    """Range check of a triple list, done ONCE per tensor identity (the result is cached, so the
-    per-step cost is a dictionary lookup): the decoder kernels index the LDS images of z / d z with
-    16-bit node ids and `weight` rows with the relation id, so an out-of-range id would corrupt
-    memory silently where the reference raises IndexError."""
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
-           None if edge_type is None else (edge_type.data_ptr(), tuple(edge_type.shape), edge_type._version),
-           int(n_nodes), int(n_rel))
-    if key in _VALID:
-        return
+    """Range check of a triple list, done ONCE per tensor (the verdict is stored on the tensor, so the per-step cost
+    is an attribute lookup): the decoder kernels index the LDS images of z / d z with 16-bit node ids and `weight`
+    rows with the relation id, so an out-of-range id would corrupt memory silently where the reference raises
+    IndexError.  (A first-time check synchronises: do not meet it inside a hipGraph capture -- the warm-up steps of
+    tip_amd.train.GraphedTrainStep take care of that.)"""
     n = edge_index.shape[-1]
     if n >= 2 ** 31:
         raise ValueError('triple lists are indexed with 32-bit positions: %d >= 2^31' % n)
-    if n:
-        lo, hi = int(edge_index.min()), int(edge_index.max())
-        if lo < 0 or hi >= n_nodes:
-            raise IndexError('node id out of range: [%d, %d] for %d nodes' % (lo, hi, n_nodes))
-        if edge_type is not None:
-            if edge_type.numel() != n:
-                raise ValueError('edge_type has %d entries for %d triples' % (edge_type.numel(), n))
-            lo, hi = int(edge_type.min()), int(edge_type.max())
-            if lo < 0 or hi >= n_rel:
-                raise IndexError('relation id out of range: [%d, %d] for %d relations' % (lo, hi, n_rel))
-    if len(_VALID) > 64:
-        _VALID.clear()
-    _VALID[key] = (edge_index, edge_type)                                    # pin: pointers stay unique
+    _range_checked(edge_index, n_nodes, 'node')
+    if edge_type is not None:
+        if edge_type.numel() != n:
+            raise ValueError('edge_type has %d entries for %d triples' % (edge_type.numel(), n))
+        _range_checked(edge_type, n_rel, 'relation')
 
 
 _TASK_CACHE = {}
@@ -759,8 +784,10 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
 
 
 def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64,
-                                   call_counter=None, wg=None):
-    """call_counter: optional int64 device tensor [2] = {position, seed} (the stream's state): the
+                                   call_counter=None, wg=None, pos_offset=None):
+    """pos_offset: optional int64 device tensor [n_rel]: Philox counter of position e of relation r = e + pos_offset[r]
+    (relation-sharded runs: the position's number in the whole triple list).
+    call_counter: optional int64 device tensor [2] = {position, seed} (the stream's state): the
     Philox key is derived on the device from it, `seed` is ignored, and the position is advanced by
     one afterwards."""
     require_device(pos_key_sorted, rel_ptr, call_counter)
@@ -769,7 +796,7 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
     wg_ptr, wg_rels = wg if (wg is not None and not os.environ.get('TIPK_NO_BITMAP')) else (None, None)
     check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
                                              ptr(call_counter), ptr(wg_ptr), ptr(wg_rels),
-                                             0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(out[0]), ptr(out[1]),
+                                             0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(pos_offset), ptr(out[0]), ptr(out[1]),
                                              8 if dtype == torch.int64 else 4, n_positions, st),
           'tipk_typed_negative_sampling')
     if call_counter is not None:
@@ -1019,8 +1046,35 @@ class _RGCN(torch.autograd.Function):
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
         elif r > 0:
-            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
+            assert graph.fwd.n_out == n and graph.fwd.n_table == r * (graph.fwd.block_width or n), 'graph/plan mismatch'
         xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
+        blockwise = r > 0 and not use_rl and getattr(graph.fwd, 'block_width', 0) > 0
+        if blockwise:
+            # Y = att . XB is 10 GB at config-5 size.  Blockwise plans (TIPK_BLOCKWISE_Y=1) cut the SOURCE nodes into
+            # blocks: the rows of Y of one block (all relations x its sources) are produced into one buffer of about a
+            # third of the Infinity Cache and the block's work items gather them from there -- neither the write nor the
+            # reads of Y go to HBM, and the product of a block reads only the block's columns of XB.
+            plan = graph.fwd
+            width = plan.block_width
+            n_seg = len(plan.seg_item_ptr) - 1
+            agg = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
+            partial = torch.empty((plan.n_slots, d_out), dtype=torch.float32, device=x.device) if plan.n_slots else None
+            buf = torch.empty((r, width * d_out), dtype=torch.float32, device=x.device)
+            xb2 = xb.view(nb, n * d_out)
+            scale = None if shard is not None else graph.scale
+            for sgi in range(n_seg):
+                s0, s1 = sgi * width, min(n, (sgi + 1) * width)
+                gemm(att, xb2[:, s0 * d_out:s1 * d_out], out=buf[:, :(s1 - s0) * d_out])
+                gather_sum_segment(plan, sgi, buf.view(r * width, d_out), agg, partial, row_scale=scale)
+            gather_sum_finish(plan, partial, agg, row_scale=scale)
+            if shard is not None:
+                shard.all_reduce(agg)
+                out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
+            else:
+                out = sum_slabs(agg.view(1, n, d_out), addend=xroot, relu=bool(relu))
+            ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
+            ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
+            return out
         y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out) if r > 0 else None     # [R N, out]
         if shard is None:
             if use_rl:
@@ -1077,7 +1131,8 @@ class _RGCN(torch.autograd.Function):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
-                csr = graph.csr_bwd if (d_out % 4 == 0 and 8 <= d_out <= 256 and not os.environ.get('TIPK_NO_CSR')) else None
+                csr = graph.csr_bwd if (d_out % 4 == 0 and 8 <= d_out <= 256 and gs.numel() * 4 < 2 ** 32     # (32-bit row offsets)
+                                        and not os.environ.get('TIPK_NO_CSR')) else None
                 if csr is not None:                                      # R N short rows: contiguous streams, no descriptors
                     g_y = gather_rows_csr(csr, gs).view(r, n * d_out)
                 else:
@@ -1174,6 +1229,16 @@ class _DrugMixMM(torch.autograd.Function):
         xd, mean, weight = _f32c(xd), _f32c(mean), _f32c(weight)
         n, ne = xd.shape
         pd_dim = weight.shape[1]
+        p = weight.shape[0]
+        ctx.fused = (p <= 64 and pd_dim <= 64 and weight.is_contiguous() and d_norm.is_contiguous()
+                     and not os.environ.get('TIPK_NO_DRUG_MIX_KERNEL'))
+        if ctx.fused:                                                     # scaling, cat | add and the dense map: one launch
+            out = torch.empty((n, ne + pd_dim if cat else ne), dtype=torch.float32, device=xd.device)
+            check(lib().tipk_drug_mix_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(mean), mean.stride(0), ptr(weight), p, pd_dim,
+                                          n, ne, int(cat), ptr(out), out.stride(0), stream_ptr(xd.device)), 'tipk_drug_mix_fwd')
+            ctx.cat, ctx.ne = cat, ne
+            ctx.save_for_backward(mean, weight, d_norm)
+            return out
         if cat:
             out = torch.empty((n, ne + pd_dim), dtype=torch.float32, device=xd.device)
             rows_affine(xd, row_div=d_norm, out=out[:, :ne])

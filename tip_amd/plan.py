@@ -62,11 +62,16 @@ class GatherPlan(object):
         self.group_slots = int(group_slots)
         self.n_edges = int(row_id.numel())
         self.max_slots = int((split_rows[:, 2] - split_rows[:, 1]).max()) if split_rows.shape[0] else 0
+        self.seg_item_ptr = None      # segment-major plans: item range of every segment (host list)
+        self.seg_rows = 0             # blockwise plans: rows of one block table (row ids are local to the block)
+        self.block_width = 0          # ... and the source nodes a block spans
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
-        return GatherPlan(self.n_out, self.n_table, mv(self.row_id), mv(self.edge_w), mv(self.items),
-                          mv(self.split_rows), self.n_slots, mv(self.perm), self.chunk, self.tag, self.group_slots)
+        p = GatherPlan(self.n_out, self.n_table, mv(self.row_id), mv(self.edge_w), mv(self.items),
+                       mv(self.split_rows), self.n_slots, mv(self.perm), self.chunk, self.tag, self.group_slots)
+        p.seg_item_ptr, p.seg_rows, p.block_width = self.seg_item_ptr, self.seg_rows, self.block_width
+        return p
 
     @property
     def device(self):
@@ -194,7 +199,7 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     return GatherPlan(n_out, n_table, row_id, w, items, split_rows, n_slots, order, chunk, tag)
 
 
-def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chunk=DEFAULT_CHUNK, tag=''):
+def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chunk=DEFAULT_CHUNK, tag='', any_order=False):
     """`build_gather_plan` for tables far larger than the caches (a D-D forward pass over
     Y = [R N, d] on a big graph: 10 GB in BASELINE config 5), where the ORDER in which the work items
     run decides the HBM traffic.
@@ -226,7 +231,10 @@ def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chu
     order = torch.sort(out_row, stable=True).indices
     key = out_row[order] * n_seg + segment[order]
     if E and bool((key[1:] < key[:-1]).any()):
-        raise ValueError('segment ids must be non-decreasing inside every output row (edges grouped by relation)')
+        if not any_order:
+            raise ValueError('segment ids must be non-decreasing inside every output row (edges grouped by relation)')
+        order = torch.sort(out_row * n_seg + segment, stable=True).indices      # (row, segment) groups, edge order inside
+        key = out_row[order] * n_seg + segment[order]
     gkey, gcount = torch.unique_consecutive(key, return_counts=True)
     grow = gkey // n_seg
     # rows without edges still get one (empty, direct) item so that the kernel writes their zeros
@@ -267,7 +275,19 @@ def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chu
         split_rows = torch.stack([split, first, first + items_per_row[split]], dim=1).to(torch.int32).contiguous()
     else:
         split_rows = torch.zeros((0, 3), dtype=torch.int32, device=dev)
-    return GatherPlan(n_out, n_table, row_id, None, items, split_rows, n_slots, order, chunk, tag)
+    plan = GatherPlan(n_out, n_table, row_id, None, items, split_rows, n_slots, order, chunk, tag)
+    # item range of every segment in launch order (host list): a caller may run the plan segment by segment, handing
+    # each launch only the table rows of that segment (tip_amd/ops.py `_RGCN.forward`: the rows of Y are produced
+    # block by block and consumed out of the Infinity Cache)
+    per_seg = torch.bincount(gseg[item_grp], minlength=n_seg)
+    plan.seg_item_ptr = [0] + torch.cumsum(per_seg, 0).tolist()
+    return plan
+
+
+def source_block_width(n_nodes, n_rel, d, budget_bytes=96 << 20):
+    """Source nodes per block of the BLOCKWISE forward pass of a large D-D graph: the block's rows of Y (all relations
+    x these sources x d floats) take about `budget_bytes` of the 256 MB Infinity Cache."""
+    return max(1, min(int(n_nodes), int(budget_bytes // max(1, n_rel * d * 4))))
 
 
 class CsrPlan(object):

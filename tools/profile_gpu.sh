@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): kernel trace + the two HBM-traffic PMC passes of the bench step
-# (+ the SQ/LDS counter passes of the D-D aggregation kernels when called with a third argument).
+# (+ the SQ/LDS counter passes of the D-D aggregation kernels when no bench arguments are given).
 #   gpurun -- 'bash tools/profile_gpu.sh r02 [bench args] '
 # Raw rocprofv3 output lands in gpurun_out/prof_<tag>/ (scratch); tools/summarize_prof.py turns it
 # into the committed summaries under profiles/.  The program itself follows `--` (no env / bash -c hop).
