@@ -686,6 +686,10 @@ def main():
                 dist.broadcast(buf, 0)
                 prm.data.copy_(buf)
         attach_shard(enc, shard)
+        if os.environ.get('TIPK_COLLECTIVE') == 'direct' and world > 1:
+            # one-shot exchange over peer-mapped mailboxes instead of the group's all-reduce (opt-in: tip_amd/dist.py)
+            shard.enable_direct_exchange(dev, max_floats=max(1 << 16, dd['n_drug'] * (2 * max(dims.values()) + 64)
+                                                             + dims['num_base'] * 128 * 128))
 
     def fence():
         torch.cuda.synchronize()
@@ -741,7 +745,10 @@ def main():
                        'parallelism': 'relation-sharded x%d%s' % (world, ' (ranks share GPUs, gloo: functional check)'
                                                                   if shared else '') if world > 1 else 'single GPU',
                        'launch': 'hipGraph replay of the captured step' if launch == 'graph'
-                       else 'eager (one ctypes call per kernel)'},
+                       else 'eager (one ctypes call per kernel)',
+                       'collective': shard.collective if shard is not None else None,
+                       'forward_routes': [list(l._cache.value.fwd_route.values()) if l._cache.value is not None else None
+                                          for l in (enc.rgcn1, enc.rgcn2)] if shard is not None else None},
             'preprocess_s': preprocess_s,
             'build_id': bid,
         }

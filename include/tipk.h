@@ -510,6 +510,29 @@ int tipk_split_scatter(const void* pairs_u, const void* pairs_v, int idx_bytes, 
                        int64_t* train_u, int64_t* train_v, int64_t* train_et,
                        int64_t* test_u, int64_t* test_v, int64_t* test_et, tipk_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * 8. One-shot all-reduce over peer-mapped mailboxes -- the xGMI-aware exchange of the relation-sharded step
+ *    (north_star: "the D-D pass shards by relation-id across the 8 GPUs of one node with an ... all-reduce of drug
+ *    embeddings over xGMI"; the reference is single-GPU, README.md:58).  SUM of one fp32 buffer of n <= max_floats
+ *    elements over `world` ranks (one process per GPU), result identical bit for bit on every rank (slots added in
+ *    rank order).  tip_amd/csrc/tipk_peer.hip describes the protocol.
+ *      tipk_peer_mailbox_bytes   size of one rank's mailbox (two halves of world slots + flags, + the call counter);
+ *      tipk_peer_alloc / _free   the mailbox: UNCACHED device memory, zeroed (explicit allocation entry points: the
+ *                                only ones of the library -- such memory cannot come from the caller's allocator);
+ *      tipk_ipc_get_handle / _open / _close   hipIpc handle (64 bytes) of the own mailbox / mapping of a peer's;
+ *      tipk_peer_allreduce       data [n] <- sum over ranks; mailboxes = HOST array [world] of the mailboxes' addresses
+ *                                in THIS process (own one at [rank]); every rank must call with the same n, in the same
+ *                                order.  Two launches (exchange + call counter), no host synchronisation: capturable.
+ */
+int64_t tipk_peer_mailbox_bytes(int world, int64_t max_floats);
+int tipk_peer_alloc(int64_t bytes, void** ptr);
+int tipk_peer_free(void* ptr);
+int tipk_ipc_get_handle(void* ptr, void* handle_out /* 64 bytes, host */);
+int tipk_ipc_open(const void* handle /* 64 bytes, host */, void** ptr);
+int tipk_ipc_close(void* ptr);
+int tipk_peer_allreduce(float* data, int64_t n, void* const* mailboxes /* host [world] */, int rank, int world,
+                        int64_t max_floats, tipk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,107 @@
+"""-m gpu: the one-shot all-reduce over peer-mapped mailboxes (include/tipk.h section 8, tip_amd/csrc/tipk_peer.hip) with
+2 and 4 ranks SHARING the one GPU of the test box (hipIpc mappings of the other processes' mailboxes on the same
+device; on an 8-GPU node the same code writes over xGMI): sums against a float64 reference, identical bits on every
+rank, repeated calls (both mailbox halves, growing sequence numbers), sizes from one element to several chunks, inside
+a captured hipGraph replayed with changing inputs, and the relation-sharded encoder layer on top of it."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ex = None
+    try:
+        from tip_amd.dist import DirectExchange, RelationShard
+        torch.cuda.set_device(0)
+        ex = DirectExchange(rank, world, None, 20000, torch.device(DEV))
+        ok = True
+        for it, n in enumerate([1, 7, 4096, 4097, 20000, 13, 20000, 4096 * 3 + 5]):
+            g = torch.Generator().manual_seed(100 * it + 1)
+            parts = [torch.randn(n, generator=g) for _ in range(world)]          # every rank knows every rank's input
+            x = parts[rank].to(DEV)
+            ex.all_reduce(x)
+            want = torch.stack(parts).double().sum(0)
+            ok = ok and torch.allclose(x.cpu().double(), want, rtol=1e-6, atol=1e-6)
+            # slots are added in rank order: the fp32 result is exactly this chain, on every rank
+            chain = parts[0].clone()
+            for r in range(1, world):
+                chain += parts[r]
+            ok = ok and torch.equal(x.cpu(), chain)
+        # inside a captured hipGraph: the sequence number lives on the device, replays exchange fresh data
+        buf = torch.zeros(5000, device=DEV)
+        src = torch.zeros(5000, device=DEV)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buf.copy_(src)
+            ex.all_reduce(buf)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        dist.barrier()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            buf.copy_(src)
+            ex.all_reduce(buf)
+        for it in range(3):
+            g = torch.Generator().manual_seed(900 + it)
+            parts = [torch.randn(5000, generator=g) for _ in range(world)]
+            src.copy_(parts[rank])
+            graph.replay()
+            torch.cuda.synchronize()
+            chain = parts[0].clone()
+            for r in range(1, world):
+                chain += parts[r]
+            ok = ok and torch.equal(buf.cpu(), chain)
+        # RelationShard routes its collectives through the exchange once enabled (larger buffers keep the group's)
+        sh = RelationShard([0], rank, world)
+        sh.direct = ex
+        small = torch.full((100,), float(rank + 1), device=DEV)
+        big = torch.full((30000,), float(rank + 1), device=DEV)
+        sh.all_reduce(small)
+        sh.all_reduce(big)                                                  # 30 000 > max_floats: gloo
+        tot = float(sum(range(1, world + 1)))
+        ok = ok and bool((small == tot).all()) and bool((big == tot).all()) and sh.collective == 'direct'
+        ret[rank] = bool(ok)
+    finally:
+        if ex is not None:
+            dist.barrier()
+            ex.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 4])
+def test_direct_exchange_ranks_sharing_one_gpu(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        if p.is_alive():                                                    # a hung exchange must not hang the suite
+            p.terminate()
+            p.join(10)
+            pytest.fail('direct exchange timed out')
+        assert p.exitcode == 0
+    assert dict(ret) == {r: True for r in range(world)}

@@ -216,5 +216,21 @@ def test_bench_two_ranks_oversubscribed_subprocess():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1 and rec['unit'] == 'edges/s'
     assert rec['value'] > 0 and rec['ms_per_step'] > 0 and rec['higher_is_better'] is True
-    assert 'relation-sharded x2' in rec['config']['parallelism']
+    assert 'relation-sharded x2' in rec['config']['parallelism'] and rec['config']['collective'] == 'gloo'
     assert np.isfinite(rec['value'])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_direct_exchange_and_timed_routes():
+    """BioSNAP over 2 ranks sharing the GPU with TIPK_COLLECTIVE=direct: the step's five all-reduces go through the
+    one-shot exchange (tip_amd/csrc/tipk_peer.hip), each layer's forward route (pair form | Y) is timed per rank."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['TIPK_COLLECTIVE'] = 'direct'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--oversubscribe', '--steps', '3',
+                          '--warmup', '1', '--no-cpu-baseline', '--no-kernel-table'], env=env, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert rec['n_gpus'] == 2 and rec['config']['collective'] == 'direct' and rec['value'] > 0
+    routes = rec['config']['forward_routes']
+    assert len(routes) == 2 and all(r and r[0][0] in ('pair', 'y') and set(r[0][1]) == {'pair', 'y'} for r in routes)

@@ -92,6 +92,13 @@ SIGNATURES = {
     'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _P, _P, _L, _P, _P, _P, _I, _L, _P]),
     'tipk_counter_advance': (_I, [_P, _P]),
     'tipk_rank_metrics': (_I, [_P, _P, _P, _L, _L, _P, _P]),
+    'tipk_peer_mailbox_bytes': (_L, [_I, _L]),
+    'tipk_peer_alloc': (_I, [_L, C.POINTER(_P)]),
+    'tipk_peer_free': (_I, [_P]),
+    'tipk_ipc_get_handle': (_I, [_P, _P]),
+    'tipk_ipc_open': (_I, [_P, C.POINTER(_P)]),
+    'tipk_ipc_close': (_I, [_P]),
+    'tipk_peer_allreduce': (_I, [_P, _L, C.POINTER(_P), _I, _I, _L, _P]),
     'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),
     'tipk_split_scatter': (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

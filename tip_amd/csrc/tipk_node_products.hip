@@ -124,10 +124,10 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
                 const int i = 2 * kk + kh;
                 const int row = i0 + i;
                 const int r = rr[kk];
-                av[kk] = np_ldg(a.att, (u32)r * ld_att4 + nb_c4);
+                if (!TIPK_DBG(a.dbg & 128)) av[kk] = np_ldg(a.att, (u32)r * ld_att4 + nb_c4);
                 const u32 rowb = (u32)(row < lim ? row : a.n_rows) * d4;
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) bv[ct][kk] = np_ldg(a.dyc, rowb + cc4[ct]);
+                for (int ct = 0; ct < NCT; ++ct) if (!TIPK_DBG(a.dbg & 256)) bv[ct][kk] = np_ldg(a.dyc, rowb + cc4[ct]);
             }
         };
         auto mfma = [&](const float (&av)[16], const float (&bv)[NCT][16]) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ct][kk], acc[ct], 0, 0, 0);
         };
         if (n_tiles > 0) {
-            float aX[16], bX[NCT][16], aY[16], bY[NCT][16];
+            float aX[16] = {}, bX[NCT][16] = {}, aY[16] = {}, bY[NCT][16] = {};
             int tile = w;
             int rX = getrel(tile), rY = getrel(tile + NP_WAVES);
             load(tile, rX, aX, bX);

@@ -58,6 +58,7 @@ class RelationShard(object):
         self.in_degree = None                     # int64 [N]: D-D in-degree over ALL relations
         self.n_train_total = None                 # directed training edges over all ranks
         self.n_train_local = None
+        self.direct = None                        # DirectExchange (one-shot all-reduce over peer-mapped mailboxes), opt-in
 
     def rel_ids_on(self, device):
         if self.rel_ids.device != device:
@@ -65,14 +66,88 @@ class RelationShard(object):
         return self.rel_ids
 
     def all_reduce(self, flat):
-        """In-place SUM all-reduce of one flat buffer."""
-        if self.world > 1 or dist.is_initialized():
+        """In-place SUM all-reduce of one flat buffer: the one-shot exchange over peer-mapped mailboxes when it was
+        enabled (`enable_direct_exchange`) and the buffer fits, the process group's all-reduce (RCCL / gloo) otherwise."""
+        if self.direct is not None and self.direct.takes(flat):
+            self.direct.all_reduce(flat)
+        elif self.world > 1 or dist.is_initialized():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def enable_direct_exchange(self, device, max_floats=1 << 21):
+        """Use `DirectExchange` for the step's collectives (all ranks must call this; collective).  -> the exchange."""
+        self.direct = DirectExchange(self.rank, self.world, self.group, max_floats, device)
+        return self.direct
+
+    @property
+    def collective(self):
+        if self.direct is not None:
+            return 'direct'
+        return dist.get_backend(self.group) if dist.is_initialized() else 'none'
 
     @property
     def loss_weight(self):
         return float(self.n_train_local) / float(max(1, self.n_train_total))
+
+
+class DirectExchange(object):
+    """One-shot all-reduce over peer-mapped mailboxes (include/tipk.h section 8, tip_amd/csrc/tipk_peer.hip): every rank
+    writes its buffer into its slot of all ranks' mailboxes -- w - 1 remote streams over w - 1 different xGMI links at
+    once -- posts flags, waits for the others' flags and adds the slots in rank order.  One kernel per rank and call
+    instead of the 2 (w - 1) dependent steps of a ring; results are identical on every rank and from run to run.
+    The mailboxes are exchanged as hipIpc handles through the process group (any backend) once, at construction.
+    OPT-IN (`RelationShard.enable_direct_exchange`, bench.py: TIPK_COLLECTIVE=direct): it is validated with ranks
+    sharing one GPU (tests/test_gpu_direct_exchange.py); RCCL stays the default on real multi-GPU nodes until it has
+    been timed there."""
+
+    def __init__(self, rank, world, group, max_floats, device):
+        import ctypes as C
+        from ._lib import lib, check
+        L = lib()
+        self.rank, self.world, self.max_floats, self.device = int(rank), int(world), int(max_floats), torch.device(device)
+        nbytes = int(L.tipk_peer_mailbox_bytes(self.world, self.max_floats))
+        if nbytes <= 0:
+            raise ValueError('direct exchange: unsupported world size %d' % world)
+        with torch.cuda.device(self.device):
+            self.own = C.c_void_p()
+            check(L.tipk_peer_alloc(nbytes, C.byref(self.own)), 'tipk_peer_alloc')
+            handle = C.create_string_buffer(64)
+            check(L.tipk_ipc_get_handle(self.own, handle), 'tipk_ipc_get_handle')
+            handles = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(handles, handle.raw, group=group)
+            self.ptrs = (C.c_void_p * self.world)()
+            self.opened = []
+            for r in range(self.world):
+                if r == self.rank:
+                    self.ptrs[r] = self.own
+                else:
+                    p = C.c_void_p()
+                    check(L.tipk_ipc_open(handles[r], C.byref(p)), 'tipk_ipc_open')
+                    self.ptrs[r] = p
+                    self.opened.append(p)
+        if self.world > 1:
+            dist.barrier(group=group)                     # every mailbox is mapped everywhere before the first exchange
+
+    def takes(self, flat):
+        return (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and 0 < flat.numel() <= self.max_floats
+                and flat.device == self.device)
+
+    def all_reduce(self, flat):
+        from ._lib import lib, check, ptr, stream_ptr
+        check(lib().tipk_peer_allreduce(ptr(flat), flat.numel(), self.ptrs, self.rank, self.world, self.max_floats,
+                                        stream_ptr(flat.device)), 'tipk_peer_allreduce')
+        return flat
+
+    def close(self):
+        from ._lib import lib
+        torch.cuda.synchronize(self.device)
+        for p in self.opened:
+            lib().tipk_ipc_close(p)
+        self.opened = []
+        if self.own is not None:
+            lib().tipk_peer_free(self.own)
+            self.own = None
 
 
 def make_shard(range_list, rank, world, group=None):

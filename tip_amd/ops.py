@@ -808,7 +808,7 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
 # ---------------------------------------------------------------------------------------------
 # static graph containers (plans in both directions + normalisers)
 # ---------------------------------------------------------------------------------------------
-PAIR_FWD_MAX_WORLD = 4   # relation-sharded runs with this many ranks or more use the Y route (see _RGCN.forward)
+PAIR_FWD_MAX_WORLD = 4   # fallback rule when the forward routes cannot be timed (first call under capture): >= 4 ranks -> Y route
 PAIR_KGROUP = 8          # source nodes whose products are summed inside one wavefront of the pair-form product
 
 
@@ -849,6 +849,7 @@ class AggGraph(object):
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
+        self.fwd_route = {}                                # sharded layers: timed choice pair form | Y route (ops._fwd_route)
 
     @property
     def rl_fwd(self):
@@ -985,6 +986,46 @@ def matmul(x, w):
     return _MatMul.apply(x, w)
 
 
+def _fwd_route(graph, x, basis, att, pair, shard):
+    """'pair' | 'y': the faster forward route of a relation-SHARDED layer for this rank's relations, timed once per
+    (graph, layer width) with HIP events on the launch stream (3 runs each after a warm-up) and remembered on the graph."""
+    n = x.shape[0]
+    nb, _, d_out = basis.shape
+    r = att.shape[0]
+    key = (int(n), int(nb), int(d_out), int(r))
+    hit = graph.fwd_route.get(key)
+    if hit is not None:
+        return hit[0]
+    if torch.cuda.is_current_stream_capturing() or _TIMING is not None:
+        return 'y' if shard.world >= PAIR_FWD_MAX_WORLD else 'pair'
+    with torch.no_grad():
+        cells, xb_nb = graph.pair_buffers(n, nb, d_out, x.device)
+        xb = gemm(x, basis)
+        gemm(x, basis, out=xb_nb[:n].permute(1, 0, 2))
+
+        def pair_route():
+            stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
+            return sum_slabs(pair_product(cells, xb_nb, symmetric=pair.symmetric).view(-1, n, d_out))
+        use_rl = rel_gather_usable(graph.rl_fwd, n, d_out, False)
+
+        def y_route():
+            y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out)
+            return sum_slabs(rel_gather(graph.rl_fwd, y, backward=False, reduce=False)) if use_rl else gather_sum(graph.fwd, y)
+        times = {}
+        for name, fn in (('pair', pair_route), ('y', y_route)):
+            fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                fn()
+            b.record()
+            torch.cuda.synchronize(x.device)
+            times[name] = a.elapsed_time(b) / 3 * 1e3
+    choice = 'pair' if times['pair'] <= times['y'] else 'y'
+    graph.fwd_route[key] = (choice, times)
+    return choice
+
+
 class _RGCN(torch.autograd.Function):
     """One basis-decomposed R-GCN layer with global-mean aggregation
     (reference MyRGCNConv2 / MyRGCNConv, src/layers.py:102-193 / :21-99):
@@ -1010,16 +1051,20 @@ class _RGCN(torch.autograd.Function):
         nb, _, d_out = basis.shape
         r = att.shape[0]
         pair = graph.pair_fwd if r > 0 else None
-        if shard is not None and shard.world >= PAIR_FWD_MAX_WORLD:
-            # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (20 us at BioSNAP, whatever
-            # the rank's share of the relations); the Y route scales with the share: (25 + 48) us / world per layer
-            pair = None
         if pair is not None and pair.symmetric and not lib().tipk_pair_product_supported(nb, d_out):
             pair = None                                      # only the dedicated product kernel reads mirrored cells
         if pair is not None and not (pair.n_table == r and pair.n_rows == n * n and stream_gather_split(r, nb)
                                      and (nb // stream_gather_split(r, nb)) // 4 == pair.lanes
                                      and not os.environ.get('TIPK_NO_PAIR_FWD')):
             pair = None
+        if pair is not None and shard is not None and shard.world > 1:
+            # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (16 us at BioSNAP, whatever
+            # the rank's share of the relations); the Y route (Y = att . XB + unit gather) scales with the share.  Which
+            # is faster for THIS rank's share is measured once per graph (both routes give the same partial aggregate
+            # up to rounding, so ranks may differ); a first call under graph capture cannot time anything and falls back
+            # to the rule of thumb from the 1-GPU timings (4 ranks or more: Y route)
+            if _fwd_route(graph, x, basis, att, pair, shard) == 'y':
+                pair = None
         if pair is not None:
             # PAIR FORM.  sum_r A_r X W_r = sum_{(u -> v)} sum_b C[v, u, b] XB_b[u],  C[v, u, :] = sum of att[r, :] over
             # the relations r that link u -> v.  A BioSNAP drug pair is linked by 66 relations on average, so the
