@@ -30,3 +30,9 @@ done
 fi
 python3 tools/summarize_prof.py $OUT $TAG
 ls -la $OUT profiles | head -60
+# 5. timeline of one replayed step, the graphed training epoch (trace + timeline), kept next to the summaries
+python3 tools/step_timeline.py $OUT/trace > profiles/${TAG}_step_timeline.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 tools/trace_train.py > $OUT/train.log 2>&1
+python3 tools/step_timeline.py $OUT/train distmult_objective_kernel > profiles/${TAG}_train_timeline.txt 2>&1
+grep "ms/epoch" $OUT/train.log >> profiles/${TAG}_train_timeline.txt
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
