@@ -526,6 +526,28 @@ def test_distmult_fused_objective(ops):
     loss_only, a, b = ops.distmult_loss(zd, wd, pos.to(DEV), neg.to(DEV), et.to(DEV), need_grad=False)
     assert a is None and b is None
     close(loss_only, O.tip_loss(ps, ns).view(1), rtol=2e-5)
+    # narrower decoders (distmult_objective_kernel<., 8 | 4>: 8 / 16 positions per scatter instruction, shuffles instead of
+    # DPP row broadcasts), int32 ids, and the k/4-lanes-per-position task kernel as cross-check
+    from tip_amd import _lib
+    for kk, idt in ((8, torch.int64), (4, torch.int32), (16, torch.int32)):
+        zk, wk = z[:, :kk].contiguous(), w[:, :kk].contiguous()
+        args = (zk.to(DEV), wk.to(DEV), pos.to(DEV, idt), neg.to(DEV, idt), et.to(DEV, idt))
+        lk, gzk, gwk = ops.distmult_loss(*args)
+        psk, nsk = O.distmult_fwd(zk.double(), pos, et, wk.double()), O.distmult_fwd(zk.double(), neg, et, wk.double())
+        close(lk, O.tip_loss(psk, nsk).view(1), rtol=2e-5)
+        gpk, gnk = O.tip_loss_bwd(psk, nsk)
+        a1, b1 = O.distmult_bwd(gpk, zk.double(), pos, et, wk.double())
+        a2, b2 = O.distmult_bwd(gnk, zk.double(), neg, et, wk.double())
+        close(gzk, a1 + a2, atol=2e-6)
+        close(gwk, b1 + b2, atol=2e-6)
+        again = ops.distmult_loss(*args)
+        assert torch.equal(again[0], lk) and torch.equal(again[1], gzk) and torch.equal(again[2], gwk)
+        _lib.set_option('dm_task_kernel', 1)
+        lt, gzt, gwt = ops.distmult_loss(*args)
+        _lib.set_option('dm_task_kernel', 0)
+        close(lt, lk.cpu(), rtol=1e-5)
+        close(gzt, gzk.cpu(), rtol=1e-4, atol=1e-7)
+        close(gwt, gwk.cpu(), rtol=1e-4, atol=1e-7)
 
 
 def test_distmult_fused_objective_mirrored_positives(ops, monkeypatch):

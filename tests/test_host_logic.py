@@ -524,3 +524,32 @@ def test_segmented_gather_plan_semantics_and_launch_order():
     with pytest.raises(ValueError):                                      # edges not grouped by relation
         build_gather_plan_segmented(dst, rel * N + src, torch.flip(rel, [0]) // 4, N, R * N, 16)
     assert relations_per_segment(10000, 128) == 13 and relations_per_segment(10 ** 9, 128) == 1
+
+
+def test_bench_roofline_helpers(tmp_path, monkeypatch):
+    """bench.py's bookkeeping (no GPU): PMC summaries are only quoted when they carry the build id of the running library,
+    the step floor prices every launch by its own bound, the roofline object of an MFMA kernel reports both flop counts."""
+    import importlib
+    import json as js
+    bench = importlib.import_module('bench')
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    doc = {'build_id': 'aaaa', 'step_hbm_bytes': 9.0e8,
+           'kernels': {'node_products_kernel<1> grid=294144x1x1': {'hbm_bytes_per_launch': 1.0e8}}}
+    (prof / 'r09_pmc_traffic.json').write_text(js.dumps(doc))
+    (prof / 'r09_kernel_by_grid.csv').write_text('# x\nkernel_and_grid,calls,avg_ns,min_ns,max_ns\n"node_products_kernel<1> grid=294144x1x1",5,40500,1,2\n')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    assert bench.pmc_traffic('node_products_kernel', None, 'bbbb') == (None, None, None)          # other build: dropped
+    t, us, src = bench.pmc_traffic('node_products_kernel', None, 'aaaa')
+    assert t == 1.0e8 and abs(us - 40.5) < 1e-9 and src == 'r09_pmc_traffic.json'
+    assert bench.step_hbm_bytes('bbbb') is None and bench.step_hbm_bytes('aaaa')[0] == 9.0e8
+    rec = {'label': 'node_products[dd.bwd,d=32]', 'key': 'node_products_kernel', 'grid': None, 'bound': 'mfma', 'work': 1.35e9,
+           'rows': 329188, 'flops_dense_form': 2.9e9}
+    roof = bench.roofline_of(rec, 40.0, 'aaaa')
+    assert roof['bound'] == 'mfma' and abs(roof['frac'] - 1.35e9 / 40e-6 / bench.MFMA_F32_PEAK) < 1e-12
+    assert abs(roof['frac_dense_form'] - 2.9e9 / 40e-6 / bench.MFMA_F32_PEAK) < 1e-12 and roof['traffic'] == 1.0e8
+    launches = [rec, {'label': 'rel_stream[dd.bwd,d=32]', 'key': 'k', 'grid': 'g', 'bound': 'lds', 'work': 1.1e9, 'aggregation': True}]
+    kern = {'gather_sum[pp.fwd,d=32]': (3, 0.02), 'node_products[x]': (3, 0.04), 'rel_stream[y]': (3, 0.03), 'misc': (6, 0.005)}
+    fl = bench.step_floor({}, launches, kern, 1_450_000, {})
+    assert fl['launches_per_step'] == 5 and abs(fl['parts_us']['node_products[dd.bwd,d=32]'] - 1.35e9 / bench.MFMA_F32_PEAK * 1e6) < 0.01
+    assert abs(fl['us'] - sum(fl['parts_us'].values())) < 0.05 and fl['parts_us']['2 other launches x 2.0 us'] == 4.0

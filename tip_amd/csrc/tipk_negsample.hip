@@ -36,6 +36,21 @@ __device__ __forceinline__ uint64_t call_key(uint64_t seed, uint64_t n) {
 
 __global__ void counter_advance_kernel(uint64_t* counter) { *counter += 1; }
 
+// (u, v) = (cand / n, cand % n).  n^2 < 2^32 for every graph whose ids fit 16 bits: one 32-bit division (a 64-bit
+// division by a run-time value is ~100 instructions per position) -- the same integers either way.
+template <typename OT>
+__device__ __forceinline__ void split_pair(uint64_t cand, int64_t n_nodes, OT* u, OT* v) {
+    if (n_nodes <= 65535) {
+        const uint32_t c = (uint32_t)cand, n = (uint32_t)n_nodes;
+        const uint32_t q = c / n;
+        *u = (OT)q;
+        *v = (OT)(c - q * n);
+    } else {
+        *u = (OT)(cand / (uint64_t)n_nodes);
+        *v = (OT)(cand % (uint64_t)n_nodes);
+    }
+}
+
 template <typename OT>
 __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restrict__ keys,
                                                          const int64_t* __restrict__ rel_ptr, int64_t n_rel,
@@ -67,8 +82,7 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
         }
         if (l == b || (uint64_t)keys[l] != cand) break;
     }
-    out_u[e] = (OT)(cand / (uint64_t)n_nodes);
-    out_v[e] = (OT)(cand % (uint64_t)n_nodes);
+    split_pair(cand, n_nodes, out_u + e, out_v + e);
 }
 
 // Bitmap variant (n_nodes^2 bits fit in LDS: BioSNAP 645^2 bits = 52 KB): a persistent 1024-thread
@@ -105,8 +119,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
                 cand = __umul64hi(philox64((uint64_t)(e + off), (uint32_t)attempt, k0, k1), nn);
                 if (!((bm[cand >> 5] >> (cand & 31)) & 1u)) break;
             }
-            out_u[e] = (OT)(cand / (uint64_t)n_nodes);
-            out_v[e] = (OT)(cand % (uint64_t)n_nodes);
+            split_pair(cand, n_nodes, out_u + e, out_v + e);
         }
     }
 }

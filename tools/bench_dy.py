@@ -12,7 +12,7 @@ for ncol in (20640, 10320):
     lib().tipk_rgcn_dy_products_plan(R, ncol, B, C.byref(s_c), C.byref(s_r))
     dxb = torch.empty(s_r.value, B, ncol, device=dev); datt = torch.empty(s_c.value, R, B, device=dev)
     def run():
-        check(lib().tipk_rgcn_dy_products(ptr(gy), ncol, ptr(att), B, ptr(xb2), ncol, R, ncol, B, ptr(dxb), ptr(datt),
+        check(lib().tipk_rgcn_dy_products(ptr(gy), ncol, ptr(att), B, ptr(xb2), ncol, R, ncol, B, None, 0, ptr(dxb), ptr(datt),
                                           stream_ptr(dev)), 'dy')
     for dbg in (0, 1, 2, 4, 3, 6, 7):
         set_option('dp_debug', dbg)
