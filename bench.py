@@ -598,7 +598,8 @@ def train_step_record(dev, epochs=20):
     from tip_amd.train import GraphedTrainStep
     torch.manual_seed(1111)
     model = TIP(Setting(), dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=True)
+    from tip_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=0.01)                        # tipk_adam_step: one launch, device-side step count
     step = GraphedTrainStep(model, opt)
     for _ in range(3):
         step()
@@ -612,7 +613,7 @@ def train_step_record(dev, epochs=20):
     loss = float(step())
     rec = {'ms_per_epoch': ms, 'edges_per_s': E / (ms * 1e-3), 'epochs_timed': epochs, 'loss_after': loss,
            'what': 'hipGraph replay of zero_grad + typed negative sampling + encoder + fused DistMult objective + backward + '
-                   'fused Adam (tip_amd/train.py), TIP-cat BioSNAP R=%d' % model.data.n_dd_et}
+                   'Adam in one launch (tip_amd/optim.py, tip_amd/train.py), TIP-cat BioSNAP R=%d' % model.data.n_dd_et}
     del step, opt, model
     release()
     return rec

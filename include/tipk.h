@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 10
+#define TIPK_ABI_VERSION 11
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -377,6 +377,9 @@ int tipk_col_sum(const float* in, int64_t ld_in, int64_t rows, int64_t cols,
  * 4. DistMult decoder  score(u,v,r) = sigma( sum_k z[u,k] z[v,k] w[r,k] )
  *    replaces MultiInnerProductDecoder.forward, src/layers.py:590-592 (K9) and its backward.
  *    idx_bytes / et_bytes: 4 (int32) or 8 (int64, the reference's dtype) -- read in place.
+ *    tipk_distmult_loss and tipk_typed_negative_sampling also take idx_bytes = 2: PACKED pairs, one uint32 word
+ *    u | v << 16 per triple in the `_u` array (the `_v` pointer is unused; n_nodes <= 65535) -- the static positives
+ *    are narrowed once, the sampler emits its negatives in this form: 66 MB of ids per BioSNAP step instead of 266 MB.
  */
 int tipk_distmult_fwd(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                       const void* idx_u, const void* idx_v, int idx_bytes,
@@ -422,6 +425,14 @@ int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_
                        int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
                        const int32_t* tasks, int64_t n_tasks,
                        float* loss_out, float* g_z, float* g_w, void* workspace, tipk_stream_t stream);
+/* Same, but loss_out / g_z / g_w are OVERWRITTEN (they need not be zeroed: three fill launches less per training
+ * step; the bits are those of tipk_distmult_loss on zeroed outputs).  Only the workspace path can do that (its finalize
+ * launch visits every output element): TIPK_EUNSUPPORTED otherwise, nothing launched. */
+int tipk_distmult_loss_store(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                             const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
+                             int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
+                             const int32_t* tasks, int64_t n_tasks,
+                             float* loss_out, float* g_z, float* g_w, void* workspace, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 4b. NNDecoder triple scoring (reference src/layers.py:598-637, the paper's DR-NN ablation; SURVEY
@@ -455,15 +466,16 @@ int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
  * call_counter != NULL: a sampler STREAM whose state lives on the device, uint64[2] = { position, seed }:
  * the Philox key is splitmix64(state[1] + (state[0] + 1) * 0x9E3779B97F4A7C15) and the host `seed`
  * argument is ignored -- a captured hipGraph draws new negatives on every replay
- * (`tipk_counter_advance` on state[0] is the next node), and re-seeding after capture (a device-side
- * write of the two words) takes effect in the replays.
+ * and re-seeding after capture (a device-side write of the words) takes effect in the replays.  The position moves
+ * on either by `tipk_counter_advance` on state[0] (a launch of its own), or -- advance != 0, state then is uint64[3] =
+ * { position, seed, ticket (0) } -- inside the sampling launch: its last workgroup to finish stores position + 1.
  * pos_offset (nullable, int64 [n_rel]): the Philox counter of position e of relation r is e + pos_offset[r] -- a rank
  * of a relation-sharded run passes (start of r's block in the WHOLE triple list) - rel_ptr[r], so that its negatives
  * are exactly the negatives the unsharded run draws for those relations, whatever the number of ranks.
  */
 int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
-                                 const uint64_t* call_counter /* nullable device uint64[2], see above */,
+                                 uint64_t* call_counter /* nullable device uint64[2 or 3], see above */, int advance,
                                  const int32_t* wg_rel_ptr /* nullable */, const int32_t* wg_rels, int64_t n_wg,
                                  const int64_t* pos_offset /* nullable */,
                                  void* out_u, void* out_v, int idx_bytes,
@@ -532,6 +544,22 @@ int tipk_ipc_open(const void* handle /* 64 bytes, host */, void** ptr);
 int tipk_ipc_close(void* ptr);
 int tipk_peer_allreduce(float* data, int64_t n, void* const* mailboxes /* host [world] */, int rank, int world,
                         int64_t max_floats, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 9. Optimizer step of the training loop -- replaces `optimizer.step()` of tip.py:24-30
+ *    (torch.optim.Adam(model.parameters(), lr=0.01): amsgrad off, maximize off, L2 weight decay).
+ *    ONE launch over a list of fp32 tensors (host arrays [n_tensors] of device pointers; element i of params, grads,
+ *    exp_avg, exp_avg_sq must share one dense layout of numel[i] elements):
+ *        g += weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g;
+ *        p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),      t = *steps[i] + 1
+ *    steps: host array [n_tensors] of device uint64 words, the steps tensor i has made (torch keeps the count per
+ *    parameter: one without a gradient sits the step out); ticket: device uint64, 0.  The launch's last workgroup adds 1 to
+ *    the counts of its tensors -- a captured hipGraph keeps counting on replay.  Tensors with numel 0 are skipped (their
+ *    count does not move).  The addresses are kernel arguments (48 tensors per launch, longer lists take several
+ *    launches): nothing is uploaded, nothing allocated. */
+int tipk_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, uint64_t* const* steps, uint64_t* ticket /* device */,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, tipk_stream_t stream);
 
 #ifdef __cplusplus
 }

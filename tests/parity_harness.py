@@ -63,7 +63,8 @@ def run_parity(dd, mod='cat', epochs=10, dev='cuda:0', threads=16, snapshots=(),
     for k in sd:
         sd[k] = p[k[len('encoder.'):]].clone() if k.startswith('encoder.') else p[k].clone()
     model.load_state_dict(sd)
-    opt = torch.optim.Adam(model.parameters(), lr=st.lr)
+    from tip_amd.optim import Adam                     # the product's optimizer step (tipk_adam_step), checked against OracleAdam
+    opt = Adam(model.parameters(), lr=st.lr)
     po = {k: v.clone() for k, v in p.items()}
     oopt = OracleAdam(po, st.lr)
     d = model.data

@@ -550,6 +550,57 @@ def test_distmult_fused_objective(ops):
         close(gwt, gwk.cpu(), rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('k', [16, 8, 4])
+def test_distmult_fused_objective_packed_pairs_bit_identical(ops, k):
+    """idx_bytes = 2 (include/tipk.h section 4): the pairs as one 32-bit word u | v << 16.  Same kernel, same order of
+    operations -> loss, d z and d w are BIT-IDENTICAL to the int64-id call; the sampler's packed output holds exactly the
+    pairs of its int64 output; shapes the packed kernel does not take fall back to plain ids with the same result."""
+    from tip_amd import neg_sampling as NS
+    g = torch.Generator().manual_seed(21)
+    n, r = 645, 37
+    sizes = torch.randint(0, 3000, (r,), generator=g)
+    halves = [torch.randint(0, n, (2, int(c)), generator=g) for c in sizes]
+    pos = torch.cat([torch.cat([h, h.flip(0)], dim=1) for h in halves], dim=1).to(DEV)      # mirrored like TIP's positives
+    et = torch.repeat_interleave(torch.arange(r), 2 * sizes).to(DEV)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(2 * sizes, 0)])
+    rg = torch.stack([ptr[:-1], ptr[1:]], 1)
+    neg = NS.typed_negative_sampling(pos, n, rg, seed=77)
+    neg_p = NS.typed_negative_sampling(pos, n, rg, seed=77, packed=True)
+    assert neg_p.dtype == torch.int32 and neg_p.shape == (pos.shape[1],) and neg_p._tipk_packed_pairs
+    assert torch.equal(ops.unpack_pairs(neg_p), neg)
+    assert torch.equal(ops.unpack_pairs(ops.packed_pairs(pos, n)), pos)
+    z = (torch.randn(n, k, generator=g) * 0.7).to(DEV)
+    w = (torch.randn(r, k, generator=g) * 0.5).to(DEV)
+    want = ops.distmult_loss(z, w, pos, neg, et)
+    got = ops.distmult_loss(z, w, pos, neg_p, et)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    lo = ops.distmult_loss(z, w, pos, neg_p, et, need_grad=False)
+    assert torch.equal(lo[0], want[0]) and lo[1] is None
+    # ids up to 65534 survive the 16-bit halves (sign bit of the word included)
+    n_big = 65535
+    pos_b = torch.randint(0, n_big, (2, 5000), generator=g).to(DEV)
+    pos_b[:, :4] = torch.tensor([[65534, 0, 65534, 32768], [65534, 65534, 0, 32767]], device=DEV)
+    assert torch.equal(ops.unpack_pairs(ops.packed_pairs(pos_b, n_big)), pos_b)
+    et_b = torch.sort(torch.randint(0, 5, (5000,), generator=g)).values.to(DEV)
+    cnt = torch.bincount(et_b.cpu(), minlength=5)
+    pb = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(cnt, 0)])
+    rg_b = torch.stack([pb[:-1], pb[1:]], 1)
+    nb = NS.typed_negative_sampling(pos_b, n_big, rg_b, seed=5)
+    nbp = NS.typed_negative_sampling(pos_b, n_big, rg_b, seed=5, packed=True)
+    assert torch.equal(ops.unpack_pairs(nbp), nb)
+    zb = (torch.randn(n_big, k, generator=g) * 0.5).to(DEV)
+    wb = (torch.randn(5, k, generator=g) * 0.5).to(DEV)
+    # (z too large for the LDS image: both calls run the generic float-atomic kernel on plain ids)
+    for a, b in zip(ops.distmult_loss(zb, wb, pos_b, nbp, et_b), ops.distmult_loss(zb, wb, pos_b, nb, et_b)):
+        close(a, b.cpu(), rtol=1e-4, atol=1e-7)
+    # a width the objective kernel does not take (k = 32): packed negatives are widened, result as with plain ids
+    z32 = (torch.randn(n, 32, generator=g) * 0.5).to(DEV)
+    w32 = (torch.randn(r, 32, generator=g) * 0.5).to(DEV)
+    for a, b in zip(ops.distmult_loss(z32, w32, pos, neg_p, et), ops.distmult_loss(z32, w32, pos, neg, et)):
+        close(a, b.cpu(), rtol=1e-4, atol=1e-7)
+
+
 def test_distmult_fused_objective_mirrored_positives(ops, monkeypatch):
     """TIP's positives list every pair in both directions per relation: the mirrored half is skipped and
     the first half counted twice -- same loss and gradients as the plain evaluation and as the oracle."""

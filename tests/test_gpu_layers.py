@@ -495,7 +495,8 @@ def test_graphed_train_step_matches_eager():
     for graphed in (False, True):
         torch.manual_seed(5)
         model = TIP(st, torch.device(DEV), data=dd)
-        opt = torch.optim.Adam(model.parameters(), lr=st.lr, capturable=True)
+        from tip_amd.optim import Adam
+        opt = Adam(model.parameters(), lr=st.lr)
         NS.manual_seed(123)
         out = []
         if graphed:

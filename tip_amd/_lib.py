@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class TipkError(RuntimeError):
@@ -87,9 +87,10 @@ SIGNATURES = {
     'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P, _P, _P]),
     'tipk_distmult_workspace_bytes': (_L, [_L, _I, _L]),
     'tipk_distmult_loss': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
+    'tipk_distmult_loss_store': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
     'tipk_pair_table_fwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_pair_table_bwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P]),
-    'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _P, _P, _L, _P, _P, _P, _I, _L, _P]),
+    'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _I, _P, _P, _L, _P, _P, _P, _I, _L, _P]),
     'tipk_counter_advance': (_I, [_P, _P]),
     'tipk_rank_metrics': (_I, [_P, _P, _P, _L, _L, _P, _P]),
     'tipk_peer_mailbox_bytes': (_L, [_I, _L]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     'tipk_ipc_open': (_I, [_P, C.POINTER(_P)]),
     'tipk_ipc_close': (_I, [_P]),
     'tipk_peer_allreduce': (_I, [_P, _L, C.POINTER(_P), _I, _I, _L, _P]),
+    'tipk_adam_step': (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_L), C.POINTER(_P), _P,
+                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),
     'tipk_split_scatter': (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
     const int ld = k + 4;                                     // z image: float4 reads, 16-byte aligned rows
     const int lg = k + 1;                                     // d z image: odd stride = all banks
     unsigned long long* gzl = lds64;                          // [n_nodes][k+1] fixed point
-    float* zl = (float*)(gzl + (int64_t)n_nodes * lg);        // [n_nodes][k+4]
+    float* zl = (float*)(gzl + (((int64_t)n_nodes * lg + 1) & ~1LL));   // [n_nodes][k+4], 16-BYTE ALIGNED: rows are read as b128 (an
+                                                              // image that starts on an odd 8-byte word costs SQ_LDS_UNALIGNED_STALL on every read)
     float* red = zl + (((int64_t)n_nodes * ld + 3) & ~3LL);   // [16 waves][k] + [16]
     uint16_t* ixl = reinterpret_cast<uint16_t*>(red + 16 * k + 16);   // [4][TASK_MAX] ids of the current task
     const bool want_grad = g_z != nullptr;
@@ -458,6 +459,11 @@ __global__ __launch_bounds__(1024) void distmult_task_kernel(
 // (phase 2 below: ids and coefficients travel by wave shuffles), so that one LDS atomic instruction touches 64 / k
 // rows of the fixed-point d z image as contiguous pieces; d w[r] is summed per task: a column per lane -> the
 // wave's groups by shuffles -> 16 waves through LDS -> one fixed-point add per column.
+// idx_bytes = 2 of tipk_distmult_loss: a pair of 16-bit node ids in one 32-bit word (u | v << 16), one array per triple
+// list -- the positives of the path are static and narrowed once, the negatives come from the sampler in this form:
+// 66 MB of ids per BioSNAP step instead of the 266 MB of four int64 arrays
+struct PackedPair { uint32_t w; };
+
 template <int I>
 __device__ __forceinline__ int pr_row_bcast(int x) {      // lane I of every 16-lane DPP row, broadcast to its row
     return __builtin_amdgcn_update_dpp(0, x, 0x150 + (I & 15), 0xf, 0xf, false);
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
     const int t = threadIdx.x;
     constexpr int ld = K + 4, lg = K + 1;
     unsigned long long* gzl = lds64;                                      // [n_nodes][K + 1] fixed point
-    float* zl = (float*)(gzl + (int64_t)n_nodes * lg);                    // [n_nodes][K + 4]
+    float* zl = (float*)(gzl + (((int64_t)n_nodes * lg + 1) & ~1LL));     // [n_nodes][K + 4], 16-byte aligned (b128 row reads)
     float* red = zl + (((int64_t)n_nodes * ld + 3) & ~3LL);               // [16 waves][K] + [16]
     float zmax = 0.f, wmax = 0.f;
     for (int i = t; i < n_nodes * K; i += 1024) {
@@ -524,7 +530,12 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         const int tb = tasks[4 * task + 1], te = tasks[4 * task + 2];
         int64_t q = (int64_t)tb + h * 1024 + t;
         q = q < te ? q : (int64_t)te - 1;
-        o.pu = (int)pu[q]; o.pv = (int)pv[q]; o.nu = (int)nu[q]; o.nv = (int)nv[q];
+        if constexpr (std::is_same<IT, PackedPair>::value) {               // one 32-bit word per pair: u | v << 16
+            const uint32_t pw = pu[q].w, nw = nu[q].w;
+            o.pu = (int)(pw & 0xffffu); o.pv = (int)(pw >> 16); o.nu = (int)(nw & 0xffffu); o.nv = (int)(nw >> 16);
+        } else {
+            o.pu = (int)pu[q]; o.pv = (int)pv[q]; o.nu = (int)nu[q]; o.nv = (int)nv[q];
+        }
     };
     Ids cur0, cur1, nx0, nx1;
     fetch(blockIdx.x, 0, cur0);
@@ -638,7 +649,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
 inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
     if (k % 4 != 0 || k < 4 || k > 64 || (k & (k - 1)) != 0) return false;
     if (n_nodes > 65535) return false;                    // ids are staged as 16-bit values
-    *lds_bytes = n_nodes * (k + 1) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float) +
+    *lds_bytes = ((n_nodes * (k + 1) + 1) & ~1LL) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * (int64_t)sizeof(float) +
                  4 * TASK_MAX * 2;
     return *lds_bytes <= 158 * 1024;
 }
@@ -646,27 +657,28 @@ inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
 // ws layout (u64 words): [n_nodes*k] d z | [n_rel*k] d w | [1] loss | 3 doubles: the three scales.
 // Converts, ADDS into the outputs (same contract as the float path) and zeroes the words again, so the caller's
 // workspace is reusable without a memset.
+// store != 0: the outputs are OVERWRITTEN (0 + value, the same bits as adding into zeroed outputs) -- no zero fills.
 __global__ __launch_bounds__(256) void det_finalize_kernel(unsigned long long* ws, int64_t n_z, int64_t n_w,
-                                                           float* loss_out, float* g_z, float* g_w) {
+                                                           float* loss_out, float* g_z, float* g_w, int store) {
     const double* sc = reinterpret_cast<const double*>(ws + n_z + n_w + 1);
     const double inv_z = 1.0 / sc[0], inv_w = 1.0 / sc[1], inv_l = 1.0 / sc[2];
     const int64_t total = n_z + n_w + 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const long long a = (long long)ws[i];
-        if (a == 0) continue;
-        ws[i] = 0ull;
-        if (i < n_z) { if (g_z) g_z[i] += (float)((double)a * inv_z); }
-        else if (i < n_z + n_w) { if (g_w) g_w[i - n_z] += (float)((double)a * inv_w); }
-        else loss_out[0] += (float)((double)a * inv_l);
+        if (a == 0 && !store) continue;
+        if (a != 0) ws[i] = 0ull;
+        if (i < n_z) { if (g_z) g_z[i] = (store ? 0.0f : g_z[i]) + (float)((double)a * inv_z); }
+        else if (i < n_z + n_w) { if (g_w) g_w[i - n_z] = (store ? 0.0f : g_w[i - n_z]) + (float)((double)a * inv_w); }
+        else loss_out[0] = (store ? 0.0f : loss_out[0]) + (float)((double)a * inv_l);
     }
 }
 
 int launch_finalize(int64_t n_nodes, int k, int64_t n_rel, float* loss_out, float* g_z, float* g_w, unsigned long long* ws,
-                    hipStream_t st) {
+                    hipStream_t st, int store) {
     const int64_t n_z = n_nodes * k, n_w = n_rel * k;
     const int64_t blocks = tipk_ceil_div(n_z + n_w + 1, 256);
     hipLaunchKernelGGL(det_finalize_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, ws, n_z,
-                       n_w, loss_out, g_z, g_w);
+                       n_w, loss_out, g_z, g_w, store);
     TIPK_RETURN_LAUNCH();
 }
 
@@ -674,7 +686,7 @@ template <typename IT, int MODE>
 int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, int64_t n_rel, const int32_t* tasks,
                  int64_t n_tasks, const void* pu, const void* pv, const void* nu, const void* nv,
                  const float* g_score, int sig, int64_t n_total, float* loss_out, float* g_z, float* g_w,
-                 int64_t lds_bytes, hipStream_t st, unsigned long long* ws = nullptr) {
+                 int64_t lds_bytes, hipStream_t st, unsigned long long* ws = nullptr, int store = 0) {
     auto kern = distmult_task_kernel<IT, MODE>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return tipk_hip_status(e);
@@ -682,14 +694,15 @@ int launch_tasks(const float* z, int64_t n_nodes, int k, const float* w, int64_t
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), (size_t)lds_bytes, st, z, (int)n_nodes, k, w, (int)n_rel,
                        tasks, (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, g_score, sig,
                        n_total, loss_out, g_z, g_w, MODE == 1 ? ws : nullptr, TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG)));
-    if (ws && MODE == 1) return launch_finalize(n_nodes, k, n_rel, loss_out, g_z, g_w, ws, st);
+    if (ws && MODE == 1) return launch_finalize(n_nodes, k, n_rel, loss_out, g_z, g_w, ws, st, store);
     TIPK_RETURN_LAUNCH();
 }
 
 int launch_objective(const float* z, int64_t n_nodes, int k, const float* w, int64_t n_rel, const int32_t* tasks,
                      int64_t n_tasks, const void* pu, const void* pv, const void* nu, const void* nv, int idx_bytes,
-                     int64_t n_total, float* loss_out, float* g_z, float* g_w, unsigned long long* ws, hipStream_t st) {
-    const size_t lds = (size_t)(n_nodes * (k + 1) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * 4);
+                     int64_t n_total, float* loss_out, float* g_z, float* g_w, unsigned long long* ws, hipStream_t st,
+                     int store) {
+    const size_t lds = (size_t)(((n_nodes * (k + 1) + 1) & ~1LL) * 8 + (((n_nodes * (k + 4) + 3) & ~3LL) + 16 * k + 16) * 4);
     const int64_t grid = n_tasks < 256 ? n_tasks : 256;              // one persistent workgroup per CU
     const int dbg = TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG));
 #define OBJ(IT, KK)                                                                                                      \
@@ -702,11 +715,12 @@ int launch_objective(const float* z, int64_t n_nodes, int k, const float* w, int
                            g_z != nullptr ? 1 : 0, ws, dbg);                                                             \
     }
     if (idx_bytes == 8) { if (k == 4) OBJ(int64_t, 4) else if (k == 8) OBJ(int64_t, 8) else OBJ(int64_t, 16) }
-    else { if (k == 4) OBJ(int32_t, 4) else if (k == 8) OBJ(int32_t, 8) else OBJ(int32_t, 16) }
+    else if (idx_bytes == 4) { if (k == 4) OBJ(int32_t, 4) else if (k == 8) OBJ(int32_t, 8) else OBJ(int32_t, 16) }
+    else { if (k == 4) OBJ(PackedPair, 4) else if (k == 8) OBJ(PackedPair, 8) else OBJ(PackedPair, 16) }
 #undef OBJ
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return tipk_hip_status(le);
-    return launch_finalize(n_nodes, k, n_rel, loss_out, g_z, g_w, ws, st);
+    return launch_finalize(n_nodes, k, n_rel, loss_out, g_z, g_w, ws, st, store);
 }
 
 constexpr int64_t LDS_GZ_LIMIT = 96 * 1024;
@@ -814,32 +828,37 @@ extern "C" int64_t tipk_distmult_workspace_bytes(int64_t n_nodes, int k, int64_t
     return (n_nodes * k + n_rel * k + 1 + 3) * 8;
 }
 
-extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
-                                  const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
-                                  int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
-                                  const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
-                                  void* workspace, tipk_stream_t stream) {
+static int distmult_loss_impl(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                              const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
+                              int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
+                              const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
+                              void* workspace, tipk_stream_t stream, int store) {
     if (n_triples <= 0 || k <= 0 || n_nodes < 0 || n_rel < 0 || n_tasks < 0) return TIPK_EINVAL;
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7)) return TIPK_EINVAL;
     unsigned long long* ws = reinterpret_cast<unsigned long long*>(workspace);
-    if (!z || !rel_w || !pos_u || !pos_v || !neg_u || !neg_v || !edge_type || !loss_out) return TIPK_EINVAL;
+    if (!z || !rel_w || !pos_u || !neg_u || !edge_type || !loss_out) return TIPK_EINVAL;
+    if (idx_bytes != 2 && (!pos_v || !neg_v)) return TIPK_EINVAL;
     if ((g_z == nullptr) != (g_w == nullptr)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = vec_ok(z, rel_w, k);
     int64_t lds_bytes = 0;
+    if (idx_bytes == 2 && !(tasks && n_tasks > 0 && vec)) return TIPK_EUNSUPPORTED;
     if (tasks && n_tasks > 0 && vec && n_tasks < 0x7fffffffLL && task_path_ok(n_nodes, k, &lds_bytes)) {
-        if (ws && (k == 4 || k == 8 || k == 16) && (idx_bytes == 8 || idx_bytes == 4) && n_nodes <= 0x7fffffffLL &&
-            !tipk_option(TIPK_OPT_DM_TASK_KERNEL))
+        if (idx_bytes == 2 && !(ws && (k == 4 || k == 8 || k == 16) && n_nodes <= 65535)) return TIPK_EUNSUPPORTED;
+        if (ws && (k == 4 || k == 8 || k == 16) && (idx_bytes == 8 || idx_bytes == 4 || idx_bytes == 2) && n_nodes <= 0x7fffffffLL &&
+            (idx_bytes == 2 || !tipk_option(TIPK_OPT_DM_TASK_KERNEL)))
             return launch_objective(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, idx_bytes,
-                                    n_triples, loss_out, g_z, g_w, ws, st);
+                                    n_triples, loss_out, g_z, g_w, ws, st, store);
+        if (store && !ws) return TIPK_EUNSUPPORTED;       // only the finalize launch of the workspace path can overwrite
         if (idx_bytes == 8)
             return launch_tasks<int64_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
-                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws);
+                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws, store);
         if (idx_bytes == 4)
             return launch_tasks<int32_t, 1>(z, n_nodes, k, rel_w, n_rel, tasks, n_tasks, pos_u, pos_v, neg_u, neg_v, nullptr,
-                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws);
+                                            1, n_triples, loss_out, g_z, g_w, lds_bytes, st, ws, store);
         return TIPK_EINVAL;
     }
+    if (idx_bytes == 2 || store) return TIPK_EUNSUPPORTED;     // packed pairs / overwriting outputs: the workspace path only
 #define CALL(IT, ET)                                                                                             \
     {                                                                                                            \
         if (vec) return launch_grad<IT, ET, 4, 1>(nullptr, nullptr, z, n_nodes, k, rel_w, pos_u, pos_v, neg_u, neg_v, \
@@ -849,4 +868,22 @@ extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const 
     }
     TIPK_DISPATCH_IDX(CALL);
 #undef CALL
+}
+
+extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                                  const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
+                                  int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
+                                  const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
+                                  void* workspace, tipk_stream_t stream) {
+    return distmult_loss_impl(z, n_nodes, k, rel_w, n_rel, pos_u, pos_v, neg_u, neg_v, idx_bytes, edge_type, et_bytes, n_triples,
+                              tasks, n_tasks, loss_out, g_z, g_w, workspace, stream, 0);
+}
+
+extern "C" int tipk_distmult_loss_store(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
+                                        const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
+                                        int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
+                                        const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
+                                        void* workspace, tipk_stream_t stream) {
+    return distmult_loss_impl(z, n_nodes, k, rel_w, n_rel, pos_u, pos_v, neg_u, neg_v, idx_bytes, edge_type, et_bytes, n_triples,
+                              tasks, n_tasks, loss_out, g_z, g_w, workspace, stream, 1);
 }

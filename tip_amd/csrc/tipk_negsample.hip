@@ -3,6 +3,7 @@
 // pair = mulhi64(random64, n^2), rejected while it is a positive of the SAME relation (binary search
 // in that relation's sorted keys, which stay L2-resident).  Bit-exact specification:
 // oracle/philox_sampler.py.
+#include <type_traits>
 #include "tipk_common.h"
 
 namespace {
@@ -36,11 +37,32 @@ __device__ __forceinline__ uint64_t call_key(uint64_t seed, uint64_t n) {
 
 __global__ void counter_advance_kernel(uint64_t* counter) { *counter += 1; }
 
+// In-kernel advance of a sampler stream (state[0] = position, state[2] = ticket): the LAST workgroup to finish moves
+// the position on.  Every workgroup derived its key from `call_no` (a use: the load has completed) before it gets here,
+// so the store cannot be seen by this launch; the next launch on the stream sees it.
+__device__ __forceinline__ void stream_advance(uint64_t* state, int advance, uint64_t call_no) {
+    if (!advance || !state) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* s = reinterpret_cast<unsigned long long*>(state);
+        if (atomicAdd(s + 2, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            s[2] = 0ull;
+            s[0] = call_no + 1ull;
+        }
+    }
+}
+
 // (u, v) = (cand / n, cand % n).  n^2 < 2^32 for every graph whose ids fit 16 bits: one 32-bit division (a 64-bit
 // division by a run-time value is ~100 instructions per position) -- the same integers either way.
+struct PackedOut { uint32_t w; };       // idx_bytes = 2: the pair as ONE 32-bit word u | v << 16 (n_nodes <= 65535), out_v unused
+
 template <typename OT>
 __device__ __forceinline__ void split_pair(uint64_t cand, int64_t n_nodes, OT* u, OT* v) {
-    if (n_nodes <= 65535) {
+    if constexpr (std::is_same<OT, PackedOut>::value) {
+        const uint32_t c = (uint32_t)cand, n = (uint32_t)n_nodes;
+        const uint32_t q = c / n;
+        u->w = q | ((c - q * n) << 16);
+    } else if (n_nodes <= 65535) {
         const uint32_t c = (uint32_t)cand, n = (uint32_t)n_nodes;
         const uint32_t q = c / n;
         *u = (OT)q;
@@ -55,14 +77,15 @@ template <typename OT>
 __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restrict__ keys,
                                                          const int64_t* __restrict__ rel_ptr, int64_t n_rel,
                                                          int64_t n_nodes, uint64_t seed,
-                                                         const uint64_t* __restrict__ call_counter,
+                                                         uint64_t* __restrict__ call_counter, int advance,
                                                          const int64_t* __restrict__ pos_offset,
                                                          OT* __restrict__ out_u, OT* __restrict__ out_v) {
-    const uint64_t key = call_counter ? call_key(call_counter[1], call_counter[0]) : seed;
+    const uint64_t call_no = call_counter ? call_counter[0] : 0ull;
+    const uint64_t key = call_counter ? call_key(call_counter[1], call_no) : seed;
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     const int64_t total = rel_ptr[n_rel];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
+    if (e < total) {
     // relation of position e: largest r with rel_ptr[r] <= e
     int64_t lo = 0, hi = n_rel;
     while (hi - lo > 1) {
@@ -83,6 +106,8 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
         if (l == b || (uint64_t)keys[l] != cand) break;
     }
     split_pair(cand, n_nodes, out_u + e, out_v + e);
+    }
+    stream_advance(call_counter, advance, call_no);
 }
 
 // Bitmap variant (n_nodes^2 bits fit in LDS: BioSNAP 645^2 bits = 52 KB): a persistent 1024-thread
@@ -93,10 +118,11 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
 template <typename OT>
 __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_rel_ptr,
-    const int32_t* __restrict__ wg_rels, int64_t n_nodes, uint64_t seed, const uint64_t* __restrict__ call_counter,
+    const int32_t* __restrict__ wg_rels, int64_t n_nodes, uint64_t seed, uint64_t* __restrict__ call_counter, int advance,
     const int64_t* __restrict__ pos_offset, OT* __restrict__ out_u, OT* __restrict__ out_v) {
     extern __shared__ unsigned bm[];
-    const uint64_t key = call_counter ? call_key(call_counter[1], call_counter[0]) : seed;
+    const uint64_t call_no = call_counter ? call_counter[0] : 0ull;
+    const uint64_t key = call_counter ? call_key(call_counter[1], call_no) : seed;
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
     const int words = (int)((nn + 31) >> 5);
@@ -122,6 +148,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
             split_pair(cand, n_nodes, out_u + e, out_v + e);
         }
     }
+    stream_advance(call_counter, advance, call_no);
 }
 
 }  // namespace
@@ -133,14 +160,14 @@ extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
 }
 
 extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
-                                            int64_t n_nodes, uint64_t seed, const uint64_t* call_counter,
+                                            int64_t n_nodes, uint64_t seed, uint64_t* call_counter, int advance,
                                             const int32_t* wg_rel_ptr, const int32_t* wg_rels, int64_t n_wg,
                                             const int64_t* pos_offset,
                                             void* out_u, void* out_v, int idx_bytes, int64_t n_positions,
                                             tipk_stream_t stream) {
     if (n_rel < 0 || n_nodes <= 0 || n_positions < 0 || n_nodes > 0xffffffffLL) return TIPK_EINVAL;
     if (n_positions == 0 || n_rel == 0) return TIPK_OK;
-    if (!pos_key_sorted || !rel_ptr || !out_u || !out_v) return TIPK_EINVAL;
+    if (!pos_key_sorted || !rel_ptr || !out_u || (!out_v && idx_bytes != 2)) return TIPK_EINVAL;
     const int64_t blocks = tipk_ceil_div(n_positions, 256);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -151,13 +178,19 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
         } else if (idx_bytes == 4) {
             auto kern = neg_sample_bitmap_kernel<int32_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
+        } else if (idx_bytes == 2 && n_nodes <= 65535) {
+            auto kern = neg_sample_bitmap_kernel<PackedOut>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
+            if (e != hipSuccess) return tipk_hip_status(e);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
+                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u);
         } else {
             return TIPK_EINVAL;
         }
@@ -165,10 +198,13 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
     }
     if (idx_bytes == 8)
         hipLaunchKernelGGL(neg_sample_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
-                           rel_ptr, n_rel, n_nodes, seed, call_counter, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
     else if (idx_bytes == 4)
         hipLaunchKernelGGL(neg_sample_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
-                           rel_ptr, n_rel, n_nodes, seed, call_counter, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
+    else if (idx_bytes == 2 && n_nodes <= 65535)
+        hipLaunchKernelGGL(neg_sample_kernel<PackedOut>, dim3((unsigned)blocks), dim3(256), 0, st, pos_key_sorted,
+                           rel_ptr, n_rel, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u);
     else
         return TIPK_EINVAL;
     TIPK_RETURN_LAUNCH();

@@ -648,9 +648,12 @@ class TIP(nn.Module):
         self.embeddings = self.__encode()
         pos_index = d.dd_train_idx
         if neg_index is None:
+            # (the fused objective reads pairs as 32-bit words: the sampler emits that form directly -- same draws)
             neg_index = typed_negative_sampling(d.dd_train_idx, d.n_drug, d.dd_train_range,
-                                                pos_offset=getattr(d, 'dd_train_pos_offset', None))
-        neg_index = neg_index.type_as(pos_index)
+                                                pos_offset=getattr(d, 'dd_train_pos_offset', None),
+                                                packed=bool(self.fused_loss and d.n_drug <= 65535 and pos_index.shape[1] > 0))
+        if not getattr(neg_index, '_tipk_packed_pairs', False):
+            neg_index = neg_index.type_as(pos_index)
         if self.shard is not None:
             return self.__sharded_objective(pos_index, neg_index)
         if self.fused_loss:

@@ -22,7 +22,7 @@ from . import ops
 
 _MASK = (1 << 64) - 1
 _state = {'seed': 1111}
-_counters = {}                 # device -> int64 [2] tensor {position, seed}: the stream's state ON THE DEVICE
+_counters = {}                 # device -> int64 [3] tensor {position, seed, ticket}: the stream's state ON THE DEVICE
 _key_cache = {}
 
 
@@ -37,9 +37,10 @@ def manual_seed(seed):
 
 
 def _state_words(seed):
-    """{position 0, seed} as int64 (the seed's bit pattern)."""
+    """{position 0, seed, ticket 0} as int64 (the seed's bit pattern).  The ticket word lets the sampling launch
+    advance the position itself (include/tipk.h section 5, advance != 0)."""
     s = seed - (1 << 64) if seed >= (1 << 63) else seed
-    return torch.tensor([0, s], dtype=torch.int64)
+    return torch.tensor([0, s, 0], dtype=torch.int64)
 
 
 def _counter(device):
@@ -110,11 +111,13 @@ def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
     return hit
 
 
-def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _range_ident=None, pos_offset=None):
+def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _range_ident=None, pos_offset=None, packed=False):
     """Drop-in for `src/neg_sampling.py:22-26`.  `seed` (optional) pins the Philox key of this
     call; by default consecutive calls use consecutive keys of the `manual_seed` stream.
     pos_offset (extension, int64 [R]): what to add to a position of relation r to get its number in the WHOLE triple
-    list of a relation-sharded run (tip_amd/dist.py) -- the rank then draws exactly the unsharded run's negatives."""
+    list of a relation-sharded run (tip_amd/dist.py) -- the rank then draws exactly the unsharded run's negatives.
+    packed (extension): return the SAME pairs as int32 [E] words u | v << 16 (num_nodes <= 65535) -- the form the fused
+    objective reads (tip_amd/ops.py `distmult_loss`); `ops.unpack_pairs` gives the int64 [2, E] tensor back."""
     num_nodes = int(num_nodes)
     keys, rel_ptr, n_rel, wg, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
     if pos_offset is not None:
@@ -122,10 +125,10 @@ def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _r
         assert pos_offset.numel() == n_rel
     if seed is not None:                                     # explicit Philox key for this call
         return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
-                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg, pos_offset=pos_offset)
+                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg, pos_offset=pos_offset, packed=packed)
     return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, _state['seed'],
                                               pos_edge_index.shape[1], dtype=torch.int64,
-                                              call_counter=_counter(pos_edge_index.device), wg=wg, pos_offset=pos_offset)
+                                              call_counter=_counter(pos_edge_index.device), wg=wg, pos_offset=pos_offset, packed=packed)
 
 
 def negative_sampling(pos_edge_index, num_nodes, seed=None):

@@ -758,24 +758,82 @@ def _det_workspace(device, n_nodes, k, n_rel):
     return ws
 
 
+def packed_pairs(edge_index, n_nodes):
+    """int32 [E]: the pair (u, v) of every triple as ONE 32-bit word u | v << 16 (include/tipk.h section 4, idx_bytes = 2).
+    Built once per tensor version (the positives of the path are static) and kept on the tensor."""
+    assert n_nodes <= 65535
+    hit = getattr(edge_index, '_tipk_packed', None)
+    if hit is not None and hit[0] == edge_index._version:
+        return hit[1]
+    w = (edge_index[0].to(torch.int64) | (edge_index[1].to(torch.int64) << 16))
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+    try:
+        edge_index._tipk_packed = (edge_index._version, w)
+    except Exception:
+        pass
+    return w
+
+
+def unpack_pairs(packed):
+    """int64 [2, E] from packed pairs (for callers that need the reference's form)."""
+    w = packed.to(torch.int64) & 0xffffffff
+    out = torch.stack([w & 0xffff, w >> 16])
+    out._tipk_sampled = getattr(packed, '_tipk_sampled', False)
+    return out
+
+
 def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     """(loss [1], g_z, g_w) of the fused TIP objective (include/tipk.h section 4); bitwise reproducible
-    (fixed-point cross-workgroup sums) unless TIPK_FLOAT_ATOMICS=1."""
+    (fixed-point cross-workgroup sums) unless TIPK_FLOAT_ATOMICS=1.
+    neg_index: int64 / int32 [2, E] like pos_index, or the sampler's PACKED form (int32 [E], u | v << 16:
+    `typed_negative_sampling(..., packed=True)`) -- the positives are then narrowed once to the same form and the kernel
+    reads 8 bytes of ids per position instead of 32."""
     z, weight = _f32c(z).contiguous(), _f32c(weight).contiguous()
     require_device(z, weight, pos_index, neg_index, edge_type)
     validate_triples(pos_index, edge_type, z.shape[0], weight.shape[0])
+    packed = bool(getattr(neg_index, '_tipk_packed_pairs', False))
+    et = edge_type.contiguous()
+    if packed:
+        tasks = relation_tasks(et, pos_index)
+        if (tasks is None or z.shape[1] not in (4, 8, 16) or os.environ.get('TIPK_FLOAT_ATOMICS') or z.shape[0] > 65535
+                or neg_index.numel() != pos_index.shape[1]):
+            neg_index, packed = unpack_pairs(neg_index).type_as(pos_index), False      # the general kernels take plain ids
+    if packed:                                             # (`_store`: the finalize launch overwrites -- no zero fills)
+        loss = torch.empty((1,), dtype=torch.float32, device=z.device)
+        g_z = torch.empty_like(z) if need_grad else None
+        g_w = torch.empty_like(weight) if need_grad else None
+        pp = packed_pairs(pos_index, z.shape[0])
+        ws = _det_workspace(z.device, z.shape[0], z.shape[1], weight.shape[0])
+        st = lib().tipk_distmult_loss_store(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pp), None,
+                                            ptr(neg_index), None, 2, ptr(et), _idx_bytes(et), pp.numel(),
+                                            ptr(tasks), tasks.shape[0], ptr(loss), ptr(g_z), ptr(g_w), ptr(ws),
+                                            stream_ptr(z.device))
+        if st != -2:                                       # TIPK_EUNSUPPORTED: z does not fit the kernel's LDS image
+            check(st, 'tipk_distmult_loss_store')
+            return loss, g_z, g_w
+        neg_index = unpack_pairs(neg_index).type_as(pos_index)
     if not getattr(neg_index, '_tipk_sampled', False):
         validate_triples(neg_index, None, z.shape[0], weight.shape[0])       # sampler output is in range by construction
     pu, pv = _uv(pos_index)
     nu, nv = _uv(neg_index)
     assert pu.dtype == nu.dtype and pu.numel() == nu.numel()
-    et = edge_type.contiguous()
-    loss = torch.zeros((1,), dtype=torch.float32, device=z.device)
-    g_z = torch.zeros_like(z) if need_grad else None
-    g_w = torch.zeros_like(weight) if need_grad else None
     tasks = relation_tasks(et, pos_index)
     ws = None if (tasks is None or os.environ.get('TIPK_FLOAT_ATOMICS')) else \
         _det_workspace(z.device, z.shape[0], z.shape[1], weight.shape[0])
+    if ws is not None:                                     # deterministic path: its finalize launch overwrites the outputs
+        loss = torch.empty((1,), dtype=torch.float32, device=z.device)
+        g_z = torch.empty_like(z) if need_grad else None
+        g_w = torch.empty_like(weight) if need_grad else None
+        st = lib().tipk_distmult_loss_store(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pu), ptr(pv),
+                                            ptr(nu), ptr(nv), _idx_bytes(pu), ptr(et), _idx_bytes(et), pu.numel(),
+                                            ptr(tasks), tasks.shape[0], ptr(loss), ptr(g_z), ptr(g_w), ptr(ws),
+                                            stream_ptr(z.device))
+        if st != -2:
+            check(st, 'tipk_distmult_loss_store')
+            return loss, g_z, g_w
+    loss = torch.zeros((1,), dtype=torch.float32, device=z.device)
+    g_z = torch.zeros_like(z) if need_grad else None
+    g_w = torch.zeros_like(weight) if need_grad else None
     check(lib().tipk_distmult_loss(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pu), ptr(pv),
                                    ptr(nu), ptr(nv), _idx_bytes(pu), ptr(et), _idx_bytes(et), pu.numel(),
                                    ptr(tasks), 0 if tasks is None else tasks.shape[0],
@@ -784,22 +842,34 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
 
 
 def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64,
-                                   call_counter=None, wg=None, pos_offset=None):
+                                   call_counter=None, wg=None, pos_offset=None, packed=False):
     """pos_offset: optional int64 device tensor [n_rel]: Philox counter of position e of relation r = e + pos_offset[r]
     (relation-sharded runs: the position's number in the whole triple list).
     call_counter: optional int64 device tensor [2] = {position, seed} (the stream's state): the
     Philox key is derived on the device from it, `seed` is ignored, and the position is advanced by
     one afterwards."""
     require_device(pos_key_sorted, rel_ptr, call_counter)
-    out = torch.empty((2, n_positions), dtype=dtype, device=pos_key_sorted.device)
-    st = stream_ptr(out.device)
+    dev = pos_key_sorted.device
+    st = stream_ptr(dev)
     wg_ptr, wg_rels = wg if (wg is not None and not os.environ.get('TIPK_NO_BITMAP')) else (None, None)
-    check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
-                                             ptr(call_counter), ptr(wg_ptr), ptr(wg_rels),
-                                             0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(pos_offset), ptr(out[0]), ptr(out[1]),
-                                             8 if dtype == torch.int64 else 4, n_positions, st),
-          'tipk_typed_negative_sampling')
-    if call_counter is not None:
+    # a stream state with a ticket word {position, seed, ticket}: the sampling launch moves the position on itself
+    adv = 1 if (call_counter is not None and call_counter.numel() >= 3 and n_positions > 0 and n_rel > 0) else 0
+    if packed:                                     # one 32-bit word u | v << 16 per position (same draws, same pairs)
+        assert n_nodes <= 65535
+        out = torch.empty((n_positions,), dtype=torch.int32, device=dev)
+        check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed, ptr(call_counter), adv,
+                                                 ptr(wg_ptr), ptr(wg_rels), 0 if wg_ptr is None else wg_ptr.numel() - 1,
+                                                 ptr(pos_offset), ptr(out), None, 2, n_positions, st),
+              'tipk_typed_negative_sampling')
+        out._tipk_packed_pairs = True
+    else:
+        out = torch.empty((2, n_positions), dtype=dtype, device=dev)
+        check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
+                                                 ptr(call_counter), adv, ptr(wg_ptr), ptr(wg_rels),
+                                                 0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(pos_offset), ptr(out[0]), ptr(out[1]),
+                                                 8 if dtype == torch.int64 else 4, n_positions, st),
+              'tipk_typed_negative_sampling')
+    if call_counter is not None and not adv:
         check(lib().tipk_counter_advance(ptr(call_counter), st), 'tipk_counter_advance')
     out._tipk_sampled = True                       # ids < n_nodes by construction: no range check downstream
     return out
@@ -1416,7 +1486,10 @@ class _DistMultLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g_z, g_w = ctx.saved_tensors
-        return g_z * g, g_w * g, None, None, None
+        if g_z is None:
+            return None, None, None, None, None
+        g_z, g_w = torch._foreach_mul([g_z, g_w], g)       # one launch for both
+        return g_z, g_w, None, None, None
 
 
 def distmult_objective(z, weight, pos_index, neg_index, edge_type):

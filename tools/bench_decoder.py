@@ -19,6 +19,10 @@ print('fwd score ms', t(lambda: ops.distmult_fwd(z, w, pos, et)))
 pos32, neg32, et32 = pos.int(), neg.int(), et.int()
 ops.relation_tasks(et32)
 print('loss+grad int32 ms', t(lambda: ops.distmult_loss(z, w, pos32, neg32, et32)))
+negp = typed_negative_sampling(pos, 645, rg, packed=True)
+print('loss+grad packed pairs ms %.3f   loss only %.3f   sampler packed %.3f' % (
+    t(lambda: ops.distmult_loss(z, w, pos, negp, et)), t(lambda: ops.distmult_loss(z, w, pos, negp, et, need_grad=False)),
+    t(lambda: typed_negative_sampling(pos, 645, rg, packed=True))))
 
 from tip_amd import _lib
 _lib.set_option('dm_task_kernel', 1)

@@ -7,7 +7,7 @@ from tip_amd.neg_sampling import typed_negative_sampling
 dd = build_data_dict(); dev = 'cuda:0'
 pos = dd['dd_train_idx'].to(dev); et = dd['dd_train_et'].to(dev); rg = dd['dd_train_range'].to(dev)
 z = torch.randn(645, 16, device=dev) * 0.5; w = torch.randn(dd['n_dd_et'], 16, device=dev) * 0.3
-neg = typed_negative_sampling(pos, 645, rg)
+neg = typed_negative_sampling(pos, 645, rg, packed='plain' not in sys.argv)     # the training step's form of the negatives
 for _ in range(3):
     ops.distmult_loss(z, w, pos, neg, et, need_grad='nograd' not in sys.argv)
 torch.cuda.synchronize()
