@@ -460,9 +460,11 @@ int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
  * -- specified bit-exactly in oracle/philox_sampler.py.  `pos_key_sorted` holds u*n+v of each
  * relation's positives sorted ascending within the relation (int64).  After 64 rejected attempts
  * the 64th candidate is kept (probability < density^64).
- * wg_rel_ptr / wg_rels (nullable): edge-balanced deal of the relations to n_wg workgroups; with it and
- * n_nodes^2 bits <= 150 KB each workgroup tests candidates against an LDS bitmap of its relation's
- * positives instead of searching the sorted keys (same output bit for bit, ~6x faster on BioSNAP).
+ * wg_unit_ptr [n_wg + 1] / wg_units [n_units][3] (nullable, int32): edge-balanced deal of UNITS = (relation, first
+ * position, end position) to n_wg workgroups -- the units tile [0, n_positions), a unit lies inside one relation (a
+ * relation larger than a workgroup's share is cut into several units); with it and n_nodes^2 bits <= 150 KB each
+ * workgroup tests candidates against an LDS bitmap of its relation's positives instead of searching the sorted keys
+ * (same output bit for bit, ~6x faster on BioSNAP).
  * call_counter != NULL: a sampler STREAM whose state lives on the device, uint64[2] = { position, seed }:
  * the Philox key is splitmix64(state[1] + (state[0] + 1) * 0x9E3779B97F4A7C15) and the host `seed`
  * argument is ignored -- a captured hipGraph draws new negatives on every replay
@@ -476,7 +478,7 @@ int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
 int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
                                  uint64_t* call_counter /* nullable device uint64[2 or 3], see above */, int advance,
-                                 const int32_t* wg_rel_ptr /* nullable */, const int32_t* wg_rels, int64_t n_wg,
+                                 const int32_t* wg_unit_ptr /* nullable */, const int32_t* wg_units, int64_t n_wg,
                                  const int64_t* pos_offset /* nullable */,
                                  void* out_u, void* out_v, int idx_bytes,
                                  int64_t n_positions /* = rel_ptr[n_rel], host copy */,

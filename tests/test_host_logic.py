@@ -553,3 +553,24 @@ def test_bench_roofline_helpers(tmp_path, monkeypatch):
     fl = bench.step_floor({}, launches, kern, 1_450_000, {})
     assert fl['launches_per_step'] == 5 and abs(fl['parts_us']['node_products[dd.bwd,d=32]'] - 1.35e9 / bench.MFMA_F32_PEAK * 1e6) < 0.01
     assert abs(fl['us'] - sum(fl['parts_us'].values())) < 0.05 and fl['parts_us']['2 other launches x 2.0 us'] == 4.0
+
+
+def test_sampler_units_tile_the_positions_and_balance():
+    """tip_amd.neg_sampling.sampler_units: the bitmap sampler's deal of (relation, range) units -- units tile [0, E),
+    stay inside their relation, and no workgroup carries much more than the mean although one relation alone is larger
+    than the mean load (BioSNAP: 51 466 positions against 32 525)."""
+    from tip_amd.neg_sampling import sampler_units
+    sizes = [51466, 48612, 0, 7, 300] + [8000 + 13 * i for i in range(900)] + [1]
+    rel_ptr = np.r_[0, np.cumsum(sizes)]
+    n_wg = 256
+    ptr, units = sampler_units(torch.from_numpy(rel_ptr), n_wg)
+    assert ptr.dtype == torch.int32 and units.dtype == torch.int32 and ptr.numel() == n_wg + 1 and int(ptr[-1]) == units.shape[0]
+    u = sorted(units.tolist(), key=lambda x: x[1])
+    assert u[0][1] == 0 and u[-1][2] == rel_ptr[-1] and all(u[i][2] == u[i + 1][1] for i in range(len(u) - 1))
+    for r, a, b in u:
+        assert rel_ptr[r] <= a < b <= rel_ptr[r + 1]
+    loads = [sum(int(x[2] - x[1]) for x in units[ptr[w]:ptr[w + 1]].tolist()) for w in range(n_wg)]
+    assert sum(loads) == rel_ptr[-1] and max(loads) < 1.15 * (sum(loads) / n_wg)
+    assert sampler_units(torch.from_numpy(rel_ptr), n_wg)[1].tolist() == units.tolist()          # deterministic
+    p0, u0 = sampler_units(torch.zeros(1, dtype=torch.int64), 4)
+    assert p0.tolist() == [0] * 5 and u0.shape == (0, 3)

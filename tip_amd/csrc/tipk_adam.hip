@@ -47,7 +47,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
     while (ti + 1 < a.n_tensors && wg >= a.first_wg[ti + 1]) ++ti;
     const unsigned long long step = *a.step[ti] + 1ull;        // (uniform: one scalar load)
     if (t == 0) {
-        const double bc1 = 1.0 - pow(a.beta1, (double)step), bc2 = 1.0 - pow(a.beta2, (double)step);
+        // beta^step by squaring (<= 64 dependent multiplies; the library pow is a few hundred double instructions on one lane)
+        double p1 = 1.0, p2 = 1.0, s1 = a.beta1, s2 = a.beta2;
+        for (unsigned long long e = step; e != 0ull; e >>= 1) {
+            if (e & 1ull) { p1 *= s1; p2 *= s2; }
+            s1 *= s1; s2 *= s2;
+        }
+        const double bc1 = 1.0 - p1, bc2 = 1.0 - p2;
         sc[0] = (float)(a.lr / bc1);
         sc[1] = (float)(1.0 / sqrt(bc2));
     }

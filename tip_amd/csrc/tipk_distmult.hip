@@ -466,8 +466,11 @@ struct PackedPair { uint32_t w; };
 
 template <int I>
 __device__ __forceinline__ int pr_row_bcast(int x) {      // lane I of every 16-lane DPP row, broadcast to its row
-    return __builtin_amdgcn_update_dpp(0, x, 0x150 + (I & 15), 0xf, 0xf, false);
+    // (no `old` value: every lane is written, and a mov_dpp without one folds into the VOP2 instruction that uses it)
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + (I & 15), 0xf, 0xf, false);
 }
+typedef __attribute__((address_space(3))) float pr_lds_f32_t;
+typedef __attribute__((address_space(3))) unsigned long long pr_lds_u64_t;
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void pr_static_for(F&& f) {
     if constexpr (I < N) {
@@ -525,6 +528,15 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
 
     // ids of (task, half h) for this lane: positions tb + h * 1024 + t (clamped; `valid` says whether it exists)
     struct Ids { int pu, pv, nu, nv; };
+    const int col = t & (K - 1);
+    auto fetch_wcol = [&](int task) -> float {                            // this lane's column of the task's w row
+        task = task < n_tasks ? task : n_tasks - 1;
+        return w[(int64_t)tasks[4 * task] * K + col];
+    };
+    // LDS byte addresses of this lane's column in row 0 of the two images (phase 2 adds a row's byte offset: one VOP2
+    // add with the DPP broadcast folded in, instead of a 64-bit multiply-add per address)
+    const unsigned c4 = (unsigned)(uintptr_t)(pr_lds_f32_t*)zl + (unsigned)col * 4u;
+    const unsigned c8 = (unsigned)(uintptr_t)(pr_lds_u64_t*)gzl + (unsigned)col * 8u;
     auto fetch = [&](int task, int h, Ids& o) {
         task = task < n_tasks ? task : n_tasks - 1;
         const int tb = tasks[4 * task + 1], te = tasks[4 * task + 2];
@@ -540,12 +552,14 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
     Ids cur0, cur1, nx0, nx1;
     fetch(blockIdx.x, 0, cur0);
     fetch(blockIdx.x, 1, cur1);
+    float wcol = fetch_wcol(blockIdx.x), nx_wcol;
     for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const int rel = tasks[4 * task], tb = tasks[4 * task + 1], te = tasks[4 * task + 2];
         const int pos_w = tasks[4 * task + 3];
         const float pw = (float)pos_w;
-        fetch(task + gridDim.x, 0, nx0);                                  // the next task's ids travel during this one
-        fetch(task + gridDim.x, 1, nx1);
+        fetch(task + gridDim.x, 0, nx0);                                  // the next task's ids (and this lane's column of
+        fetch(task + gridDim.x, 1, nx1);                                  // its w row) travel during this one: nothing the
+        nx_wcol = fetch_wcol(task + gridDim.x);                           // task itself uses comes from a vector load
         float wr[K];
 #pragma unroll
         for (int j = 0; j < K; j += 4) {
@@ -553,8 +567,8 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
             wr[j] = v.x; wr[j + 1] = v.y; wr[j + 2] = v.z; wr[j + 3] = v.w;
         }
         constexpr int G = 64 / K;                                         // positions one scatter instruction covers
-        const int col = t & (K - 1), grp = (t & 63) / K;
-        const float wcol = w[(int64_t)rel * K + col];
+        const int grp = (t & 63) / K;
+        const float wcs = wcol * scale_f;                                 // (a power of two: the products round the same)
         float gwc = 0.f;                                                  // this lane's column of d w[rel]
         // PHASE 1, one lane per position: score and the coefficient q of its gradient terms (0: nothing to add)
         auto triple = [&](int u, int v, bool negative, float weight) -> float {
@@ -574,29 +588,37 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         // PHASE 2, K lanes per row: the wave's 64 positions are revisited G at a time; lane `col` of group `grp` adds
         // column `col` of both gradient terms of position i * G + grp -- one scatter instruction touches G rows of the
         // d z image, each as one contiguous 8 K-byte piece (a lane per position made every instruction touch 64 rows:
-        // twice the time, tools/bench_decoder.py) -- and keeps its column of d w
+        // twice the time, tools/bench_decoder.py) -- and keeps its column of d w.  What travels per position is its
+        // coefficient and the BYTE OFFSETS of its two rows in the two images (multiplied once, by the position's lane):
+        // an address is one add.  Positions that do not exist carry q = 0 and clamped ids: they add zeros, no branch.
         auto scatter = [&](float q_mine, int u_mine, int v_mine) {
+            const int zu_mine = u_mine * (ld * 4), zv_mine = v_mine * (ld * 4);
+            const int gu_mine = u_mine * (lg * 8), gv_mine = v_mine * (lg * 8);
             pr_static_for<64 / G>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 float q;
-                int u, v;
+                unsigned zu, zv, gu, gv;
                 if constexpr (K == 16) {
                     // group = one DPP row of 16 lanes: lane i of every row is broadcast to its row (row_newbcast:i,
                     // a full-rate VALU move) -- group g revisits the positions of lanes 16 g .. 16 g + 15
                     q = __int_as_float(pr_row_bcast<i>(__float_as_int(q_mine)));
-                    u = pr_row_bcast<i>(u_mine);
-                    v = pr_row_bcast<i>(v_mine);
+                    zu = (unsigned)pr_row_bcast<i>(zu_mine) + c4; zv = (unsigned)pr_row_bcast<i>(zv_mine) + c4;
+                    gu = (unsigned)pr_row_bcast<i>(gu_mine) + c8; gv = (unsigned)pr_row_bcast<i>(gv_mine) + c8;
                 } else {
                     const int src = i * G + grp;
                     q = __shfl(q_mine, src, 64);
-                    u = __shfl(u_mine, src, 64);
-                    v = __shfl(v_mine, src, 64);
+                    zu = (unsigned)__shfl(zu_mine, src, 64) + c4; zv = (unsigned)__shfl(zv_mine, src, 64) + c4;
+                    gu = (unsigned)__shfl(gu_mine, src, 64) + c8; gv = (unsigned)__shfl(gv_mine, src, 64) + c8;
                 }
-                const float ua = zl[u * ld + col], vb = zl[v * ld + col];
-                const float qw = q * wcol;
-                if (q != 0.f && !TIPK_DBG(dbg & 1)) {
-                    fx_add_term(gzl + u * lg + col, qw * vb, scale_f);
-                    fx_add_term(gzl + v * lg + col, qw * ua, scale_f);
+                const float ua = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zu);
+                const float vb = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zv);
+                const float qs = q * wcs;
+                if (!TIPK_DBG(dbg & 1)) {
+                    const int tu = (int)rintf(qs * vb), tv = (int)rintf(qs * ua);     // |term * scale| < 2^30 by construction
+                    __hip_atomic_fetch_add(reinterpret_cast<pr_lds_u64_t*>((uintptr_t)gu), (unsigned long long)(long long)tu,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<pr_lds_u64_t*>((uintptr_t)gv), (unsigned long long)(long long)tv,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 gwc = fmaf(q, ua * vb, gwc);
             });
@@ -619,6 +641,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         }
         cur0 = nx0;
         cur1 = nx1;
+        wcol = nx_wcol;
         if (want_grad) {                                                  // d w[rel]: the wave's G groups, then 16 waves via LDS
 #pragma unroll
             for (int o = K; o < 64; o <<= 1) gwc += __shfl_xor(gwc, o, 64);

@@ -12,12 +12,21 @@ constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
 constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
 constexpr int MAX_ATTEMPTS = 64;
 
+// 32 x 32 -> 64-bit product in ONE quarter-rate instruction (hipcc splits the product into v_mul_hi_u32 + v_mul_lo_u32,
+// two of them: the multiplies are two thirds of the sampler's issue slots)
+__device__ __forceinline__ uint64_t mul_wide(uint32_t m, uint32_t x) {
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "s"(m), "v"(x) : "vcc");
+    return r;
+}
+
 __device__ __forceinline__ uint64_t philox64(uint64_t ctr, uint32_t attempt, uint32_t k0, uint32_t k1) {
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = attempt, c3 = 0u;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
-        const uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+        const uint64_t p0 = mul_wide(PHILOX_M0, c0), p1 = mul_wide(PHILOX_M1, c2);
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += PHILOX_W0; k1 += PHILOX_W1;
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
 // Same candidates, same acceptance rule, same output as `neg_sample_kernel` (bit-exact).
 template <typename OT>
 __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
-    const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_rel_ptr,
-    const int32_t* __restrict__ wg_rels, int64_t n_nodes, uint64_t seed, uint64_t* __restrict__ call_counter, int advance,
+    const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_unit_ptr,
+    const int32_t* __restrict__ wg_units, int64_t n_nodes, uint64_t seed, uint64_t* __restrict__ call_counter, int advance,
     const int64_t* __restrict__ pos_offset, OT* __restrict__ out_u, OT* __restrict__ out_v) {
     extern __shared__ unsigned bm[];
     const uint64_t call_no = call_counter ? call_counter[0] : 0ull;
@@ -126,26 +135,47 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
     const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
     const int words = (int)((nn + 31) >> 5);
+    const uint32_t nn32 = (uint32_t)nn, n32 = (uint32_t)n_nodes;
+    const float inv_n = 1.0f / (float)n32;
     const int t = threadIdx.x;
-    for (int ri = wg_rel_ptr[blockIdx.x]; ri < wg_rel_ptr[blockIdx.x + 1]; ++ri) {
-        const int rel = wg_rels[ri];
+    int have = -1;                                         // relation whose bitmap is in LDS
+    for (int ui = wg_unit_ptr[blockIdx.x]; ui < wg_unit_ptr[blockIdx.x + 1]; ++ui) {
+        // unit = (relation, first position, end position): a relation larger than the per-workgroup share is cut into
+        // several units (every one of them builds the relation's bitmap; BioSNAP's largest relation alone is 1.6 x
+        // the mean load of a workgroup)
+        const int rel = wg_units[3 * ui];
+        const int64_t ub = wg_units[3 * ui + 1], ue = wg_units[3 * ui + 2];
         const int64_t a = rel_ptr[rel], b = rel_ptr[rel + 1];
         const int64_t off = pos_offset ? pos_offset[rel] : 0;
-        __syncthreads();                                   // the previous relation's tests are done
-        for (int i = t; i < words; i += 1024) bm[i] = 0u;
-        __syncthreads();
-        for (int64_t e = a + t; e < b; e += 1024) {
-            const uint64_t k = (uint64_t)keys[e];
-            atomicOr(&bm[k >> 5], 1u << (k & 31));
+        if (rel != have) {
+            __syncthreads();                               // the previous relation's tests are done
+            for (int i = t; i < words; i += 1024) bm[i] = 0u;
+            __syncthreads();
+            for (int64_t e = a + t; e < b; e += 1024) {
+                const uint64_t k = (uint64_t)keys[e];
+                atomicOr(&bm[k >> 5], 1u << (k & 31));
+            }
+            __syncthreads();
+            have = rel;
         }
-        __syncthreads();
-        for (int64_t e = a + t; e < b; e += 1024) {
-            uint64_t cand = 0;
+        for (int64_t e = ub + t; e < ue; e += 1024) {
+            // n^2 < 2^24 here (the bitmap fits LDS): the candidate mulhi64(x, n^2) is two 32 x 32 -> 64 products, and
+            // (u, v) = (cand / n, cand % n) an exact float quotient with a one-step correction -- the same integers as
+            // the generic 64-bit forms of neg_sample_kernel (a 64 x 64 high product and a 32-bit division are ~60 issue
+            // slots per attempt, a quarter of the Philox rounds themselves)
+            uint32_t cand = 0;
             for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
-                cand = __umul64hi(philox64((uint64_t)(e + off), (uint32_t)attempt, k0, k1), nn);
+                const uint64_t x = philox64((uint64_t)(e + off), (uint32_t)attempt, k0, k1);
+                const uint64_t p0 = mul_wide(nn32, (uint32_t)x);
+                cand = (uint32_t)((mul_wide(nn32, (uint32_t)(x >> 32)) + (p0 >> 32)) >> 32);
                 if (!((bm[cand >> 5] >> (cand & 31)) & 1u)) break;
             }
-            split_pair(cand, n_nodes, out_u + e, out_v + e);
+            uint32_t q = (uint32_t)((float)cand * inv_n);
+            int32_t r = (int32_t)(cand - __umul24(q, n32));
+            if (r < 0) { --q; r += (int32_t)n32; }
+            else if (r >= (int32_t)n32) { ++q; r -= (int32_t)n32; }
+            if constexpr (std::is_same<OT, PackedOut>::value) out_u[e].w = q | ((uint32_t)r << 16);
+            else { out_u[e] = (OT)q; out_v[e] = (OT)r; }
         }
     }
     stream_advance(call_counter, advance, call_no);
@@ -161,7 +191,7 @@ extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
 
 extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
                                             int64_t n_nodes, uint64_t seed, uint64_t* call_counter, int advance,
-                                            const int32_t* wg_rel_ptr, const int32_t* wg_rels, int64_t n_wg,
+                                            const int32_t* wg_unit_ptr, const int32_t* wg_units, int64_t n_wg,
                                             const int64_t* pos_offset,
                                             void* out_u, void* out_v, int idx_bytes, int64_t n_positions,
                                             tipk_stream_t stream) {
@@ -172,25 +202,25 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t bm_bytes = (((int64_t)n_nodes * n_nodes + 31) / 32) * 4;
-    if (wg_rel_ptr && wg_rels && n_wg > 0 && n_wg <= 65535 && bm_bytes <= 150 * 1024) {
+    if (wg_unit_ptr && wg_units && n_wg > 0 && n_wg <= 65535 && bm_bytes <= 150 * 1024 && n_nodes <= 4095) {
         if (idx_bytes == 8) {
             auto kern = neg_sample_bitmap_kernel<int64_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
         } else if (idx_bytes == 4) {
             auto kern = neg_sample_bitmap_kernel<int32_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
         } else if (idx_bytes == 2 && n_nodes <= 65535) {
             auto kern = neg_sample_bitmap_kernel<PackedOut>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_rel_ptr, wg_rels, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u);
         } else {
             return TIPK_EINVAL;
         }

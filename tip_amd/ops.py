@@ -851,21 +851,21 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
     require_device(pos_key_sorted, rel_ptr, call_counter)
     dev = pos_key_sorted.device
     st = stream_ptr(dev)
-    wg_ptr, wg_rels = wg if (wg is not None and not os.environ.get('TIPK_NO_BITMAP')) else (None, None)
+    wg_ptr, wg_units = wg if (wg is not None and not os.environ.get('TIPK_NO_BITMAP')) else (None, None)
     # a stream state with a ticket word {position, seed, ticket}: the sampling launch moves the position on itself
     adv = 1 if (call_counter is not None and call_counter.numel() >= 3 and n_positions > 0 and n_rel > 0) else 0
     if packed:                                     # one 32-bit word u | v << 16 per position (same draws, same pairs)
         assert n_nodes <= 65535
         out = torch.empty((n_positions,), dtype=torch.int32, device=dev)
         check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed, ptr(call_counter), adv,
-                                                 ptr(wg_ptr), ptr(wg_rels), 0 if wg_ptr is None else wg_ptr.numel() - 1,
+                                                 ptr(wg_ptr), ptr(wg_units), 0 if wg_ptr is None else wg_ptr.numel() - 1,
                                                  ptr(pos_offset), ptr(out), None, 2, n_positions, st),
               'tipk_typed_negative_sampling')
         out._tipk_packed_pairs = True
     else:
         out = torch.empty((2, n_positions), dtype=dtype, device=dev)
         check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
-                                                 ptr(call_counter), adv, ptr(wg_ptr), ptr(wg_rels),
+                                                 ptr(call_counter), adv, ptr(wg_ptr), ptr(wg_units),
                                                  0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(pos_offset), ptr(out[0]), ptr(out[1]),
                                                  8 if dtype == torch.int64 else 4, n_positions, st),
               'tipk_typed_negative_sampling')

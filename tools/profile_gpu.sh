@@ -35,4 +35,6 @@ python3 tools/step_timeline.py $OUT/trace > profiles/${TAG}_step_timeline.txt 2>
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 tools/trace_train.py > $OUT/train.log 2>&1
 python3 tools/step_timeline.py $OUT/train distmult_objective_kernel > profiles/${TAG}_train_timeline.txt 2>&1
 grep "ms/epoch" $OUT/train.log >> profiles/${TAG}_train_timeline.txt
+# 6. SQ / LDS counters of the fused objective (with and without gradients)
+if [ -z "$ARGS" ]; then bash tools/pmc_decoder.sh $TAG > $OUT/pmc_decoder.log 2>&1; fi
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
