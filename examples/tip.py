@@ -32,7 +32,8 @@ else:
     settings = Setting(sp_rate=0.9, lr=0.01, prot_drug_dim=64, n_embed=64, n_hid1=32, n_hid2=16, num_base=32)
     model = TIP(settings, device, mod='add')
 
-optimizer = torch.optim.Adam(model.parameters(), lr=settings.lr, capturable=GRAPH, fused=GRAPH)   # one Adam kernel
+from tip_amd.optim import Adam                             # tipk_adam_step: the whole parameter list in one launch
+optimizer = Adam(model.parameters(), lr=settings.lr)       # (torch.optim.Adam(..., capturable=GRAPH) works as well)
 
 torch.cuda.synchronize()
 t0 = time.perf_counter()
