@@ -555,7 +555,7 @@ int tipk_peer_allreduce(float* data, int64_t n, void* const* mailboxes /* host [
  *        g += weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g;
  *        p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),      t = *steps[i] + 1
  *    steps: host array [n_tensors] of device uint64 words, the steps tensor i has made (torch keeps the count per
- *    parameter: one without a gradient sits the step out); ticket: device uint64, 0.  The launch's last workgroup adds 1 to
+ *    parameter: one without a gradient sits the step out); ticket: device uint64[528], zeros (left zeroed; 33 ticket words, one per 128-byte line).  The launch's last workgroup adds 1 to
  *    the counts of its tensors -- a captured hipGraph keeps counting on replay.  Tensors with numel 0 are skipped (their
  *    count does not move).  The addresses are kernel arguments (48 tensors per launch, longer lists take several
  *    launches): nothing is uploaded, nothing allocated. */

@@ -26,8 +26,9 @@ struct AdamArgs {
     int32_t first_wg[ADAM_MAX_TENSORS + 1];   // workgroups [first_wg[i], first_wg[i + 1]) own tensor i
     int64_t n[ADAM_MAX_TENSORS];
     unsigned long long* step[ADAM_MAX_TENSORS];   // device: steps done so far, per tensor
-    unsigned long long* ticket;               // device, 0 between launches
+    unsigned long long* ticket;               // device [33 * 16], 0 between launches
     int n_tensors;
+    int dbg;                                  // -DTIPK_DEBUG builds: 1 no ticket, 2 no bias-correction arithmetic, 4 no stores
     double lr, beta1, beta2, eps, weight_decay;
 };
 
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
     int ti = 0;
     while (ti + 1 < a.n_tensors && wg >= a.first_wg[ti + 1]) ++ti;
     const unsigned long long step = *a.step[ti] + 1ull;        // (uniform: one scalar load)
-    if (t == 0) {
+    if (t == 0 && TIPK_DBG(a.dbg & 2)) { sc[0] = (float)a.lr; sc[1] = 1.0f; }
+    else if (t == 0) {
         // beta^step by squaring (<= 64 dependent multiplies; the library pow is a few hundred double instructions on one lane)
         double p1 = 1.0, p2 = 1.0, s1 = a.beta1, s2 = a.beta2;
         for (unsigned long long e = step; e != 0ull; e >>= 1) {
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
     const float step_size = sc[0], inv_sqrt_bc2 = sc[1];
 #pragma unroll
     for (int j = 0; j < 4; ++j) adam_one(pr[j], gr[j], mr[j], vr[j], b1, b2, wd, step_size, inv_sqrt_bc2, eps);
-    if (full) {
+    if (TIPK_DBG(a.dbg & 4) && pr[0] != 12345.f) {}
+    else if (full) {
         *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pr);
         *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mr);
         *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<const float4*>(vr);
@@ -94,9 +97,22 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a) {
         for (int j = 0; j < 4; ++j)
             if (i0 + j < n) { p[i0 + j] = pr[j]; m[i0 + j] = mr[j]; v[i0 + j] = vr[j]; }
     }
-    // the last workgroup to get here advances the counts: every workgroup read its own (and waited for it) before this point
+    // the last workgroup to get here advances the counts: every workgroup read its own (and waited for it) before this point.
+    // Two-level ticket: all workgroups finish together, and 800 returning atomics on ONE word are served one after the
+    // other (9 of the kernel's 14.6 us, tools/bench_adam.py) -- a workgroup takes a ticket of its group (wg mod 32), the
+    // last of a group one of the top word: 25 + 32 atomics deep instead of 800.
     __shared__ int last;
-    if (t == 0) last = atomicAdd(a.ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+    if (TIPK_DBG(a.dbg & 1)) return;
+    if (t == 0) {
+        const unsigned n_wg = gridDim.x, grp = (unsigned)wg & 31u;
+        const unsigned in_grp = (n_wg + 31u - grp) / 32u, n_grp = n_wg < 32u ? n_wg : 32u;
+        int l = 0;
+        if (atomicAdd(a.ticket + 16 * (1 + grp), 1ull) == (unsigned long long)in_grp - 1ull) {   // (a cache line per word)
+            a.ticket[16 * (1 + grp)] = 0ull;
+            l = atomicAdd(a.ticket, 1ull) == (unsigned long long)n_grp - 1ull;
+        }
+        last = l;
+    }
     __syncthreads();
     if (last) {
         if (t < a.n_tensors) *a.step[t] += 1ull;
@@ -124,6 +140,7 @@ extern "C" int tipk_adam_step(int n_tensors, float* const* params, const float* 
         AdamArgs a;
         a.n_tensors = 0; a.first_wg[0] = 0;
         a.ticket = reinterpret_cast<unsigned long long*>(ticket);
+        a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG));
         a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
         int64_t wgs = 0;
         for (; i <= last && a.n_tensors < ADAM_MAX_TENSORS; ++i) {

@@ -1473,6 +1473,22 @@ def distmult(z, weight, edge_index, edge_type, sigmoid=True):
     return _DistMult.apply(z, weight, edge_index, edge_type, sigmoid)
 
 
+_UNIT_GRADS = {}          # data_ptr -> tensor: upstream gradients known to be exactly 1 (`unit_grad`)
+
+
+def unit_grad(device):
+    """A 0-dim ones tensor for `loss.backward(gradient=...)` that the fused objective recognises by its address: the
+    backward pass then hands out the gradients of the forward launch as they are (no seed-filling launch, no scaling
+    launch).  tip_amd.train.GraphedTrainStep uses it; the tensor must never be written."""
+    device = torch.device(device)
+    for t in _UNIT_GRADS.values():
+        if t.device == device:
+            return t
+    t = torch.ones((), dtype=torch.float32, device=device)
+    _UNIT_GRADS[t.data_ptr()] = t
+    return t
+
+
 class _DistMultLoss(torch.autograd.Function):
     """loss of TIP.forward (src/layers.py:335-340) with gradients produced in the same pass."""
 
@@ -1488,6 +1504,8 @@ class _DistMultLoss(torch.autograd.Function):
         g_z, g_w = ctx.saved_tensors
         if g_z is None:
             return None, None, None, None, None
+        if g.data_ptr() in _UNIT_GRADS:                    # the caller vouches for an upstream gradient of exactly 1
+            return g_z, g_w, None, None, None
         g_z, g_w = torch._foreach_mul([g_z, g_w], g)       # one launch for both
         return g_z, g_w, None, None, None
 

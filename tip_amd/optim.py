@@ -29,7 +29,7 @@ class Adam(torch.optim.Optimizer):
         # `capturable` is always true here (the step count lives on the device); the key is kept so that
         # tip_amd.train.GraphedTrainStep's check reads the same for both optimizers
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True))
-        self._tickets = {}                             # device -> int64 [1], 0 between launches
+        self._tickets = {}                             # device -> int64 [528] (33 ticket words, a cache line each), 0 between launches
         self._counter_pool = {}                        # device -> (int64 [256] block, words handed out)
 
     def _new_counter(self, device):
@@ -70,7 +70,7 @@ class Adam(torch.optim.Optimizer):
             dev = ps[0].device
             ticket = self._tickets.get(dev)
             if ticket is None:
-                ticket = self._tickets[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+                ticket = self._tickets[dev] = torch.zeros(528, dtype=torch.int64, device=dev)
             n = len(ps)
             arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
             numel = (C.c_int64 * n)(*[p.numel() for p in ps])

@@ -13,6 +13,8 @@ the graph, so every replay draws new negatives (tip_amd/neg_sampling.py).
 """
 import torch
 
+from . import ops
+
 
 class GraphedTrainStep(object):
     def __init__(self, model, optimizer, warmup=2):
@@ -37,7 +39,9 @@ class GraphedTrainStep(object):
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.model()
-        loss.backward()
+        # (a registered unit gradient: autograd's ones_like fill and the objective's scaling launch disappear)
+        seed = ops.unit_grad(loss.device) if loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda else None
+        loss.backward(gradient=seed)
         self.optimizer.step()
         return loss.detach()
 
