@@ -454,12 +454,18 @@ def step_floor(launch_us, launches, kern, pp_edges, dims):
                 t = pp_edges * (4 + 4 * dcol) / (L2_GATHER_GBS * 1e9) * 1e6         # the 2.4 MB table is L2-resident
                 parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
                 pp += kern[label][0] // passes
+            elif label.startswith('pp_stream['):                                    # round 3: rows out of LDS (8-byte rows)
+                dcol = int(label.split('d=')[1].rstrip(']'))
+                t = pp_edges * 4 * dcol / (LDS_PEAK_GBS * 1e9) * 1e6
+                parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
+                pp += kern[label][0] // passes
         rest = max(0, n_launches - modelled - pp)
         parts['%d other launches x %.1f us' % (rest, LAUNCH_FLOOR_US)] = rest * LAUNCH_FLOOR_US
     return {'us': sum(parts.values()), 'launches_per_step': n_launches, 'parts_us': {k: round(v, 2) for k, v in parts.items()},
             'note': 'sum over the launches of one step of max(kernel roofline time, %.1f us launch floor): D-D gathers at the LDS '
                     'ds_read_b128 peak, products at the fp32 MFMA peak (pair product: or its one pass over the cell matrix at 8 TB/s), '
-                    'P-P gathers at the L2 gather rate (18.8 TB/s: their table is L2-resident), every other launch at the floor' % LAUNCH_FLOOR_US}
+                    'P-P gathers at the LDS peak (wave streams over 2-column blocks; `gather_sum` route: the L2 gather rate, 18.8 TB/s), '
+                    'every other launch at the floor' % LAUNCH_FLOOR_US}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 11
+#define TIPK_ABI_VERSION 12
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -183,7 +183,11 @@ int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t 
  *         destination * nodes + source: cell (v, u) = sum of att[r, :] over the relations r that link u -> v
  *         (a drug pair of BioSNAP is linked by 66 relations on average), followed by ONE dense product with
  *         X . basis (tip_amd/ops.py `_RGCN.forward`): Y = att . XB is never formed.
- *     L = (d / column blocks) / 4 lanes form a slot, S = 64 / L slots a wavefront, P = tipk_stream_gather_piece()
+ *       - (round 3) the GCN layers of the P-P graph, both passes (GCNConv.forward via PPEncoder, src/layers.py:392-394):
+ *         D^-1/2 (A + I) D^-1/2 X = a row scaling on either side of the plain sum, i.e. row_scale = out_scale =
+ *         deg^-1/2, with bias and ReLU in the epilogue.  19 081 proteins fit as 2-column blocks of 8-byte rows
+ *         (max_split = 16): the rows come out of LDS instead of through the L2 gather path of tipk_gather_sum.
+ *     A lane holds 4 columns (2 when the column block is 2 wide); L = (d / column blocks) / 4 lanes (or 1) form a slot, S = 64 / L slots a wavefront, P = tipk_stream_gather_piece()
  *     steps of 8 ids a cell.  Plan (tip_amd/plan.py `build_stream_plan_rows`), all device arrays:
  *       wave_ptr[n_wg * 16 + 1]  int32: range of bands of every wavefront (wavefront = workgroup * 16 + wave)
  *       cells[n_bands][S]        uint32: row (24 bits) | steps << 24 (0 .. P) | first << 28 | last << 29 | log2 k << 30.
@@ -201,15 +205,18 @@ int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t 
  *                                = NULL: those rows are left untouched (the consumer masks them -- section 2b
  *                                row_used -- or they live in a buffer that was zeroed once)
  *     rows < 2^24.  row_scale (nullable): row_scale[i] * table[i] is what is staged.
+ *     Epilogue of a finished row (rows without edges included): relu?(out_scale[row] * sum + bias[col]); out_scale /
+ *     bias nullable.  max_split: the largest number of column blocks the caller accepts (every block walks all the ids
+ *     again): 4 on the D-D passes, 16 for the P-P graph (which also admits 2-column blocks).
  */
 /* column blocks of the launch (grid = n_wg x blocks); 0 = the table does not fit in LDS */
-int tipk_stream_gather_supported(int64_t n_table, int d);
+int tipk_stream_gather_supported(int64_t n_table, int d, int max_split);
 int tipk_stream_gather_piece(void);
 int tipk_stream_gather(const float* table, int64_t ld_table, int64_t n_table, int d, int64_t n_wg,
                         const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
                         const int32_t* zero_ptr, const int32_t* zero_rows, const float* row_scale,
                         float* out, int64_t ld_out, int kind /* 0 | 1: names the kernel instance in profiles, nothing else */,
-                        tipk_stream_t stream);
+                        int max_split, const float* out_scale, const float* bias, int relu, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2. Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).

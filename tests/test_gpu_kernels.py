@@ -845,7 +845,9 @@ def test_rel_stream_bwd(ops, N, d):
     wide = torch.randn(N, d + 8, generator=g).to(DEV)
     close(ops.rel_stream_bwd(sp, wide[:, 4:4 + d]), O.gather_sum(wide[:, 4:4 + d].cpu().double(), dst, rel * N + src, R * N))
     from tip_amd import _lib
-    assert _lib.lib().tipk_stream_gather_supported(10000, 32) == 0 and _lib.lib().tipk_stream_gather_supported(645, 24) == 0
+    assert _lib.lib().tipk_stream_gather_supported(10000, 32, 4) == 0 and _lib.lib().tipk_stream_gather_supported(645, 24, 4) == 0
+    assert _lib.lib().tipk_stream_gather_supported(19081, 32, 16) == 16 and _lib.lib().tipk_stream_gather_supported(19081, 16, 16) == 8
+    assert _lib.lib().tipk_stream_gather_supported(19081, 32, 4) == 0 and _lib.lib().tipk_stream_gather_supported(30000, 32, 16) == 0
 
 
 @pytest.mark.parametrize('N,R,nb', [(645, 1097, 32), (200, 50, 32), (100, 1500, 16), (64, 9, 8)])
@@ -1003,3 +1005,41 @@ def test_gather_rows_csr_vs_reference(ops, d):
           rtol=1e-4, atol=2e-4)
     empty = build_csr_plan(torch.zeros(0, dtype=torch.long, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV), 13, n_tab)
     assert float(ops.gather_rows_csr(empty, table.to(DEV)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('N,d,bias,relu', [(19081, 32, True, True), (19081, 16, False, False), (3000, 8, True, False)])
+def test_stream_gather_8_byte_rows_with_epilogue(ops, N, d, bias, relu):
+    """tipk_stream_gather with max_split = 16: a table too tall for 16-byte rows runs as 2-column blocks of 8-byte rows
+    (the P-P graph: 19 081 proteins); epilogue relu?(out_scale * sum + bias).  Against an fp64 index_add, and the plan
+    against its CPU interpreter."""
+    from tip_amd.plan import build_stream_plan_rows, execute_stream_plan_reference
+    g = torch.Generator().manual_seed(N + d)
+    E = 60000 if N > 5000 else 20000
+    dst = torch.randint(0, N, (E,), generator=g)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst[:3000] = 7                                                     # a hub row (wide run) ...
+    dst = torch.where(dst == 11, torch.full_like(dst, 12), dst)        # ... and a row without edges
+    split = ops.stream_gather_split(N, d, max_split=16)
+    assert split and (d // split == 2 or N < 5000)
+    dc = d // split
+    lanes, row_bytes = max(1, dc // 4), dc * 4
+    sp = build_stream_plan_rows(dst.to(DEV), src.to(DEV), N, N, max(1, 256 // split), lanes, row_bytes=row_bytes)
+    x = torch.randn(N, d, generator=g)
+    pre, post = torch.rand(N, generator=g) + 0.5, torch.rand(N, generator=g) + 0.5
+    b = torch.randn(d, generator=g) if bias else None
+    got = ops.stream_gather(sp, x.to(DEV), row_scale=pre.to(DEV), out_scale=post.to(DEV), bias=None if b is None else b.to(DEV),
+                            relu=relu, max_split=16)
+    want = torch.zeros(N, d, dtype=torch.float64).index_add_(0, dst, (x.double() * pre.double()[:, None])[src]) * post.double()[:, None]
+    if b is not None:
+        want = want + b.double()
+    if relu:
+        want = want.clamp(min=0)
+    close(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    if b is not None:
+        close(got[11], (b.double().clamp(min=0) if relu else b.double()), atol=1e-7)     # the empty row: epilogue of 0
+    again = ops.stream_gather(sp, x.to(DEV), row_scale=pre.to(DEV), out_scale=post.to(DEV), bias=None if b is None else b.to(DEV),
+                              relu=relu, max_split=16)
+    assert torch.equal(got, again)
+    if N <= 5000:
+        ref = execute_stream_plan_reference(sp.to('cpu'), x * pre[:, None])
+        close(ops.stream_gather(sp, x.to(DEV), row_scale=pre.to(DEV), max_split=16), ref.double(), rtol=1e-5, atol=1e-5)

@@ -574,3 +574,21 @@ def test_sampler_units_tile_the_positions_and_balance():
     assert sampler_units(torch.from_numpy(rel_ptr), n_wg)[1].tolist() == units.tolist()          # deterministic
     p0, u0 = sampler_units(torch.zeros(1, dtype=torch.int64), 4)
     assert p0.tolist() == [0] * 5 and u0.shape == (0, 3)
+
+
+def test_stream_plan_with_8_byte_rows_interprets_correctly():
+    """build_stream_plan_rows(row_bytes=8): the plan of the P-P graph's 2-column blocks (64 one-lane slots per wavefront),
+    executed by the CPU interpreter of the record format == a plain index_add; every row written exactly once."""
+    from tip_amd.plan import build_stream_plan_rows, execute_stream_plan_reference
+    g = torch.Generator().manual_seed(12)
+    N, E = 700, 9000
+    dst, src = torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)
+    dst[:2500] = 3                                                     # hub row -> wide run
+    dst = torch.where(dst == 5, torch.full_like(dst, 6), dst)          # row without edges
+    sp = build_stream_plan_rows(dst, src, N, N, 2, 1, row_bytes=8)
+    assert sp.row_bytes == 8 and sp.lanes == 1 and sp.cells.shape[1] == 64 and sp.idx_unit in (1, 2, 4, 8)
+    x = torch.randn(N, 2, generator=g)
+    got = execute_stream_plan_reference(sp, x)
+    want = torch.zeros(N, 2).index_add_(0, dst, x[src])
+    assert torch.allclose(got, want, atol=1e-4)
+    assert 5 in sp.zero_rows.tolist()

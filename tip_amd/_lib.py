@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class TipkError(RuntimeError):
@@ -64,9 +64,9 @@ SIGNATURES = {
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
     'tipk_pair_product_supported': (_I, [_I, _I]),
     'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P]),
-    'tipk_stream_gather_supported': (_I, [_L, _I]),
+    'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
-    'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P]),
+    'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),

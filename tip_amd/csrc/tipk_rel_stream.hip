@@ -50,20 +50,50 @@ struct RsArgs {
     float* out; int64_t ld_out;
     const float* row_scale;            // g' = row_scale[node] * table[node], applied while staging (nullable)
     int idx_mul;                       // byte offset of a table row = id * idx_mul
+    // epilogue of a finished row: relu?(out_scale[row] * sum + bias[col]) -- the GCN layer of the P-P graph
+    // (D^-1/2 (A + I) D^-1/2 = a row scaling on either side of the plain sum); all nullable / 0
+    const float* out_scale;
+    const float* bias;
+    int relu;
+};
+
+// a lane's piece of a row: float4 (16-byte rows and wider) or float2 (8-byte rows: tables of up to 19 000 nodes)
+template <int VW> struct RsVec;
+template <> struct RsVec<4> {
+    typedef float4 T;
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ void add(T& a, const T& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    static __device__ __forceinline__ void scale(T& a, float s) { a.x *= s; a.y *= s; a.z *= s; a.w *= s; }
+    static __device__ __forceinline__ T shfl_down(const T& a, int d) {
+        T o; o.x = __shfl_down(a.x, d, 64); o.y = __shfl_down(a.y, d, 64); o.z = __shfl_down(a.z, d, 64); o.w = __shfl_down(a.w, d, 64); return o;
+    }
+    static __device__ __forceinline__ void relu(T& a) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+};
+template <> struct RsVec<2> {
+    typedef float2 T;
+    static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); }
+    static __device__ __forceinline__ void add(T& a, const T& b) { a.x += b.x; a.y += b.y; }
+    static __device__ __forceinline__ void scale(T& a, float s) { a.x *= s; a.y *= s; }
+    static __device__ __forceinline__ T shfl_down(const T& a, int d) {
+        T o; o.x = __shfl_down(a.x, d, 64); o.y = __shfl_down(a.y, d, 64); return o;
+    }
+    static __device__ __forceinline__ void relu(T& a) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); }
 };
 
 // KIND only names the launch in profiles (0: rows = (relation, node), the transposed pass; 1: rows = node pairs)
-template <int L, bool UNIT, int KIND>
+template <int L, bool UNIT, int KIND, int VW = 4>
 __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];        // [n_nodes + 1][dc], last row = 0 (the pad id's row)
+    typedef RsVec<VW> V;
+    typedef typename V::T vec_t;
     constexpr int SPW = 64 / L;
-    constexpr int q4 = L;
+    constexpr int q4 = L;                                              // vectors per row of the column block
     const int t = threadIdx.x, lane = t & 63;
 #ifdef TIPK_DEBUG
     const unsigned long long st0 = __builtin_readcyclecounter();
 #endif
     const int n_nodes = a.n_nodes, dc = a.dc;
-    const int slot = lane / L, c0 = (lane & (L - 1)) * 4;
+    const int slot = lane / L, c0 = (lane & (L - 1)) * VW;
     const int col0 = blockIdx.y * dc;
     const float* table = a.table + col0;
     float* out = a.out + col0;
@@ -102,41 +132,49 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     // the whole table in ONE round trip: up to RS_STAGE float4 per thread are requested before the first is stored
     // (the LDS holds at most 10 112 float4; a loop of 4-deep batches cost a dependent round trip per 64 KB)
     for (int base = 0; base < total4; base += 1024 * RS_STAGE) {
-        float4 gv[RS_STAGE];
+        vec_t gv[RS_STAGE];
 #pragma unroll
         for (int u = 0; u < RS_STAGE; ++u) {
             int i = base + u * 1024 + t;
             i = i < total4 ? i : total4 - 1;
-            const int r = i / q4, c = (i - r * q4) * 4;
-            gv[u] = tipk_ld4(table + (int64_t)r * a.ld_t + c);
+            const int r = i / q4, c = (i - r * q4) * VW;
+            gv[u] = *reinterpret_cast<const vec_t*>(table + (int64_t)r * a.ld_t + c);
         }
         if (a.row_scale) {
 #pragma unroll
             for (int u = 0; u < RS_STAGE; ++u) {
                 int i = base + u * 1024 + t;
                 i = i < total4 ? i : total4 - 1;
-                const float sc = a.row_scale[i / q4];
-                gv[u].x *= sc; gv[u].y *= sc; gv[u].z *= sc; gv[u].w *= sc;
+                V::scale(gv[u], a.row_scale[i / q4]);
             }
         }
 #pragma unroll
         for (int u = 0; u < RS_STAGE; ++u) {
             const int i = base + u * 1024 + t;
-            if (i < total4) { const int r = i / q4, c = (i - r * q4) * 4; tipk_st4(tab + r * dc + c, gv[u]); }
+            if (i < total4) { const int r = i / q4, c = (i - r * q4) * VW; *reinterpret_cast<vec_t*>(tab + r * dc + c) = gv[u]; }
         }
     }
     __syncthreads();                                   // the only barrier of the launch
 #ifdef TIPK_DEBUG
     const unsigned long long st1 = __builtin_readcyclecounter();
 #endif
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    vec_t acc = V::zero();
+    // a finished row: relu?(out_scale[row] * sum + bias) (all optional), one store
+    vec_t bias_v = V::zero();
+    if (a.bias) bias_v = *reinterpret_cast<const vec_t*>(a.bias + col0 + c0);
+    auto finish = [&](int64_t row, vec_t v) {
+        if (a.out_scale) V::scale(v, a.out_scale[row]);
+        V::add(v, bias_v);
+        if (a.relu) V::relu(v);
+        *reinterpret_cast<vec_t*>(out + row * a.ld_out + c0) = v;
+    };
     // walk band `band` out of (cw, iw) and request band + RS_DEPTH into (nw, niw)
     auto walk = [&](int band, const uint32_t& cw, const uint4 (&iw)[RS_PIECE], uint32_t& nw, uint4 (&niw)[RS_PIECE]) {
         const uint32_t cell = band < b1 ? cw : 0u;                             // past the end: an idle cell
         fetch(band + RS_DEPTH, nw, niw);
         __builtin_amdgcn_sched_barrier(0);
         const int len = (int)((cell >> 24) & 15u);
-        if (cell & (1u << 28)) acc = make_float4(0.f, 0.f, 0.f, 0.f);          // first piece of its row
+        if (cell & (1u << 28)) acc = V::zero();                                // first piece of its row
 #pragma unroll
         for (int k = 0; k < RS_PIECE; ++k) {
             if (k < len) {
@@ -149,11 +187,11 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
                     const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
                     ad[jj] = UNIT ? tabb + idj : tabb + __umul24(idj, ldt4);
                 }
-                float4 v[8];
+                vec_t v[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const float4*>(ad[jj]);
+                for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const vec_t*>(ad[jj]);
 #pragma unroll
-                for (int jj = 7; jj >= 0; --jj) { acc.x += v[jj].x; acc.y += v[jj].y; acc.z += v[jj].z; acc.w += v[jj].w; }
+                for (int jj = 7; jj >= 0; --jj) V::add(acc, v[jj]);
             }
         }
         // a WIDE run was cut into 2^klog sub-runs in adjacent (aligned) slots: on its last band the partial sums are
@@ -165,15 +203,13 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
                 constexpr int LL = L;
                 const int delta = LL << j;
                 if (delta < 64) {
-                    float4 o;
-                    o.x = __shfl_down(acc.x, delta, 64); o.y = __shfl_down(acc.y, delta, 64);
-                    o.z = __shfl_down(acc.z, delta, 64); o.w = __shfl_down(acc.w, delta, 64);
-                    if ((int)klog > j && (slot & ((2 << j) - 1)) == 0) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+                    const vec_t o = V::shfl_down(acc, delta);
+                    if ((int)klog > j && (slot & ((2 << j) - 1)) == 0) V::add(acc, o);
                 }
             }
         }
         if (cell & (1u << 29))                                                   // the row is complete
-            tipk_st4(out + (int64_t)(cell & 0xffffffu) * a.ld_out + c0, acc);
+            finish((int64_t)(cell & 0xffffffu), acc);
     };
     for (; b < b1; b += 4) {
         walk(b, c0q, i0q, c2q, i2q);
@@ -194,13 +230,15 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     if (!a.zero_ptr) return;                           // the consumer masks those rows (tipk_rgcn_dy_products row_used)
     const int z0 = __builtin_amdgcn_readfirstlane(a.zero_ptr[gw]), z1 = __builtin_amdgcn_readfirstlane(a.zero_ptr[gw + 1]);
     for (int z = z0 + slot; z < z1; z += SPW)
-        tipk_st4(out + (int64_t)a.zero_rows[z] * a.ld_out + c0, make_float4(0.f, 0.f, 0.f, 0.f));
+        finish((int64_t)a.zero_rows[z], V::zero());
 }
 
-// column blocks of the launch (grid.y): the table of one block must fit in LDS; 0 = not supported
-inline int rel_stream_split(int64_t n_nodes, int d) {
+// column blocks of the launch (grid.y): the table of one block must fit in LDS; 0 = not supported.
+// max_split: every column block walks all the ids again -- 4 for the D-D passes (more blocks than that and the other
+// routes win), 16 for the P-P graph (19 081 proteins: 2-column blocks of 8-byte rows, 152 KB)
+inline int rel_stream_split(int64_t n_nodes, int d, int max_split) {
     if (n_nodes <= 0 || n_nodes > 65535 || d < 4 || d > 256 || (d & (d - 1)) != 0) return 0;
-    for (int split = 1; split <= 4 && d / split >= 4; split *= 2) {      // every column block walks all the ids again
+    for (int split = 1; split <= max_split && d / split >= (max_split > 4 ? 2 : 4); split *= 2) {
         const int dc = d / split;
         if (dc > 64) continue;
         if ((n_nodes + 1) * dc * 4 <= RS_LDS_LIMIT) return split;
@@ -208,11 +246,11 @@ inline int rel_stream_split(int64_t n_nodes, int d) {
     return 0;
 }
 
-template <int L>
+template <int L, int VW = 4>
 int launch_rs(const RsArgs& a, int n_wg, int split, int kind, hipStream_t st) {
     const size_t lds = (size_t)(a.n_nodes + 1) * a.dc * 4;
-    auto kern = kind ? (a.idx_mul == 1 ? stream_gather_kernel<L, true, 1> : stream_gather_kernel<L, false, 1>)
-                     : (a.idx_mul == 1 ? stream_gather_kernel<L, true, 0> : stream_gather_kernel<L, false, 0>);
+    auto kern = kind ? (a.idx_mul == 1 ? stream_gather_kernel<L, true, 1, VW> : stream_gather_kernel<L, false, 1, VW>)
+                     : (a.idx_mul == 1 ? stream_gather_kernel<L, true, 0, VW> : stream_gather_kernel<L, false, 0, VW>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return tipk_hip_status(e);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)split), dim3(1024), lds, st, a);
@@ -227,29 +265,36 @@ extern "C" int tipk_debug_rs_stamps(unsigned long long* host_out /* [4096 * 4] *
 }
 #endif
 
-extern "C" int tipk_stream_gather_supported(int64_t n_table, int d) { return rel_stream_split(n_table, d); }
+extern "C" int tipk_stream_gather_supported(int64_t n_table, int d, int max_split) {
+    return rel_stream_split(n_table, d, max_split < 1 ? 1 : max_split);
+}
 
 extern "C" int tipk_stream_gather_piece(void) { return RS_PIECE; }
 
 extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t n_nodes, int d, int64_t n_wg,
                                    const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
                                    const int32_t* zero_ptr, const int32_t* zero_rows, const float* row_scale,
-                                   float* out, int64_t ld_out, int kind, tipk_stream_t stream) {
+                                   float* out, int64_t ld_out, int kind, int max_split, const float* out_scale,
+                                   const float* bias, int relu, tipk_stream_t stream) {
     if (n_wg <= 0 || n_wg > 65535 || !table || !wave_ptr || !cells || !ids || (zero_ptr && !zero_rows) || !out ||
         (reinterpret_cast<uintptr_t>(ids) & 15))
         return TIPK_EINVAL;
-    const int split = rel_stream_split(n_nodes, d);
+    const int split = rel_stream_split(n_nodes, d, max_split < 1 ? 1 : max_split);
     if (split == 0) return TIPK_EUNSUPPORTED;
-    if (ld_table % 4 != 0 || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(table) & 15) ||
-        (reinterpret_cast<uintptr_t>(out) & 15))
+    const int dc_ = d / split;
+    const int al = dc_ >= 4 ? 4 : 2;                                   // floats per lane piece
+    if (ld_table % al != 0 || ld_out % al != 0 || (reinterpret_cast<uintptr_t>(table) & (4 * al - 1)) ||
+        (reinterpret_cast<uintptr_t>(out) & (4 * al - 1)) || (bias && (reinterpret_cast<uintptr_t>(bias) & (4 * al - 1))))
         return TIPK_EINVAL;
     RsArgs a;
     a.table = table; a.ld_t = ld_table; a.n_nodes = (int)n_nodes; a.dc = d / split;
     a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
     a.out = out; a.ld_out = ld_out; a.row_scale = row_scale;
+    a.out_scale = out_scale; a.bias = bias; a.relu = relu;
     if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || (int64_t)n_nodes * idx_unit > 65535) return TIPK_EINVAL;
     a.idx_mul = a.dc * 4 / idx_unit;
     hipStream_t st = (hipStream_t)stream;
+    if (a.dc == 2) return launch_rs<1, 2>(a, (int)n_wg, split, kind != 0, st);
     switch (a.dc / 4) {
         case 1: return launch_rs<1>(a, (int)n_wg, split, kind != 0, st);
         case 2: return launch_rs<2>(a, (int)n_wg, split, kind != 0, st);

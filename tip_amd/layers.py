@@ -148,6 +148,26 @@ def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK, d=None):
     dis = deg.pow(-0.5)
     dis[torch.isinf(dis)] = 0
     w = dis[row] * dis[col]
+    # TIPK_PP_STREAM=1 (round 3, measured SLOWER, kept as a switch): the normalised adjacency is a row scaling on either
+    # side of the PLAIN sum over (A + I), so when a 2-column (or wider) block of the table fits in LDS -- 19 081 proteins:
+    # 152 KB of 8-byte rows -- both passes can run as wave streams out of LDS (`ops.stream_gather`, include/tipk.h section
+    # 1d) instead of through the L2 gather path.  The gather itself is then cheap, but every workgroup has to stage its
+    # 2 columns of ALL rows: 8 bytes out of every 128-byte row, i.e. the whole 2.4 MB table crosses each CU's 64 B/clk
+    # L1 path -- 36 us per launch against 19 for `gather_sum` (0.434 vs 0.384 ms per step).
+    split = 0
+    if d and row.is_cuda and num_nodes <= 65535 and os.environ.get('TIPK_PP_STREAM'):
+        split = ops.stream_gather_split(num_nodes, d, max_split=16)
+    if split:
+        n_cu = torch.cuda.get_device_properties(row.device).multi_processor_count
+        n_wg = max(1, n_cu // split)
+        dc = d // split
+        lanes, row_bytes = (max(1, dc // 4), dc * 4)
+        graph = ops.AggGraph(lambda: build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd', G),
+                             lambda: build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd', G))
+        graph.pp_stream = ops.PPStream(build_stream_plan_rows(col, row, num_nodes, num_nodes, n_wg, lanes, row_bytes=row_bytes),
+                                       build_stream_plan_rows(row, col, num_nodes, num_nodes, n_wg, lanes, row_bytes=row_bytes),
+                                       dis.contiguous(), d)
+        return graph
     return ops.AggGraph(build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd', G),
                         build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd', G))
 

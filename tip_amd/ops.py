@@ -229,11 +229,12 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
     return sum_slabs(out)
 
 
-def stream_gather_split(n_table, d):
-    """column blocks `tipk_stream_gather` would use for a table [n_table, d]; 0 = it does not fit in LDS."""
+def stream_gather_split(n_table, d, max_split=4):
+    """column blocks `tipk_stream_gather` would use for a table [n_table, d]; 0 = it does not fit in LDS.
+    max_split: 4 on the D-D passes, 16 for the P-P graph (2-column blocks of 8-byte rows)."""
     if os.environ.get('TIPK_NO_RELSTREAM') or os.environ.get('TIPK_NO_RELLOCAL'):
         return 0
-    return int(lib().tipk_stream_gather_supported(n_table, d))
+    return int(lib().tipk_stream_gather_supported(n_table, d, max_split))
 
 
 rel_stream_split = stream_gather_split
@@ -253,22 +254,26 @@ def dy_products_fused(r, nc, nb):
     return s_c.value != 0
 
 
-def stream_gather(sp, table, row_scale=None, write_zeros=True, out=None, label='stream_gather', kind=0):
+def stream_gather(sp, table, row_scale=None, write_zeros=True, out=None, label='stream_gather', kind=0, max_split=4,
+                  out_scale=None, bias=None, relu=False):
     """out[row] = sum of table rows on a wave-stream plan (include/tipk.h section 1d), table [n_table, d] staged
     in LDS (scaled per row while staged).  write_zeros=False leaves the rows without edges UNTOUCHED: only for
-    a consumer that masks them (`dy_products(row_used=...)`) or an `out` buffer that was zeroed once."""
+    a consumer that masks them (`dy_products(row_used=...)`) or an `out` buffer that was zeroed once.
+    Epilogue of a finished row: relu?(out_scale[row] * sum + bias)."""
     table = _f32c(table)
-    require_device(table, sp.ids)
+    require_device(table, sp.ids, row_scale, out_scale, bias)
     d = table.shape[1]
-    split = stream_gather_split(sp.n_table, d)
-    assert table.shape[0] == sp.n_table and split and (d // split) // 4 == sp.lanes, 'plan was built for another launch shape'
+    split = stream_gather_split(sp.n_table, d, max_split)
+    assert table.shape[0] == sp.n_table and split and (d // split) * 4 == sp.row_bytes, 'plan was built for another launch shape'
+    assert table.stride(1) == 1
     if out is None:
         out = torch.empty((sp.n_rows, d), dtype=torch.float32, device=table.device)
     assert out.shape == (sp.n_rows, d) and out.is_contiguous()
     with _timed('%s[d=%d]' % (label, d)):
         check(lib().tipk_stream_gather(ptr(table), table.stride(0), sp.n_table, d, sp.n_wg, ptr(sp.wave_ptr), ptr(sp.cells),
                                        ptr(sp.ids), sp.idx_unit, ptr(sp.zero_ptr) if write_zeros else None,
-                                       ptr(sp.zero_rows), ptr(row_scale), ptr(out), d, kind, stream_ptr(table.device)),
+                                       ptr(sp.zero_rows), ptr(row_scale), ptr(out), d, kind, max_split, ptr(out_scale),
+                                       ptr(bias), int(bool(relu)), stream_ptr(table.device)),
               'tipk_stream_gather')
     return out
 
@@ -903,6 +908,17 @@ def pair_product(cells, xb_nb, symmetric=False):
     return slabs
 
 
+class PPStream(object):
+    """Wave-stream plans of a GCN-normalised graph (tip_amd.layers.gcn_norm_graph): D^-1/2 (A + I) D^-1/2 X =
+    dis * sum_{(A + I)} (dis * X), both passes out of LDS (`stream_gather` with max_split = 16)."""
+
+    def __init__(self, fwd, bwd, dis, d):
+        self.fwd, self.bwd, self.dis, self.d = fwd, bwd, dis, int(d)
+
+    def usable(self, t):
+        return t.dim() == 2 and t.shape[1] == self.d and t.stride(1) == 1 and t.stride(0) % 2 == 0 and t.data_ptr() % 8 == 0
+
+
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
@@ -917,6 +933,7 @@ class AggGraph(object):
                                                            # that build them on first use (fallback routes only)
         self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
+        self.pp_stream = None                              # PPStream: GCN-normalised graphs whose table blocks fit in LDS
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
         self.fwd_route = {}                                # sharded layers: timed choice pair form | Y route (ops._fwd_route)
@@ -1404,7 +1421,12 @@ class _GCNConv(torch.autograd.Function):
         else:
             x = _f32c(x)
             xl = gemm(x, weight.t())
-        out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=relu)
+        ps = getattr(graph, 'pp_stream', None)
+        if ps is not None and ps.usable(xl):
+            out = stream_gather(ps.fwd, xl, row_scale=ps.dis, out_scale=ps.dis, bias=bias, relu=relu, max_split=16,
+                                label='pp_stream[fwd]')
+        else:
+            out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=relu)
         ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
         ctx.save_for_backward(x, weight, out if relu else None)
         return out
@@ -1421,8 +1443,12 @@ class _GCNConv(torch.autograd.Function):
                 g_pre, bias_parts = fused
         if bias_parts is None:
             g_pre = rows_affine(g, gate=out) if ctx.relu else g
-        g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
-        g_table = gather_sum(graph.bwd, g_agg)
+        ps = getattr(graph, 'pp_stream', None)
+        if ps is not None and ps.usable(g_pre):
+            g_table = stream_gather(ps.bwd, g_pre, row_scale=ps.dis, out_scale=ps.dis, max_split=16, label='pp_stream[bwd]')
+        else:
+            g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
+            g_table = gather_sum(graph.bwd, g_agg)
         j_b = None
         if ctx.has_bias and bias_parts is None:
             j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre)

@@ -558,13 +558,14 @@ class StreamPlan(object):
         self.n_edges = 0                          # edges the plan walks
         self.n_nodes, self.n_rel = n_nodes, n_rel
         self.compact = None                       # CompactRows: the rows are the node-major compact numbering (tipk.h section 2d)
+        self.row_bytes = self.lanes * 16          # bytes of a table row of one column block in LDS
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
         sp = StreamPlan(self.n_rows, self.n_table, self.n_wg, self.lanes, self.piece, mv(self.wave_ptr), mv(self.cells),
                         mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
                         self.n_nodes, self.n_rel)
-        sp.symmetric, sp.n_edges = self.symmetric, self.n_edges
+        sp.symmetric, sp.n_edges, sp.row_bytes = self.symmetric, self.n_edges, self.row_bytes
         sp.compact = None if self.compact is None else self.compact.to(device)
         return sp
 
@@ -575,7 +576,7 @@ STREAM_BAND_OVERHEAD = 2.0     # what a band costs besides its steps (record fet
 STREAM_WIDE_STEPS = 16        # a run with more steps than this is cut into 2, 4 or 8 sub-runs walked side by side
 
 
-def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece=4, wide_steps=None):
+def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece=4, wide_steps=None, row_bytes=None):
     """Wave-stream plan for  out[o] = sum_{e: out_row[e] = o} table[tab_row[e]],  o < n_rows, table rows < n_table.
 
     The runs (one per output row with edges) are sorted by decreasing length and taken SPW = 64 / lanes at
@@ -592,7 +593,10 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     balanced (measured: capping runs at 24 steps, 4 % of the work, took the pair gather from 21.5 to 15.2 us).
     A run with more than `wide_steps` steps is therefore cut into k = 2, 4 or 8 sub-runs that sit in k
     adjacent, k-aligned slots of ONE group; their partial sums are added in a fixed tree order by the kernel
-    (cell bits 30-31 = log2 k on the set's last band) and the first slot writes the row."""
+    (cell bits 30-31 = log2 k on the set's last band) and the first slot writes the row.
+
+    row_bytes: bytes of a table row in LDS (default lanes * 16: a float4 per lane); 8 = the 2-column blocks of a table
+    too tall for 16-byte rows (the P-P graph: lanes = 1, a float2 per lane)."""
     import heapq
     dev = out_row.device
     T, S, W = int(n_table), 64 // int(lanes), int(n_wg) * 16
@@ -686,7 +690,8 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
                         | (torch.where(final, klog, torch.zeros_like(klog)) << 30), torch.zeros_like(st))
     # ---- ids
     idx_unit = 1
-    row_bytes = lanes * 16
+    row_bytes = lanes * 16 if row_bytes is None else int(row_bytes)
+    assert row_bytes == lanes * 16 or (row_bytes == 8 and lanes == 1)
     while idx_unit * 2 <= row_bytes and T * idx_unit * 2 <= 65535:
         idx_unit *= 2
     v_first = torch.full((max(n_runs, 1),), -1, dtype=torch.int64, device=dev)      # virtual index of a run's first sub-run
@@ -701,7 +706,12 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     j1 = torch.arange(E, device=dev) - run_first[ri1]                     # rank inside the run (edge order)
     q8 = q_run[ri1] * 8
     ve = v_first[ri1] + j1 // q8                                          # virtual run of every edge
-    n_cls, rot = bank_rotation(lanes)
+    if row_bytes == 8:
+        # 8-byte rows: a row sits in bank pair (id mod 32); the 64 slots of a wavefront advance in lock step, slot k
+        # starts its class sequence k mod 32 later -- any 32 neighbouring lanes then read 32 different bank pairs
+        n_cls, rot = 32, [k % 32 for k in range(S)]
+    else:
+        n_cls, rot = bank_rotation(lanes)
     tab1 = tab_row[o1]
     cls = (tab1 % n_cls - torch.tensor(rot, device=dev)[ve % S]) % n_cls
     o2 = torch.sort(ve * n_cls + cls, stable=True).indices
@@ -724,6 +734,7 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
                     ids32.to(torch.uint16).contiguous(), zero_ptr.to(torch.int32).contiguous(),
                     zero_rows.to(torch.int32).contiguous(), idx_unit)
     sp.n_edges = E
+    sp.row_bytes = row_bytes
     return sp
 
 
