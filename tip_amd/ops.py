@@ -370,7 +370,8 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
         grain = int(os.environ.get('TIPK_KSPLIT_GRAIN', '64'))
         wgs = int(os.environ.get('TIPK_KSPLIT_WGS', '512'))
         cap = int(os.environ.get('TIPK_KSPLIT_MAX', '128'))
-        want = min(k // grain, -(-wgs // tiles))
+        # (ceil: K = 645 -> 11 slabs of 64 = two K tiles each; 10 slabs made the chunk 96 = three tiles, three slabs empty)
+        want = min(-(-k // grain), -(-wgs // tiles))
         if plain and not reduce_batch and want >= 2 and tiles < 256:
             slab_mode, n_slabs = 'k', int(min(cap, want))
     elif ksplit > 1:
