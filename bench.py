@@ -270,7 +270,7 @@ def dd_launches(enc, dev):
                     xb = torch.randn(nb, n, d, device=dev)
                     dyc = ops.rel_stream_bwd(rs, g, row_scale=graph.scale)
                     rows = rs.compact.n_rows
-                    add('node_products[dd.bwd,d=%d]' % d, 'node_products_kernel', None, 'mfma', 2 * 2.0 * rows * d * nb,
+                    add('node_products[dd.bwd,d=%d]' % d, 'node_products_kernel<%d>' % d, None, 'mfma', 2 * 2.0 * rows * d * nb,
                         lambda dyc=dyc, cr=rs.compact, att=att, xb=xb: ops.node_products(dyc, cr, att, xb),
                         rows=rows, flops_dense_form=2 * 2.0 * r * n * d * nb)
             elif ops.rel_gather_usable(graph.rl_bwd if bwd else graph.rl_fwd, n, d, bwd):

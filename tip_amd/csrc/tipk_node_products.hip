@@ -75,13 +75,17 @@ __device__ __forceinline__ float4 np_ldg4(const float* base, u32 byte_off) {
 // No operand is ever masked: a row / chunk that does not exist reads the ZERO ROW of dyc on one side of the product (its
 // partner on the other side is a clamped, finite value), and result rows / columns beyond n_bases or d are not stored.
 // A `cond ? loaded : 0` next to its load makes hipcc skip the load under exec and wait for each one on the spot.
-template <int NCT>
+// D = the row width d as a template constant: the two R-GCN layers of a model launch with identical grids, and a name per
+// width keeps them apart in kernel traces and counter summaries (profiles/*_kernel_by_grid.csv); NCT = 32-column tiles per row
+template <int D>
 __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
+    constexpr int NCT = (D + 31) / 32;
     __shared__ float red[NP_WAVES * 1024];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n = lane & 31, kh = lane >> 5;
-    const int d = a.d, NB = a.NB;
+    constexpr int d = D;
+    const int NB = a.NB;
     const int nb_c = n < NB ? n : NB - 1;
     const u32 d4 = (u32)d * 4u;
 
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
         const u32 xb_n4 = (u32)nb_c * (u32)a.xb_sb * 4u, xb_su4 = (u32)a.xb_su * 4u;
         auto getpos = [&](int q) {
             q = q < q_hi ? q : q_hi - 1;
-            int node = (32 * q + 16 * kh) >> a.log2d;
+            int node = (32 * q + 16 * kh) / D;
             node = node < a.n_nodes ? node : a.n_nodes - 1;
             return __float_as_int(np_ldg(reinterpret_cast<const float*>(a.pos), (u32)node * rpad4 + pos_m4));
         };
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
             const bool q_ok = q < q_hi;
             q = q_ok ? q : q_hi - 1;
             const int f = 32 * q + 16 * kh;
-            const int node = f >> a.log2d;
+            const int node = f / D;
             const u32 c04 = (u32)(f & (d - 1)) * 4u;
             const bool ok = q_ok && node < a.n_nodes;                       // the last chunk may run past the last node
             const u32 ab = (u32)(ok ? p : a.n_rows) * d4 + c04;             // not there: the zero row
@@ -288,8 +292,9 @@ extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, 
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
     const unsigned grid = (unsigned)(a.n_nodes + a.n_role2);
     hipStream_t st = (hipStream_t)stream;
-    if (d <= 32) hipLaunchKernelGGL(node_products_kernel<1>, dim3(grid), dim3(NP_THREADS), 0, st, a);
-    else if (d == 64) hipLaunchKernelGGL(node_products_kernel<2>, dim3(grid), dim3(NP_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(node_products_kernel<4>, dim3(grid), dim3(NP_THREADS), 0, st, a);
+    if (d == 16) hipLaunchKernelGGL(node_products_kernel<16>, dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else if (d == 32) hipLaunchKernelGGL(node_products_kernel<32>, dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else if (d == 64) hipLaunchKernelGGL(node_products_kernel<64>, dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(node_products_kernel<128>, dim3(grid), dim3(NP_THREADS), 0, st, a);
     TIPK_RETURN_LAUNCH();
 }

@@ -25,7 +25,7 @@ for f in glob.glob('gpurun_out/pmc_np/p*/**/*counter_collection.csv', recursive=
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'node_products' not in k and 'stream_gather' not in k: continue
-        key = k.split('(')[0][-40:] + ' grid=' + r['Grid_Size'] + ' lds=' + r.get('LDS_Block_Size', '?')
+        key = k.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0] + ' grid=' + r['Grid_Size']
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 lines = ['backward D-D kernels of the BioSNAP step (layer 1: d = 32, layer 2: d = 16), counters summed over the device, mean of 3 launches each']
 for k in sorted(agg):
