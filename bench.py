@@ -568,14 +568,14 @@ def measure_config(workload, mod, dev, steps=20, warmup=5):
     b = Bench(dd, dims, mod, dev)
     pre = b.prepare()
     run = b.capture()
+    launches = dd_launches(b.enc, dev)                     # (before the timed region, as in main)
+    us = {l['label']: time_launch_us(l['fn'], reps=10 if workload == 'synthetic' else 20, replays=3) for l in launches
+          if l['work'] is not None}
     el = timed(run, steps, warmup, torch.cuda.synchronize)
     E = int(dd['dd_train_idx'].shape[1])
     ms = el / steps * 1e3
     rec = {'workload': name, 'mod': mod, 'directed_dd_edges': E, 'relations': dd['n_dd_et'], 'steps': steps, 'warmup': warmup,
            'ms_per_step': ms, 'value': E * steps / el, 'unit': 'edges/s', 'preprocess_s': pre, 'generate_s': gen_s}
-    launches = dd_launches(b.enc, dev)
-    us = {l['label']: time_launch_us(l['fn'], reps=10 if workload == 'synthetic' else 20, replays=3) for l in launches
-          if l['work'] is not None}
     if us:
         dom = max(us, key=us.get)
         roof = roofline_of([l for l in launches if l['label'] == dom][0], us[dom], _lib.build_id())
@@ -735,11 +735,14 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) <= 0:
             run, launch = b.step, 'eager'
-    elapsed = timed(run, args.steps, args.warmup, fence)
-
-    # the large D-D launches alone (roofline objects), then an eager per-kernel table of the whole step
+    # the large D-D launches alone (roofline objects: HIP events around graphs of 20 back-to-back launches).  They run BEFORE
+    # the headline region: a fresh process times its first milliseconds of GPU work at ramping clocks (20 steps = 7 ms;
+    # measured 0.377 ms/step with the order reversed against 0.36 here and for --steps 100 either way)
     launches = [] if args.step_only else dd_launches(enc, dev)
     launch_us = {l['label']: time_launch_us(l['fn']) for l in launches if l['work'] is not None}
+    elapsed = timed(run, args.steps, args.warmup, fence)
+
+    # an eager per-kernel table of the whole step
     kern = {}
     if not args.no_kernel_table and not args.step_only:
         ops.timing_start()
