@@ -804,6 +804,8 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
         if (tasks is None or z.shape[1] not in (4, 8, 16) or os.environ.get('TIPK_FLOAT_ATOMICS') or z.shape[0] > 65535
                 or neg_index.numel() != pos_index.shape[1]):
             neg_index, packed = unpack_pairs(neg_index).type_as(pos_index), False      # the general kernels take plain ids
+    if packed and not getattr(neg_index, '_tipk_sampled', False):      # a packed tensor that is not the sampler's own output
+        validate_triples(unpack_pairs(neg_index), None, z.shape[0], weight.shape[0])
     if packed:                                             # (`_store`: the finalize launch overwrites -- no zero fills)
         loss = torch.empty((1,), dtype=torch.float32, device=z.device)
         g_z = torch.empty_like(z) if need_grad else None
