@@ -369,7 +369,7 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
         # until a slab is one or two K tiles (knobs for sweeps: TIPK_KSPLIT_GRAIN / _WGS / _MAX)
         grain = int(os.environ.get('TIPK_KSPLIT_GRAIN', '64'))
         wgs = int(os.environ.get('TIPK_KSPLIT_WGS', '512'))
-        cap = int(os.environ.get('TIPK_KSPLIT_MAX', '128'))
+        cap = int(os.environ.get('TIPK_KSPLIT_MAX', '320'))     # (K = 19 081: 299 slabs of two K tiles; 128 slabs made five-tile chains)
         # (ceil: K = 645 -> 11 slabs of 64 = two K tiles each; 10 slabs made the chunk 96 = three tiles, three slabs empty)
         want = min(-(-k // grain), -(-wgs // tiles))
         if plain and not reduce_batch and want >= 2 and tiles < 256:
