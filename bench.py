@@ -551,8 +551,6 @@ def timed(run, steps, warmup, fence):
 def release(*objs):
     import gc
     import torch
-    from tip_amd import ops
-    ops._DYC.clear()
     gc.collect()
     torch.cuda.empty_cache()
 
@@ -695,6 +693,8 @@ def main():
                 dist.broadcast(buf, 0)
                 prm.data.copy_(buf)
         attach_shard(enc, shard)
+        if world > 1 and 'TIPK_FWD_ROUTE' not in os.environ:
+            ops.FWD_ROUTE_MODE = 'timed'                       # one timed, job-wide decision per layer (ops._fwd_route)
         if os.environ.get('TIPK_COLLECTIVE') == 'direct' and world > 1:
             # one-shot exchange over peer-mapped mailboxes instead of the group's all-reduce (opt-in: tip_amd/dist.py)
             shard.enable_direct_exchange(dev, max_floats=max(1 << 16, dd['n_drug'] * (2 * max(dims.values()) + 64)

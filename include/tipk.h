@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 12
+#define TIPK_ABI_VERSION 13
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -553,6 +553,14 @@ int tipk_ipc_open(const void* handle /* 64 bytes, host */, void** ptr);
 int tipk_ipc_close(void* ptr);
 int tipk_peer_allreduce(float* data, int64_t n, void* const* mailboxes /* host [world] */, int rank, int world,
                         int64_t max_floats, tipk_stream_t stream);
+/*      BOUNDED WAIT: the flag wait of an exchange has a wall-clock budget (default 2 000 ms).  A rank whose peer died,
+ *      skipped a call or took another collective does not spin for ever: the kernel records {sequence number << 32 |
+ *      (missing rank + 1) << 16 | chunk} in the ERROR WORD of its own mailbox (first record wins) and finishes with
+ *      whatever the slots hold.  tipk_peer_status copies that word to the host (0 = every wait was served; a synchronous
+ *      8-byte copy: call it where the host synchronises anyway, never inside a capture); the caller must treat a
+ *      non-zero word as fatal for the process group.  tipk_peer_set_timeout_ms: the budget of later launches (1 ... 600 000). */
+int tipk_peer_set_timeout_ms(int64_t ms);
+int tipk_peer_status(void* mailbox, int world, int64_t max_floats, uint64_t* error_word /* host */);
 
 /* --------------------------------------------------------------------------------------------
  * 9. Optimizer step of the training loop -- replaces `optimizer.step()` of tip.py:24-30

@@ -106,3 +106,50 @@ def test_adam_rejects_what_it_does_not_implement():
     from tip_amd._lib import TipkError
     with pytest.raises(TipkError):
         Adam(cpu).step()                                              # no CPU path
+
+
+def test_adam_state_dict_round_trip_and_torch_checkpoint():
+    """`Optimizer.load_state_dict` casts a capturable optimizer's `step` to float32; the kernel reads the word
+    as uint64.  A reloaded state (own checkpoint, or one written by torch.optim.Adam) must continue exactly like torch's
+    Adam continues from the same checkpoint."""
+    import copy
+    from tip_amd.optim import Adam
+    shapes = [(645, 16), 1000, (32, 963, 't'), 3]
+    a, b, mine, ref = _pair(shapes, 11, lr=0.01)
+    g = torch.Generator().manual_seed(4)
+
+    def feed(params_a, params_b):
+        for pa, pb in zip(params_a, params_b):
+            gr = torch.randn(pa.shape, generator=g).to(DEV)
+            pa.grad, pb.grad = gr.clone(memory_format=torch.preserve_format), gr.clone(memory_format=torch.preserve_format)
+    for _ in range(7):
+        feed(a, b)
+        mine.step(); ref.step()
+    sd_mine, sd_ref = copy.deepcopy(mine.state_dict()), copy.deepcopy(ref.state_dict())
+    # three continuations: own checkpoint -> own optimizer, torch checkpoint -> own optimizer, torch -> torch (the reference)
+    a1 = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a]
+    a2 = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in b]
+    b2 = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in b]
+    m1, m2 = Adam(a1, lr=0.01), Adam(a2, lr=0.01)
+    r2 = torch.optim.Adam(b2, lr=0.01, foreach=False, fused=False)
+    m1.load_state_dict(sd_mine); m2.load_state_dict(sd_ref); r2.load_state_dict(sd_ref)
+    for opt, ps in ((m1, a1), (m2, a2)):
+        for p in ps:
+            st = opt.state[p]['step']
+            assert st.dtype == torch.int64 and st.device == p.device and int(st) == 7
+    for _ in range(3):
+        for pa1, pa2, pb2 in zip(a1, a2, b2):
+            gr = torch.randn(pa1.shape, generator=g).to(DEV)
+            pa1.grad = gr.clone(memory_format=torch.preserve_format)
+            pa2.grad = gr.clone(memory_format=torch.preserve_format)
+            pb2.grad = gr.clone(memory_format=torch.preserve_format)
+        m1.step(); m2.step(); r2.step()
+    for pa1, pa2, pb2 in zip(a1, a2, b2):
+        torch.testing.assert_close(pa2, pb2, rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(pa1, pb2, rtol=1e-4, atol=2e-5)      # (a and b differed by a few ulps after 7 steps)
+        assert int(m1.state[pa1]['step']) == 10 == int(m2.state[pa2]['step'])
+    # a step count of the wrong type is refused, not reinterpreted
+    m1.state[a1[0]]['step'] = torch.tensor(10.0, device=DEV)
+    a1[0].grad = torch.zeros_like(a1[0])
+    with pytest.raises(TypeError):
+        m1.step()

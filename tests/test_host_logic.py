@@ -403,11 +403,23 @@ def test_triple_validation_is_cached_and_raises():
     ei = torch.tensor([[0, 1, 2], [2, 1, 0]])
     et = torch.tensor([0, 0, 1])
     ops.validate_triples(ei, et, 3, 2)
-    assert ei._tipk_range_ok == (ei._version, 3) and et._tipk_range_ok == (et._version, 2)     # the verdict lives ON the tensor:
-    assert not hasattr(ops, '_VALID')                                                          # no global cache pins index tensors
+    # the verdict lives in a side table keyed by the tensor object (weakly): nothing is pinned, nothing rides in torch.save
+    assert ops._facts(ei).get('range_ok') == 3 and ops._facts(et).get('range_ok') == 2
+    assert not hasattr(ei, '_tipk_range_ok') and not ei.__dict__
     ei[0, 0] = 1                                                       # modified in place: checked again
-    assert ei._tipk_range_ok != (ei._version, 3)
+    assert ops._facts(ei).get('range_ok') is None
     ops.validate_triples(ei, et, 3, 2)
+    import io
+    import pickle
+    buf = io.BytesIO()
+    torch.save(ei, buf)
+    back = torch.load(io.BytesIO(buf.getvalue()))
+    assert ops._facts(back).get('range_ok') is None                    # an unpickled tensor is validated again
+    n_before = len(ops._TENSOR_FACTS)
+    del back
+    import gc
+    gc.collect()
+    assert len(ops._TENSOR_FACTS) == n_before - 1                      # the entry died with its tensor
     with pytest.raises(ValueError):
         ops.validate_triples(ei, et[:2], 3, 2)                         # one relation id per triple
     with pytest.raises(IndexError):
@@ -592,3 +604,25 @@ def test_stream_plan_with_8_byte_rows_interprets_correctly():
     want = torch.zeros(N, 2).index_add_(0, dst, x[src])
     assert torch.allclose(got, want, atol=1e-4)
     assert 5 in sp.zero_rows.tolist()
+
+
+def test_adam_adopts_reloaded_step_counts():
+    """after `load_state_dict` (torch casts a capturable optimizer's `step` to float32) and for checkpoints
+    written by torch.optim.Adam, `step` is re-made as an int64 counter -- host logic only, no kernel launch."""
+    from tip_amd.optim import Adam
+    p = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(4))]
+    ref = torch.optim.Adam(p, lr=0.01)
+    for q in p:
+        q.grad = torch.ones_like(q)
+    ref.step(); ref.step()
+    mine = Adam([torch.nn.Parameter(q.detach().clone()) for q in p], lr=0.01)
+    mine.load_state_dict(ref.state_dict())
+    for q in mine.param_groups[0]['params']:
+        st = mine.state[q]
+        assert st['step'].dtype == torch.int64 and st['step'].dim() == 0 and int(st['step']) == 2
+        assert st['exp_avg'].dtype == torch.float32 and st['exp_avg'].shape == q.shape
+    again = Adam([torch.nn.Parameter(q.detach().clone()) for q in p], lr=0.01)
+    again.load_state_dict(mine.state_dict())                           # own checkpoint: torch's cast to float32 is undone
+    assert all(again.state[q]['step'].dtype == torch.int64 and int(again.state[q]['step']) == 2
+               for q in again.param_groups[0]['params'])
+    assert all(g['capturable'] for g in again.param_groups)

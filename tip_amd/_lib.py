@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class TipkError(RuntimeError):
@@ -100,6 +100,8 @@ SIGNATURES = {
     'tipk_ipc_open': (_I, [_P, C.POINTER(_P)]),
     'tipk_ipc_close': (_I, [_P]),
     'tipk_peer_allreduce': (_I, [_P, _L, C.POINTER(_P), _I, _I, _L, _P]),
+    'tipk_peer_set_timeout_ms': (_I, [_L]),
+    'tipk_peer_status': (_I, [_P, _I, _L, C.POINTER(C.c_uint64)]),
     'tipk_adam_step': (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_L), C.POINTER(_P), _P,
                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),

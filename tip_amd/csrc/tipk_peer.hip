@@ -18,6 +18,13 @@
 // already writing call s + 1 cannot overwrite what a slower rank still reads for call s, and it cannot reach call
 // s + 2 before every rank has posted s + 1, i.e. has finished reading s.
 //
+// BOUNDED WAIT: a rank that died, skipped a call or took another collective would leave the others spinning for ever --
+// on a shared node a hung lease, not an error.  The wait of step 3 therefore has a wall-clock budget (s_memrealtime,
+// 100 MHz; tipk_peer_set_timeout_ms, default 2 000 ms): when it runs out the workgroup records {sequence number, first
+// missing rank, chunk} in the mailbox's ERROR WORD and goes on with whatever the slots hold.  The result of that call is
+// garbage BY DESIGN; the host reads the error word at its next synchronisation point (tipk_peer_status) and the rank
+// exits non-zero (tip_amd.dist.DirectExchange.check) -- never a re-exec of a process that touched the GPU.
+//
 // Mailboxes are allocated and freed through explicit entry points (tipk_peer_alloc / tipk_peer_free: uncached memory
 // cannot come from the caller's allocator); the exchange itself allocates nothing.
 #include <string.h>
@@ -34,15 +41,21 @@ struct PeerArgs {
     int rank, world;
     int64_t max_floats, half_bytes, n_chunks_max;
     const unsigned long long* seq;        // device: number of exchanges done so far
+    unsigned long long* err;              // device (own mailbox): 0, or the record of the first wait that timed out
+    unsigned long long budget;            // s_memrealtime ticks (100 MHz) a flag wait may take
 };
 
-// mailbox layout (one half): slots [world][max_floats] fp32 | flags [world][n_chunks_max] u64
+// mailbox layout (one half): slots [world][max_floats] fp32, padded to 256 bytes | flags [world][n_chunks_max] u64
+// (the flag area starts on a 256-byte boundary whatever world and max_floats are: u64 system-scope atomics on it are aligned)
+__host__ __device__ __forceinline__ int64_t peer_slot_bytes(int world, int64_t max_floats) {
+    return ((int64_t)world * max_floats * 4 + 255) / 256 * 256;
+}
 __device__ __forceinline__ float* peer_slot(char* box, int half, int64_t half_bytes, int64_t max_floats, int r) {
     return reinterpret_cast<float*>(box + half * half_bytes) + (int64_t)r * max_floats;
 }
 __device__ __forceinline__ unsigned long long* peer_flag(char* box, int half, int64_t half_bytes, int64_t max_floats, int world,
                                                          int64_t n_chunks_max, int r, int64_t chunk) {
-    return reinterpret_cast<unsigned long long*>(box + half * half_bytes + (int64_t)world * max_floats * 4) + (int64_t)r * n_chunks_max + chunk;
+    return reinterpret_cast<unsigned long long*>(box + half * half_bytes + peer_slot_bytes(world, max_floats)) + (int64_t)r * n_chunks_max + chunk;
 }
 
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
@@ -68,7 +81,17 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs a) {
     // 3. wait for all ranks' flags of this chunk in the own mailbox
     if (t < a.world) {
         unsigned long long* f = peer_flag(a.box[a.rank], half, a.half_bytes, a.max_floats, a.world, a.n_chunks_max, t, chunk);
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) __builtin_amdgcn_s_sleep(2);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.budget) {
+                // record (first writer wins) and give up: bits 63..32 = sequence number, 31..16 = missing rank + 1, 15..0 = chunk
+                unsigned long long rec = (seq << 32) | ((unsigned long long)(t + 1) << 16) | (unsigned long long)(chunk & 0xffff);
+                unsigned long long expect = 0ull;
+                __hip_atomic_compare_exchange_strong(a.err, &expect, rec, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
     }
     __syncthreads();
     __threadfence_system();
@@ -84,14 +107,16 @@ __global__ void peer_seq_advance_kernel(unsigned long long* seq) { *seq += 1ull;
 
 inline int64_t peer_chunks(int64_t max_floats) { return tipk_ceil_div(max_floats, PEER_CHUNK); }
 inline int64_t peer_half_bytes(int world, int64_t max_floats) {
-    return ((int64_t)world * max_floats * 4 + (int64_t)world * peer_chunks(max_floats) * 8 + 255) / 256 * 256;
+    return peer_slot_bytes(world, max_floats) + ((int64_t)world * peer_chunks(max_floats) * 8 + 255) / 256 * 256;
 }
+constexpr int64_t PEER_TAIL_BYTES = 256;       // behind the two halves: +0 the sequence counter, +64 the error word
+unsigned long long g_peer_budget = 200000000ull;   // 2 s of s_memrealtime ticks
 
 }  // namespace
 
 extern "C" int64_t tipk_peer_mailbox_bytes(int world, int64_t max_floats) {
     if (world < 1 || world > PEER_MAX_WORLD || max_floats < 1) return 0;
-    return 2 * peer_half_bytes(world, max_floats) + 256;                   // two halves + the sequence counter
+    return 2 * peer_half_bytes(world, max_floats) + PEER_TAIL_BYTES;       // two halves + the sequence counter and the error word
 }
 
 extern "C" int tipk_peer_alloc(int64_t bytes, void** ptr) {
@@ -132,10 +157,26 @@ extern "C" int tipk_peer_allreduce(float* data, int64_t n, void* const* mailboxe
     for (int r = 0; r < world; ++r) if (!a.box[r]) return TIPK_EINVAL;
     unsigned long long* seq = reinterpret_cast<unsigned long long*>(a.box[rank] + 2 * a.half_bytes);
     a.seq = seq;
+    a.err = reinterpret_cast<unsigned long long*>(a.box[rank] + 2 * a.half_bytes + 64);
+    a.budget = g_peer_budget;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3((unsigned)tipk_ceil_div(n, PEER_CHUNK)), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tipk_hip_status(e);
     hipLaunchKernelGGL(peer_seq_advance_kernel, dim3(1), dim3(1), 0, st, seq);
     TIPK_RETURN_LAUNCH();
+}
+
+extern "C" int tipk_peer_set_timeout_ms(int64_t ms) {
+    if (ms < 1 || ms > 600000) return TIPK_EINVAL;
+    g_peer_budget = (unsigned long long)ms * 100000ull;                    // s_memrealtime counts at 100 MHz
+    return TIPK_OK;
+}
+
+// Error word of the own mailbox (0 = every wait so far was served): a SYNCHRONOUS 8-byte copy -- call it at a point where
+// the host synchronises anyway (after a step's loss has been read), never inside a stream capture.
+extern "C" int tipk_peer_status(void* mailbox, int world, int64_t max_floats, uint64_t* error_word) {
+    if (!mailbox || !error_word || world < 1 || world > PEER_MAX_WORLD || max_floats < 1) return TIPK_EINVAL;
+    const char* p = static_cast<const char*>(mailbox) + 2 * peer_half_bytes(world, max_floats) + 64;
+    return tipk_hip_status(hipMemcpy(error_word, p, 8, hipMemcpyDeviceToHost));
 }

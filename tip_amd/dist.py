@@ -90,6 +90,10 @@ class RelationShard(object):
         return float(self.n_train_local) / float(max(1, self.n_train_total))
 
 
+class PeerTimeout(RuntimeError):
+    """An exchange of `DirectExchange` ran out of its wait budget: fatal for the process group."""
+
+
 class DirectExchange(object):
     """One-shot all-reduce over peer-mapped mailboxes (include/tipk.h section 8, tip_amd/csrc/tipk_peer.hip): every rank
     writes its buffer into its slot of all ranks' mailboxes -- w - 1 remote streams over w - 1 different xGMI links at
@@ -139,8 +143,35 @@ class DirectExchange(object):
                                         stream_ptr(flat.device)), 'tipk_peer_allreduce')
         return flat
 
+    def set_timeout_ms(self, ms):
+        """Wall-clock budget of the flag wait of later exchanges (default 2 000 ms)."""
+        from ._lib import lib, check
+        check(lib().tipk_peer_set_timeout_ms(int(ms)), 'tipk_peer_set_timeout_ms')
+
+    def error_word(self):
+        """0, or the record of the first flag wait that ran out of its budget (a synchronous 8-byte copy)."""
+        import ctypes as C
+        from ._lib import lib, check
+        if self.own is None:
+            return 0
+        w = C.c_uint64(0)
+        with torch.cuda.device(self.device):
+            check(lib().tipk_peer_status(self.own, self.world, self.max_floats, C.byref(w)), 'tipk_peer_status')
+        return int(w.value)
+
+    def check(self):
+        """Raise PeerTimeout if an exchange gave up waiting for a peer (its result was garbage): call where the host
+        synchronises anyway -- after a step's loss has been read, after a timed region.  The process group is dead
+        after that: the caller exits non-zero (it must NOT re-exec itself: the process has touched the GPU)."""
+        w = self.error_word()
+        if w:
+            raise PeerTimeout('rank %d: exchange %d gave up waiting for rank %d (chunk %d): a peer died, skipped a call or '
+                              'took another collective' % (self.rank, w >> 32, ((w >> 16) & 0xffff) - 1, w & 0xffff))
+
     def close(self):
         from ._lib import lib
+        if self.own is None and not self.opened:
+            return
         torch.cuda.synchronize(self.device)
         for p in self.opened:
             lib().tipk_ipc_close(p)
@@ -148,6 +179,18 @@ class DirectExchange(object):
         if self.own is not None:
             lib().tipk_peer_free(self.own)
             self.own = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                   # interpreter shutdown: the driver reclaims the mappings
+            pass
 
 
 def make_shard(range_list, rank, world, group=None):

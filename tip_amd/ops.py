@@ -278,23 +278,18 @@ def stream_gather(sp, table, row_scale=None, write_zeros=True, out=None, label='
     return out
 
 
-_DYC = {}
-
-
 def rel_stream_bwd(sp, table, row_scale=None, write_zeros=True):
     """Transposed D-D pass: table = g [N, d] -> dY (plan of `build_stream_plan`): [R * N, d], or -- compact plans --
-    [n_rows + 1, d] node-major with a trailing zero row (a buffer kept per plan and width: the zero row is written
-    once, every call rewrites all the other rows)."""
+    [n_rows + 1, d] node-major with a trailing zero row (a buffer kept ON THE PLAN per width: the zero row is written
+    once, every call rewrites all the other rows; it lives exactly as long as the plan, i.e. as the layer's graph, so a
+    captured hipGraph that baked its address in never sees it freed or handed to someone else)."""
     if sp.compact is None:
         return stream_gather(sp, table, row_scale, write_zeros, label='rel_stream[dd.bwd]')
     d = table.shape[1]
-    key = (id(sp), d, str(table.device))
-    hit = _DYC.get(key)
-    if hit is None:
-        if len(_DYC) > 16:
-            _DYC.clear()
-        hit = _DYC[key] = (torch.zeros((sp.n_rows + 1, d), dtype=torch.float32, device=table.device), sp)   # pins the plan: ids stay unique
-    buf = hit[0]
+    key = (d, str(table.device))
+    buf = sp.dyc.get(key)
+    if buf is None:
+        buf = sp.dyc[key] = torch.zeros((sp.n_rows + 1, d), dtype=torch.float32, device=table.device)
     stream_gather(sp, table, row_scale, write_zeros=False, out=buf[:sp.n_rows], label='rel_stream[dd.bwd]')
     return buf
 
@@ -632,21 +627,40 @@ def _uv(edge_index):
     return ei[0], ei[1]
 
 
+# Derived facts about an index tensor (range verdict, packed copy) are kept in a SIDE TABLE keyed by the tensor object,
+# not as attributes on it: `torch.save(model)` (tip.py:36) pickles a tensor's __dict__, so attributes would put a 4 E-byte
+# packed copy into every checkpoint and restore a stale "range ok" verdict on load (a loaded tensor's version counter
+# restarts at 0).  An entry dies with its tensor (weakref finalizer) and is only trusted while the tensor's version,
+# storage address and shape are what they were when it was made.
+_TENSOR_FACTS = {}
+
+
+def _facts(t):
+    """The side-table entry (a dict) of tensor `t`, emptied if `t` was modified, re-pointed or re-shaped since."""
+    import weakref
+    tag = (t._version, t.data_ptr(), tuple(t.shape), str(t.device))
+    ent = _TENSOR_FACTS.get(id(t))
+    if ent is None or ent[0]() is not t:
+        ent = _TENSOR_FACTS[id(t)] = [weakref.ref(t), tag, {}]
+        weakref.finalize(t, _TENSOR_FACTS.pop, id(t), None)
+    elif ent[1] != tag:
+        ent[1], ent[2] = tag, {}
+    return ent[2]
+
+
 def _range_checked(t, limit, what):
-    """Raise IndexError unless every entry of the index tensor `t` lies in [0, limit).  The verdict is remembered ON
-    the tensor (attribute keyed by its version counter and the limit): no global cache pins index tensors, a tensor
-    that was modified in place is checked again, and a fresh tensor costs ONE fused device reduction and one sync."""
-    tag = getattr(t, '_tipk_range_ok', None)
-    if tag == (t._version, int(limit)):
+    """Raise IndexError unless every entry of the index tensor `t` lies in [0, limit).  The verdict is remembered per
+    tensor OBJECT (`_facts`: keyed by version counter, storage address, shape): no global cache pins index tensors, a
+    tensor that was modified in place -- or unpickled -- is checked again, and a fresh tensor costs ONE fused device
+    reduction and one sync."""
+    facts = _facts(t)
+    if facts.get('range_ok') == int(limit):
         return
     if t.numel():
         lo, hi = torch.stack([t.min(), t.max()]).tolist()
         if lo < 0 or hi >= limit:
             raise IndexError('%s id out of range: [%d, %d] for %d' % (what, lo, hi, limit))
-    try:
-        t._tipk_range_ok = (t._version, int(limit))
-    except Exception:
-        pass
+    facts['range_ok'] = int(limit)
 
 
 def validate_triples(edge_index, edge_type, n_nodes, n_rel):
@@ -766,17 +780,14 @@ def _det_workspace(device, n_nodes, k, n_rel):
 
 def packed_pairs(edge_index, n_nodes):
     """int32 [E]: the pair (u, v) of every triple as ONE 32-bit word u | v << 16 (include/tipk.h section 4, idx_bytes = 2).
-    Built once per tensor version (the positives of the path are static) and kept on the tensor."""
+    Built once per tensor version (the positives of the path are static) and kept in the side table (`_facts`: it is
+    derived data and must not travel with `torch.save(model)`)."""
     assert n_nodes <= 65535
-    hit = getattr(edge_index, '_tipk_packed', None)
-    if hit is not None and hit[0] == edge_index._version:
-        return hit[1]
-    w = (edge_index[0].to(torch.int64) | (edge_index[1].to(torch.int64) << 16))
-    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
-    try:
-        edge_index._tipk_packed = (edge_index._version, w)
-    except Exception:
-        pass
+    facts = _facts(edge_index)
+    w = facts.get('packed')
+    if w is None:
+        w = (edge_index[0].to(torch.int64) | (edge_index[1].to(torch.int64) << 16))
+        w = facts['packed'] = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
     return w
 
 
@@ -1076,9 +1087,20 @@ def matmul(x, w):
     return _MatMul.apply(x, w)
 
 
+FWD_ROUTE_MODE = os.environ.get('TIPK_FWD_ROUTE', 'rule')     # 'rule' | 'pair' | 'y' | 'timed' (bench.py sets 'timed' for sharded runs)
+
+
 def _fwd_route(graph, x, basis, att, pair, shard):
-    """'pair' | 'y': the faster forward route of a relation-SHARDED layer for this rank's relations, timed once per
-    (graph, layer width) with HIP events on the launch stream (3 runs each after a warm-up) and remembered on the graph."""
+    """'pair' | 'y': the forward route of a relation-SHARDED layer.  The two routes give the same partial aggregate up to
+    ROUNDING, so the choice must not depend on anything that varies from run to run or from rank to rank:
+
+      'rule'   (default) the rule of thumb from the 1-GPU timings: PAIR_FWD_MAX_WORLD ranks or more -> Y route;
+      'pair' / 'y'       pinned (parity runs);
+      'timed'  both routes are timed once per (graph, layer width) on this rank's relations -- HIP events on the launch
+               stream, 3 runs each after a warm-up -- the times are SUMMED OVER THE RANKS (one all-reduce of two floats) and
+               every rank takes the route with the smaller sum: one decision for the whole job, recorded on the graph
+               (bench.py prints it as `config.forward_routes`).  A first call under graph capture cannot time anything and
+               uses the rule."""
     n = x.shape[0]
     nb, _, d_out = basis.shape
     r = att.shape[0]
@@ -1086,8 +1108,12 @@ def _fwd_route(graph, x, basis, att, pair, shard):
     hit = graph.fwd_route.get(key)
     if hit is not None:
         return hit[0]
-    if torch.cuda.is_current_stream_capturing() or _TIMING is not None:
-        return 'y' if shard.world >= PAIR_FWD_MAX_WORLD else 'pair'
+    mode = FWD_ROUTE_MODE
+    if mode in ('pair', 'y'):
+        return mode
+    rule = 'y' if shard.world >= PAIR_FWD_MAX_WORLD else 'pair'
+    if mode != 'timed' or torch.cuda.is_current_stream_capturing() or _TIMING is not None:
+        return rule
     with torch.no_grad():
         cells, xb_nb = graph.pair_buffers(n, nb, d_out, x.device)
         xb = gemm(x, basis)
@@ -1111,8 +1137,11 @@ def _fwd_route(graph, x, basis, att, pair, shard):
             b.record()
             torch.cuda.synchronize(x.device)
             times[name] = a.elapsed_time(b) / 3 * 1e3
-    choice = 'pair' if times['pair'] <= times['y'] else 'y'
-    graph.fwd_route[key] = (choice, times)
+        total = torch.tensor([times['pair'], times['y']], dtype=torch.float32, device=x.device)
+        shard.all_reduce(total)                                   # the same two sums on every rank -> the same decision
+        total = total.tolist()
+    choice = 'pair' if total[0] <= total[1] else 'y'
+    graph.fwd_route[key] = (choice, times, {'pair': total[0], 'y': total[1]})
     return choice
 
 
@@ -1149,10 +1178,8 @@ class _RGCN(torch.autograd.Function):
             pair = None
         if pair is not None and shard is not None and shard.world > 1:
             # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (16 us at BioSNAP, whatever
-            # the rank's share of the relations); the Y route (Y = att . XB + unit gather) scales with the share.  Which
-            # is faster for THIS rank's share is measured once per graph (both routes give the same partial aggregate
-            # up to rounding, so ranks may differ); a first call under graph capture cannot time anything and falls back
-            # to the rule of thumb from the 1-GPU timings (4 ranks or more: Y route)
+            # the rank's share of the relations); the Y route (Y = att . XB + unit gather) scales with the share.  One
+            # decision for the whole job, the same from run to run unless timing is asked for (`_fwd_route`)
             if _fwd_route(graph, x, basis, att, pair, shard) == 'y':
                 pair = None
         if pair is not None:

@@ -40,6 +40,41 @@ class Adam(torch.optim.Optimizer):
         self._counter_pool[device] = (block, used + 1)
         return block[used]
 
+    def _counter_from(self, value, device):
+        c = self._new_counter(device)
+        c.fill_(int(value))
+        return c
+
+    def _adopt_state(self):
+        """Step counts -> 0-dim int64 counters on the parameter's device.  torch's `Optimizer.load_state_dict` casts a
+        capturable optimizer's `step` to a float32 tensor (and a `torch.optim.Adam` checkpoint holds a float tensor or a
+        python number): `tipk_adam_step` reads the word as uint64, so such a value has to be re-made, not reinterpreted."""
+        for p, st in self.state.items():
+            if not st:
+                continue
+            stp = st.get('step')
+            if stp is None:
+                raise ValueError('tip_amd.optim.Adam: optimizer state without a step count')
+            ok = torch.is_tensor(stp) and stp.dtype == torch.int64 and stp.dim() == 0 and stp.device == p.device
+            if not ok:
+                st['step'] = self._counter_from(round(float(stp)), p.device)
+            for k in ('exp_avg', 'exp_avg_sq'):
+                m = st[k]
+                if m.dtype != torch.float32 or m.device != p.device or m.stride() != p.stride():
+                    st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(m)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            g['capturable'] = True
+        self._adopt_state()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault('_tickets', {})
+        self.__dict__.setdefault('_counter_pool', {})
+        self._adopt_state()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -59,6 +94,11 @@ class Adam(torch.optim.Optimizer):
                     st['step'] = self._new_counter(p.device)            # 0-dim int64 on the device, as with capturable=True
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                stp = st['step']
+                if not (torch.is_tensor(stp) and stp.dtype == torch.int64 and stp.device == p.device):
+                    raise TypeError('tip_amd.optim.Adam: state["step"] must be an int64 counter on the parameter\'s device '
+                                    '(got %s): load checkpoints through load_state_dict()' % (
+                                        '%s on %s' % (stp.dtype, stp.device) if torch.is_tensor(stp) else type(stp).__name__))
                 g = p.grad
                 if g.stride() != p.stride():                       # same dense layout as the parameter (and its moments)
                     g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)

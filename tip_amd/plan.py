@@ -559,6 +559,7 @@ class StreamPlan(object):
         self.n_nodes, self.n_rel = n_nodes, n_rel
         self.compact = None                       # CompactRows: the rows are the node-major compact numbering (tipk.h section 2d)
         self.row_bytes = self.lanes * 16          # bytes of a table row of one column block in LDS
+        self.dyc = {}                             # compact plans: (width, device) -> the dY buffer [n_rows + 1, width] (ops.rel_stream_bwd)
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
