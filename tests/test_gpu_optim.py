@@ -132,7 +132,8 @@ def test_adam_state_dict_round_trip_and_torch_checkpoint():
     b2 = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in b]
     m1, m2 = Adam(a1, lr=0.01), Adam(a2, lr=0.01)
     r2 = torch.optim.Adam(b2, lr=0.01, foreach=False, fused=False)
-    m1.load_state_dict(sd_mine); m2.load_state_dict(sd_ref); r2.load_state_dict(sd_ref)
+    # (load_state_dict does not copy tensors that already have the right dtype and device: one deep copy per optimizer)
+    m1.load_state_dict(sd_mine); m2.load_state_dict(copy.deepcopy(sd_ref)); r2.load_state_dict(copy.deepcopy(sd_ref))
     for opt, ps in ((m1, a1), (m2, a2)):
         for p in ps:
             st = opt.state[p]['step']

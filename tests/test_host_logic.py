@@ -626,3 +626,39 @@ def test_adam_adopts_reloaded_step_counts():
     assert all(again.state[q]['step'].dtype == torch.int64 and int(again.state[q]['step']) == 2
                for q in again.param_groups[0]['params'])
     assert all(g['capturable'] for g in again.param_groups)
+
+
+def test_gcn_rows_subset_plans_and_compact_hierarchy_graph():
+    """conv2 of the P-P encoder only for the rows the P -> D stage reads.  The restricted plans give
+    exactly the full graph's rows (forward) and the full graph's transposed aggregate of a gradient that is zero outside the
+    rows (backward); the P -> D graph over the compact source block equals the one over the whole block."""
+    from tip_amd.layers import gcn_norm_graph, hier_graph
+    g = torch.Generator().manual_seed(21)
+    N, E, d = 57, 400, 4
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[:, :5] = torch.arange(5)                                      # self loops (replaced by unit loops)
+    rows = torch.tensor(sorted({3, 4, 9, 20, 21, 50, 56}))
+    full = gcn_norm_graph(ei, N, d=d)
+    sub = gcn_norm_graph(ei, N, d=d, rows=rows)
+    x = torch.randn(N, d, generator=g, dtype=torch.float64)
+    want = execute_plan_reference(full.fwd, x)
+    got = execute_plan_reference(sub.fwd, x)
+    assert sub.fwd.n_out == rows.numel() and sub.fwd.n_table == N and sub.bwd.n_out == N and sub.bwd.n_table == rows.numel()
+    torch.testing.assert_close(got, want[rows], rtol=1e-12, atol=1e-12)
+    gc = torch.randn(rows.numel(), d, generator=g, dtype=torch.float64)
+    gf = torch.zeros(N, d, dtype=torch.float64)
+    gf[rows] = gc
+    torch.testing.assert_close(execute_plan_reference(sub.bwd, gc), execute_plan_reference(full.bwd, gf), rtol=1e-12, atol=1e-12)
+    # P -> D over the compact block
+    n_t = 11
+    dp = torch.stack([rows[torch.randint(0, rows.numel(), (40,), generator=g)], N + torch.randint(0, n_t - 2, (40,), generator=g)])
+    hg = hier_graph(dp, N + n_t, N, table_rows=N, d=d)
+    inv = torch.full((N,), -1, dtype=torch.int64)
+    inv[rows] = torch.arange(rows.numel())
+    hc = hier_graph(torch.stack([inv[dp[0]], dp[1] - N + rows.numel()]), rows.numel() + n_t, rows.numel(), table_rows=rows.numel(), d=d)
+    h = torch.randn(N, d, generator=g, dtype=torch.float64)
+    torch.testing.assert_close(execute_plan_reference(hc.fwd, h[rows], hc.scale.double()),
+                               execute_plan_reference(hg.fwd, h, hg.scale.double()), rtol=1e-12, atol=1e-12)
+    gm = torch.randn(n_t, d, generator=g, dtype=torch.float64)
+    torch.testing.assert_close(execute_plan_reference(hc.bwd, gm), execute_plan_reference(hg.bwd, gm)[rows], rtol=1e-12, atol=1e-12)
+    assert float(execute_plan_reference(hg.bwd, gm).abs().sum() - execute_plan_reference(hg.bwd, gm)[rows].abs().sum()) == 0.0

@@ -233,6 +233,284 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
     });
 }
 
+
+// =====================================================================================================================
+// Round 4: d att through LDS (row widths 16 and 32 -- the R-GCN layers of TIP).
+//
+// What bounded the kernel above (profiles/r03_pmc_node_products.txt): not the matrix cores (46 % busy) and not HBM, but the
+// vector-memory ADDRESS path.  Role 2 fetches both MFMA operands "row per lane": every lane reads 64 contiguous bytes of
+// ITS OWN 128-byte row, so a dwordx4 wave-instruction touches 64 different 16-byte pieces in 32-64 different lines and
+// occupies the texture addresser for ~64 cycles instead of 16 -- 8 such instructions per 16 MFMAs, four SIMDs sharing one
+// addresser: 2 048 addresser cycles per 1 024 MFMA cycles (TA_BUSY 59 % of the launch, 17.8 cache accesses per load).
+// Here both operands arrive as FULL LINES by LDS-DMA (global_load_lds_dwordx4: 1 KiB contiguous per wave-instruction, no
+// VGPR destination) and the row-per-lane fragments are read from LDS:
+//
+//   workgroup = NP2_W waves = NP2_W consecutive relation tiles (one per wave: its 32 x n_bases tile of d att stays in the
+//               wave's accumulators for the whole range -- no cross-wave reduction) x a range of 32-column chunks of the
+//               flattened (node, channel) axis;
+//   stage     = one chunk: B = XB of the chunk [32 bases x 128 B], shared by the waves (it was fetched once per wave), A =
+//               the rows of dY that EXIST for (the chunk's node(s), the workgroup's 32 NP2_W relations): consecutive rows of
+//               the compact matrix, i.e. one contiguous block -- only real rows cross the fabric, each once;
+//   ring      = NP2_NS stage slots; stage i + 3 is requested while stage i is multiplied and stage i + 1 read from LDS into
+//               the second register set: one raw s_barrier per stage, counted vmcnt (LDS-DMA stays in flight across it);
+//   lane m    finds its relation's row through the tile's bit mask (rank = popcount of the lower bits; a relation without a
+//               row at this node reads a zero row kept in LDS): no `pos` table, the descriptors are scalar loads;
+//   swizzle   128-byte (64-byte) rows would put every lane of a ds_read_b128 group on two (four) bank quads; the 16-byte
+//               pieces of row r are stored at piece ^ ((r >> 1) & 7) (piece ^ ((r >> 2) & 3)) -- chosen on the SOURCE address
+//               of the DMA, whose LDS side is lane-linear -- which is conflict-free for rows that differ mod 16.
+// Role 1 (d XB per node) is the code of the kernel above; its cross-wave reduction buffer aliases the ring.
+constexpr int NP2_W = 4;                                 // waves = relation tiles per role-2 workgroup
+constexpr int NP2_NS = 3;                                // stage slots of the ring
+constexpr int NP2_STAGE = (1 + NP2_W) * 4096;            // bytes: B image 4 KiB + A region NP2_W x 4 KiB
+constexpr int NP2_P = 1 + NP2_W;                         // LDS-DMA instructions per wave and stage (20 pieces / 4 waves)
+constexpr int NP2_ZERO = NP2_NS * NP2_STAGE;             // the zero row (128 bytes)
+constexpr int NP2_LDS = NP2_ZERO + 256;
+
+struct Np2Args {
+    NpArgs a;                                            // the fields of the kernel above (pos unused)
+    const int4* recs;                                    // [n_rtg][n_nodes_pad][2]: {first row, rows, offsets of the 4 tiles (8 bits each), 0}, {masks}
+    int n_rtg, n_nodes_pad, G2, chunks_per_wg2, n_role2;
+};
+
+typedef __attribute__((address_space(3))) void np_lds_void_t;
+typedef const __attribute__((address_space(1))) void np_global_void_t;
+
+__device__ __forceinline__ void np2_dma(const char* src, char* lds_wave_base, bool on) {
+    // (lane 0 is always on: an LDS-DMA whose lanes are ALL off is skipped and would not count in vmcnt)
+    if (on) __builtin_amdgcn_global_load_lds((np_global_void_t*)src, (np_lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <int D>
+__global__ __launch_bounds__(NP_THREADS) void node_products_lds_kernel(Np2Args p) {
+    static_assert(D == 16 || D == 32, "row widths of the LDS form");
+    const NpArgs& a = p.a;
+    constexpr int NCT = 1;
+    constexpr int NPC = 32 / D;                          // nodes per chunk
+    constexpr int RB = D * 4;                            // bytes of a row of dY
+    constexpr int PR = RB / 16;                          // 16-byte pieces per row
+    constexpr int RPP = 64 / PR;                         // rows per 1-KiB DMA piece
+    constexpr int SWS = D == 32 ? 1 : 2;                 // swizzle key of row r = (r >> SWS) & (PR - 1)
+    __shared__ __attribute__((aligned(1024))) char smem[NP2_LDS];
+    float* red = reinterpret_cast<float*>(smem);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n = lane & 31, kh = lane >> 5;
+    constexpr int d = D;
+    const int NB = a.NB;
+    const int nb_c = n < NB ? n : NB - 1;
+    const u32 d4 = (u32)d * 4u;
+
+    if (TIPK_DBG(((int)blockIdx.x >= p.n_role2 ? a.dbg & 8 : a.dbg & 16))) return;
+    if ((int)blockIdx.x >= p.n_role2) {
+        // ---------------------------------------------------------------- role 1: dXB[:, u, :]  (as in the kernel above)
+        const int4 nd = a.node_desc[(int)blockIdx.x - p.n_role2];
+        const int u = __builtin_amdgcn_readfirstlane(nd.x);
+        const int i_lo = __builtin_amdgcn_readfirstlane(nd.y);
+        const int i_hi = __builtin_amdgcn_readfirstlane(nd.z);
+        const int n_tiles = (i_hi - i_lo + 31) >> 5;
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        const u32 ld_att4 = (u32)a.ld_att * 4u, nb_c4 = (u32)nb_c * 4u;
+        u32 cc4[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { const int c = ct * 32 + n; cc4[ct] = (u32)(c < d ? c : d - 1) * 4u; }
+        auto getrel = [&](int tile) {
+            tile = tile < n_tiles ? tile : n_tiles - 1;
+            int ir = i_lo + tile * 32 + n;
+            ir = ir < i_hi ? ir : i_hi - 1;
+            return a.row_rel[ir];
+        };
+        auto load = [&](int tile, int relv, float (&av)[16], float (&bv)[NCT][16]) {
+            const bool tile_ok = tile < n_tiles;
+            tile = tile_ok ? tile : n_tiles - 1;
+            const int i0 = i_lo + tile * 32;
+            const int lim = tile_ok ? i_hi : 0;
+            int rr[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) rr[kk] = __shfl(relv, 2 * kk + kh, 64);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int i = 2 * kk + kh;
+                const int row = i0 + i;
+                const int r = rr[kk];
+                av[kk] = np_ldg(a.att, (u32)r * ld_att4 + nb_c4);
+                const u32 rowb = (u32)(row < lim ? row : a.n_rows) * d4;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) bv[ct][kk] = np_ldg(a.dyc, rowb + cc4[ct]);
+            }
+        };
+        auto mfma = [&](const float (&av)[16], const float (&bv)[NCT][16]) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ct][kk], acc[ct], 0, 0, 0);
+        };
+        if (n_tiles > 0) {
+            float aX[16] = {}, bX[NCT][16] = {}, aY[16] = {}, bY[NCT][16] = {};
+            int tile = w;
+            int rX = getrel(tile), rY = getrel(tile + NP_WAVES);
+            load(tile, rX, aX, bX);
+            for (; tile < n_tiles; tile += 2 * NP_WAVES) {
+                rX = getrel(tile + 2 * NP_WAVES);
+                load(tile + NP_WAVES, rY, aY, bY);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(aX, bX);
+                __builtin_amdgcn_sched_barrier(0);
+                rY = getrel(tile + 3 * NP_WAVES);
+                load(tile + 2 * NP_WAVES, rX, aX, bX);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(aY, bY);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float* o = a.dxb + (int64_t)u * a.dxb_su;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+            np_reduce_store(red, acc[ct], t, w, lane, [&](int b, int c, float s) {
+                const int col = ct * 32 + c;
+                if (b < NB && col < d) o[(int64_t)b * a.dxb_sb + col] = s;
+            });
+        return;
+    }
+    // -------------------------------------------------------------------- role 2: NP2_W tiles of d att, one per wave
+    const int wg = (int)blockIdx.x;
+    const int rtg = __builtin_amdgcn_readfirstlane(wg / p.G2), g = __builtin_amdgcn_readfirstlane(wg % p.G2);
+    const int q_lo = g * p.chunks_per_wg2;
+    const int q_hi = q_lo + p.chunks_per_wg2 < a.n_chunks ? q_lo + p.chunks_per_wg2 : a.n_chunks;
+    const int n_st = q_hi - q_lo;                                           // stages of this workgroup (uniform over its waves)
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (t < 32) reinterpret_cast<float*>(smem + NP2_ZERO)[t] = 0.f;          // (visible behind the first barrier)
+    if (n_st > 0) {
+        const int4* recs = p.recs + (int64_t)rtg * p.n_nodes_pad * 2;
+        const int nflt = a.n_nodes * d;                                     // floats of a row of XB that exist
+        // --- per-lane constants of the DMA: row / piece of this lane inside a 1-KiB piece, swizzled source offset
+        const int l_row = lane / PR, l_pc = lane % PR;                      // A pieces: RPP rows x PR pieces
+        const int lb_row = lane >> 3, lb_pc = lane & 7;                     // B pieces: 8 rows (bases) x 8 pieces
+        const int b_row = w * 8 + lb_row;                                   // the base whose row this lane copies
+        const u32 b_src0 = (u32)(b_row < NB ? b_row : NB - 1) * (u32)a.xb_sb * 4u;
+        const int b_piece = lb_pc ^ ((b_row >> 1) & 7);                     // source piece that lands at LDS piece lb_pc
+        // --- per-lane constants of the fragment reads
+        const u32 b_rd = (u32)n * 128u;
+        const int b_key = (n >> 1) & 7;
+        u32 b_off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_off[j] = b_rd + (u32)((((kh << 2) | j) ^ b_key) << 4);
+        const u32 lt_mask = (1u << n) - 1u;
+
+        struct Rd { int o[NPC]; u32 mask[NPC]; };                           // what the fragment reads of a stage need (uniform)
+        auto stage_nodes = [&](int st, int (&node)[NPC]) {
+            const int q = q_lo + (st < n_st ? st : n_st - 1);
+#pragma unroll
+            for (int h = 0; h < NPC; ++h) node[h] = q * NPC + h;            // (may be n_nodes for the last chunk: padded record)
+        };
+        // request stage st into its slot: P = 5 LDS-DMA instructions per wave, always issued (exec-masked when the stage or
+        // the piece does not exist) so that vmcnt counts are static; returns what the reads need
+        auto request = [&](int st) -> Rd {
+            Rd rd;
+            const bool real = st < n_st;
+            int node[NPC];
+            stage_nodes(st, node);
+            char* slot = smem + (st % NP2_NS) * NP2_STAGE;
+            const int q = q_lo + (st < n_st ? st : n_st - 1);
+            // B: 8 rows of the XB image per wave.  floats [32 q, 32 q + 32) of every base's row; a piece past the end of the
+            // row (last chunk of an odd node count) re-reads the last piece that exists: finite values under zero rows of A
+            {
+                int f = 32 * q + 4 * b_piece;
+                f = f + 4 <= nflt ? f : nflt - 4;
+                np2_dma(reinterpret_cast<const char*>(a.xb) + b_src0 + (u32)f * 4u, slot + w * 1024, real || lane == 0);
+            }
+#pragma unroll
+            for (int h = 0; h < NPC; ++h) {
+                const int4 r0 = recs[node[h] * 2];                          // uniform address: scalar loads
+                const int p_lo = __builtin_amdgcn_readfirstlane(r0.x), nblk = __builtin_amdgcn_readfirstlane(r0.y);
+                const int opk = __builtin_amdgcn_readfirstlane(r0.z);
+                rd.o[h] = (opk >> (8 * w)) & 0xff;
+                rd.mask[h] = (u32)__builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(recs + node[h] * 2 + 1)[w]);
+                // A: the block's rows, NP2_W * 4 / NPC pieces per node, dealt round robin to the waves
+                constexpr int PCS = NP2_W * 4 / NPC;                        // 1-KiB pieces of a node's region
+#pragma unroll
+                for (int j = 0; j < PCS / NP2_W; ++j) {
+                    const int pc = w + NP2_W * j;
+                    const int r = pc * RPP + l_row;
+                    const int sp = l_pc ^ ((r >> SWS) & (PR - 1));
+                    const bool ok = real && r < nblk;
+                    const u32 off = ok ? (u32)(p_lo + r) * (u32)RB + (u32)(sp << 4) : 0u;
+                    np2_dma(reinterpret_cast<const char*>(a.dyc) + off, slot + 4096 + h * (NP2_W * 4096 / NPC) + pc * 1024, ok || lane == 0);
+                }
+            }
+            return rd;
+        };
+        // fragment reads of stage st (landed, behind a barrier) into one register set
+        auto read = [&](int st, const Rd& rd, float4 (&a4)[4], float4 (&b4)[4]) {
+            const u32 slot = (u32)((st % NP2_NS) * NP2_STAGE);
+            const int h = NPC == 2 ? kh : 0;
+            const u32 mask = NPC == 2 ? (kh ? rd.mask[NPC - 1] : rd.mask[0]) : rd.mask[0];
+            const int o = NPC == 2 ? (kh ? rd.o[NPC - 1] : rd.o[0]) : rd.o[0];
+            const bool ex = (mask >> n) & 1u;
+            const int r = o + __popc(mask & lt_mask);
+            const int key = (r >> SWS) & (PR - 1);
+            const u32 rowb = slot + 4096u + (u32)h * (u32)(NP2_W * 4096 / NPC) + (u32)r * (u32)RB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pcs = NPC == 2 ? j : ((kh << 2) | j);             // d = 16: the lane's node is its half, the row is all its
+                const u32 ao = ex ? rowb + (u32)((pcs ^ key) << 4) : (u32)NP2_ZERO + 16u * j;
+                a4[j] = *reinterpret_cast<const float4*>(smem + ao);
+                b4[j] = *reinterpret_cast<const float4*>(smem + slot + b_off[j]);
+            }
+        };
+        auto mfma = [&](const float4 (&a4)[4], const float4 (&b4)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc, 0, 0, 0);
+            }
+        };
+        // stages 0, 1, 2 in flight; stage 0 into register set X
+        const Rd r0 = request(0);
+        Rd nx1 = request(1), nx2 = request(2);
+        float4 aX[4], bX[4], aY[4], bY[4];
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NP2_P) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read(0, r0, aX, bX);
+        // iteration i: stage i + 1 has landed (wait + barrier: also, every wave has finished its reads of stage i, so slot
+        // i % 3 may be refilled) -> request stage i + 3 -> read stage i + 1 into the other register set -> multiply stage i
+        for (int i = 0; i < n_st; i += 2) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP2_P) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const Rd na = request(i + 3);
+            read(i + 1, nx1, aY, bY);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(aX, bX);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 >= n_st) break;                                       // (uniform over the workgroup)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP2_P) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const Rd nb = request(i + 4);
+            read(i + 2, nx2, aX, bX);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(aY, bY);
+            __builtin_amdgcn_sched_barrier(0);
+            nx1 = na; nx2 = nb;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the tail's dummy requests)
+    }
+    const int rt = rtg * NP2_W + w;
+    float* o = a.datt + (int64_t)g * a.R * NB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rel = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (rel < a.R && n < NB) o[(int64_t)rel * NB + n] = acc[r];
+    }
+}
+
 }  // namespace
 
 // relation tiles x ranges of column chunks: about one workgroup (8 waves) per CU, so that every SIMD has the
@@ -247,18 +525,32 @@ static int np_ranges(int64_t n_rel, int64_t n_chunks) {
     return (int)tipk_ceil_div(n_chunks, per);
 }
 
+// the LDS form (d = 16, 32): groups of NP2_W relation tiles x ranges of chunks -- about one role-2 workgroup per CU (the
+// LDS ring admits two workgroups per CU: the per-node workgroups of role 1 take the other place) and at least 4 stages each
+static bool np2_shape(int d) { return d == 16 || d == 32; }
+static int np2_ranges(int64_t n_rel, int64_t n_chunks) {
+    const int64_t n_rtg = tipk_ceil_div(tipk_ceil_div(n_rel, 32), NP2_W);
+    int64_t g = (256 + n_rtg / 2) / n_rtg;
+    if (g > 64) g = 64;
+    if (g > n_chunks / 4) g = n_chunks / 4;
+    if (g < 1) g = 1;
+    const int64_t per = tipk_ceil_div(n_chunks, g);
+    return (int)tipk_ceil_div(n_chunks, per);
+}
+
 extern "C" int tipk_rgcn_node_products_plan(int64_t n_nodes, int d, int64_t n_rel, int n_bases, int* att_slabs) {
     if (!att_slabs) return TIPK_EINVAL;
     *att_slabs = 0;
     if (n_nodes <= 0 || n_rel <= 0 || n_bases <= 0 || n_bases > 32) return TIPK_OK;
     if (d < 16 || d > 128 || (d & (d - 1)) != 0) return TIPK_OK;
     if (n_nodes * (int64_t)d >= (1LL << 29) || n_rel >= (1LL << 24)) return TIPK_OK;
-    *att_slabs = np_ranges(n_rel, tipk_ceil_div(n_nodes * d, 32));
+    const int64_t n_chunks = tipk_ceil_div(n_nodes * d, 32);
+    *att_slabs = np2_shape(d) ? np2_ranges(n_rel, n_chunks) : np_ranges(n_rel, n_chunks);
     return TIPK_OK;
 }
 
 extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32_t* node_desc,
-                                       const int32_t* row_rel, const int32_t* pos,
+                                       const int32_t* row_rel, const int32_t* pos, const int32_t* tile_recs,
                                        int64_t n_nodes, int64_t n_rel, const float* att, int64_t ld_att, int n_bases,
                                        const float* xb, int64_t xb_sb, int64_t xb_su,
                                        float* dxb, int64_t dxb_sb, int64_t dxb_su, float* datt_slabs,
@@ -267,8 +559,10 @@ extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, 
     const int rc = tipk_rgcn_node_products_plan(n_nodes, d, n_rel, n_bases, &G);
     if (rc != TIPK_OK) return rc;
     if (G == 0) return TIPK_EUNSUPPORTED;
-    if (!dyc || !node_desc || !row_rel || !pos || !att || !xb || !dxb || !datt_slabs || n_rows <= 0 || ld_att < n_bases)
+    const bool lds_form = np2_shape(d);
+    if (!dyc || !node_desc || !row_rel || !att || !xb || !dxb || !datt_slabs || n_rows <= 0 || ld_att < n_bases)
         return TIPK_EINVAL;
+    if (lds_form ? !tile_recs : !pos) return TIPK_EINVAL;
     // 32-bit byte offsets into dyc, att, xb and pos
     if ((n_rows + 1) * (int64_t)d >= (1LL << 29) || n_rel * ld_att >= (1LL << 29) || n_bases * xb_sb >= (1LL << 29) ||
         n_nodes * xb_su >= (1LL << 29) || n_nodes * (n_rel + 64) >= (1LL << 29))
@@ -290,11 +584,25 @@ extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, 
     a.chunks_per_wg = (int)tipk_ceil_div(a.n_chunks, G);
     a.n_role2 = a.n_rp * G;
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
-    const unsigned grid = (unsigned)(a.n_nodes + a.n_role2);
     hipStream_t st = (hipStream_t)stream;
-    if (d == 16) hipLaunchKernelGGL(node_products_kernel<16>, dim3(grid), dim3(NP_THREADS), 0, st, a);
-    else if (d == 32) hipLaunchKernelGGL(node_products_kernel<32>, dim3(grid), dim3(NP_THREADS), 0, st, a);
-    else if (d == 64) hipLaunchKernelGGL(node_products_kernel<64>, dim3(grid), dim3(NP_THREADS), 0, st, a);
+    if (lds_form) {
+        // the LDS form reads whole rows of XB [bases][node][d]: the rows of a node's chunk must be contiguous and 16-byte aligned
+        if (xb_su != d || (reinterpret_cast<uintptr_t>(tile_recs) & 15)) return TIPK_EINVAL;
+        Np2Args p;
+        p.a = a;
+        p.recs = reinterpret_cast<const int4*>(tile_recs);
+        p.n_rtg = (int)tipk_ceil_div(tipk_ceil_div(n_rel, 32), NP2_W);
+        p.n_nodes_pad = (int)(tipk_ceil_div(n_nodes, 2) * 2);
+        p.G2 = G;
+        p.chunks_per_wg2 = a.chunks_per_wg;
+        p.n_role2 = p.n_rtg * G;
+        const unsigned grid = (unsigned)(a.n_nodes + p.n_role2);
+        if (d == 16) hipLaunchKernelGGL(node_products_lds_kernel<16>, dim3(grid), dim3(NP_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(node_products_lds_kernel<32>, dim3(grid), dim3(NP_THREADS), 0, st, p);
+        TIPK_RETURN_LAUNCH();
+    }
+    const unsigned grid = (unsigned)(a.n_nodes + a.n_role2);
+    if (d == 64) hipLaunchKernelGGL(node_products_kernel<64>, dim3(grid), dim3(NP_THREADS), 0, st, a);
     else hipLaunchKernelGGL(node_products_kernel<128>, dim3(grid), dim3(NP_THREADS), 0, st, a);
     TIPK_RETURN_LAUNCH();
 }

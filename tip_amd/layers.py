@@ -135,10 +135,13 @@ class _Lin(nn.Module):
         self.weight.data.uniform_(-bound, bound)
 
 
-def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK, d=None):
+def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK, d=None, rows=None):
     """Normalised adjacency D^-1/2 (A + I) D^-1/2 as a pair of gather plans: existing self loops
     are replaced by exactly one unit loop per node, deg = in-degree incl. the loop, inf -> 0.
-    d: width of the rows the plans will aggregate (enables in-workgroup combination of split rows)."""
+    d: width of the rows the plans will aggregate (enables in-workgroup combination of split rows).
+    rows: ascending int64 node ids -- only THESE output rows are produced, as a compact [len(rows), d] matrix (same
+    weights, same edge order inside a row as in the full graph; the transposed plan reads the compact gradient and
+    writes all num_nodes rows).  FMEncoder uses it for conv2: only the proteins that are P -> D sources are ever read."""
     G = group_slots_for(d) if d else 0
     row, col = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
     keep = row != col
@@ -148,6 +151,15 @@ def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK, d=None):
     dis = deg.pow(-0.5)
     dis[torch.isinf(dis)] = 0
     w = dis[row] * dis[col]
+    if rows is not None:
+        rows = rows.to(torch.int64).to(row.device)
+        inv = torch.full((num_nodes,), -1, dtype=torch.int64, device=row.device)
+        inv[rows] = torch.arange(rows.numel(), device=row.device)
+        sel = inv[col] >= 0
+        row_s, col_s, w_s = row[sel], inv[col[sel]], w[sel]
+        n_s = int(rows.numel())
+        return ops.AggGraph(build_gather_plan(col_s, row_s, n_s, num_nodes, w_s, chunk, 'pp.fwd.rows', G),
+                            build_gather_plan(row_s, col_s, num_nodes, n_s, w_s, chunk, 'pp.bwd.rows', G))
     # TIPK_PP_STREAM=1 (round 3, measured SLOWER, kept as a switch): the normalised adjacency is a row scaling on either
     # side of the PLAIN sum over (A + I), so when a 2-column (or wider) block of the table fits in LDS -- 19 081 proteins:
     # 152 KB of 8-byte rows -- both passes can run as wave streams out of LDS (`ops.stream_gather`, include/tipk.h section
@@ -186,10 +198,16 @@ class GCNConv(nn.Module):
             self.register_parameter('bias', None)
         self._feat = _FeatureInput()
         self._cache = _PlanCache()
+        self._cache_rows = _PlanCache()
 
-    def forward(self, x, edge_index, fuse_relu=False):
+    def forward(self, x, edge_index, fuse_relu=False, rows=None):
+        """rows (extension): ascending int64 node ids -- return only these rows of the layer's output, [len(rows), out]
+        (`gcn_norm_graph(rows=...)`: the rows nobody reads are neither aggregated nor back-propagated through)."""
         n = x.shape[0]
-        graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels))
+        if rows is not None:
+            graph = self._cache_rows.get((edge_index, rows), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels, rows))
+        else:
+            graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels))
         if _is_identity_features(x):
             return ops.gcn_conv(None, self.lin.weight, self.bias, graph, fuse_relu)      # lin(I) = W^T
         if x.is_sparse:
@@ -251,6 +269,8 @@ class MyHierarchyConv(nn.Module):
         self.register_parameter('bias', None)
         self._cache = _PlanCache()
         self._cache_src = _PlanCache()
+        self._cache_src_rows = _PlanCache()
+        self._cache_rows = _PlanCache()
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -282,17 +302,37 @@ class MyHierarchyConv(nn.Module):
             return None
         return ops.matmul(ops.aggregate(x_src, graph), self.weight)
 
-    def mean_sources(self, x_src, edge_index):
+    def source_rows(self, edge_index):
+        """Ascending ids of the source nodes some edge starts at (the only rows of the source block the mean reads), or
+        None if an edge starts beyond the source block.  Cached per edge tensor."""
+        n_src = self.unique_source_num
+
+        def build():
+            if edge_index.numel() and int(edge_index[0].max()) >= n_src:
+                return None
+            return torch.unique(edge_index[0].to(torch.int64))
+        return self._cache_rows.get((edge_index,), build)
+
+    def mean_sources(self, x_src, edge_index, rows=None):
         """The mean aggregate of `forward_sources` WITHOUT the dense map (the caller applies
-        `self.weight` fused with what follows, ops.drug_mix_mm); None if unusable."""
+        `self.weight` fused with what follows, ops.drug_mix_mm); None if unusable.
+        rows: `source_rows(edge_index)` -- x_src then holds only those rows of the source block, in that order."""
         n_src = self.unique_source_num
         n_all = n_src + self.unique_target_num
 
         def build():
             if edge_index.numel() and int(edge_index[0].max()) >= n_src:
                 return None
-            return hier_graph(edge_index, n_all, n_src, self.chunk, table_rows=n_src, d=self.in_dim)
-        graph = self._cache_src.get((edge_index,), build)
+            if rows is None:
+                return hier_graph(edge_index, n_all, n_src, self.chunk, table_rows=n_src, d=self.in_dim)
+            inv = torch.full((n_src,), -1, dtype=torch.int64, device=edge_index.device)
+            inv[rows] = torch.arange(rows.numel(), device=edge_index.device)
+            src = inv[edge_index[0].to(torch.int64)]
+            assert bool((src >= 0).all())
+            n_c = int(rows.numel())                                        # compact source block + the targets behind it
+            ei = torch.stack([src, edge_index[1].to(torch.int64) - n_src + n_c])
+            return hier_graph(ei, n_c + self.unique_target_num, n_c, self.chunk, table_rows=n_c, d=self.in_dim)
+        graph = (self._cache_src if rows is None else self._cache_src_rows).get((edge_index, rows), build)
         if graph is None:
             return None
         return ops.aggregate(x_src, graph)
@@ -490,6 +530,7 @@ class FMEncoder(nn.Module):
         self.rgcn1 = MyRGCNConv2(d_in, n_hid1, num_dd_et, num_base, after_relu=False)
         self.rgcn2 = MyRGCNConv2(n_hid1, n_hid2, num_dd_et, num_base, after_relu=True)
         self._drug_feat = _FeatureInput()
+        self.prune_pp_rows = True               # conv2 of the P-P encoder only for the rows the P -> D stage reads (forward())
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -497,9 +538,19 @@ class FMEncoder(nn.Module):
 
     def forward(self, x_drug, dd_edge_index, dd_edge_type, dd_range_list, d_norm,
                 x_prot, pp_edge_index, dp_edge_index, dp_range_list):
-        h_prot = self.pp_encoder(x_prot, pp_edge_index)                               # P-P GCN x2
         xd = self._drug_feat.apply_table(x_drug, self.embed)                          # x_drug @ embed
-        mean = self.hgcn.mean_sources(h_prot, dp_edge_index)                          # P -> D mean, no cat (:526-528)
+        # Only the proteins some P -> D edge starts at are ever read from the P-P encoder's output (BioSNAP: 3 640 of
+        # 19 081; 294 k of its 1.29 M edges end there): conv2 aggregates -- and back-propagates through -- those rows only.
+        # Exact: the rows left out feed nothing.  `PPEncoder.forward` as a module of its own still returns every row.
+        rows = self.hgcn.source_rows(dp_edge_index) if self.prune_pp_rows else None
+        if rows is not None and rows.numel() < x_prot.shape[0]:
+            h1 = self.pp_encoder.conv1(x_prot, pp_edge_index, fuse_relu=True)
+            h_rows = self.pp_encoder.conv2(h1, pp_edge_index, rows=rows)              # [len(rows), hid2]
+            mean = self.hgcn.mean_sources(h_rows, dp_edge_index, rows=rows)
+            h_prot = None
+        else:
+            h_prot = self.pp_encoder(x_prot, pp_edge_index)                           # P-P GCN x2
+            mean = self.hgcn.mean_sources(h_prot, dp_edge_index)                      # P -> D mean, no cat (:526-528)
         if mean is not None:                                                          # dense map + /d_norm + cat|add fused
             x0 = ops.drug_mix_mm(xd, mean, self.hgcn.weight, d_norm, self.mod == 'cat')
         else:                                                                         # an edge starts at a drug row
