@@ -330,21 +330,15 @@ int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int6
  *       n_rows must hold zeros (pairs without an edge read it).
  *     node_desc [n_nodes][4]  { node u, first row, end row, 0 } of the nodes by DECREASING row count (launch order of
  *       the per-node workgroups; 16-byte aligned);   row_rel [n_rows]  relation of a row;
- *     pos [n_nodes][ceil(n_rel / 64) * 64]  row of (u, r), or n_rows when the pair has no edge / r >= n_rel
-       (read for d = 64, 128; may be NULL for d = 16, 32).
-     tile_recs (read for d = 16, 32: the LDS form of the d att product; may be NULL otherwise; 16-byte aligned):
-       int32 [ceil(ceil(n_rel / 32) / 4)][n_nodes rounded up to even][8] -- for a GROUP of 4 consecutive relation tiles
-       (128 relations) and a node u: { first compact row of (u, the group's relations), number of such rows, the offsets
-       of the 4 tiles' first rows inside that block as 4 bytes, 0, and the 4 tiles' bit masks (bit m of mask t = relation
-       128 group + 32 t + m has a row at u) }; the padding node's record is all zeros.
- *     xb element (b, u, c) at xb[b * xb_sb + u * xb_su + c] (strides multiples of 4 floats; d = 16, 32: xb_su = d), dxb likewise: written
+ *     pos [n_nodes][ceil(n_rel / 64) * 64]  row of (u, r), or n_rows when the pair has no edge / r >= n_rel.
+ *     xb element (b, u, c) at xb[b * xb_sb + u * xb_su + c] (strides multiples of 4 floats), dxb likewise: written
  *     COMPLETE (no slabs); datt_slabs [att_slabs][n_rel][n_bases] are added in order by tipk_sum_slabs(_group).
  *     d in {16, 32, 64, 128}, n_bases <= 32 (`tipk_rgcn_node_products_plan` returns att_slabs = 0 otherwise: use the
  *     dense form 2b).  All sums in fixed order: bitwise reproducible.
  */
 int tipk_rgcn_node_products_plan(int64_t n_nodes, int d, int64_t n_rel, int n_bases, int* att_slabs);
 int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32_t* node_desc, const int32_t* row_rel,
-                            const int32_t* pos, const int32_t* tile_recs, int64_t n_nodes, int64_t n_rel,
+                            const int32_t* pos, int64_t n_nodes, int64_t n_rel,
                             const float* att, int64_t ld_att, int n_bases,
                             const float* xb, int64_t xb_sb, int64_t xb_su,
                             float* dxb, int64_t dxb_sb, int64_t dxb_su, float* datt_slabs, tipk_stream_t stream);

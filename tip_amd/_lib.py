@@ -74,7 +74,7 @@ SIGNATURES = {
     'tipk_rgcn_dy_products_plan': (_I, [_L, _L, _I, C.POINTER(_I), C.POINTER(_I)]),
     'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _P, _P]),
     'tipk_rgcn_node_products_plan': (_I, [_L, _I, _L, _I, C.POINTER(_I)]),
-    'tipk_rgcn_node_products': (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _L, _P, _L, _I, _P, _L, _L, _P, _L, _L, _P, _P]),
+    'tipk_rgcn_node_products': (_I, [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _I, _P, _L, _L, _P, _L, _L, _P, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

@@ -481,7 +481,7 @@ def node_products(dyc, cr, att, xb):
     datt_slabs = torch.empty((g, r, nb), dtype=torch.float32, device=dev)
     with _timed('node_products[%dx%dx%d,rows=%d]' % (r, n * d, nb, n_rows)):
         check(lib().tipk_rgcn_node_products(ptr(dyc), n_rows, d, ptr(cr.node_desc), ptr(cr.row_rel), ptr(cr.pos),
-                                            ptr(cr.tile_recs), n, r, ptr(att), att.stride(0), nb, ptr(xb), xb.stride(0),
+                                            n, r, ptr(att), att.stride(0), nb, ptr(xb), xb.stride(0),
                                             xb.stride(1), ptr(dxb), dxb.stride(0), dxb.stride(1), ptr(datt_slabs),
                                             stream_ptr(dev)), 'tipk_rgcn_node_products')
     return slab_job(datt_slabs), dxb

@@ -744,13 +744,12 @@ class CompactRows(object):
     node_ptr [N + 1], row_rel [n_rows], pos [N, ceil(R / 64) * 64] (n_rows where a pair has no edge),
     node_desc [N, 4] = (node, first row, end row, 0) of the nodes by decreasing row count -- all int32 on the plan's device."""
 
-    def __init__(self, n_rows, node_ptr, row_rel, pos, node_desc, tile_recs=None):
+    def __init__(self, n_rows, node_ptr, row_rel, pos, node_desc):
         self.n_rows, self.node_ptr, self.row_rel, self.pos, self.node_desc = int(n_rows), node_ptr, row_rel, pos, node_desc
-        self.tile_recs = tile_recs                # int32 [ceil(ceil(R / 32) / 4), N rounded up to even, 8] (tipk.h section 2d)
 
     def to(self, device):
         return CompactRows(self.n_rows, self.node_ptr.to(device), self.row_rel.to(device), self.pos.to(device),
-                           self.node_desc.to(device), None if self.tile_recs is None else self.tile_recs.to(device))
+                           self.node_desc.to(device))
 
 
 def compact_rows(out_node, rel, n_nodes, n_rel):
@@ -771,43 +770,8 @@ def compact_rows(out_node, rel, n_nodes, n_rel):
     order = torch.sort(per_node, descending=True, stable=True).indices
     node_desc = torch.stack([order, node_ptr[order], node_ptr[order + 1], torch.zeros_like(order)], dim=1)
     cr = CompactRows(n_rows, node_ptr.to(torch.int32).contiguous(), (used % r_pad).to(torch.int32).contiguous(),
-                     pos.view(N, r_pad).to(torch.int32).contiguous(), node_desc.to(torch.int32).contiguous(),
-                     tile_records(has.view(N, r_pad), node_ptr, R))
+                     pos.view(N, r_pad).to(torch.int32).contiguous(), node_desc.to(torch.int32).contiguous())
     return cr, pos[key]
-
-
-NP_TILE_GROUP = 4              # relation tiles per workgroup of the LDS form of tipk_rgcn_node_products (NP2_W)
-
-
-def tile_records(has, node_ptr, n_rel):
-    """int32 [n_rtg, N rounded up to even, 8] (include/tipk.h section 2d, `tile_recs`): per group of NP_TILE_GROUP relation
-    tiles and node { first compact row, rows, the tiles' offsets inside the block (a byte each), 0, the tiles' bit masks }.
-    has: bool [N, r_pad] "pair (u, r) has a row"; node_ptr [N + 1]."""
-    dev = has.device
-    N = int(has.shape[0])
-    W = NP_TILE_GROUP
-    n_rt = -(-int(n_rel) // 32)
-    n_rtg = -(-n_rt // W)
-    cols = n_rtg * W * 32
-    hp = torch.zeros((N, cols), dtype=torch.int64, device=dev)
-    k = min(cols, int(has.shape[1]))
-    hp[:, :k] = has[:, :k].long()
-    bits = hp.view(N, n_rtg, W, 32)
-    mask = (bits << torch.arange(32, device=dev)).sum(-1)                      # [N, n_rtg, W]
-    cnt = bits.sum(-1)
-    flat = cnt.view(N, n_rtg * W)
-    start = (torch.cumsum(flat, 1) - flat).view(N, n_rtg, W)                   # first row of a tile inside its node
-    p_lo = node_ptr[:N].view(N, 1) + start[:, :, 0]
-    nblk = cnt.sum(-1)
-    off = start - start[:, :, :1]
-    assert int(off.max()) < 256 if off.numel() else True
-    opk = (off << (8 * torch.arange(W, device=dev))).sum(-1)
-    rec = torch.stack([p_lo, nblk, opk, torch.zeros_like(opk)] + [mask[:, :, j] for j in range(W)], dim=-1)   # [N, n_rtg, 8]
-    n_pad = N + (N & 1)
-    out = torch.zeros((n_rtg, n_pad, 8), dtype=torch.int64, device=dev)
-    out[:, :N] = rec.permute(1, 0, 2)
-    out = torch.where(out >= 2 ** 31, out - 2 ** 32, out)
-    return out.to(torch.int32).contiguous()
 
 
 def build_stream_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg, lanes, piece=4, compact=False):

@@ -22,16 +22,8 @@ for layer in (enc.rgcn1, enc.rgcn2):
         dyc = ops.rel_stream_bwd(rs, g, row_scale=graph.scale)
         t_p = bench.time_launch_us(lambda: ops.node_products(dyc, rs.compact, att, xb))
         if '+debug' in _lib.build_id():                       # TIPK_LIB=tip_amd/libtipk_debug.so: the two roles alone
-            lds_form = d in (16, 32)
-            variants = ((16, 'role 1 (dXB) alone'), (8, 'role 2 (d att) alone'), (24, 'empty launch'))
-            if lds_form:                                          # the LDS form of role 2 (tipk_node_products.hip, round 4)
-                variants += ((16 + 256, 'role 1, <= 2 tiles per wave'), (16 + 512, 'role 1, no MFMA'), (16 + 256 + 512, 'role 1, <= 2 tiles, no MFMA'),
-                             (8 + 32, 'role 2, no MFMA'), (8 + 64, 'role 2, no DMA'), (8 + 128, 'role 2, no fragment reads'),
-                             (8 + 32 + 128, 'role 2, DMA + barriers only'), (8 + 32 + 64 + 128, 'role 2, barriers only'))
-            else:
-                variants += ((8 + 32, 'role 2, no B loads'), (8 + 64, 'role 2, no A loads'), (8 + 96, 'role 2, pos loads only'),
-                             (16 + 128, 'role 1, no att loads'), (16 + 256, 'role 1, no dY loads'), (16 + 384, 'role 1, rel loads only'))
-            for dbg, what in variants:
+            for dbg, what in ((16, 'role 1 (dXB) alone'), (8, 'role 2 (d att) alone'), (24, 'empty launch'), (8 + 32, 'role 2, no B loads'), (8 + 64, 'role 2, no A loads'), (8 + 96, 'role 2, pos loads only'),
+                              (16 + 128, 'role 1, no att loads'), (16 + 256, 'role 1, no dY loads'), (16 + 384, 'role 1, rel loads only')):
                 _lib.set_option('dp_debug', dbg)
                 print('   %-22s %.1f us' % (what, bench.time_launch_us(lambda: ops.node_products(dyc, rs.compact, att, xb))))
             _lib.set_option('dp_debug', 0)

@@ -11,6 +11,7 @@ held to) and toggles one difference at a time:
     --final-relu       z = relu(rgcn2(...)) as in model/ddm-df_rgcn.py:59
     --ref-sampler      the reference's own sampler incl. its leaking resample loop (src/neg_sampling.py:5-19, numpy RNG)
                        instead of the Philox spec of the device sampler (exact rejection)
+    --n-embed 16 --num-base 16   the widths of the published run's name ('fm-(32-16)-(16-16-32-32-16)', evaluation.ipynb cell 11)
     --min-pairs 500    the paper's 963 relations
     --epochs 100
 
@@ -61,6 +62,8 @@ def main():
     ap.add_argument('--mod', default='cat')
     ap.add_argument('--final-relu', action='store_true')
     ap.add_argument('--ref-sampler', action='store_true')
+    ap.add_argument('--n-embed', type=int, default=None)
+    ap.add_argument('--num-base', type=int, default=32)
     ap.add_argument('--threads', type=int, default=4)
     ap.add_argument('--tag', default=None)
     a = ap.parse_args()
@@ -68,7 +71,9 @@ def main():
     dd = build_data_dict(min_pairs=a.min_pairs, max_relations=a.relations)
     R = dd['n_dd_et']
     dims = dict(prot_drug_dim=16, n_embed=48) if a.mod == 'cat' else dict(prot_drug_dim=64, n_embed=64)
-    po = O.init_params(dd['n_drug'], dd['n_prot'], R, mod=a.mod, seed=1111, **dims)
+    if a.n_embed is not None:
+        dims['n_embed'] = a.n_embed
+    po = O.init_params(dd['n_drug'], dd['n_prot'], R, mod=a.mod, seed=1111, num_base=a.num_base, **dims)
     opt = OracleAdam(po, 0.01)
     rng = np.random.RandomState(1111)
     rel_ptr = np.concatenate([[0], np.asarray(dd['dd_train_range'])[:, 1]]).astype(np.int64)
@@ -96,7 +101,7 @@ def main():
     ns = O.distmult_fwd(z, test_neg, dd['dd_test_et'], w)
     rec = auprc_auroc_ap_by_range(ps, ns, dd['dd_test_range'])
     out = {'tool': 'oracle_ablation', 'epochs': a.epochs, 'relations': R, 'mod': a.mod, 'final_relu': a.final_relu,
-           'ref_sampler': a.ref_sampler, 'loss_first': losses[0], 'loss_last': losses[-1],
+           'ref_sampler': a.ref_sampler, 'n_embed': dims['n_embed'], 'num_base': a.num_base, 'loss_first': losses[0], 'loss_last': losses[-1],
            'oracle': dict(zip(['auprc', 'auroc', 'ap'], (rec.sum(1) / R).tolist())),
            'reference_published_auprc': 0.948, 'reference_published_where': 'analysis/evaluation.ipynb:192-195 (model/*.py scripts, R = 963)',
            'train_edges': int(dd['dd_train_idx'].shape[1]), 's_total': time.time() - t0, 'threads': a.threads}
