@@ -142,6 +142,34 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ct][kk], acc[ct], 0, 0, 0);
         };
         if (n_tiles > 0) {
+            if constexpr (NCT == 1) {
+                // THREE register sets (round 4).  vmcnt counts at most 63 operations and a tile is 32 loads: two tiles in
+                // flight behind the one being multiplied.  The relation ids of a tile are requested TWO steps before the loads
+                // that need them and IN FRONT of that step's loads: vector-memory operations complete in order, so an id
+                // requested behind a tile's loads makes its use wait for that tile -- which kept the two-set form below at
+                // one tile in flight (a hub node's 9 tiles per wave: 9 load round trips in a row).
+                constexpr int NF = 3;
+                float av[NF][16], bv[NF][1][16];
+                int rl[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) rl[f] = getrel(w + f * NP_WAVES);
+#pragma unroll
+                for (int f = 0; f < NF - 1; ++f) load(w + f * NP_WAVES, rl[f], av[f], bv[f]);
+                rl[0] = getrel(w + NF * NP_WAVES);
+                for (int tile = w; tile < n_tiles; tile += NF * NP_WAVES) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const int cur = tile + f * NP_WAVES;             // multiplied now (set f)
+                        if (cur < n_tiles) {                             // (uniform over the wave)
+                            rl[(f + 1) % NF] = getrel(cur + (NF + 1) * NP_WAVES);
+                            load(cur + (NF - 1) * NP_WAVES, rl[(f + NF - 1) % NF], av[(f + NF - 1) % NF], bv[(f + NF - 1) % NF]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mfma(av[f], bv[f]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            } else {
             float aX[16] = {}, bX[NCT][16] = {}, aY[16] = {}, bY[NCT][16] = {};
             int tile = w;
             int rX = getrel(tile), rY = getrel(tile + NP_WAVES);
@@ -157,6 +185,7 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma(aY, bY);                                            // (a tile past the end multiplies zero rows)
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
         }
         float* o = a.dxb + (int64_t)u * a.dxb_su;
