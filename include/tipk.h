@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 13
+#define TIPK_ABI_VERSION 14
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -374,6 +374,30 @@ int tipk_gate_colsum(const float* in, int64_t ld_in, const float* gate, int64_t 
  * xd [rows x ne], mean [rows x p], W [p x q] row-major contiguous, p, q <= 64; d_norm nullable (= 1). */
 int tipk_drug_mix_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* mean, int64_t ld_mean,
                       const float* w, int p, int q, int64_t rows, int ne, int cat, float* out, int64_t ld_out,
+                      tipk_stream_t stream);
+
+/* The P -> D stage fused with the drug feature mix, one launch per pass (src/layers.py:526-539 with MyHierarchyConv,
+ * :229-242: mean over a drug's protein targets, dense map, /d_norm, cat | add):
+ *     mean[d, :] = scale[d] * sum_{e in [ptr[d], ptr[d + 1])} h[src[e], :]         (scale = 1 / max(1, #targets))
+ *     out[d, :]  = cat(xd[d] / d_norm[d], mean[d] W)   (cat != 0)   or   xd[d] / d_norm[d] + mean[d] W   (q == ne)
+ *   h [n_src x p] (row stride ld_h), W [p x q] contiguous, p and q even and <= 64 (tipk_drug_mix_gather_supported),
+ *   CSR by drug: ptr int32 [rows + 1], src int32 [edges]; `mean` [rows x p] contiguous is an OUTPUT (kept for the backward).
+ *   wg_desc int32 [n_wg][2] = { first drug, drugs } of a 16-wave workgroup: up to 16 consecutive drugs, a wavefront each, or
+ *   ONE drug whose edges the 16 wavefronts share (hub rows: one BioSNAP drug has 2 834 targets) -- every drug exactly once.
+ * Backward, from g = d out [rows x (cat ? ne + q : ne)], one launch (tipk_drug_mix_bwd):
+ *     g_xd   = g[:, :ne] / d_norm                          (nullable: not wanted)
+ *     g_mean = g_pd W^T                                    [rows x p] contiguous (nullable), g_pd = the last q (cat) / all
+ *                                                          (add) columns of g; the caller gathers it back to the source rows
+ *                                                          on the transposed plan (tipk_gather_sum, edge weights = scale)
+ *     g_w    = mean^T g_pd                                 [p x q]
+ * All sums in fixed order. */
+int tipk_drug_mix_gather_supported(int p, int q);
+int tipk_drug_mix_gather_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
+                             const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc, int64_t n_wg,
+                             const float* w, int p, int q, int64_t rows, int ne, int cat, float* out, int64_t ld_out,
+                             float* mean, tipk_stream_t stream);
+int tipk_drug_mix_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
+                      int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_mean, float* g_w,
                       tipk_stream_t stream);
 
 /* out[c] = sum_r in[r, c]  (bias gradients of GCNConv).  `scratch` holds >= 256*cols floats. */

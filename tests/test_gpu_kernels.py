@@ -1043,3 +1043,44 @@ def test_stream_gather_8_byte_rows_with_epilogue(ops, N, d, bias, relu):
     if N <= 5000:
         ref = execute_stream_plan_reference(sp.to('cpu'), x * pre[:, None])
         close(ops.stream_gather(sp, x.to(DEV), row_scale=pre.to(DEV), max_split=16), ref.double(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,n_src,p,q,ne,cat', [(645, 3640, 16, 16, 48, True), (645, 3640, 16, 64, 64, False), (37, 19, 8, 4, 5, True),
+                                                (5, 300, 6, 10, 10, False), (130, 64, 64, 64, 3, True)])
+def test_drug_mix_gather_fused_launches(ops, n, n_src, p, q, ne, cat):
+    """tipk_drug_mix_gather_fwd / tipk_drug_mix_bwd (tipk.h section 3): P -> D mean (MyHierarchyConv, src/layers.py:229-242) + dense map +
+    /d_norm + cat | add (:532-539) in one launch each way == the fp64 formula, drugs without targets, repeated edges,
+    non-unit d_norm, a strided upstream gradient; bitwise reproducible."""
+    from tip_amd.layers import hier_graph
+    g = torch.Generator().manual_seed(n + p + q)
+    E = 6 * n + 3
+    src = torch.randint(0, n_src, (E,), generator=g)
+    dst = torch.randint(0, max(1, n - 2), (E,), generator=g)          # the last two targets have no edge
+    src[:4] = src[4:8]; dst[:4] = dst[4:8]                            # repeated edges
+    ei = torch.stack([src, dst + n_src]).to(DEV)
+    graph = hier_graph(ei, n_src + n, n_src, table_rows=n_src, d=p)
+    xd = torch.randn(n, ne, generator=g)
+    h = torch.randn(n_src, p, generator=g)
+    w = torch.randn(p, q, generator=g)
+    dn = torch.rand(n, generator=g) + 0.5
+    cnt = torch.bincount(dst, minlength=n).clamp(min=1).double()
+    mean = torch.zeros(n, p, dtype=torch.float64).index_add_(0, dst, h.double()[src]) / cnt.unsqueeze(1)
+    mapped = mean @ w.double()
+    base = xd.double() / dn.double().unsqueeze(1)
+    want = torch.cat([base, mapped], 1) if cat else base + mapped
+    xd_d, h_d, w_d = (t.to(DEV).requires_grad_() for t in (xd, h, w))
+    out = ops.drug_mix_gather(xd_d, h_d, w_d, dn.to(DEV), cat, graph)
+    close(out, want, rtol=2e-5, atol=2e-5)
+    gup = torch.randn(n, want.shape[1] + 3, generator=g)[:, 1:-2]      # a column-slice view: strided rows
+    out.backward(gup.to(DEV))
+    gd = gup.double()
+    g_pd = gd[:, ne:] if cat else gd
+    close(xd_d.grad, (gd[:, :ne] / dn.double().unsqueeze(1)), rtol=2e-5, atol=2e-6)
+    close(w_d.grad, mean.t() @ g_pd, rtol=2e-5, atol=2e-5 * float((mean.t() @ g_pd).abs().max()))
+    g_mean = (g_pd @ w.double().t()) / cnt.unsqueeze(1)
+    want_h = torch.zeros(n_src, p, dtype=torch.float64).index_add_(0, src, g_mean[dst])
+    close(h_d.grad, want_h, rtol=2e-5, atol=2e-5 * float(want_h.abs().max()))
+    xd2, h2, w2 = (t.to(DEV).requires_grad_() for t in (xd, h, w))
+    out2 = ops.drug_mix_gather(xd2, h2, w2, dn.to(DEV), cat, graph)
+    out2.backward(gup.to(DEV))
+    assert torch.equal(out2, out) and torch.equal(h2.grad, h_d.grad) and torch.equal(w2.grad, w_d.grad)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class TipkError(RuntimeError):
@@ -82,6 +82,9 @@ SIGNATURES = {
     'tipk_gate_colsum_groups': (_I, [_L, _L]),
     'tipk_gate_colsum': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _P, _P]),
     'tipk_drug_mix_fwd': (_I, [_P, _L, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P]),
+    'tipk_drug_mix_gather_supported': (_I, [_I, _I]),
+    'tipk_drug_mix_gather_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P]),
+    'tipk_drug_mix_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P]),
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),
     'tipk_distmult_fwd': (_I, [_P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P, _P, _P]),

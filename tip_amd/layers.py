@@ -247,9 +247,28 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     G = group_slots_for(d) if d else 0
     scale = (1.0 / cnt).contiguous()
     # the transposed plan carries 1/count as per-edge weights: no scaling pass before the backward gather
-    return ops.AggGraph(build_gather_plan(dst, src, n_t, n_tab, None, chunk, 'pd.fwd', G),
-                        build_gather_plan(src, dst, n_tab, n_t, scale[dst], chunk, 'pd.bwd', G), scale,
-                        bwd_scaled=True)
+    graph = ops.AggGraph(build_gather_plan(dst, src, n_t, n_tab, None, chunk, 'pd.fwd', G),
+                         build_gather_plan(src, dst, n_tab, n_t, scale[dst], chunk, 'pd.bwd', G), scale,
+                         bwd_scaled=True)
+    # CSR by target (edge order kept inside a target) for the fused P -> D + drug-mix forward launch (ops.drug_mix_gather;
+    # include/tipk.h section 3)
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    of = torch.sort(dst, stable=True).indices
+    ptr = lambda idx, n: i32(torch.cat([idx.new_zeros(1), torch.cumsum(torch.bincount(idx, minlength=n), 0)]))
+    # workgroups of the forward launch: 16 consecutive targets, a wavefront each -- a target with more than 512 edges
+    # (BioSNAP: one drug has 2 834 protein targets) gets the 16 wavefronts of a workgroup to itself
+    cnt_t = torch.bincount(dst, minlength=n_t).tolist()
+    wgs, start = [], 0
+    for tgt, c_ in enumerate(cnt_t):
+        if c_ > 512:
+            if tgt > start:
+                wgs += [[b0, min(16, tgt - b0)] for b0 in range(start, tgt, 16)]
+            wgs.append([tgt, 1])
+            start = tgt + 1
+    wgs += [[b0, min(16, n_t - b0)] for b0 in range(start, n_t, 16)]
+    fwd_wg = torch.tensor(wgs, dtype=torch.int32, device=src.device).view(-1, 2).contiguous()
+    graph.pd_csr = dict(fwd_ptr=ptr(dst, n_t), fwd_src=i32(src[of]), scale=scale, fwd_wg=fwd_wg, n_src=int(n_tab))
+    return graph
 
 
 class MyHierarchyConv(nn.Module):
@@ -313,7 +332,7 @@ class MyHierarchyConv(nn.Module):
             return torch.unique(edge_index[0].to(torch.int64))
         return self._cache_rows.get((edge_index,), build)
 
-    def mean_sources(self, x_src, edge_index, rows=None):
+    def mean_sources(self, x_src, edge_index, rows=None, graph_only=False):
         """The mean aggregate of `forward_sources` WITHOUT the dense map (the caller applies
         `self.weight` fused with what follows, ops.drug_mix_mm); None if unusable.
         rows: `source_rows(edge_index)` -- x_src then holds only those rows of the source block, in that order."""
@@ -335,6 +354,8 @@ class MyHierarchyConv(nn.Module):
         graph = (self._cache_src if rows is None else self._cache_src_rows).get((edge_index, rows), build)
         if graph is None:
             return None
+        if graph_only:
+            return graph
         return ops.aggregate(x_src, graph)
 
     def __repr__(self):
@@ -545,13 +566,21 @@ class FMEncoder(nn.Module):
         rows = self.hgcn.source_rows(dp_edge_index) if self.prune_pp_rows else None
         if rows is not None and rows.numel() < x_prot.shape[0]:
             h1 = self.pp_encoder.conv1(x_prot, pp_edge_index, fuse_relu=True)
-            h_rows = self.pp_encoder.conv2(h1, pp_edge_index, rows=rows)              # [len(rows), hid2]
-            mean = self.hgcn.mean_sources(h_rows, dp_edge_index, rows=rows)
-            h_prot = None
+            h_prot = self.pp_encoder.conv2(h1, pp_edge_index, rows=rows)              # [len(rows), hid2]
         else:
+            rows = None
             h_prot = self.pp_encoder(x_prot, pp_edge_index)                           # P-P GCN x2
-            mean = self.hgcn.mean_sources(h_prot, dp_edge_index)                      # P -> D mean, no cat (:526-528)
-        if mean is not None:                                                          # dense map + /d_norm + cat|add fused
+        pd_graph = self.hgcn.mean_sources(None, dp_edge_index, rows=rows, graph_only=True)
+        if pd_graph is not None and ops.drug_mix_gather_supported(h_prot, self.hgcn.weight, d_norm):
+            # P -> D mean, dense map, /d_norm and cat | add: ONE launch forward (tipk_drug_mix_gather_fwd), two backward
+            x0 = ops.drug_mix_gather(xd, h_prot, self.hgcn.weight, d_norm, self.mod == 'cat', pd_graph)
+            mean = None
+        else:
+            mean = self.hgcn.mean_sources(h_prot, dp_edge_index, rows=rows)           # P -> D mean, no cat (:526-528)
+            x0 = None
+        if x0 is not None:
+            pass
+        elif mean is not None:                                                        # dense map + /d_norm + cat|add fused
             x0 = ops.drug_mix_mm(xd, mean, self.hgcn.weight, d_norm, self.mod == 'cat')
         else:                                                                         # an edge starts at a drug row
             if self.hdrug.device != h_prot.device:

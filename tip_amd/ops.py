@@ -1428,6 +1428,60 @@ def drug_mix_mm(xd, mean, weight, d_norm, cat):
     return _DrugMixMM.apply(xd, mean, weight, d_norm, cat)
 
 
+def drug_mix_gather_supported(h, weight, d_norm):
+    p, q = weight.shape
+    return bool(h.is_cuda and h.dtype == torch.float32 and h.stride(1) == 1 and weight.is_contiguous() and
+                (d_norm is None or d_norm.is_contiguous()) and lib().tipk_drug_mix_gather_supported(int(p), int(q)))
+
+
+class _DrugMixGather(torch.autograd.Function):
+    """x0 = cat(xd / d_norm, mean(H) W) or xd / d_norm + mean(H) W with mean(H)[d] = the mean of the source rows that point
+    at d (MyHierarchyConv, src/layers.py:229-242, + the mix of :532-539): one launch forward; backward one launch for
+    d xd, d mean and d W + the transposed gather of d mean on its plan (include/tipk.h section 3, csrc/tipk_drugmix.hip)."""
+
+    @staticmethod
+    def forward(ctx, xd, h, weight, d_norm, cat, graph):
+        xd, h, weight = _f32c(xd), _f32c(h), _f32c(weight).contiguous()
+        csr = graph.pd_csr
+        require_device(xd, h, weight, d_norm, csr['fwd_ptr'])
+        n, ne = xd.shape
+        p, q = weight.shape
+        assert h.shape == (csr['n_src'], p) and csr['fwd_ptr'].numel() == n + 1
+        out = torch.empty((n, ne + q if cat else ne), dtype=torch.float32, device=xd.device)
+        mean = torch.empty((n, p), dtype=torch.float32, device=xd.device)
+        with _timed('drug_mix_gather_fwd[%dx%dx%d]' % (n, p, q)):
+            check(lib().tipk_drug_mix_gather_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(h), h.stride(0), ptr(csr['fwd_ptr']),
+                                                 ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), csr['fwd_wg'].shape[0],
+                                                 ptr(weight), p, q, n, ne, int(cat),
+                                                 ptr(out), out.stride(0), ptr(mean), stream_ptr(xd.device)),
+                  'tipk_drug_mix_gather_fwd')
+        ctx.cat, ctx.ne, ctx.graph = cat, ne, graph
+        ctx.save_for_backward(mean, weight, d_norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mean, weight, d_norm = ctx.saved_tensors
+        g = _f32c(g)
+        n, p = mean.shape
+        q = weight.shape[1]
+        dev = g.device
+        g_xd = torch.empty((n, ctx.ne), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        g_mean = torch.empty((n, p), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        g_w = torch.empty((p, q), dtype=torch.float32, device=dev)
+        with _timed('drug_mix_bwd[%dx%dx%d]' % (n, p, q)):
+            check(lib().tipk_drug_mix_bwd(ptr(g), g.stride(0), ptr(d_norm), ptr(mean), ptr(weight), p, q, n, ctx.ne, int(ctx.cat),
+                                          ptr(g_xd), g_xd.stride(0) if g_xd is not None else 0, ptr(g_mean), ptr(g_w),
+                                          stream_ptr(dev)), 'tipk_drug_mix_bwd')
+        # back to the source rows: the transposed plan carries 1 / count of the edge's target as edge weights
+        g_h = gather_sum(ctx.graph.bwd, g_mean) if g_mean is not None else None
+        return g_xd, g_h, g_w, None, None, None
+
+
+def drug_mix_gather(xd, h, weight, d_norm, cat, graph):
+    return _DrugMixGather.apply(xd, h, weight, d_norm, cat, graph)
+
+
 _ONES = {}
 
 
