@@ -592,3 +592,33 @@ def test_nn_decoder_golden():
     close(z.grad, g['grad_z'], atol=1e-5)
     for k in ('w1_l1', 'w1_l2', 'w2_l1', 'w2_l2'):
         close(getattr(m, k).grad, g['grad.' + k], atol=1e-5)
+
+
+def test_rgcn_backward_after_another_forward_recomputes_xb():
+    """The pair-form forward keeps XB in a buffer that belongs to the GRAPH (the next forward pass rewrites it); a backward
+    pass that runs after another forward must not read the other pass's XB (ops._RGCN: stamp -> recompute)."""
+    from tip_amd.layers import MyRGCNConv2
+    g = torch.Generator().manual_seed(3)
+    N, R, d_in, d_out = 40, 6, 8, 16
+    half = [torch.randint(0, N, (2, 30), generator=g) for _ in range(R)]
+    ei = torch.cat([torch.cat([h, h.flip(0)], 1) for h in half], 1).to(DEV)
+    sizes = torch.tensor([60] * R)
+    end = torch.cumsum(sizes, 0)
+    rg = torch.stack([end - sizes, end], 1)
+    et = torch.repeat_interleave(torch.arange(R), sizes).to(DEV)
+    layer = MyRGCNConv2(d_in, d_out, R, 32, after_relu=False).to(DEV)
+    x1 = torch.randn(N, d_in, generator=g).to(DEV).requires_grad_()
+    x2 = (torch.randn(N, d_in, generator=g) * 3).to(DEV).requires_grad_()
+    gup = torch.randn(N, d_out, generator=g).to(DEV)
+
+    def grads(x, disturb):
+        layer.zero_grad()
+        x.grad = None
+        out = layer(x, ei, et, rg)
+        if disturb:
+            layer(x2, ei, et, rg)                                         # rewrites the graph's XB buffer
+        out.backward(gup)
+        return [x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    clean, mixed = grads(x1, False), grads(x1, True)
+    for a, b in zip(clean, mixed):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)

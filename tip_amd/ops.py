@@ -474,6 +474,7 @@ def node_products(dyc, cr, att, xb):
     nb, n = xb.shape[0], xb.shape[1]
     r = att.shape[0]
     assert cr.n_rows == n_rows and xb.shape[2] == d and xb.stride(2) == 1 and att.stride(1) == 1 and dyc.is_contiguous()
+    assert xb.stride(0) % 4 == 0 and xb.stride(1) % 4 == 0
     g = node_products_slabs(n, d, r, nb)
     assert g > 0
     dev = dyc.device
@@ -1192,7 +1193,19 @@ class _RGCN(torch.autograd.Function):
             # 16 KB contiguous per operand tile (destination-major cells made every tile 128 separate 128-byte rows:
             # 2.5 TB/s); the u range is padded to a multiple of PAIR_KGROUP with cells / XB rows that stay zero
             cells, xb_nb = graph.pair_buffers(n, nb, d_out, x.device)
-            xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+            rs = graph.rs_bwd
+            if rs is not None and rs.compact is not None and any(ctx.needs_input_grad[:3]):
+                # XB is computed ONCE, into the node-major buffer the pair product reads; the backward pass
+                # (`node_products` on the compact dY) takes the same buffer through strides -- a node's 32 rows are one
+                # 4-KB block there.  The buffer belongs to the graph and the next forward pass rewrites it: the stamp tells
+                # a backward pass that runs after ANOTHER forward to recompute XB instead of reading someone else's.
+                _, xroot = gemm_group([gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+                xb = xb_nb[:n].permute(1, 0, 2)
+                graph.pair_stamp = getattr(graph, 'pair_stamp', 0) + 1
+                ctx.xb_stamp = graph.pair_stamp
+            else:
+                xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+                ctx.xb_stamp = None
             stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
             slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric)
             if shard is None:
@@ -1202,8 +1215,9 @@ class _RGCN(torch.autograd.Function):
                 shard.all_reduce(agg)
                 out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
             ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
-            ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
+            ctx.save_for_backward(x, basis, att, root, xb if ctx.xb_stamp is None else None, out if relu is True else None)
             return out
+        ctx.xb_stamp = None
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)   # (the unit plan is built here, on first use)
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
@@ -1272,7 +1286,12 @@ class _RGCN(torch.autograd.Function):
         n, d_in = x.shape
         nb, _, d_out = basis.shape
         r = att.shape[0]
-        xb2 = xb.view(nb, n * d_out)
+        if ctx.xb_stamp is not None:                                     # XB lives in the graph's node-major buffer (forward)
+            if getattr(graph, 'pair_stamp', 0) == ctx.xb_stamp:
+                xb = graph.pair_buffers(n, nb, d_out, x.device)[1][:n].permute(1, 0, 2)
+            else:                                                        # another forward pass has rewritten it: same values again
+                xb = gemm(x, basis)
+        xb2 = xb.view(nb, n * d_out) if xb.is_contiguous() else None
         if r > 0:
             rs = graph.rs_bwd
             used = None
