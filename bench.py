@@ -527,6 +527,40 @@ class Bench(object):
         self.static_grads = {k: prm.grad for k, prm in self.enc.named_parameters()}
         return graph.replay
 
+    def replicated_stage_us(self, reps=20):
+        """us per replay of the part of the step that a relation-sharded run computes on EVERY rank: P-P GCN x2, P -> D mean,
+        drug mix -- forward and backward with a fixed upstream gradient, as its own hipGraph."""
+        import torch
+        enc, d = self.enc, self.d
+        params = [enc.embed, enc.hgcn.weight] + list(enc.pp_encoder.parameters())
+
+        def stage():
+            for prm in params:
+                prm.grad = None
+            x0 = enc.mixed_drug_features(d.d_feat, d.d_norm, d.p_feat, d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
+            x0.backward(self._g_x0)
+        with torch.no_grad():
+            probe = enc.mixed_drug_features(d.d_feat, d.d_norm, d.p_feat, d.pp_train_indices, d.dp_edge_index, d.dp_range_list)
+        self._g_x0 = torch.randn(probe.shape, generator=torch.Generator().manual_seed(1)).to(self.dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            stage()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            stage()
+        for _ in range(3):
+            graph.replay()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            graph.replay()
+        b_.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b_) / reps * 1e3
+
     def outputs(self):
         """(z, {name: gradient}) of the most recent step: the replayed graph's buffers, or the eager tensors."""
         if self.graph is not None:
@@ -695,10 +729,19 @@ def main():
         attach_shard(enc, shard)
         if world > 1 and 'TIPK_FWD_ROUTE' not in os.environ:
             ops.FWD_ROUTE_MODE = 'timed'                       # one timed, job-wide decision per layer (ops._fwd_route)
-        if os.environ.get('TIPK_COLLECTIVE') == 'direct' and world > 1:
-            # one-shot exchange over peer-mapped mailboxes instead of the group's all-reduce (opt-in: tip_amd/dist.py)
-            shard.enable_direct_exchange(dev, max_floats=max(1 << 16, dd['n_drug'] * (2 * max(dims.values()) + 64)
-                                                             + dims['num_base'] * 128 * 128))
+        coll_mode = os.environ.get('TIPK_COLLECTIVE', 'auto')              # auto | direct | group (rccl / gloo)
+        if world > 1 and coll_mode != 'group':
+            # The step's five all-reduces are 41 ... 430 KB: pure latency.  The one-shot exchange over peer-mapped mailboxes
+            # (tip_amd/csrc/tipk_peer.hip) is set up if every rank can map every mailbox and a timed self-test sums right;
+            # 'auto' then times it against the process group for the step's message sizes and keeps the faster per size
+            # (before any capture; the same decision on every rank).  Anything that fails -> the process group.
+            n_d, nb_ = dd['n_drug'], dims['num_base']
+            d0 = dims['n_embed'] + dims['prot_drug_dim'] if args.mod == 'cat' else dims['n_embed']
+            sizes = [n_d * dims['n_hid1'], n_d * dims['n_hid2'], n_d * d0 + nb_ * d0 * dims['n_hid1'],
+                     n_d * dims['n_hid1'] + nb_ * dims['n_hid1'] * dims['n_hid2']]
+            ex = shard.try_direct_exchange(dev, max_floats=max(1 << 16, max(sizes)))
+            if ex is not None and coll_mode == 'auto':
+                shard.choose_collective(sizes, dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -750,10 +793,17 @@ def main():
             b.step()
         fence()
         kern = ops.timing_stop()
+    per_rank_ms, replicated = None, None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)
+        if shard is not None and shard.direct is not None:
+            shard.direct.check()                                           # a wait that ran out -> PeerTimeout: non-zero exit
+    if sharded and args.workload.startswith('biosnap'):
+        replicated = b.replicated_stage_us()                               # what every rank computes redundantly
 
     rc = 0
     if rank == 0:
@@ -772,11 +822,23 @@ def main():
                        'launch': 'hipGraph replay of the captured step' if launch == 'graph'
                        else 'eager (one ctypes call per kernel)',
                        'collective': shard.collective if shard is not None else None,
+                       'collective_timing': shard.collective_report if shard is not None else None,
+                       'rccl_ranks': world if (shard is not None and dist.is_initialized() and dist.get_backend() == 'nccl') else 0,
                        'forward_routes': [list(l._cache.value.fwd_route.values()) if l._cache.value is not None else None
                                           for l in (enc.rgcn1, enc.rgcn2)] if shard is not None else None},
             'preprocess_s': preprocess_s, 'init_s': init_s,
             'build_id': bid,
         }
+        if per_rank_ms is not None:
+            out['per_rank_ms_per_step'] = [round(v, 4) for v in per_rank_ms]
+        if replicated is not None:
+            # P-P GCN x2 + P -> D + drug mix (forward and backward) are computed on EVERY rank: with N ranks the step cannot
+            # get shorter than that.  est_single_rank = replicated + N x (this step - replicated): what one rank would need
+            sh_us = max(0.0, ms * 1e3 - replicated)
+            out['replicated'] = {'replicated_us': round(replicated, 1), 'sharded_and_collectives_us': round(sh_us, 1),
+                                 'amdahl_ceiling': round((replicated + world * sh_us) / replicated, 2),
+                                 'what': 'P-P / P->D / drug-mix stage of the encoder, graph-timed on rank 0; ceiling = speed-up '
+                                         'over one rank that no number of ranks can exceed while this stage is replicated'}
         if launch_us:
             by = {l['label']: l for l in launches}
             dom = max(launch_us, key=launch_us.get)                               # the longest kernel of the step

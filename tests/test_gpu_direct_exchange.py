@@ -88,7 +88,7 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_direct_exchange_ranks_sharing_one_gpu(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
@@ -105,3 +105,64 @@ def test_direct_exchange_ranks_sharing_one_gpu(world):
             pytest.fail('direct exchange timed out')
         assert p.exitcode == 0
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def _timeout_worker(rank, world, port, ret):
+    """Rank 1 skips the second exchange: rank 0's wait runs out of its budget, records the missing rank and goes on."""
+    import time
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ex = None
+    try:
+        from tip_amd.dist import DirectExchange, PeerTimeout
+        torch.cuda.set_device(0)
+        ex = DirectExchange(rank, world, None, 5000, torch.device(DEV))
+        ex.set_timeout_ms(300)
+        x = torch.full((4097,), float(rank + 1), device=DEV)
+        ex.all_reduce(x)
+        torch.cuda.synchronize()
+        ok = bool((x == 3.0).all()) and ex.error_word() == 0
+        ex.check()                                                          # nothing to report
+        dist.barrier()
+        if rank == 0:
+            t0 = time.perf_counter()
+            ex.all_reduce(x)                                                # the peer never posts: bounded wait, then garbage
+            torch.cuda.synchronize()
+            waited = time.perf_counter() - t0
+            w = ex.error_word()
+            ok = ok and 0.2 < waited < 5.0 and w != 0 and (w >> 32) == 2 and ((w >> 16) & 0xffff) - 1 == 1
+            try:
+                ex.check()
+                ok = False
+            except PeerTimeout as e:
+                ok = ok and 'rank 1' in str(e)
+        dist.barrier()
+        ret[rank] = bool(ok)
+    finally:
+        if ex is not None:
+            ex.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_direct_exchange_wait_is_bounded():
+    """ADVICE r3 / VERDICT r3 item 3b: a peer that skips a call does not hang the others -- the flag wait gives up after
+    its wall-clock budget, the error word names the exchange and the missing rank, `check()` raises."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+            pytest.fail('the bounded wait did not return')
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True}

@@ -207,6 +207,7 @@ def test_bench_two_ranks_oversubscribed_subprocess():
     fields."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['TIPK_COLLECTIVE'] = 'group'                                      # the process group only (no peer-mailbox exchange)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--oversubscribe', '--workload',
                           'synthetic-small', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
                          env=env, capture_output=True, text=True, timeout=850)
@@ -234,3 +235,27 @@ def test_bench_two_ranks_direct_exchange_and_timed_routes():
     assert rec['n_gpus'] == 2 and rec['config']['collective'] == 'direct' and rec['value'] > 0
     routes = rec['config']['forward_routes']
     assert len(routes) == 2 and all(r and r[0][0] in ('pair', 'y') and set(r[0][1]) == {'pair', 'y'} for r in routes)
+
+
+@pytest.mark.timeout(1500)
+def test_bench_eight_ranks_oversubscribed_auto_collective():
+    """`bench.py --gpus 8 --oversubscribe` on BioSNAP (BASELINE config 4's rank count; the ranks share the one GPU, gloo):
+    the exchange is set up behind its self-test, both collectives are timed per message size and the faster kept, and the
+    line carries what the first real 8-GPU run will be read by: per-rank step times, the collective's timings, the
+    replicated stage and the Amdahl ceiling it implies."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.pop('TIPK_COLLECTIVE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--oversubscribe', '--steps', '3',
+                          '--warmup', '1', '--no-cpu-baseline', '--no-kernel-table'], env=env, capture_output=True, text=True, timeout=1400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert rec['n_gpus'] == 8 and rec['value'] > 0 and 'relation-sharded x8' in rec['config']['parallelism']
+    assert len(rec['per_rank_ms_per_step']) == 8 and all(v > 0 for v in rec['per_rank_ms_per_step'])
+    assert abs(max(rec['per_rank_ms_per_step']) - rec['ms_per_step']) < 1e-3
+    ct = rec['config']['collective_timing']
+    assert ct and (('per_size' in ct and len(ct['per_size']) >= 3 and
+                    all(v['chosen'] in ('direct', 'group') for v in ct['per_size'].values())) or 'why' in ct)
+    rp = rec['replicated']
+    assert rp['replicated_us'] > 10 and rp['amdahl_ceiling'] > 1.0
+    assert rec['config']['rccl_ranks'] == 0                                # gloo here; 8 on a real node

@@ -58,7 +58,9 @@ class RelationShard(object):
         self.in_degree = None                     # int64 [N]: D-D in-degree over ALL relations
         self.n_train_total = None                 # directed training edges over all ranks
         self.n_train_local = None
-        self.direct = None                        # DirectExchange (one-shot all-reduce over peer-mapped mailboxes), opt-in
+        self.direct = None                        # DirectExchange (one-shot all-reduce over peer-mapped mailboxes)
+        self.direct_sizes = None                  # None: every buffer the exchange takes; else {numel: True | False} (choose_collective)
+        self.collective_report = None
 
     def rel_ids_on(self, device):
         if self.rel_ids.device != device:
@@ -68,22 +70,113 @@ class RelationShard(object):
     def all_reduce(self, flat):
         """In-place SUM all-reduce of one flat buffer: the one-shot exchange over peer-mapped mailboxes when it was
         enabled (`enable_direct_exchange`) and the buffer fits, the process group's all-reduce (RCCL / gloo) otherwise."""
-        if self.direct is not None and self.direct.takes(flat):
+        if self.direct is not None and self.direct.takes(flat) and self._direct_for(flat.numel()):
             self.direct.all_reduce(flat)
         elif self.world > 1 or dist.is_initialized():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def _direct_for(self, numel):
+        if self.direct_sizes is None:
+            return True
+        hit = self.direct_sizes.get(int(numel))
+        if hit is not None:
+            return hit
+        won = [n for n, use in self.direct_sizes.items() if use]             # an untimed size: as its next larger timed one
+        return bool(won) and int(numel) <= max(won)
 
     def enable_direct_exchange(self, device, max_floats=1 << 21):
         """Use `DirectExchange` for the step's collectives (all ranks must call this; collective).  -> the exchange."""
         self.direct = DirectExchange(self.rank, self.world, self.group, max_floats, device)
         return self.direct
 
+    def _all_ok(self, ok, device):
+        """Every rank's verdict AND-ed through the process group (the one path that is known to work)."""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=device if dist.get_backend(self.group) == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t.item()) > 0
+
+    def try_direct_exchange(self, device, max_floats=1 << 21, selftest_timeout_ms=500):
+        """Set the one-shot exchange up IF it works here, on every rank: hipIpc mapping of all mailboxes, then a timed
+        self-test (a known sum with a short wait budget, the error word checked).  Any rank's failure -- an exception, a
+        wrong sum, a wait that ran out -- makes every rank fall back to the process group.  -> the exchange or None."""
+        ex, ok, why = None, True, ''
+        try:
+            ex = DirectExchange(self.rank, self.world, self.group, max_floats, device)
+        except Exception as exc:                                            # noqa: BLE001
+            ok, why = False, 'setup: %r' % (exc,)
+        if not self._all_ok(ok, device):
+            if ex is not None:
+                ex.close()
+            self.collective_report = {'direct': 'unavailable', 'why': why or 'another rank failed to map the mailboxes'}
+            return None
+        try:
+            ex.set_timeout_ms(selftest_timeout_ms)
+            n = min(max_floats, 70001)
+            x = torch.full((n,), float(self.rank + 1), dtype=torch.float32, device=device)
+            for _ in range(3):                                              # both mailbox halves
+                x.fill_(float(self.rank + 1))
+                ex.all_reduce(x)
+            torch.cuda.synchronize(device)
+            ok = ex.error_word() == 0 and bool((x == float(self.world * (self.world + 1) // 2)).all())
+            why = '' if ok else 'self-test: wrong sum or a wait ran out (error word %#x)' % ex.error_word()
+            ex.set_timeout_ms(2000)
+        except Exception as exc:                                            # noqa: BLE001
+            ok, why = False, 'self-test: %r' % (exc,)
+        if not self._all_ok(ok, device):
+            ex.close()
+            self.collective_report = {'direct': 'failed its self-test', 'why': why or 'on another rank'}
+            return None
+        self.direct = ex
+        return ex
+
+    def choose_collective(self, sizes, device, reps=20):
+        """Time the process group's all-reduce and the one-shot exchange for every message size of the step (floats) --
+        `reps` calls each after 3 warm-up calls, host-synchronised, the MAX over the ranks -- and keep the faster per size
+        (the same decision on every rank).  Call before any capture.  -> the report (also `self.collective_report`)."""
+        import time
+        assert self.direct is not None
+        rep = {}
+        use = {}
+        on_dev = dist.get_backend(self.group) == 'nccl'
+        for n in sorted(set(int(s_) for s_ in sizes)):
+            if n <= 0 or n > self.direct.max_floats:
+                continue
+            x = torch.zeros(n, dtype=torch.float32, device=device)
+            t = {}
+            for name in ('group', 'direct'):
+                fn = (lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)) if name == 'group' else \
+                    (lambda: self.direct.all_reduce(x))
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(device)
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(device)
+                t[name] = (time.perf_counter() - t0) / reps * 1e6
+            tt = torch.tensor([t['group'], t['direct']], dtype=torch.float32, device=device if on_dev else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
+            g_us, d_us = [float(v) for v in tt.tolist()]
+            use[n] = d_us < g_us
+            rep[str(n)] = {'group_us': round(g_us, 1), 'direct_us': round(d_us, 1), 'chosen': 'direct' if use[n] else 'group'}
+        self.direct.check()
+        self.direct_sizes = use
+        self.collective_report = {'per_size': rep, 'group_backend': dist.get_backend(self.group),
+                                  'how': 'eager calls, host-synchronised, max over ranks'}
+        return self.collective_report
+
     @property
     def collective(self):
-        if self.direct is not None:
+        group = dist.get_backend(self.group) if dist.is_initialized() else 'none'
+        if self.direct is None:
+            return group
+        if self.direct_sizes is None or all(self.direct_sizes.values()):
             return 'direct'
-        return dist.get_backend(self.group) if dist.is_initialized() else 'none'
+        if not any(self.direct_sizes.values()):
+            return group
+        return 'direct<=%d floats, %s above' % (max(n for n, u in self.direct_sizes.items() if u), group)
 
     @property
     def loss_weight(self):
@@ -100,38 +193,62 @@ class DirectExchange(object):
     once -- posts flags, waits for the others' flags and adds the slots in rank order.  One kernel per rank and call
     instead of the 2 (w - 1) dependent steps of a ring; results are identical on every rank and from run to run.
     The mailboxes are exchanged as hipIpc handles through the process group (any backend) once, at construction.
-    OPT-IN (`RelationShard.enable_direct_exchange`, bench.py: TIPK_COLLECTIVE=direct): it is validated with ranks
-    sharing one GPU (tests/test_gpu_direct_exchange.py); RCCL stays the default on real multi-GPU nodes until it has
-    been timed there."""
+    It is validated with ranks SHARING one GPU (tests/test_gpu_direct_exchange.py: 2, 4 and 8 ranks, a peer that skips a
+    call); over xGMI it has never run.  `RelationShard.try_direct_exchange` therefore sets it up only if every rank can map
+    every mailbox and a timed self-test gives the right sums, `choose_collective` then times it against the process
+    group per message size and keeps the faster (bench.py does both for N > 1); the flag wait is bounded, and a wait that
+    ran out is reported by `check()`."""
 
     def __init__(self, rank, world, group, max_floats, device):
+        """Collective over `group`.  A rank whose mailbox cannot be allocated or mapped does NOT leave the others waiting
+        in the handle exchange: failures travel with the handles, and every rank raises together."""
         import ctypes as C
         from ._lib import lib, check
         L = lib()
         self.rank, self.world, self.max_floats, self.device = int(rank), int(world), int(max_floats), torch.device(device)
+        self.own, self.opened = None, []
         nbytes = int(L.tipk_peer_mailbox_bytes(self.world, self.max_floats))
         if nbytes <= 0:
             raise ValueError('direct exchange: unsupported world size %d' % world)
+        err = None
+        handle = C.create_string_buffer(64)
         with torch.cuda.device(self.device):
-            self.own = C.c_void_p()
-            check(L.tipk_peer_alloc(nbytes, C.byref(self.own)), 'tipk_peer_alloc')
-            handle = C.create_string_buffer(64)
-            check(L.tipk_ipc_get_handle(self.own, handle), 'tipk_ipc_get_handle')
+            try:
+                own = C.c_void_p()
+                check(L.tipk_peer_alloc(nbytes, C.byref(own)), 'tipk_peer_alloc')
+                self.own = own
+                check(L.tipk_ipc_get_handle(self.own, handle), 'tipk_ipc_get_handle')
+            except Exception as exc:                                        # noqa: BLE001
+                err = repr(exc)
             handles = [None] * self.world
+            mine = (handle.raw if err is None else None, err)
             if self.world > 1:
-                dist.all_gather_object(handles, handle.raw, group=group)
-            self.ptrs = (C.c_void_p * self.world)()
-            self.opened = []
-            for r in range(self.world):
-                if r == self.rank:
-                    self.ptrs[r] = self.own
-                else:
-                    p = C.c_void_p()
-                    check(L.tipk_ipc_open(handles[r], C.byref(p)), 'tipk_ipc_open')
-                    self.ptrs[r] = p
-                    self.opened.append(p)
-        if self.world > 1:
-            dist.barrier(group=group)                     # every mailbox is mapped everywhere before the first exchange
+                dist.all_gather_object(handles, mine, group=group)
+            else:
+                handles = [mine]
+            bad = [(r, h[1]) for r, h in enumerate(handles) if h[0] is None]
+            if not bad:
+                self.ptrs = (C.c_void_p * self.world)()
+                try:
+                    for r in range(self.world):
+                        if r == self.rank:
+                            self.ptrs[r] = self.own
+                        else:
+                            p = C.c_void_p()
+                            check(L.tipk_ipc_open(handles[r][0], C.byref(p)), 'tipk_ipc_open')
+                            self.ptrs[r] = p
+                            self.opened.append(p)
+                except Exception as exc:                                    # noqa: BLE001
+                    err = repr(exc)
+                oks = [None] * self.world
+                if self.world > 1:
+                    dist.all_gather_object(oks, err, group=group)           # (also: every mailbox is mapped everywhere
+                else:                                                       #  before the first exchange)
+                    oks = [err]
+                bad = [(r, e) for r, e in enumerate(oks) if e is not None]
+        if bad:
+            self.close()
+            raise RuntimeError('direct exchange unavailable: ' + '; '.join('rank %d: %s' % b for b in bad))
 
     def takes(self, flat):
         return (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and 0 < flat.numel() <= self.max_floats
@@ -170,7 +287,7 @@ class DirectExchange(object):
 
     def close(self):
         from ._lib import lib
-        if self.own is None and not self.opened:
+        if getattr(self, 'own', None) is None and not getattr(self, 'opened', None):
             return
         torch.cuda.synchronize(self.device)
         for p in self.opened:

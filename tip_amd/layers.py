@@ -559,6 +559,14 @@ class FMEncoder(nn.Module):
 
     def forward(self, x_drug, dd_edge_index, dd_edge_type, dd_range_list, d_norm,
                 x_prot, pp_edge_index, dp_edge_index, dp_range_list):
+        x0 = self.mixed_drug_features(x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list)
+        # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
+        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream')
+        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True)
+
+    def mixed_drug_features(self, x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list):
+        """The input of the D-D layers (src/layers.py:522-539): P-P GCN x2 -> P -> D mean -> dense map, drug embedding /
+        d_norm, cat | add.  (The part of the step a relation-sharded run repeats on every rank.)"""
         xd = self._drug_feat.apply_table(x_drug, self.embed)                          # x_drug @ embed
         # Only the proteins some P -> D edge starts at are ever read from the P-P encoder's output (BioSNAP: 3 640 of
         # 19 081; 294 k of its 1.29 M edges end there): conv2 aggregates -- and back-propagates through -- those rows only.
@@ -587,9 +595,7 @@ class FMEncoder(nn.Module):
                 self.hdrug = self.hdrug.to(h_prot.device)
             pd = self.hgcn(torch.cat((h_prot, self.hdrug)), dp_edge_index, dp_range_list)
             x0 = ops.drug_mix(xd, pd, d_norm, self.mod == 'cat')                      # /d_norm, cat|add
-        # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
-        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream')
-        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True)
+        return x0
 
 
 class FMEncoderCat(FMEncoder):
