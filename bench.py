@@ -67,7 +67,6 @@ def parse():
     ap.add_argument('--mod', default='cat', choices=['cat', 'add'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
-    ap.add_argument('--chunk', type=int, default=None, help='gather plan chunk (edges per work item)')
     ap.add_argument('--launch', default=None, choices=['graph', 'eager'],
                     help='graph: the step is captured once into a hipGraph and replayed (default); '
                          'eager: one ctypes launch per kernel')
@@ -300,8 +299,6 @@ def dd_launches(enc, dev):
                         edges=csr.n_edges, row_floats=d, aggregation=True)
                     continue
                 plan = graph.bwd if bwd else graph.fwd
-                if getattr(plan, 'block_width', 0):            # blockwise forward (TIPK_BLOCKWISE_Y): ~100 small launches, not timed alone
-                    continue
                 waves = -(-plan.items.shape[0] // (64 // lanes))
                 fn = (lambda plan=plan, g=g: ops.gather_sum(plan, g)) if bwd else (lambda plan=plan, y=y: ops.gather_sum(plan, y))
                 add('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), 'gather_sum_kernel<4, %d' % lanes,
@@ -699,8 +696,6 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from tip_amd import ops
-    if args.chunk:
-        os.environ['TIPK_CHUNK'] = str(args.chunk)
     launch = args.launch or ('eager' if shared else 'graph')
 
     dd, dims, wl_name = make_workload(args)

@@ -4,11 +4,16 @@ same final `torch.save(model, ...)`.  Differences: the import line, the device (
 default the epoch loop is replayed as one hipGraph (`--eager` runs the reference's loop line for line).
 Run from the repo root:
 
-    python examples/tip.py [cat|add] [epochs]
+    python examples/tip.py [cat|add] [epochs] [--eager] [--log=train_log.jsonl]
+
+The loss of every epoch is printed as the reference prints it (tip.py:28); `--log=FILE` ('-' = stdout) also writes one JSON
+object per epoch -- {"epoch", "loss", "ms_per_epoch", "train_edges_per_s"} -- and a final {"event": "test", "auprc", "auroc",
+"ap"} record (metrics / logging).
 
 If ./data/data_dict.pkl (written by the reference's prepare.py) exists it is used; otherwise the
 bundled BioSNAP graph is split with seed 1111.
 """
+import json
 import os
 import sys
 import time
@@ -21,6 +26,15 @@ from tip_amd.layers import Setting, TIP          # reference: `from src.layers i
 MOD = sys.argv[1] if len(sys.argv) > 1 else 'cat'
 MAX_EPOCH = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 GRAPH = '--eager' not in sys.argv      # default: the whole step replays as one hipGraph (tip_amd/train.py)
+LOG = next((a.split('=', 1)[1] for a in sys.argv if a.startswith('--log=')), None)
+log_f = None if LOG is None else (sys.stdout if LOG == '-' else open(LOG, 'w'))
+
+
+def log(**rec):
+    if log_f is not None:
+        log_f.write(json.dumps(rec) + '\n')
+        log_f.flush()
+
 
 device = torch.device('cuda:0')                  # no CPU path in this build
 
@@ -41,23 +55,36 @@ if GRAPH:
     from tip_amd.train import GraphedTrainStep
     model.train()
     step = GraphedTrainStep(model, optimizer, warmup=2)       # 2 eager epochs, then the captured graph
-    losses = [step() .clone() for e in range(MAX_EPOCH - 2)]
-    for v in torch.stack(losses).tolist():
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    losses = [step() .clone() for e in range(MAX_EPOCH - 2)]  # no host synchronisation inside the loop
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t1) / max(1, MAX_EPOCH - 2)
+    for e, v in enumerate(torch.stack(losses).tolist()):
         print(v)
+        log(epoch=e + 2, loss=v, ms_per_epoch=per * 1e3, train_edges_per_s=model.data.dd_train_idx.shape[1] / per)
 else:
     for e in range(MAX_EPOCH):                                # the reference's loop, line for line
+        te = time.perf_counter()
         model.train()
         optimizer.zero_grad()
         loss = model()
         print(loss.item())
         loss.backward()
         optimizer.step()
+        if log_f is not None:
+            torch.cuda.synchronize()
+            per = time.perf_counter() - te
+            log(epoch=e, loss=loss.item(), ms_per_epoch=per * 1e3, train_edges_per_s=model.data.dd_train_idx.shape[1] / per)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print('%d epochs in %.2f s (%.1f ms/epoch, %.2f M train edges/s incl. sampler, decoder, loss, Adam)'
       % (MAX_EPOCH, dt, dt / MAX_EPOCH * 1e3, model.data.dd_train_idx.shape[1] * MAX_EPOCH / dt / 1e6))
 
-model.test()
+record = model.test()
+if record is not None:
+    auprc, auroc, ap = (float(v) for v in record.sum(axis=1) / record.shape[1])
+    log(event='test', auprc=auprc, auroc=auroc, ap=ap, relations=int(record.shape[1]))
 
 os.makedirs('saved_model', exist_ok=True)
 torch.save(model, f'saved_model/tip-{model.mod}-example.pt')      # whole model, as tip.py:36 (load: weights_only=False)

@@ -246,13 +246,9 @@ def test_encoder_other_dimensions_vs_oracle(dims):
         close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
 
 
-@pytest.mark.parametrize('blockwise', [False, True])
-def test_synthetic_encoder_large_node_set_vs_oracle(blockwise, monkeypatch):
+def test_synthetic_encoder_large_node_set_vs_oracle():
     """More drugs than the LDS-resident kernel takes (N > 1024): the fabric-gather path, its finalize
-    launch, dy_products with hundreds of column chunks -- the route BASELINE config 5 takes -- vs the oracle.
-    blockwise: the opt-in forward pass that produces Y per block of source nodes (TIPK_BLOCKWISE_Y = block bytes)."""
-    if blockwise:
-        monkeypatch.setenv('TIPK_BLOCKWISE_Y', '400000')
+    launch, dy_products with hundreds of column chunks -- the route BASELINE config 5 takes -- vs the oracle."""
     from tip_amd.data import synthetic_data_dict, Data
     from tip_amd.layers import FMEncoder
     from tip_amd import ops
@@ -275,7 +271,6 @@ def test_synthetic_encoder_large_node_set_vs_oracle(blockwise, monkeypatch):
     close(z, zo, rtol=1e-3)
     for k, prm in enc.named_parameters():
         close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
-    assert bool(enc.rgcn1._cache.value.fwd.block_width) == blockwise
 
 
 @pytest.fixture(scope='module')

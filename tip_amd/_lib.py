@@ -115,8 +115,6 @@ _lib = None
 
 # environment switch -> library option (translated ONCE, when the library is loaded; the library
 # itself never reads the environment).  Tests and tools flip options with `set_option`.
-_ENV_OPTIONS = {'TIPK_NO_STREAM_GEMM': 'gemm_no_stream', 'TIPK_THIN_K_NARROW': 'gemm_thin_k_narrow',
-                'TIPK_STREAM_KK': 'gemm_stream_kk', 'TIPK_RG_OCC': 'rg_occupancy', 'TIPK_DM_TASK_KERNEL': 'dm_task_kernel'}
 
 
 def source_digest():
@@ -194,13 +192,6 @@ def lib():
         fn.argtypes = args
     if handle.tipk_abi_version() != ABI_VERSION:
         raise TipkError('libtipk.so ABI %d != binding ABI %d: rebuild' % (handle.tipk_abi_version(), ABI_VERSION))
-    for env, opt in _ENV_OPTIONS.items():
-        if os.environ.get(env):
-            try:
-                val = int(os.environ[env])
-            except ValueError:                         # `=yes`, `=on`: the switch is present -> 1
-                val = 1
-            handle.tipk_set_option(opt.encode(), val)
     _lib = handle
     return _lib
 

@@ -23,7 +23,7 @@ from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
 from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
-                   relations_per_segment, source_block_width, DEFAULT_CHUNK)
+                   relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
 EPS = 1e-13                    # src/layers.py:15
@@ -160,26 +160,6 @@ def gcn_norm_graph(edge_index, num_nodes, chunk=DEFAULT_CHUNK, d=None, rows=None
         n_s = int(rows.numel())
         return ops.AggGraph(build_gather_plan(col_s, row_s, n_s, num_nodes, w_s, chunk, 'pp.fwd.rows', G),
                             build_gather_plan(row_s, col_s, num_nodes, n_s, w_s, chunk, 'pp.bwd.rows', G))
-    # TIPK_PP_STREAM=1 (round 3, measured SLOWER, kept as a switch): the normalised adjacency is a row scaling on either
-    # side of the PLAIN sum over (A + I), so when a 2-column (or wider) block of the table fits in LDS -- 19 081 proteins:
-    # 152 KB of 8-byte rows -- both passes can run as wave streams out of LDS (`ops.stream_gather`, include/tipk.h section
-    # 1d) instead of through the L2 gather path.  The gather itself is then cheap, but every workgroup has to stage its
-    # 2 columns of ALL rows: 8 bytes out of every 128-byte row, i.e. the whole 2.4 MB table crosses each CU's 64 B/clk
-    # L1 path -- 36 us per launch against 19 for `gather_sum` (0.434 vs 0.384 ms per step).
-    split = 0
-    if d and row.is_cuda and num_nodes <= 65535 and os.environ.get('TIPK_PP_STREAM'):
-        split = ops.stream_gather_split(num_nodes, d, max_split=16)
-    if split:
-        n_cu = torch.cuda.get_device_properties(row.device).multi_processor_count
-        n_wg = max(1, n_cu // split)
-        dc = d // split
-        lanes, row_bytes = (max(1, dc // 4), dc * 4)
-        graph = ops.AggGraph(lambda: build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd', G),
-                             lambda: build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd', G))
-        graph.pp_stream = ops.PPStream(build_stream_plan_rows(col, row, num_nodes, num_nodes, n_wg, lanes, row_bytes=row_bytes),
-                                       build_stream_plan_rows(row, col, num_nodes, num_nodes, n_wg, lanes, row_bytes=row_bytes),
-                                       dis.contiguous(), d)
-        return graph
     return ops.AggGraph(build_gather_plan(col, row, num_nodes, num_nodes, w, chunk, 'pp.fwd', G),
                         build_gather_plan(row, col, num_nodes, num_nodes, w, chunk, 'pp.bwd', G))
 
@@ -405,8 +385,6 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         split_b = ops.rel_gather_split(n_nodes, d_out, True) if on_dev else 0
         lanes_f = (d_out // split_f) // 4 if split_f else None
         lanes_b = (d_out // split_b) // 4 if split_b else None
-        if os.environ.get('TIPK_RG_PLAIN_ORDER'):
-            lanes_f = lanes_b = None
         cap_f = None           # (cutting forward units to the id chunk was measured slower: smaller units fill fewer bands)
         rl_fwd = lambda: build_rel_plan(dst, src, rel, n_nodes, n_rel, wg_f, lanes=lanes_f, unit_cap=cap_f)
         # forward pass in pair form: cells (source, destination) <- sums of att rows (LDS-resident att table)
@@ -416,8 +394,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             # with u <= v only, from half the edges; the product reads the mirrored ones at their transposed place
             k_fw = torch.sort((rel * n_nodes + src) * n_nodes + dst).values
             k_bw = torch.sort((rel * n_nodes + dst) * n_nodes + src).values
-            symmetric = bool(torch.equal(k_fw, k_bw)) and bool(ops.lib().tipk_pair_product_supported(n_bases, d_out)) \
-                and not os.environ.get('TIPK_NO_PAIR_SYMMETRY')
+            symmetric = bool(torch.equal(k_fw, k_bw)) and bool(ops.lib().tipk_pair_product_supported(n_bases, d_out))
             keep = src <= dst if symmetric else torch.ones_like(src, dtype=torch.bool)
             pair_fwd = build_stream_plan_rows(src[keep] * n_nodes + dst[keep], rel[keep], n_nodes * n_nodes, n_rel, n_cu,
                                               (n_bases // split_p) // 4, ops.rel_stream_piece())
@@ -436,16 +413,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         # relation block, so that a row of Y gathered by several edges crosses the fabric once
         y_bytes = n_rel * n_nodes * (d_out or 0) * 4
         ordered = rel.numel() < 2 or bool((rel[1:] >= rel[:-1]).all())
-        bw = int(os.environ.get('TIPK_BLOCKWISE_Y', '0') or 0)            # 1 = default block budget, > 1 = the budget in bytes
-        if bw and y_bytes > 2 * (bw if bw > 1 else (96 << 20)):
-            # segments = blocks of SOURCE nodes; table rows are local to the block (relation * width + source - first):
-            # Y is produced block by block (all relations x the block's sources) and gathered out of the Infinity Cache
-            width = source_block_width(n_nodes, n_rel, d_out, bw if bw > 1 else (96 << 20))
-            plan = build_gather_plan_segmented(dst, rel * width + src % width, src // width, n_nodes, n_rel * width, chunk,
-                                               'dd.fwd', any_order=True)
-            plan.seg_rows, plan.block_width = n_rel * width, width
-            return plan
-        if y_bytes > (192 << 20) and ordered and not os.environ.get('TIPK_NO_SEGMENTS'):
+        if y_bytes > (192 << 20) and ordered:
             per = relations_per_segment(n_nodes, d_out)
             return build_gather_plan_segmented(dst, yrow, rel // per, n_nodes, n_rel * n_nodes, chunk, 'dd.fwd')
         return build_gather_plan(dst, yrow, n_nodes, n_rel * n_nodes, None, chunk, 'dd.fwd')

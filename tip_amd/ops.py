@@ -22,54 +22,6 @@ def _f32c(t):
 
 
 # ---------------------------------------------------------------------------------------------
-# fork / join: independent launches of one layer run on a second HIP stream
-# ---------------------------------------------------------------------------------------------
-# At BioSNAP scale most kernels are a few microseconds long, so a step is bound by the dependent
-# chain of ~60 launches (about 5 us each even inside a hipGraph), not by throughput.  Products that
-# nothing downstream waits for (parameter gradients d root, d att, d basis, d W; X root in the
-# forward pass) are therefore issued on a side stream: `fork()` makes the side stream wait for the
-# current one and switches to it, `join()` makes the current stream wait for the side stream.  Under
-# `torch.cuda.graph` capture this becomes a graph with parallel branches.
-# MEASURED (MI355X, ROCm 7.2, BioSNAP step): the branchy hipGraph replays in 0.77 ms against 0.67 ms
-# for the linear one, and eager mode pays the event record/wait on the host (1.8 ms vs 1.2 ms) --
-# cross-stream edges cost more than the ~5 us kernels they hide.  So this is OFF unless TIPK_OVERLAP=1.
-_SIDE = {}
-_OVERLAP = bool(os.environ.get('TIPK_OVERLAP'))
-
-
-class fork(object):
-    def __init__(self, device):
-        self.device = device
-        self.on = _OVERLAP and _TIMING is None
-
-    def __enter__(self):
-        if not self.on:
-            return self
-        main = torch.cuda.current_stream(self.device)
-        key = (self.device.index, main.cuda_stream)
-        side = _SIDE.get(key)
-        if side is None:
-            side = _SIDE[key] = torch.cuda.Stream(self.device)
-        side.wait_stream(main)
-        self.side = side
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
-
-
-def join(device):
-    """The current stream waits for everything forked from it (call before results are consumed)."""
-    main = torch.cuda.current_stream(device)
-    side = _SIDE.get((device.index, main.cuda_stream))
-    if side is not None and _OVERLAP:
-        main.wait_stream(side)
-
-
-# ---------------------------------------------------------------------------------------------
 # optional per-kernel timing (bench.py): HIP events recorded on the launch stream around one launch
 # ---------------------------------------------------------------------------------------------
 _TIMING = None          # None (off) or dict: label -> list of (start_event, end_event)
@@ -133,23 +85,6 @@ def gather_sum_finish(plan, partial, out, row_scale=None, bias=None, relu=False)
         check(lib().tipk_gather_sum_finalize(ptr(partial), ptr(plan.split_rows), plan.split_rows.shape[0], ptr(out),
                                              out.stride(0), ptr(row_scale), ptr(bias), int(relu), d, plan.max_slots,
                                              stream_ptr(out.device)), 'tipk_gather_sum_finalize')
-
-
-def gather_sum_segment(plan, seg, table_block, out, partial, row_scale=None):
-    """The work items of segment `seg` of a blockwise plan over `table_block` [plan.seg_rows, d] (the plan's row ids are
-    local to the block).  Rows a single item completes are written to `out` (scaled), pieces to `partial`;
-    `gather_sum_finish` ends the pass."""
-    d = table_block.shape[1]
-    lo, hi = plan.seg_item_ptr[seg], plan.seg_item_ptr[seg + 1]
-    if hi == lo:
-        return
-    assert table_block.is_contiguous() and table_block.shape[0] == plan.seg_rows
-    import ctypes as C
-    items = C.c_void_p(plan.items.data_ptr() + lo * 16)
-    with _timed('gather_sum[%s.block,d=%d]' % (plan.tag, d)):
-        check(lib().tipk_gather_sum(ptr(table_block), d, plan.seg_rows, ptr(plan.row_id), None, items, hi - lo, ptr(out),
-                                    out.stride(0), ptr(partial), ptr(row_scale), None, 0, d, 0, stream_ptr(out.device)),
-              'tipk_gather_sum')
 
 
 def gather_rows_csr(plan, table):
@@ -232,7 +167,7 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
 def stream_gather_split(n_table, d, max_split=4):
     """column blocks `tipk_stream_gather` would use for a table [n_table, d]; 0 = it does not fit in LDS.
     max_split: 4 on the D-D passes, 16 for the P-P graph (2-column blocks of 8-byte rows)."""
-    if os.environ.get('TIPK_NO_RELSTREAM') or os.environ.get('TIPK_NO_RELLOCAL'):
+    if os.environ.get('TIPK_NO_RELLOCAL'):                 # (test hook: the generic fabric-gather route on a small graph)
         return 0
     return int(lib().tipk_stream_gather_supported(n_table, d, max_split))
 
@@ -361,10 +296,9 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
         slab_mode, n_slabs = 'q', z
     elif ksplit is None:
         # a workgroup's K loop is a chain of dependent ~1.5 us load round trips: small products are cut
-        # until a slab is one or two K tiles (knobs for sweeps: TIPK_KSPLIT_GRAIN / _WGS / _MAX)
-        grain = int(os.environ.get('TIPK_KSPLIT_GRAIN', '64'))
-        wgs = int(os.environ.get('TIPK_KSPLIT_WGS', '512'))
-        cap = int(os.environ.get('TIPK_KSPLIT_MAX', '320'))     # (K = 19 081: 299 slabs of two K tiles; 128 slabs made five-tile chains)
+        # until a slab is one or two K tiles (the three constants were swept in rounds 2 and 3: all at their optimum)
+        grain, wgs = 64, 512
+        cap = 320                                               # (K = 19 081: 299 slabs of two K tiles; 128 slabs made five-tile chains)
         # (ceil: K = 645 -> 11 slabs of 64 = two K tiles each; 10 slabs made the chunk 96 = three tiles, three slabs empty)
         want = min(-(-k // grain), -(-wgs // tiles))
         if plain and not reduce_batch and want >= 2 and tiles < 256:
@@ -460,8 +394,6 @@ def node_products_slabs(n_nodes, d, n_rel, nb):
     """d att slabs `node_products` produces for this shape; 0 = shape not supported (dense `dy_products` then)."""
     import ctypes as C
     g = C.c_int(0)
-    if os.environ.get('TIPK_NO_NODE_PRODUCTS'):
-        return 0
     check(lib().tipk_rgcn_node_products_plan(n_nodes, d, n_rel, nb, C.byref(g)), 'tipk_rgcn_node_products_plan')
     return g.value
 
@@ -923,17 +855,6 @@ def pair_product(cells, xb_nb, symmetric=False):
     return slabs
 
 
-class PPStream(object):
-    """Wave-stream plans of a GCN-normalised graph (tip_amd.layers.gcn_norm_graph): D^-1/2 (A + I) D^-1/2 X =
-    dis * sum_{(A + I)} (dis * X), both passes out of LDS (`stream_gather` with max_split = 16)."""
-
-    def __init__(self, fwd, bwd, dis, d):
-        self.fwd, self.bwd, self.dis, self.d = fwd, bwd, dis, int(d)
-
-    def usable(self, t):
-        return t.dim() == 2 and t.shape[1] == self.d and t.stride(1) == 1 and t.stride(0) % 2 == 0 and t.data_ptr() % 8 == 0
-
-
 class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
@@ -948,7 +869,6 @@ class AggGraph(object):
                                                            # that build them on first use (fallback routes only)
         self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
-        self.pp_stream = None                              # PPStream: GCN-normalised graphs whose table blocks fit in LDS
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
         self.fwd_route = {}                                # sharded layers: timed choice pair form | Y route (ops._fwd_route)
@@ -1020,13 +940,11 @@ class _Aggregate(torch.autograd.Function):
         g_pre = rows_affine(g, gate=out) if ctx.relu else g
         g_bias = None
         if ctx.has_bias:
-            with fork(g.device):
-                g_bias = col_sum(g_pre)
+            g_bias = col_sum(g_pre)
         g_agg = g_pre
         if graph.scale is not None and not graph.bwd_scaled:
             g_agg = rows_affine(g_pre, row_mul=graph.scale)
         g_table = gather_sum(graph.bwd, g_agg) if ctx.needs_input_grad[0] else None
-        join(g.device)
         return g_table, g_bias, None, None
 
 
@@ -1174,8 +1092,7 @@ class _RGCN(torch.autograd.Function):
         if pair is not None and pair.symmetric and not lib().tipk_pair_product_supported(nb, d_out):
             pair = None                                      # only the dedicated product kernel reads mirrored cells
         if pair is not None and not (pair.n_table == r and pair.n_rows == n * n and stream_gather_split(r, nb)
-                                     and (nb // stream_gather_split(r, nb)) // 4 == pair.lanes
-                                     and not os.environ.get('TIPK_NO_PAIR_FWD')):
+                                     and (nb // stream_gather_split(r, nb)) // 4 == pair.lanes):
             pair = None
         if pair is not None and shard is not None and shard.world > 1:
             # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (16 us at BioSNAP, whatever
@@ -1222,35 +1139,8 @@ class _RGCN(torch.autograd.Function):
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
         elif r > 0:
-            assert graph.fwd.n_out == n and graph.fwd.n_table == r * (graph.fwd.block_width or n), 'graph/plan mismatch'
+            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
-        blockwise = r > 0 and not use_rl and getattr(graph.fwd, 'block_width', 0) > 0
-        if blockwise:
-            # Y = att . XB is 10 GB at config-5 size.  Blockwise plans (TIPK_BLOCKWISE_Y=1) cut the SOURCE nodes into
-            # blocks: the rows of Y of one block (all relations x its sources) are produced into one buffer of about a
-            # third of the Infinity Cache and the block's work items gather them from there -- neither the write nor the
-            # reads of Y go to HBM, and the product of a block reads only the block's columns of XB.
-            plan = graph.fwd
-            width = plan.block_width
-            n_seg = len(plan.seg_item_ptr) - 1
-            agg = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
-            partial = torch.empty((plan.n_slots, d_out), dtype=torch.float32, device=x.device) if plan.n_slots else None
-            buf = torch.empty((r, width * d_out), dtype=torch.float32, device=x.device)
-            xb2 = xb.view(nb, n * d_out)
-            scale = None if shard is not None else graph.scale
-            for sgi in range(n_seg):
-                s0, s1 = sgi * width, min(n, (sgi + 1) * width)
-                gemm(att, xb2[:, s0 * d_out:s1 * d_out], out=buf[:, :(s1 - s0) * d_out])
-                gather_sum_segment(plan, sgi, buf.view(r * width, d_out), agg, partial, row_scale=scale)
-            gather_sum_finish(plan, partial, agg, row_scale=scale)
-            if shard is not None:
-                shard.all_reduce(agg)
-                out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
-            else:
-                out = sum_slabs(agg.view(1, n, d_out), addend=xroot, relu=bool(relu))
-            ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
-            ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
-            return out
         y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out) if r > 0 else None     # [R N, out]
         if shard is None:
             if use_rl:
@@ -1305,15 +1195,14 @@ class _RGCN(torch.autograd.Function):
             elif rs is not None and rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes:
                 # dY_r = A_r^T (D^-1 g), 1/deg fused.  Rows (relation, node) without edges -- half of them -- are
                 # neither written here nor read as data by the fused products (row mask)
-                masked = dy_products_fused(r, n * d_out, nb) and xb.stride(-1) == 1 and not os.environ.get('TIPK_DY_ZEROS')
+                masked = dy_products_fused(r, n * d_out, nb) and xb.stride(-1) == 1
                 g_y = rel_stream_bwd(rs, g, row_scale=graph.scale, write_zeros=not masked).view(r, n * d_out)
                 used = rs.row_used if masked else None
             elif rel_gather_usable(graph.rl_bwd, n, d_out, True):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
-                csr = graph.csr_bwd if (d_out % 4 == 0 and 8 <= d_out <= 256 and gs.numel() * 4 < 2 ** 32     # (32-bit row offsets)
-                                        and not os.environ.get('TIPK_NO_CSR')) else None
+                csr = graph.csr_bwd if (d_out % 4 == 0 and 8 <= d_out <= 256 and gs.numel() * 4 < 2 ** 32) else None   # (32-bit row offsets)
                 if csr is not None:                                      # R N short rows: contiguous streams, no descriptors
                     g_y = gather_rows_csr(csr, gs).view(r, n * d_out)
                 else:
@@ -1411,8 +1300,7 @@ class _DrugMixMM(torch.autograd.Function):
         n, ne = xd.shape
         pd_dim = weight.shape[1]
         p = weight.shape[0]
-        ctx.fused = (p <= 64 and pd_dim <= 64 and weight.is_contiguous() and d_norm.is_contiguous()
-                     and not os.environ.get('TIPK_NO_DRUG_MIX_KERNEL'))
+        ctx.fused = p <= 64 and pd_dim <= 64 and weight.is_contiguous() and d_norm.is_contiguous()
         if ctx.fused:                                                     # scaling, cat | add and the dense map: one launch
             out = torch.empty((n, ne + pd_dim if cat else ne), dtype=torch.float32, device=xd.device)
             check(lib().tipk_drug_mix_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(mean), mean.stride(0), ptr(weight), p, pd_dim,
@@ -1524,12 +1412,7 @@ class _GCNConv(torch.autograd.Function):
         else:
             x = _f32c(x)
             xl = gemm(x, weight.t())
-        ps = getattr(graph, 'pp_stream', None)
-        if ps is not None and ps.usable(xl):
-            out = stream_gather(ps.fwd, xl, row_scale=ps.dis, out_scale=ps.dis, bias=bias, relu=relu, max_split=16,
-                                label='pp_stream[fwd]')
-        else:
-            out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=relu)
+        out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=relu)
         ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
         ctx.save_for_backward(x, weight, out if relu else None)
         return out
@@ -1546,12 +1429,8 @@ class _GCNConv(torch.autograd.Function):
                 g_pre, bias_parts = fused
         if bias_parts is None:
             g_pre = rows_affine(g, gate=out) if ctx.relu else g
-        ps = getattr(graph, 'pp_stream', None)
-        if ps is not None and ps.usable(g_pre):
-            g_table = stream_gather(ps.bwd, g_pre, row_scale=ps.dis, out_scale=ps.dis, max_split=16, label='pp_stream[bwd]')
-        else:
-            g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
-            g_table = gather_sum(graph.bwd, g_agg)
+        g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
+        g_table = gather_sum(graph.bwd, g_agg)
         j_b = None
         if ctx.has_bias and bias_parts is None:
             j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre)

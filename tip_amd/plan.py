@@ -19,7 +19,6 @@ The reference re-derives everything from COO `edge_index` on every call (PyG `pr
 Everything here is index arithmetic in torch (runs on CPU or GPU; unit-tested on CPU).  The layout
 of `items` / `split_rows` is the contract of include/tipk.h section 1.
 """
-import os
 
 import torch
 
@@ -63,14 +62,12 @@ class GatherPlan(object):
         self.n_edges = int(row_id.numel())
         self.max_slots = int((split_rows[:, 2] - split_rows[:, 1]).max()) if split_rows.shape[0] else 0
         self.seg_item_ptr = None      # segment-major plans: item range of every segment (host list)
-        self.seg_rows = 0             # blockwise plans: rows of one block table (row ids are local to the block)
-        self.block_width = 0          # ... and the source nodes a block spans
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
         p = GatherPlan(self.n_out, self.n_table, mv(self.row_id), mv(self.edge_w), mv(self.items),
                        mv(self.split_rows), self.n_slots, mv(self.perm), self.chunk, self.tag, self.group_slots)
-        p.seg_item_ptr, p.seg_rows, p.block_width = self.seg_item_ptr, self.seg_rows, self.block_width
+        p.seg_item_ptr = self.seg_item_ptr
         return p
 
     @property
@@ -86,7 +83,7 @@ def group_slots_for(d):
     need = d // 4 if d % 4 == 0 else d
     while lanes < need:
         lanes *= 2
-    cap = int(os.environ.get('TIPK_GROUP_SLOTS', '128'))               # sweep knob (power of two)
+    cap = 128                                                          # (swept in round 2)
     return max(min(cap, 1024 // lanes), 64 // lanes)
 
 
@@ -127,7 +124,7 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     dev = out_row.device
     E = int(out_row.numel())
     if chunk is None:
-        chunk = int(os.environ.get('TIPK_CHUNK', '0')) or auto_chunk(E)      # env override for sweeps
+        chunk = auto_chunk(E)
     if E >= 2 ** 31 - 1 or n_out >= 2 ** 31 - 1 or n_table >= 2 ** 31 - 1:
         raise ValueError('graph too large for int32 plans')
     if E:
@@ -199,7 +196,7 @@ def build_gather_plan(out_row, table_row, n_out, n_table, edge_w=None, chunk=DEF
     return GatherPlan(n_out, n_table, row_id, w, items, split_rows, n_slots, order, chunk, tag)
 
 
-def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chunk=DEFAULT_CHUNK, tag='', any_order=False):
+def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chunk=DEFAULT_CHUNK, tag=''):
     """`build_gather_plan` for tables far larger than the caches (a D-D forward pass over
     Y = [R N, d] on a big graph: 10 GB in BASELINE config 5), where the ORDER in which the work items
     run decides the HBM traffic.
@@ -218,7 +215,7 @@ def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chu
     dev = out_row.device
     E = int(out_row.numel())
     if chunk is None:
-        chunk = int(os.environ.get('TIPK_CHUNK', '0')) or auto_chunk(E)
+        chunk = auto_chunk(E)
     if E >= 2 ** 31 - 1 or n_out >= 2 ** 31 - 1 or n_table >= 2 ** 31 - 1:
         raise ValueError('graph too large for int32 plans')
     if E:
@@ -231,10 +228,7 @@ def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chu
     order = torch.sort(out_row, stable=True).indices
     key = out_row[order] * n_seg + segment[order]
     if E and bool((key[1:] < key[:-1]).any()):
-        if not any_order:
-            raise ValueError('segment ids must be non-decreasing inside every output row (edges grouped by relation)')
-        order = torch.sort(out_row * n_seg + segment, stable=True).indices      # (row, segment) groups, edge order inside
-        key = out_row[order] * n_seg + segment[order]
+        raise ValueError('segment ids must be non-decreasing inside every output row (edges grouped by relation)')
     gkey, gcount = torch.unique_consecutive(key, return_counts=True)
     grow = gkey // n_seg
     # rows without edges still get one (empty, direct) item so that the kernel writes their zeros
@@ -282,12 +276,6 @@ def build_gather_plan_segmented(out_row, table_row, segment, n_out, n_table, chu
     per_seg = torch.bincount(gseg[item_grp], minlength=n_seg)
     plan.seg_item_ptr = [0] + torch.cumsum(per_seg, 0).tolist()
     return plan
-
-
-def source_block_width(n_nodes, n_rel, d, budget_bytes=96 << 20):
-    """Source nodes per block of the BLOCKWISE forward pass of a large D-D graph: the block's rows of Y (all relations
-    x these sources x d floats) take about `budget_bytes` of the 256 MB Infinity Cache."""
-    return max(1, min(int(n_nodes), int(budget_bytes // max(1, n_rel * d * 4))))
 
 
 class CsrPlan(object):
@@ -483,7 +471,7 @@ def build_rel_plan(out_node, tab_node, rel, n_nodes, n_rel, n_wg=256, fixed_cost
         # measured on BioSNAP (tools/bench_relgather.py): forward units re-stage the relation's table, so
         # only relations above ~1.2x the per-workgroup average are cut; backward units are cheap (0.55x)
         mean_load = int(size_r.sum()) // max(n_wg, 1)
-        max_unit = int(os.environ.get('TIPK_RG_MAX_UNIT', '0')) or max(4096, int(mean_load * (0.55 if backward else 1.2)))
+        max_unit = max(4096, int(mean_load * (0.55 if backward else 1.2)))
         if unit_cap:                               # ids the kernel stages per pass: a larger unit reloads synchronously
             max_unit = min(max_unit, int(unit_cap))
     k_r = torch.clamp((size_r + max_unit - 1) // max_unit, min=1, max=max(N, 1))          # units per relation
@@ -603,7 +591,7 @@ def build_stream_plan_rows(out_row, tab_row, n_rows, n_table, n_wg, lanes, piece
     T, S, W = int(n_table), 64 // int(lanes), int(n_wg) * 16
     assert T <= 65535 and n_rows < 2 ** 24, 'cells hold the output row in 24 bits, ids are 16-bit'
     if wide_steps is None:
-        wide_steps = int(os.environ.get('TIPK_RS_WIDE_STEPS', '0')) or STREAM_WIDE_STEPS
+        wide_steps = STREAM_WIDE_STEPS
     E = int(out_row.numel())
     cnt_rows = torch.bincount(out_row, minlength=n_rows)
     zero_rows = torch.nonzero(cnt_rows == 0).flatten()

@@ -27,14 +27,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--epochs', type=int, default=100)
     ap.add_argument('--relations', type=int, default=None)
+    ap.add_argument('--min-pairs', type=int, default=None, help='500 = the 963 relations of the published runs')
     ap.add_argument('--mod', default='cat')
     ap.add_argument('--threads', type=int, default=16)
     ap.add_argument('--tag', default=None)
     args = ap.parse_args()
-    dd = build_data_dict(max_relations=args.relations)
+    dd = build_data_dict(max_relations=args.relations, min_pairs=args.min_pairs)
     res = run_parity(dd, args.mod, args.epochs, threads=args.threads, log=lambda s: print(s, flush=True))
     out = {k: v for k, v in res.items() if k not in ('snapshots', 'rec_hip', 'rec_oracle', 'loss')}
     out['loss_first'], out['loss_last'] = res['loss'][0], res['loss'][-1]
+    out['reference_published'] = {'auprc': 0.948, 'where': 'analysis/evaluation.ipynb:192-195 (R = 963, 100 epochs, model/*.py scripts)'}
     print(json.dumps(out))
     if args.tag:
         os.makedirs('profiles', exist_ok=True)
