@@ -74,6 +74,7 @@ def parse():
                     help='allow more ranks than GPUs (ranks share devices, gloo collectives): functional check only')
     ap.add_argument('--no-kernel-table', action='store_true', help='skip the eager per-kernel event pass')
     ap.add_argument('--no-extras', action='store_true', help='skip other_configs / train_step')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 --pmc child passes (HBM traffic of this run)')
     ap.add_argument('--step-only', action='store_true',
                     help='run nothing but the warm-up and timed steps (PMC passes: bytes / (steps + warmup) = bytes per step)')
     return ap.parse_args()
@@ -250,13 +251,14 @@ def dd_launches(enc, dev):
                 split = ops.stream_gather_split(r, nb)
                 key = 'stream_gather_kernel<%d, %s, 1' % (nb // split // 4, 'true' if pair.idx_unit == nb // split * 4 else 'false')
                 att = torch.randn(r, nb, device=dev)
-                cells, xb_nb = graph.pair_buffers(n, nb, d, dev)
+                cells, xb_nb, _zeros = graph.pair_buffers(n, nb, d, dev)
                 add('pair_cells[dd.fwd,d=%d]' % d, key, '%dx%dx1' % (pair.n_wg * 1024, split), 'lds', pair.n_edges * (4 + 4 * nb),
                     lambda pair=pair, att=att, cells=cells, nb=nb, n=n: ops.stream_gather(
                         pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1),
                     edges=pair.n_edges, row_floats=nb, aggregation=True)
                 add('pair_product[dd.fwd,d=%d]' % d, 'pair_product_kernel', None, 'mfma', 2.0 * n * n * nb * d,
-                    lambda cells=cells, xb_nb=xb_nb, pair=pair: ops.pair_product(cells, xb_nb, symmetric=pair.symmetric),
+                    lambda cells=cells, xb_nb=xb_nb, pair=pair, z=_zeros: ops.pair_product(cells, xb_nb, symmetric=pair.symmetric,
+                                                                                           live=pair.live, zeros=z),
                     hbm_bytes=cells.numel() * 4.0 / (2 if pair.symmetric else 1))
             elif rs is not None and ops.rel_stream_split(n, d):
                 split = ops.rel_stream_split(n, d)
@@ -338,6 +340,71 @@ def time_launch_us(fn, reps=20, replays=5):
     return a.elapsed_time(b) * 1e3 / (reps * replays)
 
 
+_LIVE_PMC = None          # {'kernels': {name + grid: hbm bytes per launch}, 'step_hbm_bytes': ..} measured by THIS run (below)
+
+
+def measure_pmc_in_run(args):
+    """HBM traffic of the step's kernels measured BY THIS RUN: two child processes under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots) run `bench.py --step-only
+    --launch eager` for a few steps before this process touches the GPU; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per
+    launch (gfx950: FETCH_SIZE counts half of a wide read), keyed by kernel name and full grid.  Any failure -> None (the
+    committed summaries of the same build id are looked up instead)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None
+    csv.field_size_limit(1 << 30)
+
+    def short(name):
+        name = re.sub(r'\(anonymous namespace\)::', '', name)
+        name = re.sub(r'^void ', '', name)
+        m = re.match(r'([A-Za-z0-9_:]+(<[^(]*>)?)\(', name)
+        return (m.group(1) if m else name)[:110]
+    tmp = tempfile.mkdtemp(prefix='tipk_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', TIPK_BENCH_CHILD='1')
+    steps, warm = 3, 1
+    try:
+        per = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', 'python3',
+                   os.path.join(ROOT, 'bench.py'), '--steps', str(steps), '--warmup', str(warm), '--launch', 'eager', '--step-only',
+                   '--no-cpu-baseline', '--workload', args.workload, '--mod', args.mod]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return None
+            fn = sorted(glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True))
+            tr = sorted(glob.glob(os.path.join(out, '**', '*kernel_trace.csv'), recursive=True))
+            if not fn or not tr:
+                return None
+            shape = {row['Dispatch_Id']: '%sx%sx%s' % (row['Grid_Size_X'], row['Grid_Size_Y'], row['Grid_Size_Z'])
+                     for row in csv.DictReader(open(tr[0]))}
+            acc = defaultdict(list)
+            for row in csv.DictReader(open(fn[0])):
+                if row['Counter_Name'] == counter:
+                    acc['%s grid=%s' % (short(row['Kernel_Name']), shape.get(row['Dispatch_Id'], '?'))].append(float(row['Counter_Value']))
+            for k, v in acc.items():
+                per.setdefault(k, {})[counter] = (sum(v) / len(v), len(v))
+        kernels, total = {}, 0.0
+        for k, d in per.items():
+            f_kb, n_f = d.get('FETCH_SIZE', (0.0, 0))
+            w_kb, n_w = d.get('WRITE_SIZE', (0.0, 0))
+            kernels[k] = (2.0 * f_kb + w_kb) * 1024.0
+            if not (k.startswith('at::') or k.startswith('rocprim') or 'elementwise' in k or k.startswith('__amd_rocclr')):
+                total += kernels[k] * max(n_f, n_w)
+        return {'kernels': kernels, 'step_hbm_bytes': total / (steps + warm)}
+    except Exception:                                                      # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic(key_prefix, grid, build_id):
     """(HBM bytes per launch, trace us, source file) of a kernel from the newest committed summaries
     (profiles/*_pmc_traffic.json / *_kernel_by_grid.csv: separate rocprofv3 --pmc FETCH_SIZE /
@@ -351,6 +418,10 @@ def pmc_traffic(key_prefix, grid, build_id):
 
     def match(name):
         return name.startswith(key_prefix) and (grid is None or name.endswith('grid=' + grid))
+    if _LIVE_PMC is not None:
+        hits = [b for name, b in _LIVE_PMC['kernels'].items() if match(name)]
+        if hits:                                       # (the toy graph of `init_s` launches the same kernels on a small grid)
+            return max(hits), None, 'this run'
     try:
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
             doc = json.load(open(fn))
@@ -377,6 +448,8 @@ def step_hbm_bytes(build_id):
     """(HBM bytes of ONE step, file) from the newest committed PMC summary of THIS build that has the total
     (tools/summarize_prof.py: all libtipk launches of `bench.py --step-only` / (steps + warmup))."""
     import glob
+    if _LIVE_PMC is not None and _LIVE_PMC.get('step_hbm_bytes'):
+        return float(_LIVE_PMC['step_hbm_bytes']), 'this run'
     try:
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
             doc = json.load(open(fn))
@@ -416,7 +489,8 @@ def roofline_of(rec, us, build_id):
     roof['traffic'] = traffic
     if traffic is not None:
         roof['hbm_traffic_frac'] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
-        roof['traffic_source'] = 'profiles/' + src + ' (same build id)'
+        roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (child processes, eager launches)'
+                                  if src == 'this run' else 'profiles/' + src + ' (same build id)')
     if trace_us is not None:
         roof['rocprof_trace_us'] = trace_us
     return roof
@@ -659,6 +733,10 @@ def main():
     if 'RANK' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))               # children first: this process never touches the GPU
 
+    global _LIVE_PMC
+    if (int(os.environ.get('WORLD_SIZE', '1')) == 1 and not args.step_only and not args.no_pmc and not os.environ.get('TIPK_BENCH_CHILD')
+            and not os.environ.get('TIPK_FORCE_SHARD') and args.workload.startswith('biosnap')):
+        _LIVE_PMC = measure_pmc_in_run(args)       # child processes: before this one touches the GPU
     import torch
     from tip_amd import _lib
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -855,7 +933,7 @@ def main():
             hb = step_hbm_bytes(bid)
             if hb is not None:
                 out['step_hbm'] = {'bytes_measured': hb[0], 'frac_of_8TBps': hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   'source': 'profiles/' + hb[1] + ' (same build id)'}
+                                   'source': 'rocprofv3 --pmc passes of this run' if hb[1] == 'this run' else 'profiles/' + hb[1] + ' (same build id)'}
         if kern:
             out['kernels_eager_ms'] = {
                 'note': 'one HIP event pair per EAGER launch: includes ~5-8 us of event/launch overhead each; '

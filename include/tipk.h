@@ -290,10 +290,13 @@ int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, in
  *     (`tipk_pair_product_supported`; otherwise tipk_gemm_f32 with kbatch = group does the same sums).
  *     symmetric != 0: every relation links u -> v iff it links v -> u (BioSNAP), so cells[u][v] == cells[v][u]
  *     and the gather only built the cells with u <= v (half the edges); cell (u, v) with v < u is read at (v, u).
+ *     live (nullable): uint8 [n_src / group][ceil(n_dst / 32)], bit q = "some pair (group's node q, one of the tile's 32
+ *     destinations) is linked": tiles without a link are not fetched (their cells are zeros by construction; `zeros` =
+ *     >= 64 bytes of zeros, 16-byte aligned, read in their place).
  */
 int tipk_pair_product_supported(int n_bases, int d);
 int tipk_pair_product(const float* cells, const float* xb, int64_t n_src, int64_t n_dst, int n_bases, int d,
-                      int group, int symmetric, float* slabs, tipk_stream_t stream);
+                      int group, int symmetric, const uint8_t* live, const float* zeros, float* slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2b. Both consumers of dY (the gradient of Y = att . XB, src/layers.py:163-172 under autograd) in

@@ -63,7 +63,7 @@ SIGNATURES = {
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
     'tipk_pair_product_supported': (_I, [_I, _I]),
-    'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P]),
+    'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
     'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),

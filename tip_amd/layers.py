@@ -399,6 +399,13 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             pair_fwd = build_stream_plan_rows(src[keep] * n_nodes + dst[keep], rel[keep], n_nodes * n_nodes, n_rel, n_cu,
                                               (n_bases // split_p) // 4, ops.rel_stream_piece())
             pair_fwd.symmetric = symmetric
+            # which (32 destinations, source node) tiles of the cell matrix hold a linked pair: the product does not fetch
+            # the others (uint8 [sources / 8][ceil(N / 32)], bit q = node 8 g + q; tipk.h section 2c `live`)
+            n8, n32 = -(-n_nodes // 8) * 8, -(-n_nodes // 32) * 32
+            link = torch.zeros((n8, n32), dtype=torch.bool, device=src.device)
+            link[src, dst] = True
+            tiles = link.view(n8 // 8, 8, n32 // 32, 32).any(-1)                        # [groups, 8, tiles]
+            pair_fwd.live = (tiles.long() << torch.arange(8, device=src.device).view(1, 8, 1)).sum(1).to(torch.uint8).contiguous()
         # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
         split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
         if split_s:

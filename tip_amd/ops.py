@@ -834,7 +834,7 @@ PAIR_FWD_MAX_WORLD = 4   # fallback rule when the forward routes cannot be timed
 PAIR_KGROUP = 8          # source nodes whose products are summed inside one wavefront of the pair-form product
 
 
-def pair_product(cells, xb_nb, symmetric=False):
+def pair_product(cells, xb_nb, symmetric=False, live=None, zeros=None):
     """slabs[g] = sum_{u in group g} cells[u] (N x bases) @ xb_nb[u] (bases x out)  (include/tipk.h section 2c):
     cells [N_pad, N, bases], xb_nb [N_pad, bases, out] -- or a column slice [..., :out] of a buffer whose rows are
     padded to 32 columns with zeros (what the dedicated kernel reads) -> [N_pad / PAIR_KGROUP, N, out]."""
@@ -850,8 +850,8 @@ def pair_product(cells, xb_nb, symmetric=False):
     assert padded, 'tipk_pair_product reads XB rows padded to 32 columns (AggGraph.pair_buffers)'
     slabs = torch.empty((n_pad // PAIR_KGROUP, n, d), dtype=torch.float32, device=cells.device)
     with _timed('pair_product[%dx%dx%dx%d]' % (n_pad, n, nb, d)):
-        check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(slabs),
-                                      stream_ptr(cells.device)), 'tipk_pair_product')
+        check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(live), ptr(zeros),
+                                      ptr(slabs), stream_ptr(cells.device)), 'tipk_pair_product')
     return slabs
 
 
@@ -907,8 +907,10 @@ class AggGraph(object):
         if buf is None:
             n_pad = -(-n // PAIR_KGROUP) * PAIR_KGROUP
             xb_pad = torch.zeros((n_pad, nb, 32 if d_out <= 32 else d_out), dtype=torch.float32, device=device)
-            buf = self._pair_cells[key] = (torch.zeros((n_pad, n, nb), dtype=torch.float32, device=device),
-                                           xb_pad[:, :, :d_out])           # rows padded to 32 columns: the product kernel's layout
+            flat = torch.zeros(n_pad * n * nb + 64, dtype=torch.float32, device=device)     # (+ a block of zeros behind the cells)
+            buf = self._pair_cells[key] = (flat[:n_pad * n * nb].view(n_pad, n, nb),
+                                           xb_pad[:, :, :d_out],           # rows padded to 32 columns: the product kernel's layout
+                                           flat[n_pad * n * nb:])
         return buf
 
     @property
@@ -1034,7 +1036,7 @@ def _fwd_route(graph, x, basis, att, pair, shard):
     if mode != 'timed' or torch.cuda.is_current_stream_capturing() or _TIMING is not None:
         return rule
     with torch.no_grad():
-        cells, xb_nb = graph.pair_buffers(n, nb, d_out, x.device)
+        cells, xb_nb, _ = graph.pair_buffers(n, nb, d_out, x.device)
         xb = gemm(x, basis)
         gemm(x, basis, out=xb_nb[:n].permute(1, 0, 2))
 
@@ -1109,7 +1111,7 @@ class _RGCN(torch.autograd.Function):
             # cells are kept SOURCE-major, C[u, v, :]: the product  sum_u C[u] (N x bases) . XB[u] (bases x out)  then reads
             # 16 KB contiguous per operand tile (destination-major cells made every tile 128 separate 128-byte rows:
             # 2.5 TB/s); the u range is padded to a multiple of PAIR_KGROUP with cells / XB rows that stay zero
-            cells, xb_nb = graph.pair_buffers(n, nb, d_out, x.device)
+            cells, xb_nb, zeros = graph.pair_buffers(n, nb, d_out, x.device)
             rs = graph.rs_bwd
             if rs is not None and rs.compact is not None and any(ctx.needs_input_grad[:3]):
                 # XB is computed ONCE, into the node-major buffer the pair product reads; the backward pass
@@ -1124,7 +1126,7 @@ class _RGCN(torch.autograd.Function):
                 xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
                 ctx.xb_stamp = None
             stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
-            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric)
+            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, live=getattr(pair, 'live', None), zeros=zeros)
             if shard is None:
                 out = sum_slabs(slabs.view(-1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
             else:

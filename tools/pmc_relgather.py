@@ -19,7 +19,7 @@ for rec in bench.dd_launches(enc, dev):
 n, nb = 645, 32
 for layer in (enc.rgcn1, enc.rgcn2):
     graph = layer._cache.value
-    cells, xb_nb = graph.pair_buffers(n, layer.num_bases, layer.out_channels, dev)
+    cells, xb_nb, _zeros = graph.pair_buffers(n, layer.num_bases, layer.out_channels, dev)
     for _ in range(3):
-        ops.pair_product(cells, xb_nb, symmetric=graph.pair_fwd.symmetric)
+        ops.pair_product(cells, xb_nb, symmetric=graph.pair_fwd.symmetric, live=graph.pair_fwd.live, zeros=_zeros)
 torch.cuda.synchronize()
