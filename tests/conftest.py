@@ -30,6 +30,22 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def start_ranks(procs):
+    """Start spawned rank processes with ONE host thread each, as torch.distributed.run sets it: `world` OpenMP pools
+    spinning on the test box's few cores made build_data_dict alone take 144 s in a 4-rank test (2 s in a process of
+    its own)."""
+    omp = os.environ.get('OMP_NUM_THREADS')
+    os.environ['OMP_NUM_THREADS'] = '1'
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        if omp is None:
+            del os.environ['OMP_NUM_THREADS']
+        else:
+            os.environ['OMP_NUM_THREADS'] = omp
+
+
 def load_golden(name, dtype=None):
     """tests/golden/<name>.npz as a dict of torch tensors (floats optionally cast)."""
     z = np.load(os.path.join(GOLDEN, name + '.npz'))

@@ -167,8 +167,8 @@ def test_sharded_rgcn_and_objective_equal_unsharded_world2():
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
-    for p in procs:
-        p.start()
+    from conftest import start_ranks
+    start_ranks(procs)
     for p in procs:
         p.join(100)
         assert p.exitcode == 0

@@ -95,8 +95,8 @@ def test_direct_exchange_ranks_sharing_one_gpu(world):
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
-    for p in procs:
-        p.start()
+    from conftest import start_ranks
+    start_ranks(procs)
     for p in procs:
         p.join(240)
         if p.is_alive():                                                    # a hung exchange must not hang the suite
@@ -156,8 +156,8 @@ def test_direct_exchange_wait_is_bounded():
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, ret)) for r in range(2)]
-    for p in procs:
-        p.start()
+    from conftest import start_ranks
+    start_ranks(procs)
     for p in procs:
         p.join(200)
         if p.is_alive():

@@ -389,56 +389,91 @@ def _shard_worker(rank, world, port, ret, max_relations=12):
         from tip_amd.dist import make_shard, shard_state_dict, gather_state_dict, shard_edges, LOCAL_ROWS
         from tip_amd.layers import TIP, Setting
         from tip_amd.neg_sampling import typed_negative_sampling
+        import time
+        t_start = time.perf_counter()
+
+        def stamp(what):                                                   # TIPK_TEST_STAMPS=1 pytest -s: where a rank's time goes
+            if os.environ.get('TIPK_TEST_STAMPS'):
+                torch.cuda.synchronize()
+                print('[rank %d] %7.1f s  %s' % (rank, time.perf_counter() - t_start, what), flush=True)
         dd = build_data_dict(max_relations=max_relations)
         R = dd['n_dd_et']
         st = Setting()
         from tip_amd import neg_sampling as NS
-        torch.manual_seed(3)
-        NS.manual_seed(77)
-        ref = TIP(st, torch.device(DEV), data=dd)                          # unsharded
-        full_sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+        stamp('data dict')
+        # the UNSHARDED model runs on rank 0 only (8 ranks share one GPU: eight full-size references cost 9 minutes);
+        # what the other ranks compare against travels through the process group
+        ref_pack = [None]
+        if rank == 0:
+            torch.manual_seed(3)
+            NS.manual_seed(77)
+            ref = TIP(st, torch.device(DEV), data=dd)
+            stamp('reference model built')
+            full_sd = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
+            neg = typed_negative_sampling(ref.data.dd_train_idx, ref.data.n_drug, ref.data.dd_train_range, seed=5)
+            opt_r = torch.optim.Adam(ref.parameters(), lr=0.01)
+            steps_r = []
+            for step in range(2):
+                opt_r.zero_grad()
+                loss_r = ref(neg_index=neg)
+                loss_r.backward()
+                steps_r.append({'loss': float(loss_r), 'emb': ref.embeddings.detach().cpu().clone(),
+                                'grads': {k: p.grad.detach().cpu().clone() for k, p in ref.named_parameters()}})
+                opt_r.step()
+                stamp('reference step %d' % step)
+            ref_pack = [{'full_sd': full_sd, 'test_neg': ref.test_neg_index.cpu(), 'neg': neg.cpu(), 'steps': steps_r,
+                         'final_sd': {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()},
+                         'rec': ref.test(print_output=False)}]
+            stamp('reference test()')
+            del ref, opt_r
+            torch.cuda.empty_cache()
+        dist.broadcast_object_list(ref_pack, src=0)
+        stamp('reference results received')
+        rp = ref_pack[0]
+        full_sd, neg = rp['full_sd'], rp['neg'].to(DEV)
+        ref_test_neg = rp['test_neg'].to(DEV)
         shard = make_shard(dd['dd_train_range'], rank, world)
         assert 0 < shard.rel_ids.numel() < R
         NS.manual_seed(77)
         model = TIP(st, torch.device(DEV), data=dd, shard=shard)           # this rank's relations only
+        stamp('sharded model built')
         # the sampler's counters run over GLOBAL positions: a rank draws the unsharded run's negatives of its relations
-        assert torch.equal(model.test_neg_index, shard_edges(ref.test_neg_index, dd['dd_test_range'], shard.rel_ids)[0])
+        assert torch.equal(model.test_neg_index, shard_edges(ref_test_neg, dd['dd_test_range'], shard.rel_ids)[0])
         assert model.data.dd_train_idx.shape[1] == shard.n_train_local < shard.n_train_total
         assert model.decoder.weight.shape[0] == model.encoder.rgcn1.att.shape[0] == shard.rel_ids.numel()
         model.load_state_dict(shard_state_dict(full_sd, shard))
-        model.test_neg_index, _ = shard_edges(ref.test_neg_index, dd['dd_test_range'], shard.rel_ids)
-        neg = typed_negative_sampling(ref.data.dd_train_idx, ref.data.n_drug, ref.data.dd_train_range, seed=5)
+        model.test_neg_index, _ = shard_edges(ref_test_neg, dd['dd_test_range'], shard.rel_ids)
         neg_l, _ = shard_edges(neg, dd['dd_train_range'], shard.rel_ids)
-        opt_r = torch.optim.Adam(ref.parameters(), lr=0.01)
         opt_s = torch.optim.Adam(model.parameters(), lr=0.01)
         ok = True
         for step in range(2):
-            opt_r.zero_grad(); opt_s.zero_grad()
-            loss_r = ref(neg_index=neg)
-            loss_r.backward()
+            opt_s.zero_grad()
+            want_step = rp['steps'][step]
             loss_s = model(neg_index=neg_l.contiguous())
             loss_s.backward()
-            ok = ok and abs(float(loss_r) - float(loss_s)) <= 1e-5 * abs(float(loss_r))
-            ok = ok and torch.allclose(model.embeddings, ref.embeddings, rtol=1e-4, atol=1e-5)
-            gr = dict(ref.named_parameters())
+            ok = ok and abs(want_step['loss'] - float(loss_s)) <= 1e-5 * abs(want_step['loss'])
+            ok = ok and torch.allclose(model.embeddings.cpu(), want_step['emb'], rtol=1e-4, atol=1e-5)
             for k, p in model.named_parameters():
-                want = gr[k].grad
+                want = want_step['grads'][k]
                 if k in LOCAL_ROWS:
-                    want = want[shard.rel_ids_on(want.device)]
-                good = torch.allclose(p.grad, want, rtol=2e-3, atol=2e-5 * max(1e-6, float(want.abs().max())))
+                    want = want[shard.rel_ids.cpu()]
+                good = torch.allclose(p.grad.cpu(), want, rtol=2e-3, atol=2e-5 * max(1e-6, float(want.abs().max())))
                 if not good:
-                    print('rank', rank, 'step', step, 'grad mismatch', k, float((p.grad - want).abs().max()), flush=True)
+                    print('rank', rank, 'step', step, 'grad mismatch', k, float((p.grad.cpu() - want).abs().max()), flush=True)
                 ok = ok and good
-            opt_r.step(); opt_s.step()
+            opt_s.step()
+            stamp('sharded step %d' % step)
         # after two Adam steps: gathered full state == the unsharded model's state
         got = gather_state_dict(model, shard)
-        for k, v in ref.state_dict().items():
-            good = torch.allclose(got[k], v.cpu(), rtol=0, atol=2e-3)      # 20 % of one Adam step of 0.01
+        for k, v in rp['final_sd'].items():
+            good = torch.allclose(got[k], v, rtol=0, atol=2e-3)            # 20 % of one Adam step of 0.01
             if not good:
-                print('rank', rank, 'state mismatch', k, float((got[k] - v.cpu()).abs().max()), flush=True)
+                print('rank', rank, 'state mismatch', k, float((got[k] - v).abs().max()), flush=True)
             ok = ok and good
+        rec_r = rp['rec']
+        stamp('state gathered')
         rec_s = model.test(print_output=False)
-        rec_r = ref.test(print_output=False)
+        stamp('sharded test()')
         ok = ok and rec_s.shape == (3, R) and bool(np.allclose(rec_s, rec_r, atol=2e-4))
         ret[rank] = bool(ok)
     finally:
@@ -455,8 +490,8 @@ def _run_shard_workers(world, max_relations):
     ctx = mp.get_context('spawn')
     ret = ctx.Manager().dict()
     procs = [ctx.Process(target=_shard_worker, args=(r, world, port, ret, max_relations)) for r in range(world)]
-    for p in procs:
-        p.start()
+    from conftest import start_ranks
+    start_ranks(procs)
     for p in procs:
         p.join(800 if world <= 4 else 1400)
         assert p.exitcode == 0
@@ -471,10 +506,9 @@ def test_sharded_training_step_two_ranks():
 @pytest.mark.timeout(900)
 def test_config4_biosnap_sharded_over_four_ranks():
     """BASELINE config 4 (TIP-cat, relations sharded by relation id) over 4 ranks sharing the one GPU of the test box over
-    gloo, the first 400 relations (the FULL graph runs at the 8 ranks BASELINE names, below): every rank's loss,
-    embeddings, gradients (shard-local rows against the matching rows), the parameters after two Adam steps and the
-    gathered test() record equal the unsharded model's."""
-    _run_shard_workers(4, 400)
+    gloo, FULL size (all 1 097 relations): every rank's loss, embeddings, gradients (shard-local rows against the matching
+    rows), the parameters after two Adam steps and the gathered test() record equal the unsharded model's."""
+    _run_shard_workers(4, None)
 
 
 @pytest.mark.timeout(1500)

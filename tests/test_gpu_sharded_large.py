@@ -41,8 +41,8 @@ def _spawn(target, world, args, timeout):
     ret = ctx.Manager().dict()
     port = _free_port()
     procs = [ctx.Process(target=target, args=(r, world, port, ret) + tuple(args)) for r in range(world)]
-    for p in procs:
-        p.start()
+    from conftest import start_ranks
+    start_ranks(procs)
     for p in procs:
         p.join(timeout)
         assert p.exitcode == 0, 'rank process failed (exit code %r)' % p.exitcode
