@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 14
+#define TIPK_ABI_VERSION 15
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -277,6 +277,30 @@ typedef struct tipk_slab_sum_desc {
     float* out;
 } tipk_slab_sum_desc;
 int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, int32_t count, tipk_stream_t stream);
+
+/* Products whose reduction is split over the 16 waves of ONE workgroup, plus ordered slab sums that are ready at
+ * the same point, in ONE launch.  The backward pass of an R-GCN layer (autograd of src/layers.py:159-184) ends in
+ * d basis[b] = X^T dXB[b], d root = X^T g and dX = sum_b dXB[b] basis[b]^T + g root^T: few output tiles, reductions of
+ * 645 .. 1 056 terms.  A workgroup owns a 32 x 32 output tile, deals its K tiles (32 terms; the kbatch terms of p and the
+ * optional second product a2 . b2 are further tiles) to its waves in contiguous runs and adds the partial tiles in
+ * wave order (deterministic) -- no slabs, no second launch.
+ *   p:     as tipk_gemm_f32 (batch, kbatch, strides, c_in, alpha, relu); ksplit must be 1
+ *   a2/b2: nullable second product [m x k2] . [k2 x n] added to the same output (batch must be 1)
+ *   gate:  nullable, laid out like the output: out = gate > 0 ? value : 0
+ * Shapes: at most 128 K tiles in all, at most 4096 output tiles (TIPK_EUNSUPPORTED otherwise: tipk_gemm_f32_group). */
+typedef struct tipk_wg_gemm_desc {
+    tipk_gemm_desc p;
+    const float* a2; int64_t a2_sm, a2_sk;
+    const float* b2; int64_t b2_sk, b2_sn;
+    int64_t k2;
+    const float* gate; int64_t gate_sm, gate_sz;
+} tipk_wg_gemm_desc;
+#define TIPK_WG_GEMM_MAX 4
+#define TIPK_WG_SUMS_MAX 3
+int tipk_gemm_wg_group_supported(const tipk_wg_gemm_desc* desc /* host */);
+int tipk_gemm_wg_group(const tipk_wg_gemm_desc* descs /* host, [count <= TIPK_WG_GEMM_MAX] */, int32_t count,
+                       const tipk_slab_sum_desc* sums /* host, [n_sums <= TIPK_WG_SUMS_MAX], nullable */, int32_t n_sums,
+                       tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2c. The dense half of the pair-form D-D forward pass (src/layers.py:159-180; tip_amd/ops.py `_RGCN.forward`):

@@ -379,6 +379,52 @@ def test_gemm_group_bit_identical_to_single_launches(ops):
     assert ops.gemm_group([]) == []
 
 
+@pytest.mark.parametrize('n,d_in,d_out,nb', [(645, 64, 32, 32), (645, 32, 16, 32), (37, 10, 7, 3), (1000, 48, 40, 5)])
+def test_wg_gemm_group_vs_fp64_exact_on_integers_and_repeatable(ops, n, d_in, d_out, nb):
+    """tipk_gemm_wg_group: the four products that end an R-GCN layer's backward pass (batched X^T dXB, X^T g, the
+    batch-reduced dXB basis^T with g root^T added as a second product and the ReLU gate of the layer's input) and a slab
+    sum in ONE launch, reductions split over the waves of one workgroup per output tile: vs fp64, exact on small
+    integers (any order of the sum), bit-identical when repeated, ragged tiles and transposed views."""
+    g = torch.Generator().manual_seed(5 + n)
+    for integers in (False, True):
+        def rnd(*shape):
+            if integers:
+                return torch.randint(-3, 4, shape, generator=g).float().to(DEV)
+            return torch.randn(*shape, generator=g).to(DEV)
+        x, gr, g_xb = rnd(n, d_in), rnd(n, d_out), rnd(nb, n, d_out)
+        basis, root = rnd(nb, d_in, d_out), rnd(d_in, d_out)
+        part = rnd(6, 50, 8)
+        outs = []
+        for rep in range(2):
+            jb = ops.wg_gemm_job(x.t(), g_xb)
+            jr = ops.wg_gemm_job(x.t(), gr)
+            jx = ops.wg_gemm_job(g_xb, basis.transpose(1, 2), reduce_batch=True, a2=gr, b2=root.t(), gate=x, alpha=0.5)
+            assert jb is not None and jr is not None and jx is not None
+            sj = ops.slab_job(part, alpha=2.0)
+            ops.wg_gemm_group([jb, jr, jx], [sj])
+            outs.append([jb.out.clone(), jr.out.clone(), jx.out.clone(), sj.out.clone()])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        xd, gd, xbd, bd, rd = (t.double().cpu() for t in (x, gr, g_xb, basis, root))
+        want = [torch.einsum('nk,bno->bko', xd, xbd), xd.t() @ gd,
+                torch.where(xd > 0, 0.5 * (torch.einsum('bno,bko->nk', xbd, bd) + gd @ rd.t()), torch.zeros(())),
+                2.0 * part.double().cpu().sum(0)]
+        for got, w in zip(outs[0], want):
+            if integers:
+                assert torch.equal(got.double().cpu(), w)
+            else:
+                close(got, w, rtol=1e-5, atol=2e-4)
+    assert torch.equal(outs[0][3], ops.sum_slabs(part, alpha=2.0))
+    # a plain product with output strides (a column block of a wider buffer) and no second term; a long reduction is refused
+    wide = torch.zeros(n, d_in + 8, device=DEV)
+    j = ops.wg_gemm_job(gr, root.t(), out=wide[:, 8:])
+    ops.wg_gemm_group([j])
+    assert torch.equal(wide[:, :8], torch.zeros(n, 8, device=DEV))
+    want_w = gr.double().cpu() @ root.double().cpu().t()
+    assert torch.equal(wide[:, 8:].double().cpu(), want_w) if integers else True
+    assert ops.wg_gemm_job(torch.zeros(4, 5000, device=DEV), torch.zeros(5000, 4, device=DEV)) is None
+
+
 def test_gemm_reduce_batch_in_groups(ops):
     """sum_z a[z] @ b[z] with the terms summed in groups of `kgroup` (one slab per group): the pair-form D-D product."""
     g = torch.Generator().manual_seed(12)

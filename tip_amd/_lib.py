@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class TipkError(RuntimeError):
@@ -44,7 +44,17 @@ class SlabSumDesc(C.Structure):
                 ('out', C.c_void_p)]
 
 
+class WgGemmDesc(C.Structure):
+    """struct tipk_wg_gemm_desc (include/tipk.h)."""
+    _fields_ = [('p', GemmDesc),
+                ('a2', C.c_void_p), ('a2_sm', C.c_int64), ('a2_sk', C.c_int64),
+                ('b2', C.c_void_p), ('b2_sk', C.c_int64), ('b2_sn', C.c_int64),
+                ('k2', C.c_int64),
+                ('gate', C.c_void_p), ('gate_sm', C.c_int64), ('gate_sz', C.c_int64)]
+
+
 GROUP_MAX = 6                                  # TIPK_GROUP_MAX
+WG_GEMM_MAX, WG_SUMS_MAX = 4, 3                # TIPK_WG_GEMM_MAX, TIPK_WG_SUMS_MAX
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -71,6 +81,8 @@ SIGNATURES = {
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),
     'tipk_gemm_f32_group': (_I, [C.POINTER(GemmDesc), C.c_int32, _P]),
     'tipk_sum_slabs_group': (_I, [C.POINTER(SlabSumDesc), C.c_int32, _P]),
+    'tipk_gemm_wg_group_supported': (_I, [C.POINTER(WgGemmDesc)]),
+    'tipk_gemm_wg_group': (_I, [C.POINTER(WgGemmDesc), C.c_int32, C.POINTER(SlabSumDesc), C.c_int32, _P]),
     'tipk_rgcn_dy_products_plan': (_I, [_L, _L, _I, C.POINTER(_I), C.POINTER(_I)]),
     'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _P, _P]),
     'tipk_rgcn_node_products_plan': (_I, [_L, _I, _L, _I, C.POINTER(_I)]),

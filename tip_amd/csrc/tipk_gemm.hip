@@ -627,20 +627,16 @@ struct SlabGroupArgs {
 // tipk_sum_slabs_group: several ordered slab sums in one launch.  1024 threads = `lanes` slab lanes
 // x (1024 / lanes) elements; per element the additions happen in exactly the order of
 // sum_slabs_kernel<lanes>.
-__global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa) {
-    __shared__ float red[1024];
-    SlabArgs a = sa.s[0];
-    int first = 0;
-#pragma unroll
-    for (int q = 1; q < GROUP_MAX; ++q)
-        if (q < sa.count && (int)blockIdx.x >= sa.first_block[q]) { a = sa.s[q]; first = sa.first_block[q]; }
+// one workgroup (1024 threads) of an ordered slab sum: `block` = its index inside the sum, red = 1024 floats of LDS
+__device__ __forceinline__ void slab_sum_body(const SlabArgs& a, int block, float* red) {
+    const int first = 0;
     const float* __restrict__ in = a.in;
     if (a.lanes == 1) {
         // 4 slab lanes, vectorised: ONE thread owns 4 consecutive elements and plays all four slab lanes itself
         // (lane j = slabs j, j+4, ... in order; then ((s0 + s1) + s2) + s3: bit for bit the sums of the 4-lane
         // layout below) -- 16-byte loads, eight of them in flight, no LDS and no barrier.  The dword layout
         // moved the 21 MB of the layer-1 d XB / d att slabs at 1.7 TB/s.
-        const int64_t i = ((int64_t)((int)blockIdx.x - first) * 1024 + threadIdx.x) * 4;
+        const int64_t i = ((int64_t)(block - first) * 1024 + threadIdx.x) * 4;
         if (i >= a.count) return;
         const float4* p = reinterpret_cast<const float4*>(in + i);
         const int64_t st4 = a.slab_stride / 4;
@@ -689,7 +685,7 @@ __global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa)
     }
     const int lanes = a.lanes, epb = 1024 / lanes;
     const int e = threadIdx.x % epb, j = threadIdx.x / epb;
-    const int64_t i = (int64_t)((int)blockIdx.x - first) * epb + e;
+    const int64_t i = (int64_t)(block - first) * epb + e;
     float s = 0.f;
     if (i < a.count) {
         const float* p = in + i;                           // four loads in flight, original order of additions
@@ -713,6 +709,159 @@ __global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa)
         if (a.relu) s = fmaxf(s, 0.f);
         if (a.gate && !(a.gate[i] > 0.f)) s = 0.f;
         a.out[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sum_slabs_group_kernel(SlabGroupArgs sa) {
+    __shared__ float red[1024];
+    SlabArgs a = sa.s[0];
+    int first = 0;
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+        if (q < sa.count && (int)blockIdx.x >= sa.first_block[q]) { a = sa.s[q]; first = sa.first_block[q]; }
+    slab_sum_body(a, (int)blockIdx.x - first, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Products whose reduction is split over the 16 WAVES OF ONE WORKGROUP (tipk_gemm_wg_group).
+//
+// The backward pass of an R-GCN layer ends in four small products with few output tiles and a reduction of
+// 645 .. 1 056 terms (d basis = X^T dXB per base, d root = X^T g, dX = sum_b dXB_b basis_b^T + g root^T).  As grouped
+// split-K GEMMs they were cut into slabs over workgroups and finished by a second launch (tipk_sum_slabs_group): 10.4 +
+// 7.6 us of the step per layer for 0.2 GFLOP, both launches a chain of dependent round trips.  Here ONE workgroup owns a
+// 32 x 32 output tile: its K tiles (32 terms each; batch terms of a reduce-batch product and an optional SECOND product
+// added on top count as further tiles) are dealt to the 16 waves in contiguous runs, every wave loads its operands
+// straight from global memory in the register layout of v_mfma_f32_32x32x2_f32 (next tile in flight during the MFMAs),
+// the partial tiles are added through LDS in wave order (deterministic) and the epilogue (alpha, c_in, ReLU, gate) is
+// applied once.  Ordered slab sums that are ready at the same point (the d att slabs of tipk_rgcn_node_products) ride in
+// the same launch as further workgroups.
+constexpr int WGK_MAX = 4, WGK_SUMS = 3, WGK_WAVES = 16;
+
+struct WgkJob {
+    const float* a; int64_t a_sm, a_sk, a_sq, a_sz;
+    const float* b; int64_t b_sk, b_sn, b_sq, b_sz;
+    const float* a2; int64_t a2_sm, a2_sk;              // nullable second product (k2 terms), added to the same tile
+    const float* b2; int64_t b2_sk, b2_sn;
+    float* c; int64_t c_sm, c_sz;
+    const float* c_in; int64_t cin_sm, cin_sz;
+    const float* gate; int64_t gate_sm, gate_sz;        // nullable: out = gate > 0 ? value : 0
+    int m, n, k, k2, kbatch;
+    int mt, nt;                                         // output tiles
+    int tiles_q, n_kt, per, nw;                         // K tiles per batch term, in all, per wave; waves with work
+    int vec1, vec2;                                     // both operands of the (first / second) product are contiguous in k
+    float alpha; int relu;
+};
+struct WgkArgs {
+    int n_gemm, n_sum;
+    int first[WGK_MAX + WGK_SUMS + 1];
+    WgkJob g[WGK_MAX];
+    SlabArgs s[WGK_SUMS];
+};
+
+__global__ __launch_bounds__(1024) void gemm_wgk_group_kernel(WgkArgs wa) {
+    __shared__ __attribute__((aligned(16))) float red[WGK_WAVES * 1024];
+    const int blk = (int)blockIdx.x;
+    if (blk >= wa.first[WGK_MAX]) {                     // the slab sums follow the products
+        SlabArgs sa = wa.s[0];
+        int first = wa.first[WGK_MAX];
+#pragma unroll
+        for (int q = 1; q < WGK_SUMS; ++q)
+            if (q < wa.n_sum && blk >= wa.first[WGK_MAX + q]) { sa = wa.s[q]; first = wa.first[WGK_MAX + q]; }
+        slab_sum_body(sa, blk - first, red);
+        return;
+    }
+    WgkJob g = wa.g[0];
+    int first = 0;
+#pragma unroll
+    for (int q = 1; q < WGK_MAX; ++q)
+        if (q < wa.n_gemm && blk >= wa.first[q]) { g = wa.g[q]; first = wa.first[q]; }
+    const int local = blk - first;
+    const int nt_i = local % g.nt, mt_i = (local / g.nt) % g.mt, z = local / (g.nt * g.mt);
+    const int t = threadIdx.x, lane = t & 63, row = lane & 31, kh = lane >> 5;
+    const int w = uniform(t >> 6);
+    const int m0 = mt_i * 32, n0 = nt_i * 32;
+    const int n_first = g.kbatch * g.tiles_q;           // K tiles of the first product
+    const u32 am = (u32)(m0 + row < g.m ? m0 + row : g.m - 1), bn = (u32)(n0 + row < g.n ? n0 + row : g.n - 1);
+    const u32 m_mask = m0 + row < g.m ? 0xffffffffu : 0u;
+
+    f32x16 acc = zero16();
+    float a0[16], b0[16], a1[16], b1[16];
+    int left0 = 0, left1 = 0;                           // valid k of the tile in each buffer (negative: the vector layout)
+    // Which k a lane's register kk holds is free as long as both operands agree: when BOTH are contiguous in k (dX: rows of
+    // dXB against rows of basis) lane half kh takes k0 + 16 kh .. + 15 as four 16-byte loads -- a dword per (row, k) made
+    // every load touch 32 lines for 4 useful bytes each: 31.7 us for the dX product alone (tools/bench_wg_gemm.py)
+    auto load = [&](int tile, float (&av)[16], float (&bv)[16], int& left) {
+        const bool second = tile >= n_first;
+        const int tq = second ? tile - n_first : tile;
+        const int q = second ? 0 : tq / g.tiles_q;
+        const int kt = second ? tq : tq - q * g.tiles_q;
+        const int kk_total = second ? g.k2 : g.k;
+        const int k0 = kt * 32;
+        left = kk_total - k0 < 32 ? kk_total - k0 : 32;
+        const float* ap = second ? g.a2 : g.a + (int64_t)z * g.a_sz + (int64_t)q * g.a_sq;
+        const float* bp = second ? g.b2 : g.b + (int64_t)z * g.b_sz + (int64_t)q * g.b_sq;
+        const u32 s_am = (u32)(second ? g.a2_sm : g.a_sm), s_ak = (u32)(second ? g.a2_sk : g.a_sk);
+        const u32 s_bk = (u32)(second ? g.b2_sk : g.b_sk), s_bn = (u32)(second ? g.b2_sn : g.b_sn);
+        const u32 ao = am * s_am, bo = bn * s_bn;
+        if (second ? g.vec2 : g.vec1) {                 // (uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kb = 16 * kh + 4 * j;
+                const u32 kc = (u32)(k0 + (kb < left ? kb : left - 4));
+                const float4 xa = ldg4(ap, (ao + kc) * 4u), xb = ldg4(bp, (bo + kc) * 4u);
+                av[4 * j] = xa.x; av[4 * j + 1] = xa.y; av[4 * j + 2] = xa.z; av[4 * j + 3] = xa.w;
+                bv[4 * j] = xb.x; bv[4 * j + 1] = xb.y; bv[4 * j + 2] = xb.z; bv[4 * j + 3] = xb.w;
+            }
+            left = -left;
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int kl = 2 * kk + kh;
+            const u32 kc = (u32)(k0 + (kl < left ? kl : left - 1));
+            av[kk] = ldg(ap, (ao + kc * s_ak) * 4u);
+            bv[kk] = ldg(bp, (kc * s_bk + bo) * 4u);
+        }
+    };
+    auto mma = [&](const float (&av)[16], const float (&bv)[16], int left) {
+        const int lim = left < 0 ? -left - 16 * kh : left - kh;     // register kk is valid: kk < lim (vector) / 2 kk < lim
+        const int step = left < 0 ? 1 : 2;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(and_mask(av[kk], step * kk < lim ? m_mask : 0u), bv[kk], acc, 0, 0, 0);
+    };
+    const int t_lo = w * g.per, t_hi = t_lo + g.per < g.n_kt ? t_lo + g.per : g.n_kt;
+    if (t_lo < t_hi) {
+        load(t_lo, a0, b0, left0);
+#pragma unroll 1
+        for (int tile = t_lo; tile < t_hi; tile += 2) {
+            if (tile + 1 < t_hi) load(tile + 1, a1, b1, left1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0, left0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + 1 < t_hi) {
+                if (tile + 2 < t_hi) load(tile + 2, a0, b0, left0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1, left1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * 1024 + r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    {
+        float s = g.nw > 0 ? red[t] : 0.f;
+        for (int q = 1; q < g.nw; ++q) s += red[q * 1024 + t];
+        const int r = t >> 6, l = t & 63;
+        const int rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), cc = n0 + (l & 31);
+        if (rr < g.m && cc < g.n) {
+            s *= g.alpha;
+            if (g.c_in) s += g.c_in[(int64_t)z * g.cin_sz + (int64_t)rr * g.cin_sm + cc];
+            if (g.relu) s = fmaxf(s, 0.f);
+            if (g.gate && !(g.gate[(int64_t)z * g.gate_sz + (int64_t)rr * g.gate_sm + cc] > 0.f)) s = 0.f;
+            g.c[(int64_t)z * g.c_sz + (int64_t)rr * g.c_sm + cc] = s;
+        }
     }
 }
 
@@ -810,35 +959,108 @@ extern "C" int tipk_gemm_f32_group(const tipk_gemm_desc* descs, int32_t count, t
     TIPK_RETURN_LAUNCH();
 }
 
+// converts one slab-sum descriptor (shared by tipk_sum_slabs_group and tipk_gemm_wg_group); returns its workgroups, 0 = nothing to do
+static int64_t fill_slab_args(const tipk_slab_sum_desc& d, SlabArgs& a, int* rc) {
+    *rc = TIPK_OK;
+    if (d.n_slabs < 0 || d.count < 0 || (d.row_scale && d.cols <= 0)) { *rc = TIPK_EINVAL; return 0; }
+    if (d.count == 0) return 0;
+    if (!d.out || (d.n_slabs > 0 && !d.in)) { *rc = TIPK_EINVAL; return 0; }
+    a.in = d.in; a.n_slabs = d.n_slabs; a.slab_stride = d.slab_stride; a.count = d.count; a.alpha = d.alpha;
+    a.accumulate = d.accumulate; a.row_scale = d.row_scale; a.cols = d.cols; a.addend = d.addend; a.relu = d.relu;
+    a.gate = d.gate; a.out = d.out;
+    // same slab-lane rule as tipk_sum_slabs_ex, so grouped and single launches add in the same order
+    a.lanes = (d.n_slabs >= 32 && tipk_ceil_div(d.count, 64) < 2048) ? 16 : 4;
+    // the 4-lane sums run vectorised (lanes = 1: same order of additions, 16-byte accesses) when alignment allows
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (a.lanes == 4 && d.count % 4 == 0 && d.slab_stride % 4 == 0 && al16(d.in) && al16(d.out) && al16(d.addend) &&
+        al16(d.gate) && (!d.row_scale || d.cols % 4 == 0) && d.count >= 4096)
+        a.lanes = 1;
+    return a.lanes == 1 ? tipk_ceil_div(d.count, 4096) : tipk_ceil_div(d.count, 1024 / a.lanes);
+}
+
 extern "C" int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs, int32_t count, tipk_stream_t stream) {
     if (count < 0 || count > GROUP_MAX || (count > 0 && !descs)) return TIPK_EINVAL;
     SlabGroupArgs sa;
     sa.count = 0;
     int64_t blocks = 0;
     for (int i = 0; i < count; ++i) {
-        const tipk_slab_sum_desc& d = descs[i];
-        if (d.n_slabs < 0 || d.count < 0 || (d.row_scale && d.cols <= 0)) return TIPK_EINVAL;
-        if (d.count == 0) continue;
-        if (!d.out || (d.n_slabs > 0 && !d.in)) return TIPK_EINVAL;
-        SlabArgs& a = sa.s[sa.count];
-        a.in = d.in; a.n_slabs = d.n_slabs; a.slab_stride = d.slab_stride; a.count = d.count; a.alpha = d.alpha;
-        a.accumulate = d.accumulate; a.row_scale = d.row_scale; a.cols = d.cols; a.addend = d.addend; a.relu = d.relu;
-        a.gate = d.gate; a.out = d.out;
-        // same slab-lane rule as tipk_sum_slabs_ex, so grouped and single launches add in the same order
-        a.lanes = (d.n_slabs >= 32 && tipk_ceil_div(d.count, 64) < 2048) ? 16 : 4;
-        // the 4-lane sums run vectorised (lanes = 1: same order of additions, 16-byte accesses) when alignment allows
-        const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        if (a.lanes == 4 && d.count % 4 == 0 && d.slab_stride % 4 == 0 && al16(d.in) && al16(d.out) && al16(d.addend) &&
-            al16(d.gate) && (!d.row_scale || d.cols % 4 == 0) && d.count >= 4096)
-            a.lanes = 1;
+        int rc;
+        const int64_t nb = fill_slab_args(descs[i], sa.s[sa.count], &rc);
+        if (rc != TIPK_OK) return rc;
+        if (nb == 0) continue;
         sa.first_block[sa.count] = (int)blocks;
-        blocks += a.lanes == 1 ? tipk_ceil_div(d.count, 4096) : tipk_ceil_div(d.count, 1024 / a.lanes);
+        blocks += nb;
         if (blocks > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
         ++sa.count;
     }
     if (sa.count == 0) return TIPK_OK;
     sa.first_block[sa.count] = (int)blocks;
     hipLaunchKernelGGL(sum_slabs_group_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, sa);
+    TIPK_RETURN_LAUNCH();
+}
+
+static int fill_wgk(const tipk_wg_gemm_desc& d, WgkJob& j) {
+    const tipk_gemm_desc& p = d.p;
+    if (p.m <= 0 || p.n <= 0 || p.k < 0 || p.batch <= 0 || p.kbatch < 1 || p.ksplit != 1) return TIPK_EINVAL;
+    if (!p.a || !p.b || !p.c || p.a_sm < 0 || p.a_sk < 0 || p.b_sk < 0 || p.b_sn < 0) return TIPK_EINVAL;
+    const bool second = d.a2 != nullptr;
+    if (second && (!d.b2 || d.k2 <= 0 || p.batch != 1 || d.a2_sm < 0 || d.a2_sk < 0 || d.b2_sk < 0 || d.b2_sn < 0)) return TIPK_EINVAL;
+    const int64_t lim = 1LL << 30;                       // element offsets inside one term: 32-bit byte offsets
+    if (p.m > lim || p.n > lim || p.k > lim || p.m * p.a_sm + p.k * p.a_sk >= lim || p.k * p.b_sk + p.n * p.b_sn >= lim) return TIPK_EUNSUPPORTED;
+    if (second && (d.k2 > lim || p.m * d.a2_sm + d.k2 * d.a2_sk >= lim || d.k2 * d.b2_sk + p.n * d.b2_sn >= lim)) return TIPK_EUNSUPPORTED;
+    const int64_t tiles_q = tipk_ceil_div(p.k, 32);
+    const int64_t n_kt = p.kbatch * tiles_q + (second ? tipk_ceil_div(d.k2, 32) : 0);
+    const int64_t mt = tipk_ceil_div(p.m, 32), nt = tipk_ceil_div(p.n, 32);
+    if (n_kt < 1 || n_kt > WGK_WAVES * 8 || mt * nt * p.batch > 4096) return TIPK_EUNSUPPORTED;
+    j.a = p.a; j.a_sm = p.a_sm; j.a_sk = p.a_sk; j.a_sq = p.a_sq; j.a_sz = p.a_sz;
+    j.b = p.b; j.b_sk = p.b_sk; j.b_sn = p.b_sn; j.b_sq = p.b_sq; j.b_sz = p.b_sz;
+    j.a2 = d.a2; j.a2_sm = d.a2_sm; j.a2_sk = d.a2_sk; j.b2 = d.b2; j.b2_sk = d.b2_sk; j.b2_sn = d.b2_sn;
+    j.c = p.c; j.c_sm = p.c_sm; j.c_sz = p.c_sz;
+    j.c_in = p.c_in; j.cin_sm = p.cin_sm; j.cin_sz = p.cin_sz;
+    j.gate = d.gate; j.gate_sm = d.gate_sm; j.gate_sz = d.gate_sz;
+    j.m = (int)p.m; j.n = (int)p.n; j.k = (int)p.k; j.k2 = second ? (int)d.k2 : 0; j.kbatch = (int)p.kbatch;
+    j.mt = (int)mt; j.nt = (int)nt;
+    j.tiles_q = (int)tiles_q; j.n_kt = (int)n_kt;
+    j.per = (int)tipk_ceil_div(n_kt, WGK_WAVES);
+    j.nw = (int)tipk_ceil_div(n_kt, j.per);
+    j.alpha = p.alpha; j.relu = p.relu;
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    j.vec1 = p.a_sk == 1 && p.b_sk == 1 && p.k % 4 == 0 && ((p.a_sm | p.b_sn | p.a_sq | p.b_sq | p.a_sz | p.b_sz) & 3) == 0 && al16(p.a) && al16(p.b);
+    j.vec2 = second && d.a2_sk == 1 && d.b2_sk == 1 && d.k2 % 4 == 0 && ((d.a2_sm | d.b2_sn) & 3) == 0 && al16(d.a2) && al16(d.b2);
+    return TIPK_OK;
+}
+
+extern "C" int tipk_gemm_wg_group_supported(const tipk_wg_gemm_desc* d) {
+    WgkJob j;
+    return d && fill_wgk(*d, j) == TIPK_OK;
+}
+
+extern "C" int tipk_gemm_wg_group(const tipk_wg_gemm_desc* descs, int32_t count, const tipk_slab_sum_desc* sums,
+                                  int32_t n_sums, tipk_stream_t stream) {
+    if (count < 0 || count > WGK_MAX || n_sums < 0 || n_sums > WGK_SUMS || (count > 0 && !descs) || (n_sums > 0 && !sums)) return TIPK_EINVAL;
+    WgkArgs wa;
+    wa.n_gemm = count; wa.n_sum = 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const int rc = fill_wgk(descs[i], wa.g[i]);
+        if (rc != TIPK_OK) return rc;
+        wa.first[i] = (int)blocks;
+        blocks += (int64_t)wa.g[i].mt * wa.g[i].nt * descs[i].p.batch;
+    }
+    for (int i = count; i <= WGK_MAX; ++i) wa.first[i] = (int)blocks;
+    for (int i = 0; i < n_sums; ++i) {
+        int rc;
+        const int64_t nb = fill_slab_args(sums[i], wa.s[wa.n_sum], &rc);
+        if (rc != TIPK_OK) return rc;
+        if (nb == 0) continue;
+        wa.first[WGK_MAX + wa.n_sum] = (int)blocks;
+        blocks += nb;
+        if (blocks > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+        ++wa.n_sum;
+    }
+    for (int i = wa.n_sum; i <= WGK_SUMS; ++i) wa.first[WGK_MAX + i] = (int)blocks;
+    if (blocks == 0) return TIPK_OK;
+    hipLaunchKernelGGL(gemm_wgk_group_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, wa);
     TIPK_RETURN_LAUNCH();
 }
 

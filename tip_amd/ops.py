@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import SlabSumDesc, GemmDesc, check, lib, ptr, stream_ptr, require_device
+from ._lib import SlabSumDesc, GemmDesc, WgGemmDesc, check, lib, ptr, stream_ptr, require_device
 
 def _f32c(t):
     """fp32, unit column stride (row stride free)."""
@@ -493,6 +493,79 @@ def gemm_group(jobs, slab_jobs=()):
     return [j.out for j in jobs]
 
 
+class WgGemmJob(object):
+    """A product whose reduction runs inside one workgroup per output tile (`wg_gemm_group`)."""
+    __slots__ = ('desc', 'out', 'keep', 'label')
+
+
+def wg_gemm_job(a, b, out=None, reduce_batch=False, a2=None, b2=None, gate=None, alpha=1.0):
+    """Prepare out = gate?(alpha * (a @ b [summed over the batch] + a2 @ b2)) for `wg_gemm_group` (include/tipk.h
+    `tipk_gemm_wg_group`): a [M, K] or [Z, M, K], b [K, N] or [Z, K, N], arbitrary strides; a2 [M, K2], b2 [K2, N]
+    optional (only without a surviving batch); gate: a tensor shaped like the output.  Returns None when the shape is
+    not taken (reductions beyond 128 K tiles of 32, more than 4096 output tiles): the caller uses `gemm_job` then."""
+    require_device(a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    z = max(a.shape[0] if a.dim() == 3 else 1, b.shape[0] if b.dim() == 3 else 1)
+    batched = a.dim() == 3 or b.dim() == 3
+    m, k = a.shape[-2], a.shape[-1]
+    k_b, n = b.shape[-2], b.shape[-1]
+    assert k == k_b, (a.shape, b.shape)
+    reduce_batch = bool(reduce_batch and batched)
+    oshape = (z, m, n) if (batched and not reduce_batch) else (m, n)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=a.device)
+    assert tuple(out.shape) == oshape and out.stride(-1) == 1, (out.shape, oshape, out.stride())
+    a_sz, a_sm, a_sk = _strides3(a)
+    b_sz, b_sk, b_sn = _strides3(b)
+    d = WgGemmDesc()
+    g = d.p
+    g.m, g.n, g.k, g.ksplit = m, n, k, 1
+    g.a, g.b = a.data_ptr(), b.data_ptr()
+    g.a_sm, g.a_sk, g.b_sk, g.b_sn = a_sm, a_sk, b_sk, b_sn
+    if reduce_batch:
+        g.batch, g.kbatch = 1, z
+        g.a_sq, g.b_sq, g.a_sz, g.b_sz = a_sz, b_sz, 0, 0
+    else:
+        g.batch, g.kbatch = (z if batched else 1), 1
+        g.a_sq, g.b_sq, g.a_sz, g.b_sz = 0, 0, a_sz, b_sz
+    g.c, g.c_sm = out.data_ptr(), out.stride(-2)
+    g.c_sz = out.stride(0) if out.dim() == 3 else 0
+    g.c_ss = 0
+    g.c_in, g.cin_sm, g.cin_sz = None, 0, 0
+    g.alpha, g.relu = alpha, 0
+    if a2 is not None:
+        require_device(a2, b2)
+        assert a2.dim() == 2 and b2.dim() == 2 and a2.shape[0] == m and b2.shape[1] == n and a2.shape[1] == b2.shape[0]
+        assert a2.dtype == torch.float32 and b2.dtype == torch.float32 and len(oshape) == 2
+        d.a2, d.a2_sm, d.a2_sk = a2.data_ptr(), a2.stride(0), a2.stride(1)
+        d.b2, d.b2_sk, d.b2_sn = b2.data_ptr(), b2.stride(0), b2.stride(1)
+        d.k2 = a2.shape[1]
+    if gate is not None:
+        require_device(gate)
+        assert tuple(gate.shape) == oshape and gate.stride(-1) == 1 and gate.dtype == torch.float32
+        d.gate, d.gate_sm = gate.data_ptr(), gate.stride(-2)
+        d.gate_sz = gate.stride(0) if gate.dim() == 3 else 0
+    if not lib().tipk_gemm_wg_group_supported(d):
+        return None
+    job = WgGemmJob()
+    job.desc, job.out, job.keep = d, out, (a, b, a2, b2, gate)
+    job.label = '%dx%dx%d,z=%d%s' % (m, n, k, z, '+%d' % a2.shape[1] if a2 is not None else '')
+    return job
+
+
+def wg_gemm_group(jobs, slab_jobs=()):
+    """Run up to 4 `wg_gemm_job`s and up to 3 ordered slab sums (`slab_job`) in ONE launch; returns the products' outputs."""
+    jobs, slab_jobs = list(jobs), list(slab_jobs)
+    assert len(jobs) <= _lib.WG_GEMM_MAX and len(slab_jobs) <= _lib.WG_SUMS_MAX and (jobs or slab_jobs)
+    dev = (jobs[0].out if jobs else slab_jobs[0].out).device
+    arr = (WgGemmDesc * max(1, len(jobs)))(*[j.desc for j in jobs])
+    sums = (SlabSumDesc * max(1, len(slab_jobs)))(*[s.desc for s in slab_jobs])
+    with _timed('wg_gemm_group[%s%s]' % (' | '.join(j.label for j in jobs),
+                                          ''.join(' | sum %dx%d' % (s.desc.n_slabs, s.desc.count) for s in slab_jobs))):
+        check(lib().tipk_gemm_wg_group(arr, len(jobs), sums, len(slab_jobs), stream_ptr(dev)), 'tipk_gemm_wg_group')
+    return [j.out for j in jobs]
+
+
 def transpose(x):
     """x^T as a row-major tensor; a view when x is stored column-major already (no launch)."""
     if x.dim() == 2 and x.t().is_contiguous() and x.dtype == torch.float32:
@@ -522,7 +595,10 @@ def rows_affine(x, row_mul=None, row_div=None, gate=None, out=None, accumulate=F
 
 
 def gate_colsum(x, gate):
-    """(x * (gate > 0), partial column sums [G, 1, cols] of it) in one pass; None if unsupported."""
+    """(x * (gate > 0), partial column sums [G, 1, cols] of it) in one pass; None if unsupported.
+    (Round 4: letting the launch's LAST workgroup add the partial rows behind a ticket -- no sum_slabs launch -- made the
+    step 16 us SLOWER: handing data between workgroups inside a launch takes a device-scope release in every workgroup,
+    i.e. an L2 write-back per XCD on MI355X.)"""
     x, gate = _f32c(x), _f32c(gate)
     require_device(x, gate)
     rows, cols = x.shape
@@ -1220,7 +1296,29 @@ class _RGCN(torch.autograd.Function):
         extra = [] if j_att is None else [j_att]                         # the d att slabs ride in this layer's grouped slab sum
         if j_att is not None:
             g_att = j_att.out
-        # d basis, d root and both halves of dX are independent given dXB and g: one grouped launch
+        # d basis, d root and both halves of dX are independent given dXB and g: one grouped launch.  When the reductions
+        # fit the waves of one workgroup per output tile (BioSNAP: 645 and 1 056 terms) the products are FINISHED by that
+        # launch, together with the d att slab sum (round 4: 10.4 + 7.6 us of split-K slabs + their sum per layer before)
+        if len(extra) <= _lib.WG_SUMS_MAX:
+            flat = None
+            if shard is not None:
+                flat = torch.empty(n * d_in + nb * d_in * d_out, dtype=torch.float32, device=x.device)
+            w_basis = wg_gemm_job(x.t(), g_xb, out=None if flat is None else flat[n * d_in:].view(nb, d_in, d_out))
+            w_root = wg_gemm_job(x.t(), g)
+            if shard is None:
+                w_x = wg_gemm_job(g_xb, basis.transpose(1, 2), reduce_batch=True, a2=g, b2=root.t(),
+                                  gate=x if ctx.gate_input else None)
+            else:
+                w_x = wg_gemm_job(g_xb, basis.transpose(1, 2), reduce_batch=True, out=flat[:n * d_in].view(n, d_in))
+            if w_basis is not None and w_root is not None and w_x is not None:
+                wg_gemm_group([w_basis, w_root, w_x], extra)
+                g_x = w_x.out
+                if shard is not None:
+                    shard.all_reduce(flat)
+                    g_x = gemm(g, root.t(), out=g_x, c_in=g_x)           # replicated term, added once
+                    if ctx.gate_input:
+                        g_x = rows_affine(g_x, gate=x)
+                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None
         j_root = gemm_job(x.t(), g)
         if shard is None:
             j_basis = gemm_job(x.t(), g_xb)                              # [B, in, out]
