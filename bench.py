@@ -268,11 +268,14 @@ def dd_launches(enc, dev):
                     aggregation=True)
                 if rs.compact is not None:
                     att = torch.randn(r, nb, device=dev)
-                    xb = torch.randn(nb, n, d, device=dev)
+                    # the operands as the step hands them over: XB node-major (rows padded to 32 columns: the pair product's
+                    # buffer, through strides) and a second time as [N, d, bases] for the d att product
+                    xb = torch.randn(n, nb, 32 if d <= 32 else d, device=dev).permute(1, 0, 2)[:, :, :d]
+                    xbt = xb.permute(1, 2, 0).contiguous()
                     dyc = ops.rel_stream_bwd(rs, g, row_scale=graph.scale)
                     rows = rs.compact.n_rows
-                    add('node_products[dd.bwd,d=%d]' % d, 'node_products_kernel<%d>' % d, None, 'mfma', 2 * 2.0 * rows * d * nb,
-                        lambda dyc=dyc, cr=rs.compact, att=att, xb=xb: ops.node_products(dyc, cr, att, xb),
+                    add('node_products[dd.bwd,d=%d]' % d, 'node_products_kernel<%d, true>' % d, None, 'mfma', 2 * 2.0 * rows * d * nb,
+                        lambda dyc=dyc, cr=rs.compact, att=att, xb=xb, xbt=xbt: ops.node_products(dyc, cr, att, xb, xbt),
                         rows=rows, flops_dense_form=2 * 2.0 * r * n * d * nb)
             elif ops.rel_gather_usable(graph.rl_bwd if bwd else graph.rl_fwd, n, d, bwd):
                 rp = graph.rl_bwd if bwd else graph.rl_fwd

@@ -317,10 +317,13 @@ int tipk_gemm_wg_group(const tipk_wg_gemm_desc* descs /* host, [count <= TIPK_WG
  *     live (nullable): uint8 [n_src / group][ceil(n_dst / 32)], bit q = "some pair (group's node q, one of the tile's 32
  *     destinations) is linked": tiles without a link are not fetched (their cells are zeros by construction; `zeros` =
  *     >= 64 bytes of zeros, 16-byte aligned, read in their place).
+ *     xbt (nullable, [n_dst][d][n_bases], 16-byte aligned): XB of the first n_dst source nodes written back with the bases
+ *     innermost -- the operand layout of the backward pass (tipk_rgcn_node_products xbt), from the LDS stage of this kernel.
  */
 int tipk_pair_product_supported(int n_bases, int d);
 int tipk_pair_product(const float* cells, const float* xb, int64_t n_src, int64_t n_dst, int n_bases, int d,
-                      int group, int symmetric, const uint8_t* live, const float* zeros, float* slabs, tipk_stream_t stream);
+                      int group, int symmetric, const uint8_t* live, const float* zeros, float* xbt /* nullable */,
+                      float* slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2b. Both consumers of dY (the gradient of Y = att . XB, src/layers.py:163-172 under autograd) in
@@ -360,6 +363,8 @@ int tipk_rgcn_dy_products(const float* dy, int64_t ld_dy, const float* att, int6
  *     pos [n_nodes][ceil(n_rel / 64) * 64]  row of (u, r), or n_rows when the pair has no edge / r >= n_rel.
  *     xb element (b, u, c) at xb[b * xb_sb + u * xb_su + c] (strides multiples of 4 floats), dxb likewise: written
  *     COMPLETE (no slabs); datt_slabs [att_slabs][n_rel][n_bases] are added in order by tipk_sum_slabs(_group).
+ *     xbt (optional): the same values as [n_nodes][d][n_bases] (contiguous) -- the d att product then reads a column of
+ *     all bases as ONE 128-byte line instead of 32 lines (the vector-memory address path bounds that product).
  *     d in {16, 32, 64, 128}, n_bases <= 32 (`tipk_rgcn_node_products_plan` returns att_slabs = 0 otherwise: use the
  *     dense form 2b).  All sums in fixed order: bitwise reproducible.
  */
@@ -367,7 +372,7 @@ int tipk_rgcn_node_products_plan(int64_t n_nodes, int d, int64_t n_rel, int n_ba
 int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32_t* node_desc, const int32_t* row_rel,
                             const int32_t* pos, int64_t n_nodes, int64_t n_rel,
                             const float* att, int64_t ld_att, int n_bases,
-                            const float* xb, int64_t xb_sb, int64_t xb_su,
+                            const float* xb, int64_t xb_sb, int64_t xb_su, const float* xbt /* nullable */,
                             float* dxb, int64_t dxb_sb, int64_t dxb_su, float* datt_slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

@@ -275,6 +275,10 @@ def test_node_products_compact(ops, R, N, d, nb):
     job2, g_xb2 = ops.node_products(dyc, cr, att.to(DEV), xb.to(DEV))
     ops.gemm_group([], [job2])
     assert torch.equal(job2.out, job.out) and torch.equal(g_xb2, g_xb)
+    # XB handed over a second time as [N, d, bases] (the d att product reads it coalesced): the same sums in the same order
+    job3, g_xb3 = ops.node_products(dyc, cr, att.to(DEV), xb.to(DEV), xb.permute(1, 2, 0).contiguous().to(DEV))
+    ops.gemm_group([], [job3])
+    assert torch.equal(job3.out, job.out) and torch.equal(g_xb3, g_xb)
     # exact on integers
     gi = torch.randint(-3, 4, (N, d), generator=g).float()
     ai = torch.randint(-3, 4, (R, nb), generator=g).float()
@@ -466,8 +470,15 @@ def test_pair_product(ops, n, nb, d, monkeypatch):
     want = torch.einsum('guvb,gubc->gvc', cells.double().view(-1, ops.PAIR_KGROUP, n, nb), xb.double().view(-1, ops.PAIR_KGROUP, nb, d))
     close(slabs, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
     assert torch.equal(slabs, ops.pair_product(cells.to(DEV), xb.to(DEV)))
+    # XB written back with the bases innermost (the backward pass's operand), by the kernel and by the fallback
+    want_t = xb.to(DEV)[:n].permute(0, 2, 1).contiguous()
+    xbt = torch.full((n, d, nb), float('nan'), device=DEV)
+    assert torch.equal(slabs, ops.pair_product(cells.to(DEV), xb.to(DEV), xbt=xbt)) and torch.equal(xbt, want_t)
     monkeypatch.setenv('TIPK_NO_PAIR_PRODUCT', '1')
     close(ops.pair_product(cells.to(DEV), xb.to(DEV)), want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+    xbt = torch.full((n, d, nb), float('nan'), device=DEV)
+    ops.pair_product(cells.to(DEV), xb.to(DEV), xbt=xbt)
+    assert torch.equal(xbt, want_t)
     monkeypatch.delenv('TIPK_NO_PAIR_PRODUCT')
     # symmetric cells: only the half with source <= destination is stored, the other half may hold anything
     sym = cells.clone()

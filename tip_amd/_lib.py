@@ -73,7 +73,7 @@ SIGNATURES = {
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
     'tipk_pair_product_supported': (_I, [_I, _I]),
-    'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
     'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),
@@ -86,7 +86,7 @@ SIGNATURES = {
     'tipk_rgcn_dy_products_plan': (_I, [_L, _L, _I, C.POINTER(_I), C.POINTER(_I)]),
     'tipk_rgcn_dy_products': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _P, _P]),
     'tipk_rgcn_node_products_plan': (_I, [_L, _I, _L, _I, C.POINTER(_I)]),
-    'tipk_rgcn_node_products': (_I, [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _I, _P, _L, _L, _P, _L, _L, _P, _P]),
+    'tipk_rgcn_node_products': (_I, [_P, _L, _I, _P, _P, _P, _L, _L, _P, _L, _I, _P, _L, _L, _P, _P, _L, _L, _P, _P]),
     'tipk_sum_slabs': (_I, [_P, _L, _L, _L, _F, _I, _P, _P]),
     'tipk_sum_slabs_ex': (_I, [_P, _L, _L, _L, _F, _I, _P, _L, _P, _I, _P, _P]),
     'tipk_transpose': (_I, [_P, _L, _L, _P, _P]),

@@ -32,6 +32,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32;
 
 constexpr int NP_WAVES = 4;                             // waves per workgroup (both roles)
+#ifndef NP_THREE_SETS
+#define NP_THREE_SETS 1
+#endif
 constexpr int NP_THREADS = NP_WAVES * 64;
 
 struct NpArgs {
@@ -40,6 +43,7 @@ struct NpArgs {
     int n_nodes, n_rows, R, R_pad, NB;
     const float* att; int64_t ld_att;
     const float* xb; int64_t xb_sb, xb_su;
+    const float* xbt;                                   // nullable: the same XB as [node][column][base] (role 2 reads it coalesced)
     float* dxb; int64_t dxb_sb, dxb_su;
     float* datt;                                        // slabs [G][R][NB]
     int G, n_rp, n_chunks, chunks_per_wg, n_role2;
@@ -77,7 +81,7 @@ __device__ __forceinline__ float4 np_ldg4(const float* base, u32 byte_off) {
 // A `cond ? loaded : 0` next to its load makes hipcc skip the load under exec and wait for each one on the spot.
 // D = the row width d as a template constant: the two R-GCN layers of a model launch with identical grids, and a name per
 // width keeps them apart in kernel traces and counter summaries (profiles/*_kernel_by_grid.csv); NCT = 32-column tiles per row
-template <int D>
+template <int D, bool XBT = false>
 __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
     constexpr int NCT = (D + 31) / 32;
     __shared__ float red[NP_WAVES * 1024];
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ct][kk], acc[ct], 0, 0, 0);
         };
         if (n_tiles > 0) {
-            if constexpr (NCT == 1) {
+            if constexpr (NCT == 1 && NP_THREE_SETS) {
                 // THREE register sets (round 4).  vmcnt counts at most 63 operations and a tile is 32 loads: two tiles in
                 // flight behind the one being multiplied.  The relation ids of a tile are requested TWO steps before the loads
                 // that need them and IN FRONT of that step's loads: vector-memory operations complete in order, so an id
@@ -223,6 +227,23 @@ __global__ __launch_bounds__(NP_THREADS) void node_products_kernel(NpArgs a) {
             const bool ok = q_ok && node < a.n_nodes;                       // the last chunk may run past the last node
             const u32 ab = (u32)(ok ? p : a.n_rows) * d4 + c04;             // not there: the zero row
             const u32 bb = xb_n4 + (u32)(node < a.n_nodes ? node : a.n_nodes - 1) * xb_su4 + c04;
+            if constexpr (XBT) {
+                // XB as [node][column][base]: lane n reads base n of ONE column per load -- the 32 lanes of a half share a
+                // 128-byte line (2 lines per instruction).  From the [base][node][column] operand every lane's 64 bytes sit
+                // in a line of their own: 32 lines per 16-byte load, four loads per chunk, and the vector-memory address
+                // path was what bounded this role (TA busy 59 %: profiles/r04_node_products_experiments.md)
+                const u32 tb = ((u32)(node < a.n_nodes ? node : a.n_nodes - 1) * (u32)D + (u32)(f & (d - 1))) * (u32)NB * 4u + (u32)nb_c * 4u;
+                const u32 nb4 = (u32)NB * 4u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!TIPK_DBG(a.dbg & 64)) a4[j] = np_ldg4(a.dyc, ab + 16u * j);
+                    if (!TIPK_DBG(a.dbg & 32)) {
+                        b4[j].x = np_ldg(a.xbt, tb + (4 * j) * nb4); b4[j].y = np_ldg(a.xbt, tb + (4 * j + 1) * nb4);
+                        b4[j].z = np_ldg(a.xbt, tb + (4 * j + 2) * nb4); b4[j].w = np_ldg(a.xbt, tb + (4 * j + 3) * nb4);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!TIPK_DBG(a.dbg & 64)) a4[j] = np_ldg4(a.dyc, ab + 16u * j);
@@ -289,7 +310,7 @@ extern "C" int tipk_rgcn_node_products_plan(int64_t n_nodes, int d, int64_t n_re
 extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32_t* node_desc,
                                        const int32_t* row_rel, const int32_t* pos,
                                        int64_t n_nodes, int64_t n_rel, const float* att, int64_t ld_att, int n_bases,
-                                       const float* xb, int64_t xb_sb, int64_t xb_su,
+                                       const float* xb, int64_t xb_sb, int64_t xb_su, const float* xbt,
                                        float* dxb, int64_t dxb_sb, int64_t dxb_su, float* datt_slabs,
                                        tipk_stream_t stream) {
     int G = 0;
@@ -311,7 +332,7 @@ extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, 
     a.n_nodes = (int)n_nodes; a.n_rows = (int)n_rows; a.R = (int)n_rel; a.R_pad = (int)(tipk_ceil_div(n_rel, 64) * 64);
     a.NB = n_bases;
     a.att = att; a.ld_att = ld_att;
-    a.xb = xb; a.xb_sb = xb_sb; a.xb_su = xb_su;
+    a.xb = xb; a.xb_sb = xb_sb; a.xb_su = xb_su; a.xbt = xbt;
     a.dxb = dxb; a.dxb_sb = dxb_sb; a.dxb_su = dxb_su;
     a.datt = datt_slabs;
     a.G = G; a.n_rp = a.R_pad / 32;
@@ -321,7 +342,11 @@ extern "C" int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, 
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
     const unsigned grid = (unsigned)(a.n_nodes + a.n_role2);
     hipStream_t st = (hipStream_t)stream;
-    if (d == 16) hipLaunchKernelGGL(node_products_kernel<16>, dim3(grid), dim3(NP_THREADS), 0, st, a);
+    if (xbt && d == 16) hipLaunchKernelGGL((node_products_kernel<16, true>), dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else if (xbt && d == 32) hipLaunchKernelGGL((node_products_kernel<32, true>), dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else if (xbt && d == 64) hipLaunchKernelGGL((node_products_kernel<64, true>), dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else if (xbt) hipLaunchKernelGGL((node_products_kernel<128, true>), dim3(grid), dim3(NP_THREADS), 0, st, a);
+    else if (d == 16) hipLaunchKernelGGL(node_products_kernel<16>, dim3(grid), dim3(NP_THREADS), 0, st, a);
     else if (d == 32) hipLaunchKernelGGL(node_products_kernel<32>, dim3(grid), dim3(NP_THREADS), 0, st, a);
     else if (d == 64) hipLaunchKernelGGL(node_products_kernel<64>, dim3(grid), dim3(NP_THREADS), 0, st, a);
     else hipLaunchKernelGGL(node_products_kernel<128>, dim3(grid), dim3(NP_THREADS), 0, st, a);

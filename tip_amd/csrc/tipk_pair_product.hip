@@ -33,6 +33,7 @@ struct PpArgs {
     int symmetric;                     // cells hold only source <= destination: C[u][v] for v < u is read at C[v][u]
     const uint8_t* live;               // nullable: [n_groups][ceil(n_dst / 32)] bit q = some cell (u0 + q, the 32 rows) is linked
     const float* zeros;                // >= 64 bytes of zeros (read in place of the cells of a tile without links)
+    float* xbt;                        // nullable: [n_dst][d][NB] -- XB written back base-innermost (by the row-tile-0 workgroups)
 };
 
 template <int NB>
@@ -55,6 +56,20 @@ __global__ __launch_bounds__(256) void pair_product_kernel(PpArgs a) {
         for (int j = 0; j < N4; ++j) tipk_st4(xbl + (j * 256 + t) * 4, x[j]);
     }
     __syncthreads();
+    // The group's XB blocks are in LDS: the workgroups of row tile 0 write them back TRANSPOSED, xbt[u][c][0 .. NB) -- the
+    // layout in which the backward pass reads a column of all bases as one 128-byte line (tipk_rgcn_node_products xbt).
+    // 8 lanes = the 8 float4 of one (node, column): full lines.  (As a second output of the XB product -- 4-byte stores,
+    // one line each -- the forward pass lost the 5 us the backward pass gained; as a product of its own 4.7 us.)
+    if (a.xbt && rt == 0) {
+        constexpr int B4 = NB / 4;
+        for (int e = t; e < PP_GROUP * a.d * B4; e += 256) {
+            const int b4 = e % B4, c = (e / B4) % a.d, q = e / (B4 * a.d);
+            if (u0 + q < a.n_dst) {
+                const float* x = xbl + (q * NB + 4 * b4) * 32 + c;
+                tipk_st4(a.xbt + ((int64_t)(u0 + q) * a.d + c) * NB + 4 * b4, make_float4(x[0], x[32], x[64], x[96]));
+            }
+        }
+    }
     const int v0 = rt * 128 + wv * 32;
     if (v0 >= a.n_dst) return;
     const int v = v0 + row < a.n_dst ? v0 + row : a.n_dst - 1;                  // clamped: rows past the end are not stored
@@ -113,16 +128,17 @@ extern "C" int tipk_pair_product_supported(int n_bases, int d) {
 }
 
 extern "C" int tipk_pair_product(const float* cells, const float* xb, int64_t n_src, int64_t n_dst, int n_bases, int d,
-                                 int group, int symmetric, const uint8_t* live, const float* zeros, float* slabs,
-                                 tipk_stream_t stream) {
+                                 int group, int symmetric, const uint8_t* live, const float* zeros, float* xbt,
+                                 float* slabs, tipk_stream_t stream) {
     if (!cells || !xb || !slabs || n_src <= 0 || n_dst <= 0 || group != PP_GROUP || n_src % group != 0) return TIPK_EINVAL;
     if (live && (!zeros || (reinterpret_cast<uintptr_t>(zeros) & 15))) return TIPK_EINVAL;
+    if (xbt && ((reinterpret_cast<uintptr_t>(xbt) & 15) || n_src < n_dst)) return TIPK_EINVAL;   // (sources = destinations = the drugs)
     if (!tipk_pair_product_supported(n_bases, d)) return TIPK_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(cells) & 15) || (reinterpret_cast<uintptr_t>(xb) & 15) || n_src * n_dst * n_bases >= (1LL << 40)) return TIPK_EINVAL;
     PpArgs a;
     a.cells = cells; a.xb = xb; a.slabs = slabs;
     a.n_src = (int)n_src; a.n_dst = (int)n_dst; a.d = d; a.group = group; a.symmetric = symmetric != 0;
-    a.live = live; a.zeros = live ? zeros : cells;
+    a.live = live; a.zeros = live ? zeros : cells; a.xbt = xbt;
     a.row_tiles = (int)tipk_ceil_div(n_dst, 128);
     a.n_groups = (int)(n_src / group);
     const int64_t blocks = (int64_t)a.row_tiles * a.n_groups;

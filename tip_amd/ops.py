@@ -398,15 +398,17 @@ def node_products_slabs(n_nodes, d, n_rel, nb):
     return g.value
 
 
-def node_products(dyc, cr, att, xb):
+def node_products(dyc, cr, att, xb, xbt=None):
     """(pending slab sum of d att, d XB [bases, N, d]) from the COMPACT node-major dY (include/tipk.h section 2d):
     dyc [n_rows + 1, d] as written by `stream_gather` on a compact plan (last row zero), cr = plan.compact,
-    xb [bases, N, d].  d XB is complete; the d att slabs are summed by the caller's next grouped slab sum."""
+    xb [bases, N, d]; xbt (optional) the same values as a contiguous [N, d, bases] (read coalesced by the d att product).
+    d XB is complete; the d att slabs are summed by the caller's next grouped slab sum."""
     n_rows, d = dyc.shape[0] - 1, dyc.shape[1]
     nb, n = xb.shape[0], xb.shape[1]
     r = att.shape[0]
     assert cr.n_rows == n_rows and xb.shape[2] == d and xb.stride(2) == 1 and att.stride(1) == 1 and dyc.is_contiguous()
     assert xb.stride(0) % 4 == 0 and xb.stride(1) % 4 == 0
+    assert xbt is None or (tuple(xbt.shape) == (n, d, nb) and xbt.is_contiguous() and xbt.dtype == torch.float32)
     g = node_products_slabs(n, d, r, nb)
     assert g > 0
     dev = dyc.device
@@ -415,7 +417,7 @@ def node_products(dyc, cr, att, xb):
     with _timed('node_products[%dx%dx%d,rows=%d]' % (r, n * d, nb, n_rows)):
         check(lib().tipk_rgcn_node_products(ptr(dyc), n_rows, d, ptr(cr.node_desc), ptr(cr.row_rel), ptr(cr.pos),
                                             n, r, ptr(att), att.stride(0), nb, ptr(xb), xb.stride(0),
-                                            xb.stride(1), ptr(dxb), dxb.stride(0), dxb.stride(1), ptr(datt_slabs),
+                                            xb.stride(1), ptr(xbt), ptr(dxb), dxb.stride(0), dxb.stride(1), ptr(datt_slabs),
                                             stream_ptr(dev)), 'tipk_rgcn_node_products')
     return slab_job(datt_slabs), dxb
 
@@ -910,24 +912,28 @@ PAIR_FWD_MAX_WORLD = 4   # fallback rule when the forward routes cannot be timed
 PAIR_KGROUP = 8          # source nodes whose products are summed inside one wavefront of the pair-form product
 
 
-def pair_product(cells, xb_nb, symmetric=False, live=None, zeros=None):
+def pair_product(cells, xb_nb, symmetric=False, live=None, zeros=None, xbt=None):
     """slabs[g] = sum_{u in group g} cells[u] (N x bases) @ xb_nb[u] (bases x out)  (include/tipk.h section 2c):
     cells [N_pad, N, bases], xb_nb [N_pad, bases, out] -- or a column slice [..., :out] of a buffer whose rows are
-    padded to 32 columns with zeros (what the dedicated kernel reads) -> [N_pad / PAIR_KGROUP, N, out]."""
+    padded to 32 columns with zeros (what the dedicated kernel reads) -> [N_pad / PAIR_KGROUP, N, out].
+    xbt (optional, [N, out, bases] contiguous): filled with XB of the N nodes, bases innermost (`node_products` reads it)."""
     n_pad, n, nb = cells.shape
     d = xb_nb.shape[2]
+    assert xbt is None or (tuple(xbt.shape) == (n, d, nb) and xbt.is_contiguous() and xbt.dtype == torch.float32)
     assert cells.is_contiguous() and xb_nb.shape[:2] == (n_pad, nb) and n_pad % PAIR_KGROUP == 0
     padded = xb_nb.stride() == (nb * 32, 32, 1) and d <= 32
     if (not lib().tipk_pair_product_supported(nb, d) or os.environ.get('TIPK_NO_PAIR_PRODUCT') or not padded) and not symmetric:
         job = gemm_job(cells, xb_nb, reduce_batch=True, kgroup=PAIR_KGROUP)      # same sums on the tiled GEMM
         with _timed('gemm[%s]' % job.label):
             check(lib().tipk_gemm_f32(job.desc, stream_ptr(cells.device)), 'tipk_gemm_f32')
+        if xbt is not None:
+            xbt.copy_(xb_nb[:n].permute(0, 2, 1))
         return job.slabs
     assert padded, 'tipk_pair_product reads XB rows padded to 32 columns (AggGraph.pair_buffers)'
     slabs = torch.empty((n_pad // PAIR_KGROUP, n, d), dtype=torch.float32, device=cells.device)
     with _timed('pair_product[%dx%dx%dx%d]' % (n_pad, n, nb, d)):
         check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(live), ptr(zeros),
-                                      ptr(slabs), stream_ptr(cells.device)), 'tipk_pair_product')
+                                      ptr(xbt), ptr(slabs), stream_ptr(cells.device)), 'tipk_pair_product')
     return slabs
 
 
@@ -987,6 +993,15 @@ class AggGraph(object):
             buf = self._pair_cells[key] = (flat[:n_pad * n * nb].view(n_pad, n, nb),
                                            xb_pad[:, :, :d_out],           # rows padded to 32 columns: the product kernel's layout
                                            flat[n_pad * n * nb:])
+        return buf
+
+    def xbt_buffer(self, n, nb, d_out, device):
+        """XB a second time as [N, out, bases] -- what the d att product of the backward pass reads (`node_products`): a
+        column of all bases is one 128-byte line there (it is 32 lines in the node-major buffer of the pair product)."""
+        key = ('xbt', int(n), int(nb), int(d_out), str(device))
+        buf = self._pair_cells.get(key)
+        if buf is None:
+            buf = self._pair_cells[key] = torch.empty((n, d_out, nb), dtype=torch.float32, device=device)
         return buf
 
     @property
@@ -1195,14 +1210,17 @@ class _RGCN(torch.autograd.Function):
                 # 4-KB block there.  The buffer belongs to the graph and the next forward pass rewrites it: the stamp tells
                 # a backward pass that runs after ANOTHER forward to recompute XB instead of reading someone else's.
                 _, xroot = gemm_group([gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+                # ... and the pair product, which stages every node's XB block in LDS anyway, writes it back a second time as
+                # [N, out, bases]: what the d att product of the backward pass reads (`node_products` xbt)
+                xbt = graph.xbt_buffer(n, nb, d_out, x.device)
                 xb = xb_nb[:n].permute(1, 0, 2)
                 graph.pair_stamp = getattr(graph, 'pair_stamp', 0) + 1
                 ctx.xb_stamp = graph.pair_stamp
             else:
                 xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
-                ctx.xb_stamp = None
+                ctx.xb_stamp, xbt = None, None
             stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
-            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, live=getattr(pair, 'live', None), zeros=zeros)
+            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, live=getattr(pair, 'live', None), zeros=zeros, xbt=xbt)
             if shard is None:
                 out = sum_slabs(slabs.view(-1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
             else:
@@ -1254,9 +1272,11 @@ class _RGCN(torch.autograd.Function):
         n, d_in = x.shape
         nb, _, d_out = basis.shape
         r = att.shape[0]
+        xbt = None
         if ctx.xb_stamp is not None:                                     # XB lives in the graph's node-major buffer (forward)
             if getattr(graph, 'pair_stamp', 0) == ctx.xb_stamp:
                 xb = graph.pair_buffers(n, nb, d_out, x.device)[1][:n].permute(1, 0, 2)
+                xbt = graph.xbt_buffer(n, nb, d_out, x.device)
             else:                                                        # another forward pass has rewritten it: same values again
                 xb = gemm(x, basis)
         xb2 = xb.view(nb, n * d_out) if xb.is_contiguous() else None
@@ -1269,7 +1289,7 @@ class _RGCN(torch.autograd.Function):
                 # dY_r = A_r^T (D^-1 g) in COMPACT node-major form: only the (relation, source) rows that have an edge
                 # exist; both products of dY run on that form (d XB complete, d att as a few small slabs)
                 dyc = rel_stream_bwd(rs, g, row_scale=graph.scale)
-                j_att, g_xb = node_products(dyc, rs.compact, att, xb)
+                j_att, g_xb = node_products(dyc, rs.compact, att, xb, xbt)
             elif rs is not None and rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes:
                 # dY_r = A_r^T (D^-1 g), 1/deg fused.  Rows (relation, node) without edges -- half of them -- are
                 # neither written here nor read as data by the fused products (row mask)
