@@ -542,6 +542,30 @@ def step_floor(launch_us, launches, kern, pp_edges, dims):
                     'every other launch at the floor' % LAUNCH_FLOOR_US}
 
 
+IC_GATHER_GBS = 8600.0            # MI355X_MICROARCH.md gather table: uniformly random rows of a table held by the Infinity Cache
+
+
+def dense_route_floor(r, n, e, dims, other_us=200.0):
+    """What bounds a step on the DENSE route (Y = att . XB and dY materialised: node sets whose pair cells do not fit, config
+    5): per layer the Y product (fp32 MFMA peak, or its one write of Y at 8 TB/s), the forward gather of E rows of Y at the
+    Infinity-Cache gather rate, the transposed pass (E rows of g' gathered out of L2, dY written once at 8 TB/s) and both
+    products of dY (fp32 MFMA peak, or one read of dY at 8 TB/s); everything else (P-P / P->D stage, parameter-gradient
+    products, slab sums: `other_us`, the launch floors of ~30 launches + their 10 GB-scale slab traffic) as measured."""
+    nb = dims['num_base']
+    parts = {}
+    for li, name in enumerate(('n_hid1', 'n_hid2')):
+        d = dims[name]
+        y_bytes = 4.0 * r * n * d
+        parts['Y = att . XB [layer %d, d=%d]' % (li + 1, d)] = max(2.0 * r * nb * n * d / MFMA_F32_PEAK, y_bytes / (HBM_PEAK_GBS * 1e9)) * 1e6
+        parts['gather of Y [layer %d, d=%d]' % (li + 1, d)] = e * (4 + 4.0 * d) / (IC_GATHER_GBS * 1e9) * 1e6
+        parts['transposed pass, dY written [layer %d, d=%d]' % (li + 1, d)] = max(e * (4 + 4.0 * d) / (L2_GATHER_GBS * 1e9), y_bytes / (HBM_PEAK_GBS * 1e9)) * 1e6
+        parts['both products of dY [layer %d, d=%d]' % (li + 1, d)] = max(2 * 2.0 * r * nb * n * d / MFMA_F32_PEAK, y_bytes / (HBM_PEAK_GBS * 1e9)) * 1e6
+    parts['everything else (measured)'] = other_us
+    return {'us': sum(parts.values()), 'parts_us': {k: round(v, 1) for k, v in parts.items()},
+            'note': 'dense route: Y / dY round trips at 8 TB/s or the fp32 MFMA peak of their products, the gather of Y at the '
+                    'Infinity-Cache gather rate (8.6 TB/s), the gather of g\' rows out of L2 (18.8 TB/s)'}
+
+
 # ---------------------------------------------------------------------------------------------
 # one configuration: build, capture, time
 # ---------------------------------------------------------------------------------------------
@@ -928,6 +952,10 @@ def main():
         if args.workload.startswith('synthetic'):
             out['whole_step'] = {'alg_bytes': E * per_edge, 'bytes_per_edge': per_edge, 'GBps': E * per_edge / (ms * 1e-3) / 1e9,
                                  'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if world == 1:
+                fl = dense_route_floor(dd['n_dd_et'], dd['n_drug'], E, dims)
+                fl['frac'] = fl['us'] / (ms * 1e3)
+                out['step_floor'] = fl
         elif launch_us and world == 1:
             pp_edges = int(dd['pp_train_indices'].shape[1]) + dd['n_prot']
             fl = step_floor(launch_us, launches, kern, pp_edges, dims)
