@@ -105,6 +105,19 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
                              const float* row_scale, const float* bias, int relu,
                              int d, int max_slots, tipk_stream_t stream);
 
+/* tipk_gather_sum on a GROUPED plan with a linear map of every finished row in the same launch:
+ *     out[row]  = row_scale[row] * sum (as tipk_gather_sum, no bias / ReLU)          [n_out x d]
+ *     out2[row] = relu2?( out[row] . w^T + bias2 )                                     [n_out x d2],  w element (o, i) at w[o w_so + i w_si]
+ * Aggregate-then-transform of a GCN layer whose output is needed for FEW rows (conv2 of the P-P encoder: 3 640 of 19 081
+ * proteins are read by the P->D stage): A_hat (x W^T) = (A_hat x) W^T, so the dense map runs on the rows that are kept
+ * (src/layers.py:392-394 with the rows nobody reads left out), and the layer's forward pass is ONE launch.
+ * d in {16, 32, 64} (L = d / 4 lanes hold a row), d2 in {L, 2 L, 4 L} and <= 16, group_slots > 0 (`tipk_gather_sum_lin_supported`). */
+int tipk_gather_sum_lin_supported(int d, int d2, int group_slots);
+int tipk_gather_sum_lin(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id, const float* edge_w,
+                        const int32_t* items, int64_t n_items, float* out, int64_t ld_out, const float* row_scale,
+                        const float* w, int64_t w_so, int64_t w_si, const float* bias2 /* nullable */, int relu2,
+                        float* out2, int64_t ld_out2, int d, int d2, int group_slots, tipk_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * 1c. CSR rows -- the TRANSPOSED D-D pass of a large graph (autograd backward of K5/K6,
  *     src/layers.py:159-180): out[r] = sum_{e in [row_ptr[r], row_ptr[r+1])} table[row_id[e]] for every one
@@ -287,7 +300,7 @@ int tipk_sum_slabs_group(const tipk_slab_sum_desc* descs /* host, [count] */, in
  *   p:     as tipk_gemm_f32 (batch, kbatch, strides, c_in, alpha, relu); ksplit must be 1
  *   a2/b2: nullable second product [m x k2] . [k2 x n] added to the same output (batch must be 1)
  *   gate:  nullable, laid out like the output: out = gate > 0 ? value : 0
- * Shapes: at most 128 K tiles in all, at most 4096 output tiles (TIPK_EUNSUPPORTED otherwise: tipk_gemm_f32_group). */
+ * Shapes: at most 64 K tiles in all (2 048 terms), at most 4096 output tiles (TIPK_EUNSUPPORTED otherwise: tipk_gemm_f32_group). */
 typedef struct tipk_wg_gemm_desc {
     tipk_gemm_desc p;
     const float* a2; int64_t a2_sm, a2_sk;

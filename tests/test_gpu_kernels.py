@@ -383,7 +383,7 @@ def test_gemm_group_bit_identical_to_single_launches(ops):
     assert ops.gemm_group([]) == []
 
 
-@pytest.mark.parametrize('n,d_in,d_out,nb', [(645, 64, 32, 32), (645, 32, 16, 32), (37, 10, 7, 3), (1000, 48, 40, 5)])
+@pytest.mark.parametrize('n,d_in,d_out,nb', [(645, 64, 32, 32), (645, 32, 16, 32), (37, 10, 7, 3), (1000, 48, 40, 5)])  # (<= 64 K tiles)
 def test_wg_gemm_group_vs_fp64_exact_on_integers_and_repeatable(ops, n, d_in, d_out, nb):
     """tipk_gemm_wg_group: the four products that end an R-GCN layer's backward pass (batched X^T dXB, X^T g, the
     batch-reduced dXB basis^T with g root^T added as a second product and the ReLU gate of the layer's input) and a slab
@@ -427,6 +427,57 @@ def test_wg_gemm_group_vs_fp64_exact_on_integers_and_repeatable(ops, n, d_in, d_
     want_w = gr.double().cpu() @ root.double().cpu().t()
     assert torch.equal(wide[:, 8:].double().cpu(), want_w) if integers else True
     assert ops.wg_gemm_job(torch.zeros(4, 5000, device=DEV), torch.zeros(5000, 4, device=DEV)) is None
+
+
+@pytest.mark.parametrize('n,d_in,d_out,n_rows', [(19081, 32, 16, 3640), (500, 16, 16, 77), (300, 64, 16, 300), (200, 32, 8, 50)])
+def test_gcn_conv_aggregate_first_on_kept_rows(ops, n, d_in, d_out, n_rows):
+    """`gather_sum_lin` / `ops.gcn_conv_agg_first`: a GCN layer for a subset of its rows, aggregation first and the dense
+    map on the kept rows in the same launch -- output and all three gradients equal the transform-first layer restricted
+    to the rows (fp64 reference through the dense normalised adjacency), bitwise repeatable."""
+    from tip_amd.layers import gcn_norm_graph
+    from tip_amd.plan import group_slots_for
+    g = torch.Generator().manual_seed(n + d_in)
+    e = 12 * n
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)])
+    ei[1, : e // 20] = 3                                                   # a hub row: split into pieces
+    rows = torch.sort(torch.randperm(n, generator=g)[:n_rows]).values
+    if 3 not in rows.tolist():
+        rows = torch.sort(torch.cat([rows[:-1], torch.tensor([3])])).values
+    assert ops.gather_sum_lin_supported(d_in, d_out, group_slots_for(d_in))
+    graph = gcn_norm_graph(ei.to(DEV), n, d=d_in, rows=rows.to(DEV))
+    x = torch.randn(n, d_in, generator=g).to(DEV).requires_grad_()
+    wt = torch.randn(d_in, d_out, generator=g).to(DEV)                     # the layers' storage: [in, out] behind a [out, in] view
+    w = wt.t().requires_grad_()
+    b = torch.randn(d_out, generator=g).to(DEV).requires_grad_()
+    up = torch.randn(n_rows, d_out, generator=g).to(DEV)
+    outs = []
+    for rep in range(2):
+        for t in (x, w, b):
+            t.grad = None
+        out = ops.gcn_conv_agg_first(x, w, b, graph, relu=True)
+        out.backward(up)
+        outs.append([out.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()])
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    # fp64 reference: dense D^-1/2 (A + I) D^-1/2 restricted to the kept rows
+    row, col = ei[0], ei[1]
+    keep = row != col
+    row, col = torch.cat([row[keep], torch.arange(n)]), torch.cat([col[keep], torch.arange(n)])
+    deg = torch.bincount(col, minlength=n).double()
+    dis = deg.pow(-0.5)
+    xd = x.detach().double().cpu().requires_grad_()
+    wd = w.detach().double().cpu().requires_grad_()
+    bd = b.detach().double().cpu().requires_grad_()
+    xl = xd @ wd.t()
+    msg = xl[row] * (dis[row] * dis[col]).unsqueeze(1)
+    ref = torch.relu(torch.zeros(n, d_out, dtype=torch.float64).index_add_(0, col, msg)[rows] + bd)
+    ref.backward(up.double().cpu())
+    scale = float(ref.abs().max())
+    close(outs[0][0], ref.detach(), rtol=1e-5, atol=1e-5 * scale)
+    close(outs[0][1], xd.grad, rtol=1e-5, atol=1e-5 * float(xd.grad.abs().max()))
+    close(outs[0][2], wd.grad, rtol=1e-5, atol=1e-5 * float(wd.grad.abs().max()))
+    close(outs[0][3], bd.grad, rtol=1e-5, atol=1e-5 * float(bd.grad.abs().max()))
+    assert outs[0][2].stride() == w.stride()                               # d W in the parameter's own layout
 
 
 def test_gemm_reduce_batch_in_groups(ops):

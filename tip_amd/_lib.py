@@ -68,6 +68,8 @@ SIGNATURES = {
     'tipk_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     'tipk_gather_sum': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
+    'tipk_gather_sum_lin_supported': (_I, [_I, _I, _I]),
+    'tipk_gather_sum_lin': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _P, _L, _I, _I, _I, _P]),
     'tipk_gather_rows_csr': (_I, [_P, _L, _L, _P, _P, _L, _P, _L, _I, _P]),
     'tipk_rel_gather_supported': (_I, [_L, _I, _I]),
     'tipk_rel_gather_occupancy': (_I, [_L, _I, _I]),

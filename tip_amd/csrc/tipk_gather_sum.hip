@@ -24,7 +24,79 @@ struct Epilogue {
     const float* row_scale;
     const float* bias;
     int relu;
+    // LIN kernels only (tipk_gather_sum_lin): out2[row, 0 .. d2) = relu2?(finished row . w^T + bias2), w element (o, i) at
+    // w[o * w_so + i * w_si]
+    const float* w; int64_t w_so, w_si;
+    const float* bias2; int relu2;
+    float* out2; int64_t ld_out2;
 };
+
+// A linear map of the FINISHED row, applied by the L lanes that hold it (4 columns each, d == 4 L): every lane forms its
+// 4-column share of all N = L * PER outputs, then a reduce-scatter over the slot (log2 L exchange steps, the kept half
+// halves every step: N - PER shuffles instead of N log2 L) leaves PER complete outputs in every lane -- fixed order.
+template <int N> struct LinVec { typedef float type __attribute__((ext_vector_type(N))); };
+
+template <int L, int PER>
+__device__ __forceinline__ void lin_store(const float4& v, const Epilogue& ep, const float* wl, const float (&b2)[PER], int64_t row, int col, int sub) {
+    constexpr int N = L * PER;
+    static_assert(N % 4 == 0, "outputs are read four at a time");
+    // w sits in LDS as wl[input column][N + 4] (staged by the whole workgroup before the launch's barrier): global loads
+    // inside this exec-masked branch were waited for one by one -- 64 dependent round trips, 16 us for the 3 640 rows of conv2
+    // (a register VECTOR, constant element numbers only: with `float p[N]` hipcc folded `hi ? p[j] : p[j + half]` into ONE
+    // load at a lane-dependent index and expanded that into compare / select chains over all N elements -- +6.4 us)
+    typename LinVec<N>::type p;
+    const float vc[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* wr = wl + (col + c) * (N + 4);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(wr + 4 * q);
+            if (c == 0) { p[4 * q] = vc[0] * t.x; p[4 * q + 1] = vc[0] * t.y; p[4 * q + 2] = vc[0] * t.z; p[4 * q + 3] = vc[0] * t.w; }
+            else {
+                p[4 * q] = fmaf(vc[c], t.x, p[4 * q]); p[4 * q + 1] = fmaf(vc[c], t.y, p[4 * q + 1]);
+                p[4 * q + 2] = fmaf(vc[c], t.z, p[4 * q + 2]); p[4 * q + 3] = fmaf(vc[c], t.w, p[4 * q + 3]);
+            }
+        }
+    }
+    int base = 0;
+#pragma unroll
+    for (int st = 0; (1 << st) < L; ++st) {
+        const int o = 1 << st;
+        const int half = N >> (st + 1);
+        const bool hi = (sub & o) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const float lo_v = p[j], hi_v = p[j + half];
+            const float send = hi ? lo_v : hi_v;
+            const float keep = hi ? hi_v : lo_v;
+            p[j] = keep + __shfl_xor(send, o, 64);
+        }
+        base += hi ? half : 0;
+    }
+    // (base == lin_base<L, PER>(sub): the caller loaded b2 = bias2[base ..] before any divergence -- a global load in here is
+    // waited for on the spot)
+    float* o2 = ep.out2 + row * ep.ld_out2 + base;
+    float r[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        r[k] = p[k] + b2[k];
+        if (ep.relu2) r[k] = fmaxf(r[k], 0.f);
+    }
+    if constexpr (PER == 4) tipk_st4(o2, make_float4(r[0], r[1], r[2], r[3]));
+    else if constexpr (PER == 2) *reinterpret_cast<float2*>(o2) = make_float2(r[0], r[1]);
+    else o2[0] = r[0];
+}
+
+// first output a lane of the slot ends up with after lin_store's reduce-scatter
+template <int L, int PER>
+__device__ __forceinline__ int lin_base(int sub) {
+    int base = 0;
+#pragma unroll
+    for (int st = 0; (1 << st) < L; ++st)
+        if (sub & (1 << st)) base += (L * PER) >> (st + 1);
+    return base;
+}
 
 template <int V>
 struct Acc;
@@ -84,7 +156,7 @@ struct Acc<1> {
 // ONE 24-bit or 32-bit multiply per row; the general path pays a 64-bit multiply-add (three quarter-rate
 // v_mul_lo_u32 / v_mad_u64_u32 and two adds) per row, which made the narrow-row launches (P-P graph: 32- and
 // 16-float rows, 8 rows per wave-instruction) issue-bound rather than L2-bound.
-template <int V, int L, bool HAS_W, bool GROUPED, bool SMALL>
+template <int V, int L, bool HAS_W, bool GROUPED, bool SMALL, int LIN = 0>   // LIN = outputs per lane of the fused linear map (0: none)
 __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
     const float* __restrict__ table, int64_t ld_table, const int32_t* __restrict__ row_id,
     const float* __restrict__ edge_w, const int4* __restrict__ items, int64_t n_items,
@@ -107,6 +179,22 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
 
     Acc<V> acc;
     acc.zero();
+    if constexpr (LIN > 0) {
+        // the dense map's matrix -> LDS, behind the pieces' combine buffer: wl[input column][L LIN + 4] (ordered by the barrier
+        // every thread of a grouped launch passes before a row is finished)
+        extern __shared__ __attribute__((aligned(16))) unsigned char lin_raw[];
+        float* wl = reinterpret_cast<float*>(lin_raw + (size_t)blockDim.x * sizeof(Acc<V>));
+        constexpr int N = L * LIN;
+        for (int i = threadIdx.x; i < d * N; i += blockDim.x) {
+            const int ii = i / N, o = i - ii * N;
+            wl[ii * (N + 4) + o] = ep.w[(int64_t)o * ep.w_so + (int64_t)ii * ep.w_si];
+        }
+    }
+    float lin_b[LIN > 0 ? LIN : 1];
+    if constexpr (LIN > 0) {
+#pragma unroll
+        for (int k = 0; k < LIN; ++k) lin_b[k] = ep.bias2 ? ep.bias2[lin_base<L, LIN>(sub) + k] : 0.f;
+    }
     // software-pipelined ids: the slot's next STEP edge ids are requested before the current rows;
     // lane `sub` holds the ids of edges e0 + q * L + sub (coalesced per q)
     int id_next[IPL];
@@ -169,27 +257,31 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
         }
     }
     const int fl = active ? it.w : ITEM_NULL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char comb_raw[];
+    bool finished = false;                              // this slot holds a complete row (ONE epilogue site for both cases)
     if (GROUPED) {
         // pieces of a split row sit in consecutive slots of this workgroup: the leader adds them in
         // slot order through LDS (fixed order -> reproducible; no partial buffer, no second launch)
-        extern __shared__ __attribute__((aligned(16))) unsigned char comb_raw[];
         Acc<V>* comb = reinterpret_cast<Acc<V>*>(comb_raw);
         if (fl & ITEM_PIECE) comb[threadIdx.x] = acc;
         __syncthreads();
         if ((fl & ITEM_LEADER) && col_ok) {
             const int cnt = fl >> 8;
             for (int j = 1; j < cnt; ++j) acc.add(comb[threadIdx.x + j * L]);
-            acc.epilogue(ep, it.z, col);
-            acc.store(out + (int64_t)it.z * ld_out + col);
+            finished = true;
         }
     }
-    if (!col_ok || (fl & (ITEM_PIECE | ITEM_NULL))) return;
-    if (fl & ITEM_DIRECT) {
-        acc.epilogue(ep, it.z, col);
-        acc.store(out + (int64_t)it.z * ld_out + col);
-    } else {
-        acc.store(partial + (int64_t)it.z * d + col);
+    if (!finished) {
+        if (!col_ok || (fl & (ITEM_PIECE | ITEM_NULL))) return;
+        if (!(fl & ITEM_DIRECT)) {
+            acc.store(partial + (int64_t)it.z * d + col);
+            return;
+        }
     }
+    acc.epilogue(ep, it.z, col);
+    acc.store(out + (int64_t)it.z * ld_out + col);
+    if constexpr (LIN > 0 && V == 4)                    // (d == 4 L: all lanes of the slot are here)
+        lin_store<L, LIN>(acc.v, ep, reinterpret_cast<const float*>(comb_raw + (size_t)blockDim.x * sizeof(Acc<V>)), lin_b, it.z, col, sub);
 }
 
 // One WAVE per split row (4 rows per workgroup): the wave's 64/LPR lane groups add the row's slots
@@ -295,7 +387,7 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_t
     if (n_items == 0) return TIPK_OK;
     if (!aligned16(items)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    Epilogue ep{row_scale, bias, relu};
+    Epilogue ep{row_scale, bias, relu, nullptr, 0, 0, nullptr, 0, nullptr, 0};
     const bool small = n_table > 0 && ld_table > 0 && n_table * ld_table * 4 < (1LL << 32);   // 32-bit row offsets
     const bool vec = d % 4 == 0 && ld_table % 4 == 0 && ld_out % 4 == 0 && aligned16(table) && aligned16(out) &&
                      (!partial || aligned16(partial)) && (!bias || aligned16(bias));
@@ -327,6 +419,59 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_t
 #undef TIPK_GS
 }
 
+namespace {
+
+template <int L, int PER>
+int launch_gather_lin(const float* table, int64_t ld_table, const int32_t* row_id, const float* edge_w, const int32_t* items,
+                      int64_t n_items, float* out, int64_t ld_out, const Epilogue& ep, int d, int group_slots, hipStream_t st) {
+    const int threads = group_slots * L;
+    if (threads > 1024 || threads % TIPK_WAVE != 0) return TIPK_EUNSUPPORTED;
+    const int64_t blocks = tipk_ceil_div(n_items, group_slots);
+    if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    const size_t lds = (size_t)threads * sizeof(Acc<4>) + (size_t)d * (L * PER + 4) * sizeof(float);
+    const int4* it4 = reinterpret_cast<const int4*>(items);
+    if (edge_w)
+        hipLaunchKernelGGL((gather_sum_kernel<4, L, true, true, true, PER>), dim3((unsigned)blocks), dim3(threads), lds, st, table,
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, (float*)nullptr, ep, d);
+    else
+        hipLaunchKernelGGL((gather_sum_kernel<4, L, false, true, true, PER>), dim3((unsigned)blocks), dim3(threads), lds, st, table,
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, (float*)nullptr, ep, d);
+    TIPK_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+// d = 4 L floats per row with L in {4, 8, 16} lanes, d2 = L, 2 L or 4 L <= 16 outputs, grouped plans (rows finished inside the launch)
+extern "C" int tipk_gather_sum_lin_supported(int d, int d2, int group_slots) {
+    if (group_slots <= 0 || (d != 16 && d != 32 && d != 64)) return 0;
+    const int L = d / 4;
+    if (group_slots * L > 1024 || (group_slots * L) % TIPK_WAVE != 0) return 0;
+    return (d2 == L || d2 == 2 * L || d2 == 4 * L) && d2 <= 16;          // (32 outputs per lane spill: 128 VGPRs at 1024 threads)
+}
+
+extern "C" int tipk_gather_sum_lin(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
+                                   const float* edge_w, const int32_t* items, int64_t n_items, float* out, int64_t ld_out,
+                                   const float* row_scale, const float* w, int64_t w_so, int64_t w_si, const float* bias2,
+                                   int relu2, float* out2, int64_t ld_out2, int d, int d2, int group_slots,
+                                   tipk_stream_t stream) {
+    if (n_items < 0 || !items || !out || !w || !out2 || (n_items > 0 && (!table || !row_id))) return TIPK_EINVAL;
+    if (!tipk_gather_sum_lin_supported(d, d2, group_slots)) return TIPK_EUNSUPPORTED;
+    if (n_items == 0) return TIPK_OK;
+    if (!(n_table > 0 && ld_table > 0 && n_table * ld_table * 4 < (1LL << 32))) return TIPK_EUNSUPPORTED;   // 32-bit row offsets
+    if (!aligned16(items) || !aligned16(table) || !aligned16(out) || ld_table % 4 != 0 || ld_out % 4 != 0) return TIPK_EINVAL;
+    Epilogue ep{row_scale, nullptr, 0, w, w_so, w_si, bias2, relu2, out2, ld_out2};
+    hipStream_t st = (hipStream_t)stream;
+    const int L = d / 4, per = d2 / L;
+#define TIPK_GL(LL, PP) return launch_gather_lin<LL, PP>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, ep, d, group_slots, st)
+    if (L == 4 && per == 1) TIPK_GL(4, 1);
+    if (L == 4 && per == 2) TIPK_GL(4, 2);
+    if (L == 4) TIPK_GL(4, 4);
+    if (L == 8 && per == 1) TIPK_GL(8, 1);
+    if (L == 8) TIPK_GL(8, 2);
+    TIPK_GL(16, 1);
+#undef TIPK_GL
+}
+
 extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t n_rows, float* out,
                                         int64_t ld_out, const float* row_scale, const float* bias, int relu,
                                         int d, int max_slots, tipk_stream_t stream) {
@@ -334,7 +479,7 @@ extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* row
     if (n_rows == 0) return TIPK_OK;
     if (!partial || !rows || !out || n_rows > 0x7fffffffLL) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    Epilogue ep{row_scale, bias, relu};
+    Epilogue ep{row_scale, bias, relu, nullptr, 0, 0, nullptr, 0, nullptr, 0};
     const bool vec = d % 4 == 0 && ld_out % 4 == 0 && aligned16(partial) && aligned16(out) && (!bias || aligned16(bias));
     if (vec && max_slots > 0 && max_slots <= 8 && d <= 128) {
         switch (pow2_at_least(d / 4)) {

@@ -184,6 +184,13 @@ class GCNConv(nn.Module):
         """rows (extension): ascending int64 node ids -- return only these rows of the layer's output, [len(rows), out]
         (`gcn_norm_graph(rows=...)`: the rows nobody reads are neither aggregated nor back-propagated through)."""
         n = x.shape[0]
+        if rows is not None and not x.is_sparse and not _is_identity_features(x) and \
+                ops.gather_sum_lin_supported(self.in_channels, self.out_channels, group_slots_for(self.in_channels)):
+            # few rows kept: aggregate first, the dense map on the kept rows in the gather's own launch (ops._GCNConvAggFirst);
+            # the plans move rows of in_channels floats
+            graph = self._cache_rows.get((edge_index, rows),
+                                         lambda: gcn_norm_graph(edge_index, n, self.chunk, self.in_channels, rows))
+            return ops.gcn_conv_agg_first(x, self.lin.weight, self.bias, graph, fuse_relu)
         if rows is not None:
             graph = self._cache_rows.get((edge_index, rows), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels, rows))
         else:

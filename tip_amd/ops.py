@@ -87,6 +87,27 @@ def gather_sum_finish(plan, partial, out, row_scale=None, bias=None, relu=False)
                                              stream_ptr(out.device)), 'tipk_gather_sum_finalize')
 
 
+def gather_sum_lin_supported(d, d2, group_slots):
+    return bool(lib().tipk_gather_sum_lin_supported(int(d), int(d2), int(group_slots)))
+
+
+def gather_sum_lin(plan, table, weight, bias=None, relu=False, row_scale=None):
+    """(agg, out2): agg = the plan's row sums over `table` [n_table, d] (x row_scale), out2 = relu?(agg @ weight^T + bias) for
+    weight [d2, d] (any strides), in ONE launch on a grouped plan (include/tipk.h `tipk_gather_sum_lin`)."""
+    table = _f32c(table)
+    require_device(table, plan.items, weight)
+    d, d2 = table.shape[1], weight.shape[0]
+    assert table.shape[0] == plan.n_table and weight.shape[1] == d and plan.group_slots > 0 and not plan.n_slots
+    agg = torch.empty((plan.n_out, d), dtype=torch.float32, device=table.device)
+    out2 = torch.empty((plan.n_out, d2), dtype=torch.float32, device=table.device)
+    with _timed('gather_sum_lin[%s,d=%d->%d]' % (plan.tag, d, d2)):
+        check(lib().tipk_gather_sum_lin(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_id), ptr(plan.edge_w),
+                                        ptr(plan.items), plan.items.shape[0], ptr(agg), agg.stride(0), ptr(row_scale),
+                                        ptr(weight), weight.stride(0), weight.stride(1), ptr(bias), int(relu), ptr(out2),
+                                        out2.stride(0), d, d2, plan.group_slots, stream_ptr(table.device)), 'tipk_gather_sum_lin')
+    return agg, out2
+
+
 def gather_rows_csr(plan, table):
     """out[n_out, d] = per-row sums over a CsrPlan (include/tipk.h section 1c)."""
     table = _f32c(table)
@@ -504,7 +525,7 @@ def wg_gemm_job(a, b, out=None, reduce_batch=False, a2=None, b2=None, gate=None,
     """Prepare out = gate?(alpha * (a @ b [summed over the batch] + a2 @ b2)) for `wg_gemm_group` (include/tipk.h
     `tipk_gemm_wg_group`): a [M, K] or [Z, M, K], b [K, N] or [Z, K, N], arbitrary strides; a2 [M, K2], b2 [K2, N]
     optional (only without a surviving batch); gate: a tensor shaped like the output.  Returns None when the shape is
-    not taken (reductions beyond 128 K tiles of 32, more than 4096 output tiles): the caller uses `gemm_job` then."""
+    not taken (reductions beyond 64 K tiles of 32, more than 4096 output tiles): the caller uses `gemm_job` then."""
     require_device(a, b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32
     z = max(a.shape[0] if a.dim() == 3 else 1, b.shape[0] if b.dim() == 3 else 1)
@@ -1580,6 +1601,53 @@ class _GCNConv(torch.autograd.Function):
 def gcn_conv(x, weight, bias, graph, relu=False):
     """x = None means identity features."""
     return _GCNConv.apply(x, weight, bias, graph, relu)
+
+
+class _GCNConvAggFirst(torch.autograd.Function):
+    """out = relu?((A_hat x) W^T + bias) -- the same map as `_GCNConv` (A_hat (x W^T) = (A_hat x) W^T), aggregate FIRST: for a
+    layer whose output is needed for a few rows only (`gcn_norm_graph(rows=...)`: conv2 of the P-P encoder, 3 640 of 19 081
+    proteins) the dense map then runs on the kept rows inside the gather's launch (`gather_sum_lin`), and the backward pass
+    is one launch for g W, d W = g^T (A_hat x) and d bias (reductions over the kept rows: `wg_gemm_group`) + the transposed
+    gather -- 1 + 2 launches where transform-first took 2 + 3 (src/layers.py:392-394)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, graph, relu):
+        x = _f32c(x)
+        agg, out = gather_sum_lin(graph.fwd, x, weight, bias, relu, row_scale=graph.scale)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
+        ctx.save_for_backward(agg, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        agg, weight, out = ctx.saved_tensors
+        graph = ctx.graph
+        g = _f32c(g).contiguous()
+        if ctx.relu:
+            g = rows_affine(g, gate=out)
+        # d W in the parameter's own memory layout (tip_amd.layers._Lin keeps [in, out] storage behind the [out, in] shape)
+        w_t = weight.t().is_contiguous() and not weight.is_contiguous()
+        j_w = wg_gemm_job(agg.t(), g) if w_t else wg_gemm_job(g.t(), agg)
+        j_x = wg_gemm_job(g, weight) if ctx.needs_input_grad[0] else None
+        j_b = wg_gemm_job(_ones(g.shape[0], g.device), g) if ctx.has_bias else None
+        if j_w is None or (ctx.needs_input_grad[0] and j_x is None) or (ctx.has_bias and j_b is None):
+            # reductions beyond one workgroup's reach: the grouped split-K products and their slab sum
+            j_w = gemm_job(agg.t(), g) if w_t else gemm_job(g.t(), agg)
+            j_x = gemm_job(g, weight) if ctx.needs_input_grad[0] else None
+            j_b = gemm_job(_ones(g.shape[0], g.device), g) if ctx.has_bias else None
+            gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
+        else:
+            wg_gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
+        g_w = j_w.out.t() if w_t else j_w.out
+        g_x = None
+        if j_x is not None:
+            gw = j_x.out if graph.scale is None else rows_affine(j_x.out, row_mul=graph.scale)
+            g_x = gather_sum(graph.bwd, gw)
+        return g_x, g_w, (j_b.out.view(-1) if j_b is not None else None), None, None
+
+
+def gcn_conv_agg_first(x, weight, bias, graph, relu=False):
+    return _GCNConvAggFirst.apply(x, weight, bias, graph, relu)
 
 
 class _DistMult(torch.autograd.Function):
