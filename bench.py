@@ -499,7 +499,7 @@ def roofline_of(rec, us, build_id):
     return roof
 
 
-def step_floor(launch_us, launches, kern, pp_edges, dims):
+def step_floor(launch_us, launches, kern, pp_edges, dims, pp_rows_edges=None):
     """What the step's own kernels' bounds allow: sum over its launches of the larger of the kernel's roofline time
     and the launch floor.  launches: records of `dd_launches` (modelled); kern: the eager per-kernel table
     (label -> (launches per pass ..)) -- every launch that is not modelled counts LAUNCH_FLOOR_US, the four P-P
@@ -523,13 +523,14 @@ def step_floor(launch_us, launches, kern, pp_edges, dims):
         n_launches = int(round(sum(v[0] for v in kern.values()) / max(1, passes)))
         pp = 0
         for label in kern:
-            if label.startswith('gather_sum[pp.'):
-                dcol = int(label.split('d=')[1].rstrip(']'))
-                t = pp_edges * (4 + 4 * dcol) / (L2_GATHER_GBS * 1e9) * 1e6         # the 2.4 MB table is L2-resident
+            if label.startswith('gather_sum[pp.') or label.startswith('gather_sum_lin[pp.'):
+                dcol = int(label.split('d=')[1].split(']')[0].split('->')[0])       # ('...,d=32]+2 sums': slab sums riding in the launch)
+                n_e = pp_rows_edges if ('.rows' in label and pp_rows_edges) else pp_edges    # conv2: only the rows that are read
+                t = n_e * (4 + 4 * dcol) / (L2_GATHER_GBS * 1e9) * 1e6              # the 2.4 MB table is L2-resident
                 parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
                 pp += kern[label][0] // passes
             elif label.startswith('pp_stream['):                                    # round 3: rows out of LDS (8-byte rows)
-                dcol = int(label.split('d=')[1].rstrip(']'))
+                dcol = int(label.split('d=')[1].split(']')[0])
                 t = pp_edges * 4 * dcol / (LDS_PEAK_GBS * 1e9) * 1e6
                 parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
                 pp += kern[label][0] // passes
@@ -958,7 +959,10 @@ def main():
                 out['step_floor'] = fl
         elif launch_us and world == 1:
             pp_edges = int(dd['pp_train_indices'].shape[1]) + dd['n_prot']
-            fl = step_floor(launch_us, launches, kern, pp_edges, dims)
+            rows_graph = getattr(getattr(getattr(enc, 'pp_encoder', None), 'conv2', None), '_cache_rows', None)
+            rows_graph = rows_graph.value if rows_graph is not None else None
+            fl = step_floor(launch_us, launches, kern, pp_edges, dims,
+                            pp_rows_edges=int(rows_graph.fwd.n_edges) if rows_graph is not None else None)
             fl['frac'] = fl['us'] / (ms * 1e3)
             out['step_floor'] = fl
             hb = step_hbm_bytes(bid)

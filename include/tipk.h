@@ -105,6 +105,18 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
                              const float* row_scale, const float* bias, int relu,
                              int d, int max_slots, tipk_stream_t stream);
 
+/* tipk_gather_sum on a GROUPED plan whose workgroups have 1024 threads (group_slots x lanes per item; `_supported`), with up
+ * to 3 ordered slab sums (section 2: tipk_sum_slabs_group) that are READY at the same point riding in the launch as further
+ * workgroups -- the bias-gradient partials of GCNConv 1 next to its transposed aggregation, the split-K slabs of conv2's
+ * d W / d bias next to its transposed aggregation (src/layers.py:392-394 under autograd): a dependent 4-us launch less each. */
+struct tipk_slab_sum_desc;                         /* section 2 */
+int tipk_gather_sum_riders_supported(int d, int group_slots);
+int tipk_gather_sum_riders(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id, const float* edge_w,
+                           const int32_t* items, int64_t n_items, float* out, int64_t ld_out, const float* row_scale,
+                           const float* bias, int relu, int d, int group_slots,
+                           const struct tipk_slab_sum_desc* sums /* host, [n_sums <= 3] */, int32_t n_sums,
+                           tipk_stream_t stream);
+
 /* tipk_gather_sum on a GROUPED plan with a linear map of every finished row in the same launch:
  *     out[row]  = row_scale[row] * sum (as tipk_gather_sum, no bias / ReLU)          [n_out x d]
  *     out2[row] = relu2?( out[row] . w^T + bias2 )                                     [n_out x d2],  w element (o, i) at w[o w_so + i w_si]

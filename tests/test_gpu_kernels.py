@@ -480,6 +480,30 @@ def test_gcn_conv_aggregate_first_on_kept_rows(ops, n, d_in, d_out, n_rows):
     assert outs[0][2].stride() == w.stride()                               # d W in the parameter's own layout
 
 
+def test_gather_sum_with_slab_sums_riding_in_the_launch(ops):
+    """tipk_gather_sum_riders: ordered slab sums as further workgroups of a grouped gather whose workgroups have 1024
+    threads -- the gather's result and every sum equal the separate launches bit for bit; a plan with narrower workgroups
+    (16-float rows) takes the riders as a launch of their own."""
+    from tip_amd.plan import build_gather_plan, group_slots_for
+    g = torch.Generator().manual_seed(21)
+    n_out, n_tab = 3000, 700
+    e = 40000
+    dst, src = torch.randint(0, n_out, (e,), generator=g), torch.randint(0, n_tab, (e,), generator=g)
+    dst[:5000] = 7                                                         # a hub row
+    w = torch.rand(e, generator=g)
+    parts = [torch.randn(256, 1, 32, generator=g).to(DEV), torch.randn(11, 32, 16, generator=g).to(DEV), torch.randn(57, 1, 16, generator=g).to(DEV)]
+    for d in (32, 16):
+        plan = build_gather_plan(dst, src, n_out, n_tab, w, 64, 'test', group_slots_for(d)).to(DEV)
+        table = torch.randn(n_tab, d, generator=g).to(DEV)
+        want = ops.gather_sum(plan, table)
+        jobs = [ops.slab_job(p_, alpha=0.5) for p_ in parts]
+        got = ops.gather_sum(plan, table, riders=jobs)
+        assert torch.equal(got, want)
+        for j, p_ in zip(jobs, parts):
+            assert torch.equal(j.out, ops.sum_slabs(p_, alpha=0.5))
+        assert bool(ops.lib().tipk_gather_sum_riders_supported(d, plan.group_slots)) == (d == 32)
+
+
 def test_gemm_reduce_batch_in_groups(ops):
     """sum_z a[z] @ b[z] with the terms summed in groups of `kgroup` (one slab per group): the pair-form D-D product."""
     g = torch.Generator().manual_seed(12)

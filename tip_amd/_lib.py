@@ -68,6 +68,8 @@ SIGNATURES = {
     'tipk_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     'tipk_gather_sum': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
+    'tipk_gather_sum_riders_supported': (_I, [_I, _I]),
+    'tipk_gather_sum_riders': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _I, C.POINTER(SlabSumDesc), C.c_int32, _P]),
     'tipk_gather_sum_lin_supported': (_I, [_I, _I, _I]),
     'tipk_gather_sum_lin': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _P, _L, _I, _I, _I, _P]),
     'tipk_gather_rows_csr': (_I, [_P, _L, _L, _P, _P, _L, _P, _L, _I, _P]),
@@ -132,10 +134,10 @@ _lib = None
 
 
 def source_digest():
-    """sha1 (16 hex digits) over csrc/*.hip, csrc/*.cpp, csrc/tipk_common.h (sorted by name) and
+    """sha1 (16 hex digits) over csrc/*.hip, csrc/*.cpp, csrc/*.h (sorted by name) and
     include/tipk.h -- the same bytes, in the same order, as csrc/Makefile's BUILD_ID."""
-    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
-    names = sorted(names + ['tipk_common.h'])
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp'))
+                   + glob.glob(os.path.join(CSRC, '*.h')))
     h = hashlib.sha1()
     for n in names:
         with open(os.path.join(CSRC, n), 'rb') as f:

@@ -10,6 +10,7 @@
 // all: rows split over several items are combined in slot order by `gather_sum_finalize`
 // (bitwise reproducible).  Items are pre-sorted by length so the slots of a wave finish together.
 #include "tipk_common.h"
+#include "tipk_slabs.h"
 
 namespace {
 
@@ -19,6 +20,15 @@ constexpr int ITEM_PIECE = 2;       // piece of a row combined inside the workgr
 constexpr int ITEM_LEADER = 4;      // first piece: adds the next (flags >> 8) - 1 slots and stores
 constexpr int ITEM_NULL = 8;        // padding of a block
                                     // 0: piece of a row combined by tipk_gather_sum_finalize
+
+// Ordered slab sums that are ready when a grouped gather is launched ride in it as further 1024-thread workgroups
+// (tipk_gather_sum_riders): a dependent 4-us launch less each.
+constexpr int GS_RIDERS = 3;
+struct Riders {
+    int count;
+    int first[GS_RIDERS + 1];          // first[0] = workgroups of the gather itself
+    SlabArgs s[GS_RIDERS];
+};
 
 struct Epilogue {
     const float* row_scale;
@@ -34,6 +44,8 @@ struct Epilogue {
 // A linear map of the FINISHED row, applied by the L lanes that hold it (4 columns each, d == 4 L): every lane forms its
 // 4-column share of all N = L * PER outputs, then a reduce-scatter over the slot (log2 L exchange steps, the kept half
 // halves every step: N - PER shuffles instead of N log2 L) leaves PER complete outputs in every lane -- fixed order.
+constexpr int lin_log2(int x) { return x <= 1 ? 0 : 1 + lin_log2(x / 2); }
+
 template <int N> struct LinVec { typedef float type __attribute__((ext_vector_type(N))); };
 
 template <int L, int PER>
@@ -61,7 +73,7 @@ __device__ __forceinline__ void lin_store(const float4& v, const Epilogue& ep, c
     }
     int base = 0;
 #pragma unroll
-    for (int st = 0; (1 << st) < L; ++st) {
+    for (int st = 0; st < lin_log2(L); ++st) {
         const int o = 1 << st;
         const int half = N >> (st + 1);
         const bool hi = (sub & o) != 0;
@@ -93,7 +105,7 @@ template <int L, int PER>
 __device__ __forceinline__ int lin_base(int sub) {
     int base = 0;
 #pragma unroll
-    for (int st = 0; (1 << st) < L; ++st)
+    for (int st = 0; st < lin_log2(L); ++st)
         if (sub & (1 << st)) base += (L * PER) >> (st + 1);
     return base;
 }
@@ -160,7 +172,17 @@ template <int V, int L, bool HAS_W, bool GROUPED, bool SMALL, int LIN = 0>   // 
 __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
     const float* __restrict__ table, int64_t ld_table, const int32_t* __restrict__ row_id,
     const float* __restrict__ edge_w, const int4* __restrict__ items, int64_t n_items,
-    float* __restrict__ out, int64_t ld_out, float* __restrict__ partial, Epilogue ep, int d) {
+    float* __restrict__ out, int64_t ld_out, float* __restrict__ partial, Epilogue ep, int d, Riders rd) {
+    if (GROUPED && rd.count > 0 && (int)blockIdx.x >= rd.first[0]) {      // a rider workgroup: one block of an ordered slab sum
+        extern __shared__ __attribute__((aligned(16))) unsigned char rider_raw[];
+        SlabArgs sa = rd.s[0];
+        int first = rd.first[0];
+#pragma unroll
+        for (int q = 1; q < GS_RIDERS; ++q)
+            if (q < rd.count && (int)blockIdx.x >= rd.first[q]) { sa = rd.s[q]; first = rd.first[q]; }
+        slab_sum_body(sa, (int)blockIdx.x - first, reinterpret_cast<float*>(rider_raw));
+        return;
+    }
     constexpr int SLOTS = TIPK_WAVE / L;
     constexpr int U = 8;                                   // row loads kept in flight per lane
     constexpr int IPL = L < U ? U / L : 1;                 // edge ids held per lane: narrow slots (d <= 16) used to
@@ -343,7 +365,7 @@ int launch_finalize_small(const float* partial, const int32_t* rows, int64_t n_r
 template <int V, int L>
 int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, const float* edge_w,
                   const int32_t* items, int64_t n_items, float* out, int64_t ld_out, float* partial,
-                  Epilogue ep, int d, int group_slots, bool small, hipStream_t st) {
+                  Epilogue ep, int d, int group_slots, bool small, hipStream_t st, Riders rd = Riders{}) {
     constexpr int SLOTS = TIPK_WAVE / L;
     const int4* it4 = reinterpret_cast<const int4*>(items);
     if (group_slots > 0) {                              // one workgroup = one block of the plan
@@ -352,13 +374,22 @@ int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, c
         const int64_t blocks = tipk_ceil_div(n_items, group_slots);
         if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
         const size_t lds = (size_t)threads * sizeof(Acc<V>);
+        int64_t grid = blocks;
+        if (rd.count > 0) {                             // riders: 1024-thread workgroups behind the gather's own
+            if (threads != 1024) return TIPK_EUNSUPPORTED;
+            const int rider_blocks = rd.first[rd.count];        // (filled relative to 0 by the caller)
+            for (int q = 0; q <= rd.count; ++q) rd.first[q] += (int)blocks;
+            grid += rider_blocks;
+            if (grid > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+        }
 #define TIPK_GS_LAUNCH(W, G, S, GRID, BLOCK, LDS)                                                             \
         hipLaunchKernelGGL((gather_sum_kernel<V, L, W, G, S>), dim3((unsigned)(GRID)), dim3(BLOCK), LDS, st, table, \
-                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d)
-        if (edge_w) { if (small) TIPK_GS_LAUNCH(true, true, true, blocks, threads, lds); else TIPK_GS_LAUNCH(true, true, false, blocks, threads, lds); }
-        else { if (small) TIPK_GS_LAUNCH(false, true, true, blocks, threads, lds); else TIPK_GS_LAUNCH(false, true, false, blocks, threads, lds); }
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d, rd)
+        if (edge_w) { if (small) TIPK_GS_LAUNCH(true, true, true, grid, threads, lds); else TIPK_GS_LAUNCH(true, true, false, grid, threads, lds); }
+        else { if (small) TIPK_GS_LAUNCH(false, true, true, grid, threads, lds); else TIPK_GS_LAUNCH(false, true, false, grid, threads, lds); }
         TIPK_RETURN_LAUNCH();
     }
+    if (rd.count > 0) return TIPK_EUNSUPPORTED;         // riders need the 1024-thread workgroups of a grouped plan
     const int64_t waves = tipk_ceil_div(n_items, SLOTS);
     const int64_t blocks = tipk_ceil_div(waves, 4);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
@@ -378,10 +409,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
-                               const float* edge_w, const int32_t* items, int64_t n_items, float* out,
-                               int64_t ld_out, float* partial, const float* row_scale, const float* bias,
-                               int relu, int d, int group_slots, tipk_stream_t stream) {
+static int gather_sum_impl(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
+                           const float* edge_w, const int32_t* items, int64_t n_items, float* out,
+                           int64_t ld_out, float* partial, const float* row_scale, const float* bias,
+                           int relu, int d, int group_slots, const Riders& rd, tipk_stream_t stream) {
     if (n_items < 0 || d <= 0 || group_slots < 0 || !items || !out || (n_items > 0 && (!table || !row_id)))
         return TIPK_EINVAL;
     if (n_items == 0) return TIPK_OK;
@@ -393,7 +424,7 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_t
                      (!partial || aligned16(partial)) && (!bias || aligned16(bias));
 #define TIPK_GS(V, L) \
     return launch_gather<V, L>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, partial, ep, d, \
-                               group_slots, small, st)
+                               group_slots, small, st, rd)
     if (vec) {
         if (d > 256) return TIPK_EUNSUPPORTED;
         switch (pow2_at_least(d / 4)) {
@@ -419,6 +450,44 @@ extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_t
 #undef TIPK_GS
 }
 
+extern "C" int tipk_gather_sum(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
+                               const float* edge_w, const int32_t* items, int64_t n_items, float* out,
+                               int64_t ld_out, float* partial, const float* row_scale, const float* bias,
+                               int relu, int d, int group_slots, tipk_stream_t stream) {
+    return gather_sum_impl(table, ld_table, n_table, row_id, edge_w, items, n_items, out, ld_out, partial, row_scale, bias,
+                           relu, d, group_slots, Riders{}, stream);
+}
+
+extern "C" int tipk_gather_sum_riders_supported(int d, int group_slots) {
+    if (group_slots <= 0 || d <= 0) return 0;
+    const int lanes = d % 4 == 0 ? pow2_at_least(d / 4) : pow2_at_least(d);
+    return group_slots * lanes == 1024;
+}
+
+extern "C" int tipk_gather_sum_riders(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
+                                      const float* edge_w, const int32_t* items, int64_t n_items, float* out,
+                                      int64_t ld_out, const float* row_scale, const float* bias, int relu, int d,
+                                      int group_slots, const tipk_slab_sum_desc* sums, int32_t n_sums, tipk_stream_t stream) {
+    if (n_sums < 0 || n_sums > GS_RIDERS || (n_sums > 0 && !sums)) return TIPK_EINVAL;
+    if (!tipk_gather_sum_riders_supported(d, group_slots) || n_items <= 0) return TIPK_EUNSUPPORTED;
+    Riders rd;
+    rd.count = 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < n_sums; ++i) {
+        int rc;
+        const int64_t nb = fill_slab_args(sums[i], rd.s[rd.count], &rc);
+        if (rc != TIPK_OK) return rc;
+        if (nb == 0) continue;
+        rd.first[rd.count] = (int)blocks;
+        blocks += nb;
+        if (blocks > 0x3fffffffLL) return TIPK_EUNSUPPORTED;
+        ++rd.count;
+    }
+    for (int i = rd.count; i <= GS_RIDERS; ++i) rd.first[i] = (int)blocks;
+    return gather_sum_impl(table, ld_table, n_table, row_id, edge_w, items, n_items, out, ld_out, nullptr, row_scale, bias,
+                           relu, d, group_slots, rd, stream);
+}
+
 namespace {
 
 template <int L, int PER>
@@ -432,10 +501,10 @@ int launch_gather_lin(const float* table, int64_t ld_table, const int32_t* row_i
     const int4* it4 = reinterpret_cast<const int4*>(items);
     if (edge_w)
         hipLaunchKernelGGL((gather_sum_kernel<4, L, true, true, true, PER>), dim3((unsigned)blocks), dim3(threads), lds, st, table,
-                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, (float*)nullptr, ep, d);
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, (float*)nullptr, ep, d, Riders{});
     else
         hipLaunchKernelGGL((gather_sum_kernel<4, L, false, true, true, PER>), dim3((unsigned)blocks), dim3(threads), lds, st, table,
-                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, (float*)nullptr, ep, d);
+                           ld_table, row_id, edge_w, it4, n_items, out, ld_out, (float*)nullptr, ep, d, Riders{});
     TIPK_RETURN_LAUNCH();
 }
 

@@ -57,24 +57,38 @@ class _timed(object):
 # ---------------------------------------------------------------------------------------------
 # launch wrappers (one C call each)
 # ---------------------------------------------------------------------------------------------
-def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None):
-    """out[n_out, d] per `plan` over `table` [n_table, d] (include/tipk.h section 1)."""
+def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None, riders=()):
+    """out[n_out, d] per `plan` over `table` [n_table, d] (include/tipk.h section 1).
+    riders: up to 3 `slab_job`s that are ready now -- summed by further workgroups of the SAME launch when the plan's
+    workgroups have 1024 threads (`tipk_gather_sum_riders`), by a grouped slab-sum launch of their own otherwise."""
     table = _f32c(table)
     require_device(table, plan.items)
     d = table.shape[1]
     assert table.shape[0] == plan.n_table, (table.shape, plan.n_table)
     if out is None:
         out = torch.empty((plan.n_out, d), dtype=torch.float32, device=table.device)
+    riders = list(riders)
+    st = stream_ptr(table.device)
+    L = lib()
+    if riders and len(riders) <= 3 and not plan.n_slots and plan.items.shape[0] > 0 and \
+            L.tipk_gather_sum_riders_supported(d, plan.group_slots):
+        arr = (SlabSumDesc * len(riders))(*[r.desc for r in riders])
+        with _timed('gather_sum[%s,d=%d]+%d sums' % (plan.tag, d, len(riders))):
+            check(L.tipk_gather_sum_riders(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_id), ptr(plan.edge_w),
+                                           ptr(plan.items), plan.items.shape[0], ptr(out), out.stride(0), ptr(row_scale),
+                                           ptr(bias), int(relu), d, plan.group_slots, arr, len(riders), st),
+                  'tipk_gather_sum_riders')
+        return out
     partial = None
     if plan.n_slots:
         partial = torch.empty((plan.n_slots, d), dtype=torch.float32, device=table.device)
-    st = stream_ptr(table.device)
-    L = lib()
     with _timed('gather_sum[%s,d=%d]' % (plan.tag, d)):
         check(L.tipk_gather_sum(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_id), ptr(plan.edge_w), ptr(plan.items),
                                 plan.items.shape[0], ptr(out), out.stride(0), ptr(partial), ptr(row_scale),
                                 ptr(bias), int(relu), d, plan.group_slots, st), 'tipk_gather_sum')
     gather_sum_finish(plan, partial, out, row_scale, bias, relu)
+    if riders:
+        gemm_group([], riders)
     return out
 
 
@@ -482,10 +496,12 @@ def _slab_desc_of(job):
     return d
 
 
-def gemm_group(jobs, slab_jobs=()):
+def gemm_group(jobs, slab_jobs=(), defer_sums=False):
     """Run independent products in ONE grouped launch, then ONE grouped ordered slab sum for those
     that were split (plus any extra `slab_jobs` that are ready at the same point).  Results are
-    bit-identical to running the jobs one by one.  Returns the jobs' outputs."""
+    bit-identical to running the jobs one by one.  Returns the jobs' outputs.
+    defer_sums: do NOT launch the slab sums -- return them as a list of `slab_job`-like riders (the caller hands them
+    to the next launch that takes riders: `gather_sum(..., riders=...)`); the jobs' outputs are complete only then."""
     jobs = list(jobs)
     slab_jobs = list(slab_jobs)
     if not jobs and not slab_jobs:
@@ -508,6 +524,13 @@ def gemm_group(jobs, slab_jobs=()):
         with _timed('gemm_group[%s]' % ' | '.join(j.label for j in part)):
             check(lib().tipk_gemm_f32_group(arr, len(part), st), 'tipk_gemm_f32_group')
     sums = [_slab_desc_of(j) for j in jobs if j.slabs is not None] + [s.desc for s in slab_jobs]
+    if defer_sums:
+        riders = []
+        for dsc, keep in zip(sums, [j for j in jobs if j.slabs is not None] + list(slab_jobs)):
+            r = SlabJob()
+            r.desc, r.out, r.keep = dsc, keep.out, keep
+            riders.append(r)
+        return riders
     for i in range(0, len(sums), _lib.GROUP_MAX):
         part = sums[i:i + _lib.GROUP_MAX]
         arr = (SlabSumDesc * len(part))(*part)
@@ -1571,7 +1594,13 @@ class _GCNConv(torch.autograd.Function):
         if bias_parts is None:
             g_pre = rows_affine(g, gate=out) if ctx.relu else g
         g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
-        g_table = gather_sum(graph.bwd, g_agg)
+        s_bias = None
+        if ctx.identity and bias_parts is not None:
+            # identity features: nothing else is summed after the transposed aggregation -- the bias partials ride in ITS launch
+            s_bias = slab_job(bias_parts)
+            g_table = gather_sum(graph.bwd, g_agg, riders=[s_bias])
+        else:
+            g_table = gather_sum(graph.bwd, g_agg)
         j_b = None
         if ctx.has_bias and bias_parts is None:
             j_b = gemm_job(_ones(g_pre.shape[0], g.device), g_pre)
@@ -1579,8 +1608,8 @@ class _GCNConv(torch.autograd.Function):
             # d W = (d lin)^T: a VIEW when the parameter is stored transposed (tip_amd.layers._Lin), its strides
             # then equal the parameter's, so the optimizer's fused / foreach paths apply
             g_w = g_table.t() if weight.t().is_contiguous() else transpose(g_table)
-            if bias_parts is not None:
-                return None, g_w, sum_slabs(bias_parts).view(-1), None, None
+            if s_bias is not None:
+                return None, g_w, s_bias.out.view(-1), None, None
             if j_b is not None:
                 gemm_group([j_b])
             return None, g_w, (j_b.out.view(-1) if j_b else None), None, None
@@ -1635,14 +1664,18 @@ class _GCNConvAggFirst(torch.autograd.Function):
             j_w = gemm_job(agg.t(), g) if w_t else gemm_job(g.t(), agg)
             j_x = gemm_job(g, weight) if ctx.needs_input_grad[0] else None
             j_b = gemm_job(_ones(g.shape[0], g.device), g) if ctx.has_bias else None
-            gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
+            # ... whose slab sums ride in the transposed aggregation's launch (it only needs g W, which is written directly)
+            riders = gemm_group([j for j in (j_w, j_x, j_b) if j is not None], defer_sums=j_x is not None and j_x.slabs is None)
+            if j_x is None or j_x.slabs is not None:
+                riders = []
         else:
             wg_gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
+            riders = []
         g_w = j_w.out.t() if w_t else j_w.out
         g_x = None
         if j_x is not None:
             gw = j_x.out if graph.scale is None else rows_affine(j_x.out, row_mul=graph.scale)
-            g_x = gather_sum(graph.bwd, gw)
+            g_x = gather_sum(graph.bwd, gw, riders=riders)
         return g_x, g_w, (j_b.out.view(-1) if j_b is not None else None), None, None
 
 
