@@ -722,6 +722,9 @@ def measure_config(workload, mod, dev, steps=20, warmup=5):
         rec['mfma_side'] = {'flops_per_step': flops, 'ms_at_fp32_mfma_peak': flops / MFMA_F32_PEAK * 1e3,
                             'note': 'Y = att . XB forward and the two products of dY backward, per layer; the HBM side prices '
                                     '%d B per edge' % per_edge}
+        fl = dense_route_floor(r, n, E, dims)                            # what the route's own passes allow (composite)
+        fl['frac'] = fl['us'] / (ms * 1e3)
+        rec['step_floor'] = fl
     del launches, run, b
     release()
     return rec
