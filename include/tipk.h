@@ -108,12 +108,17 @@ int tipk_gather_sum_finalize(const float* partial, const int32_t* rows, int64_t 
 /* tipk_gather_sum on a GROUPED plan whose workgroups have 1024 threads (group_slots x lanes per item; `_supported`), with up
  * to 3 ordered slab sums (section 2: tipk_sum_slabs_group) that are READY at the same point riding in the launch as further
  * workgroups -- the bias-gradient partials of GCNConv 1 next to its transposed aggregation, the split-K slabs of conv2's
- * d W / d bias next to its transposed aggregation (src/layers.py:392-394 under autograd): a dependent 4-us launch less each. */
+ * d W / d bias next to its transposed aggregation (src/layers.py:392-394 under autograd): a dependent 4-us launch less each.
+ * Two optional extensions of the epilogue, for the transposed aggregation whose rows are gradients of a ReLU layer's output:
+ *   gate [n_out x d] (row stride ld_gate):  out[row] = gate[row] > 0 ? value : 0  (the ReLU backward, src/layers.py:393);
+ *   colsum [workgroups x d] (workgroups = ceil(n_items / group_slots), d % 4 == 0): column sums of the finished rows of every
+ *   workgroup, in slot order -- the bias gradient's partial rows, added in order by a slab sum (riding in the NEXT gather). */
 struct tipk_slab_sum_desc;                         /* section 2 */
 int tipk_gather_sum_riders_supported(int d, int group_slots);
 int tipk_gather_sum_riders(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id, const float* edge_w,
                            const int32_t* items, int64_t n_items, float* out, int64_t ld_out, const float* row_scale,
                            const float* bias, int relu, int d, int group_slots,
+                           const float* gate /* nullable */, int64_t ld_gate, float* colsum /* nullable */,
                            const struct tipk_slab_sum_desc* sums /* host, [n_sums <= 3] */, int32_t n_sums,
                            tipk_stream_t stream);
 

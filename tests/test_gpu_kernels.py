@@ -478,6 +478,18 @@ def test_gcn_conv_aggregate_first_on_kept_rows(ops, n, d_in, d_out, n_rows):
     close(outs[0][2], wd.grad, rtol=1e-5, atol=1e-5 * float(wd.grad.abs().max()))
     close(outs[0][3], bd.grad, rtol=1e-5, atol=1e-5 * float(bd.grad.abs().max()))
     assert outs[0][2].stride() == w.stride()                               # d W in the parameter's own layout
+    # ReLU hand-over: x as the ReLU output of a producer -- dx comes back masked with (x > 0), the column sums of the masked dx
+    # as partial rows in the link (what `_GCNConv(relu='gated_downstream')` turns into its bias gradient)
+    if ops.gather_sum_epilogue_supported(graph.bwd, d_in):
+        link = ops.GateLink()
+        x2 = torch.relu(x.detach()).requires_grad_()
+        out2 = ops.gcn_conv_agg_first(x2, w, b, graph, True, True, link)
+        out2.backward(up)
+        x3 = torch.relu(x.detach()).requires_grad_()
+        ops.gcn_conv_agg_first(x3, w, b, graph, True).backward(up)
+        masked = torch.where(x3.detach() > 0, x3.grad, torch.zeros_like(x3.grad))
+        assert torch.equal(x2.grad, masked)
+        close(link.parts.double().cpu().sum((0, 1)), masked.double().cpu().sum(0), rtol=1e-5, atol=1e-5 * float(masked.abs().sum(0).max()))
 
 
 def test_gather_sum_with_slab_sums_riding_in_the_launch(ops):
@@ -502,6 +514,35 @@ def test_gather_sum_with_slab_sums_riding_in_the_launch(ops):
         for j, p_ in zip(jobs, parts):
             assert torch.equal(j.out, ops.sum_slabs(p_, alpha=0.5))
         assert bool(ops.lib().tipk_gather_sum_riders_supported(d, plan.group_slots)) == (d == 32)
+
+
+def test_gather_sum_gate_and_column_sums_in_the_epilogue(ops):
+    """tipk_gather_sum_riders with gate / colsum: out = gate > 0 ? sum : 0 and the per-workgroup column sums of those rows --
+    == the plain gather masked afterwards (bit for bit) and its column sums (fp64), riders alongside, repeatable."""
+    from tip_amd.plan import build_gather_plan, group_slots_for
+    g = torch.Generator().manual_seed(31)
+    n_out, n_tab, e, d = 19081, 3640, 300000, 32
+    dst, src = torch.randint(0, n_out, (e,), generator=g), torch.randint(0, n_tab, (e,), generator=g)
+    dst[:9000] = 11                                                        # a hub row
+    w = torch.rand(e, generator=g)
+    plan = build_gather_plan(dst, src, n_out, n_tab, w, 64, 'test', group_slots_for(d)).to(DEV)
+    assert ops.gather_sum_epilogue_supported(plan, d)
+    table = torch.randn(n_tab, d, generator=g).to(DEV)
+    gate = torch.randn(n_out, d, generator=g).to(DEV)
+    part = torch.randn(40, 1, 16, generator=g).to(DEV)
+    plain = ops.gather_sum(plan, table)
+    want = torch.where(gate > 0, plain, torch.zeros_like(plain))
+    res = []
+    for rep in range(2):
+        job = ops.slab_job(part)
+        out, parts = ops.gather_sum(plan, table, riders=[job], gate=gate, colsum=True)
+        assert torch.equal(out, want) and torch.equal(job.out, ops.sum_slabs(part))
+        assert parts.shape == (-(-plan.items.shape[0] // plan.group_slots), 1, d)
+        close(parts.double().cpu().sum((0, 1)), want.double().cpu().sum(0), rtol=1e-5, atol=1e-4 * float(want.abs().sum(0).max()))
+        res.append(parts.clone())
+    assert torch.equal(res[0], res[1])
+    only_gate = ops.gather_sum(plan, table, gate=gate)
+    assert torch.equal(only_gate, want)
 
 
 def test_gemm_reduce_batch_in_groups(ops):

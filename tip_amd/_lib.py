@@ -69,7 +69,7 @@ SIGNATURES = {
     'tipk_gather_sum': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_finalize': (_I, [_P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
     'tipk_gather_sum_riders_supported': (_I, [_I, _I]),
-    'tipk_gather_sum_riders': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _I, C.POINTER(SlabSumDesc), C.c_int32, _P]),
+    'tipk_gather_sum_riders': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _P, _L, _P, C.POINTER(SlabSumDesc), C.c_int32, _P]),
     'tipk_gather_sum_lin_supported': (_I, [_I, _I, _I]),
     'tipk_gather_sum_lin': (_I, [_P, _L, _L, _P, _P, _P, _L, _P, _L, _P, _P, _L, _L, _P, _I, _P, _L, _I, _I, _I, _P]),
     'tipk_gather_rows_csr': (_I, [_P, _L, _L, _P, _P, _L, _P, _L, _I, _P]),

@@ -39,6 +39,10 @@ struct Epilogue {
     const float* w; int64_t w_so, w_si;
     const float* bias2; int relu2;
     float* out2; int64_t ld_out2;
+    // tipk_gather_sum_riders only: gate [n_out x d] (row stride ld_gate): finished value = gate > 0 ? value : 0 -- the ReLU backward
+    // of the layer whose output the rows are gradients of; colsum [workgroups x d]: column sums of the workgroup's finished rows
+    const float* gate; int64_t ld_gate;
+    float* colsum;
 };
 
 // A linear map of the FINISHED row, applied by the L lanes that hold it (4 columns each, d == 4 L): every lane forms its
@@ -139,6 +143,10 @@ struct Acc<4> {
         if (ep.row_scale) { float s = ep.row_scale[row]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
         if (ep.bias) { float4 b = tipk_ld4(ep.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (ep.gate) {
+            const float4 g = tipk_ld4(ep.gate + (int64_t)row * ep.ld_gate + col);
+            v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+        }
     }
     __device__ __forceinline__ void store(float* p) const { tipk_st4(p, v); }
 };
@@ -159,6 +167,7 @@ struct Acc<1> {
         if (ep.row_scale) v *= ep.row_scale[row];
         if (ep.bias) v += ep.bias[col];
         if (ep.relu) v = fmaxf(v, 0.f);
+        if (ep.gate && !(ep.gate[(int64_t)row * ep.ld_gate + col] > 0.f)) v = 0.f;
     }
     __device__ __forceinline__ void store(float* p) const { *p = v; }
 };
@@ -293,6 +302,37 @@ __global__ __launch_bounds__(GROUPED ? 1024 : 256) void gather_sum_kernel(
             finished = true;
         }
     }
+    if constexpr (LIN == -1 && V == 4 && GROUPED) {
+        // COLUMN SUMS of the workgroup's finished rows next to the rows themselves (the bias gradient of the layer the rows
+        // are gradients of, behind the gate): no early exits -- slot order, two levels through the combine buffer
+        const bool fin = finished || (col_ok && !(fl & (ITEM_PIECE | ITEM_NULL)) && (fl & ITEM_DIRECT));
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fin) {
+            acc.epilogue(ep, it.z, col);
+            acc.store(out + (int64_t)it.z * ld_out + col);
+            cs = acc.v;
+        }
+        Acc<V>* comb = reinterpret_cast<Acc<V>*>(comb_raw);
+        __syncthreads();                                // (the leaders have read the pieces)
+        comb[threadIdx.x].v = cs;
+        __syncthreads();
+        constexpr int PARTS = 16;
+        const int per = ((int)blockDim.x / L) / PARTS;  // slots per part (1024 threads: a multiple of 16 slots)
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)threadIdx.x < PARTS * L) {
+            const int p = (int)threadIdx.x / L;
+            for (int q = p * per; q < (p + 1) * per; ++q) { const float4 t4 = comb[q * L + sub].v; s1.x += t4.x; s1.y += t4.y; s1.z += t4.z; s1.w += t4.w; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < PARTS * L) comb[threadIdx.x].v = s1;
+        __syncthreads();
+        if ((int)threadIdx.x < L && col_ok) {
+            float4 tot = comb[sub].v;
+            for (int p = 1; p < PARTS; ++p) { const float4 t4 = comb[p * L + sub].v; tot.x += t4.x; tot.y += t4.y; tot.z += t4.z; tot.w += t4.w; }
+            tipk_st4(ep.colsum + (int64_t)blockIdx.x * d + col, tot);
+        }
+        return;
+    }
     if (!finished) {
         if (!col_ok || (fl & (ITEM_PIECE | ITEM_NULL))) return;
         if (!(fl & ITEM_DIRECT)) {
@@ -385,10 +425,25 @@ int launch_gather(const float* table, int64_t ld_table, const int32_t* row_id, c
 #define TIPK_GS_LAUNCH(W, G, S, GRID, BLOCK, LDS)                                                             \
         hipLaunchKernelGGL((gather_sum_kernel<V, L, W, G, S>), dim3((unsigned)(GRID)), dim3(BLOCK), LDS, st, table, \
                            ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d, rd)
+        if (ep.colsum) {                                // (tipk_gather_sum_riders checked: V == 4, 1024 threads, 32-bit row offsets)
+            if constexpr (V == 4) {
+                if (threads != 1024 || !small) return TIPK_EUNSUPPORTED;
+                if (edge_w)
+                    hipLaunchKernelGGL((gather_sum_kernel<V, L, true, true, true, -1>), dim3((unsigned)grid), dim3(threads), lds, st, table,
+                                       ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d, rd);
+                else
+                    hipLaunchKernelGGL((gather_sum_kernel<V, L, false, true, true, -1>), dim3((unsigned)grid), dim3(threads), lds, st, table,
+                                       ld_table, row_id, edge_w, it4, n_items, out, ld_out, partial, ep, d, rd);
+                TIPK_RETURN_LAUNCH();
+            } else {
+                return TIPK_EUNSUPPORTED;
+            }
+        }
         if (edge_w) { if (small) TIPK_GS_LAUNCH(true, true, true, grid, threads, lds); else TIPK_GS_LAUNCH(true, true, false, grid, threads, lds); }
         else { if (small) TIPK_GS_LAUNCH(false, true, true, grid, threads, lds); else TIPK_GS_LAUNCH(false, true, false, grid, threads, lds); }
         TIPK_RETURN_LAUNCH();
     }
+    if (ep.colsum) return TIPK_EUNSUPPORTED;
     if (rd.count > 0) return TIPK_EUNSUPPORTED;         // riders need the 1024-thread workgroups of a grouped plan
     const int64_t waves = tipk_ceil_div(n_items, SLOTS);
     const int64_t blocks = tipk_ceil_div(waves, 4);
@@ -412,13 +467,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int gather_sum_impl(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
                            const float* edge_w, const int32_t* items, int64_t n_items, float* out,
                            int64_t ld_out, float* partial, const float* row_scale, const float* bias,
-                           int relu, int d, int group_slots, const Riders& rd, tipk_stream_t stream) {
+                           int relu, int d, int group_slots, const Riders& rd, tipk_stream_t stream,
+                           const float* gate = nullptr, int64_t ld_gate = 0, float* colsum = nullptr) {
     if (n_items < 0 || d <= 0 || group_slots < 0 || !items || !out || (n_items > 0 && (!table || !row_id)))
         return TIPK_EINVAL;
     if (n_items == 0) return TIPK_OK;
     if (!aligned16(items)) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    Epilogue ep{row_scale, bias, relu, nullptr, 0, 0, nullptr, 0, nullptr, 0};
+    Epilogue ep{row_scale, bias, relu, nullptr, 0, 0, nullptr, 0, nullptr, 0, gate, ld_gate, colsum};
+    if (gate && (ld_gate % 4 != 0 || !aligned16(gate))) return TIPK_EINVAL;
+    if (colsum && (d % 4 != 0 || !aligned16(colsum))) return TIPK_EUNSUPPORTED;
     const bool small = n_table > 0 && ld_table > 0 && n_table * ld_table * 4 < (1LL << 32);   // 32-bit row offsets
     const bool vec = d % 4 == 0 && ld_table % 4 == 0 && ld_out % 4 == 0 && aligned16(table) && aligned16(out) &&
                      (!partial || aligned16(partial)) && (!bias || aligned16(bias));
@@ -467,7 +525,8 @@ extern "C" int tipk_gather_sum_riders_supported(int d, int group_slots) {
 extern "C" int tipk_gather_sum_riders(const float* table, int64_t ld_table, int64_t n_table, const int32_t* row_id,
                                       const float* edge_w, const int32_t* items, int64_t n_items, float* out,
                                       int64_t ld_out, const float* row_scale, const float* bias, int relu, int d,
-                                      int group_slots, const tipk_slab_sum_desc* sums, int32_t n_sums, tipk_stream_t stream) {
+                                      int group_slots, const float* gate, int64_t ld_gate, float* colsum,
+                                      const tipk_slab_sum_desc* sums, int32_t n_sums, tipk_stream_t stream) {
     if (n_sums < 0 || n_sums > GS_RIDERS || (n_sums > 0 && !sums)) return TIPK_EINVAL;
     if (!tipk_gather_sum_riders_supported(d, group_slots) || n_items <= 0) return TIPK_EUNSUPPORTED;
     Riders rd;
@@ -485,7 +544,7 @@ extern "C" int tipk_gather_sum_riders(const float* table, int64_t ld_table, int6
     }
     for (int i = rd.count; i <= GS_RIDERS; ++i) rd.first[i] = (int)blocks;
     return gather_sum_impl(table, ld_table, n_table, row_id, edge_w, items, n_items, out, ld_out, nullptr, row_scale, bias,
-                           relu, d, group_slots, rd, stream);
+                           relu, d, group_slots, rd, stream, gate, ld_gate, colsum);
 }
 
 namespace {
@@ -528,7 +587,7 @@ extern "C" int tipk_gather_sum_lin(const float* table, int64_t ld_table, int64_t
     if (n_items == 0) return TIPK_OK;
     if (!(n_table > 0 && ld_table > 0 && n_table * ld_table * 4 < (1LL << 32))) return TIPK_EUNSUPPORTED;   // 32-bit row offsets
     if (!aligned16(items) || !aligned16(table) || !aligned16(out) || ld_table % 4 != 0 || ld_out % 4 != 0) return TIPK_EINVAL;
-    Epilogue ep{row_scale, nullptr, 0, w, w_so, w_si, bias2, relu2, out2, ld_out2};
+    Epilogue ep{row_scale, nullptr, 0, w, w_so, w_si, bias2, relu2, out2, ld_out2, nullptr, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int L = d / 4, per = d2 / L;
 #define TIPK_GL(LL, PP) return launch_gather_lin<LL, PP>(table, ld_table, row_id, edge_w, items, n_items, out, ld_out, ep, d, group_slots, st)
@@ -548,7 +607,7 @@ extern "C" int tipk_gather_sum_finalize(const float* partial, const int32_t* row
     if (n_rows == 0) return TIPK_OK;
     if (!partial || !rows || !out || n_rows > 0x7fffffffLL) return TIPK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    Epilogue ep{row_scale, bias, relu, nullptr, 0, 0, nullptr, 0, nullptr, 0};
+    Epilogue ep{row_scale, bias, relu, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr};
     const bool vec = d % 4 == 0 && ld_out % 4 == 0 && aligned16(partial) && aligned16(out) && (!bias || aligned16(bias));
     if (vec && max_slots > 0 && max_slots <= 8 && d <= 128) {
         switch (pow2_at_least(d / 4)) {

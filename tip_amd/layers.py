@@ -180,27 +180,35 @@ class GCNConv(nn.Module):
         self._cache = _PlanCache()
         self._cache_rows = _PlanCache()
 
-    def forward(self, x, edge_index, fuse_relu=False, rows=None):
+    def aggregates_first(self, x, rows):
+        """True if forward(x, ..., rows=rows) takes the aggregate-first route (the only one that honours gate_input)."""
+        return rows is not None and not x.is_sparse and not _is_identity_features(x) and \
+            ops.gather_sum_lin_supported(self.in_channels, self.out_channels, group_slots_for(self.in_channels))
+
+    def forward(self, x, edge_index, fuse_relu=False, rows=None, gate_input=False, link=None):
         """rows (extension): ascending int64 node ids -- return only these rows of the layer's output, [len(rows), out]
-        (`gcn_norm_graph(rows=...)`: the rows nobody reads are neither aggregated nor back-propagated through)."""
+        (`gcn_norm_graph(rows=...)`: the rows nobody reads are neither aggregated nor back-propagated through).
+        fuse_relu='gated_downstream' / gate_input / link (extension, `ops.GateLink`): the ReLU hand-over between this layer
+        and the ONE consumer of its output (FMEncoder: conv1 -> conv2)."""
         n = x.shape[0]
-        if rows is not None and not x.is_sparse and not _is_identity_features(x) and \
-                ops.gather_sum_lin_supported(self.in_channels, self.out_channels, group_slots_for(self.in_channels)):
+        if gate_input and not self.aggregates_first(x, rows):
+            raise NotImplementedError('gate_input is wired for the aggregate-first route only')
+        if self.aggregates_first(x, rows):
             # few rows kept: aggregate first, the dense map on the kept rows in the gather's own launch (ops._GCNConvAggFirst);
             # the plans move rows of in_channels floats
             graph = self._cache_rows.get((edge_index, rows),
                                          lambda: gcn_norm_graph(edge_index, n, self.chunk, self.in_channels, rows))
-            return ops.gcn_conv_agg_first(x, self.lin.weight, self.bias, graph, fuse_relu)
+            return ops.gcn_conv_agg_first(x, self.lin.weight, self.bias, graph, fuse_relu, gate_input, link)
         if rows is not None:
             graph = self._cache_rows.get((edge_index, rows), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels, rows))
         else:
             graph = self._cache.get((edge_index,), lambda: gcn_norm_graph(edge_index, n, self.chunk, self.out_channels))
         if _is_identity_features(x):
-            return ops.gcn_conv(None, self.lin.weight, self.bias, graph, fuse_relu)      # lin(I) = W^T
+            return ops.gcn_conv(None, self.lin.weight, self.bias, graph, fuse_relu, link)      # lin(I) = W^T
         if x.is_sparse:
             xl = self._feat.apply_table(x, ops.linear_t(None, self.lin.weight))
             return ops.aggregate(xl, graph, bias=self.bias, relu=fuse_relu)
-        return ops.gcn_conv(x, self.lin.weight, self.bias, graph, fuse_relu)
+        return ops.gcn_conv(x, self.lin.weight, self.bias, graph, fuse_relu, link)
 
     def __repr__(self):
         return 'GCNConv(%d, %d)' % (self.in_channels, self.out_channels)
@@ -555,8 +563,19 @@ class FMEncoder(nn.Module):
         # Exact: the rows left out feed nothing.  `PPEncoder.forward` as a module of its own still returns every row.
         rows = self.hgcn.source_rows(dp_edge_index) if self.prune_pp_rows else None
         if rows is not None and rows.numel() < x_prot.shape[0]:
-            h1 = self.pp_encoder.conv1(x_prot, pp_edge_index, fuse_relu=True)
-            h_prot = self.pp_encoder.conv2(h1, pp_edge_index, rows=rows)              # [len(rows), hid2]
+            c1, c2 = self.pp_encoder.conv1, self.pp_encoder.conv2
+            g_in = group_slots_for(c2.in_channels)
+            if (_is_identity_features(x_prot) or not x_prot.is_sparse) and \
+                    ops.gather_sum_lin_supported(c2.in_channels, c2.out_channels, g_in) and \
+                    ops.lib().tipk_gather_sum_riders_supported(c2.in_channels, g_in):
+                # conv2 runs aggregate-first and its transposed aggregation has 1024-thread workgroups: conv1's ReLU backward
+                # and the partial rows of conv1's bias gradient are produced in THAT launch's epilogue (h1 has no other consumer)
+                link = ops.GateLink() if c1.bias is not None else None
+                h1 = c1(x_prot, pp_edge_index, fuse_relu='gated_downstream', link=link)
+                h_prot = c2(h1, pp_edge_index, rows=rows, gate_input=True, link=link)     # [len(rows), hid2]
+            else:
+                h1 = c1(x_prot, pp_edge_index, fuse_relu=True)
+                h_prot = c2(h1, pp_edge_index, rows=rows)                                  # [len(rows), hid2]
         else:
             rows = None
             h_prot = self.pp_encoder(x_prot, pp_edge_index)                           # P-P GCN x2

@@ -57,10 +57,17 @@ class _timed(object):
 # ---------------------------------------------------------------------------------------------
 # launch wrappers (one C call each)
 # ---------------------------------------------------------------------------------------------
-def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None, riders=()):
+def gather_sum_epilogue_supported(plan, d):
+    """True if `gather_sum(..., gate=, colsum=True, riders=)` runs as ONE launch on this plan (grouped, 1024-thread workgroups)."""
+    return bool(not plan.n_slots and plan.items.shape[0] > 0 and d % 4 == 0 and lib().tipk_gather_sum_riders_supported(d, plan.group_slots))
+
+
+def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None, riders=(), gate=None, colsum=False):
     """out[n_out, d] per `plan` over `table` [n_table, d] (include/tipk.h section 1).
     riders: up to 3 `slab_job`s that are ready now -- summed by further workgroups of the SAME launch when the plan's
-    workgroups have 1024 threads (`tipk_gather_sum_riders`), by a grouped slab-sum launch of their own otherwise."""
+    workgroups have 1024 threads (`tipk_gather_sum_riders`), by a grouped slab-sum launch of their own otherwise.
+    gate [n_out, d]: out = gate > 0 ? out : 0;  colsum: also return the per-workgroup column sums of out as [W, 1, d] (both only
+    where `gather_sum_epilogue_supported`)."""
     table = _f32c(table)
     require_device(table, plan.items)
     d = table.shape[1]
@@ -70,15 +77,22 @@ def gather_sum(plan, table, row_scale=None, bias=None, relu=False, out=None, rid
     riders = list(riders)
     st = stream_ptr(table.device)
     L = lib()
-    if riders and len(riders) <= 3 and not plan.n_slots and plan.items.shape[0] > 0 and \
-            L.tipk_gather_sum_riders_supported(d, plan.group_slots):
-        arr = (SlabSumDesc * len(riders))(*[r.desc for r in riders])
+    one_launch = (riders or gate is not None or colsum) and len(riders) <= 3 and gather_sum_epilogue_supported(plan, d)
+    assert one_launch or (gate is None and not colsum), 'gate / colsum need a grouped plan with 1024-thread workgroups'
+    if one_launch:
+        arr = (SlabSumDesc * max(1, len(riders)))(*[r.desc for r in riders])
+        parts = None
+        if colsum:
+            parts = torch.empty((-(-plan.items.shape[0] // plan.group_slots), 1, d), dtype=torch.float32, device=table.device)
+        if gate is not None:
+            assert tuple(gate.shape) == tuple(out.shape) and gate.stride(1) == 1 and gate.dtype == torch.float32
         with _timed('gather_sum[%s,d=%d]+%d sums' % (plan.tag, d, len(riders))):
             check(L.tipk_gather_sum_riders(ptr(table), table.stride(0), table.shape[0], ptr(plan.row_id), ptr(plan.edge_w),
                                            ptr(plan.items), plan.items.shape[0], ptr(out), out.stride(0), ptr(row_scale),
-                                           ptr(bias), int(relu), d, plan.group_slots, arr, len(riders), st),
+                                           ptr(bias), int(relu), d, plan.group_slots, ptr(gate),
+                                           gate.stride(0) if gate is not None else 0, ptr(parts), arr, len(riders), st),
                   'tipk_gather_sum_riders')
-        return out
+        return (out, parts) if colsum else out
     partial = None
     if plan.n_slots:
         partial = torch.empty((plan.n_slots, d), dtype=torch.float32, device=table.device)
@@ -1569,16 +1583,19 @@ class _GCNConv(torch.autograd.Function):
     1-row product) -- leave in ONE grouped launch (PyG GCNConv.forward; src/layers.py:392-394)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, graph, relu):
+    def forward(ctx, x, weight, bias, graph, relu, link=None):
+        """relu: False | True | 'gated_downstream' -- the ReLU is applied here, its backward mask AND the column sums of the
+        masked gradient (d bias, as partial rows in `link.parts`) are produced by the ONE consumer of the output, which runs
+        with gate_input=True and the same `link` (`_GCNConvAggFirst`: in the epilogue of its transposed aggregation)."""
         ctx.identity = x is None
         if x is None:
             xl = transpose(weight)                                       # lin(I) = W^T
         else:
             x = _f32c(x)
             xl = gemm(x, weight.t())
-        out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=relu)
-        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
-        ctx.save_for_backward(x, weight, out if relu else None)
+        out = gather_sum(graph.fwd, xl, row_scale=graph.scale, bias=bias, relu=bool(relu))
+        ctx.graph, ctx.relu, ctx.has_bias, ctx.link = graph, relu, bias is not None, link
+        ctx.save_for_backward(x, weight, out if relu is True else None)
         return out
 
     @staticmethod
@@ -1587,11 +1604,17 @@ class _GCNConv(torch.autograd.Function):
         graph = ctx.graph
         g = _f32c(g).contiguous()
         bias_parts = None
-        if ctx.relu and ctx.has_bias:                                   # ReLU gate + stage 1 of d bias in one pass
+        handed = ctx.relu == 'gated_downstream'                         # g arrives masked; its column sums may come with it
+        if handed:
+            g_pre = g
+            bias_parts = ctx.link.parts if (ctx.link is not None and ctx.has_bias) else None
+            if ctx.link is not None:
+                ctx.link.parts = None
+        elif ctx.relu and ctx.has_bias:                                 # ReLU gate + stage 1 of d bias in one pass
             fused = gate_colsum(g, out)
             if fused is not None:
                 g_pre, bias_parts = fused
-        if bias_parts is None:
+        if bias_parts is None and not handed:
             g_pre = rows_affine(g, gate=out) if ctx.relu else g
         g_agg = rows_affine(g_pre, row_mul=graph.scale) if graph.scale is not None else g_pre
         s_bias = None
@@ -1609,10 +1632,10 @@ class _GCNConv(torch.autograd.Function):
             # then equal the parameter's, so the optimizer's fused / foreach paths apply
             g_w = g_table.t() if weight.t().is_contiguous() else transpose(g_table)
             if s_bias is not None:
-                return None, g_w, s_bias.out.view(-1), None, None
+                return None, g_w, s_bias.out.view(-1), None, None, None
             if j_b is not None:
                 gemm_group([j_b])
-            return None, g_w, (j_b.out.view(-1) if j_b else None), None, None
+            return None, g_w, (j_b.out.view(-1) if j_b else None), None, None, None
         # d W in the parameter's own memory layout (tip_amd.layers._Lin keeps [in, out] storage behind the [out, in]
         # shape): autograd's AccumulateGrad otherwise re-lays the gradient out with a copy kernel of its own
         w_t = weight.t().is_contiguous() and not weight.is_contiguous()
@@ -1622,14 +1645,23 @@ class _GCNConv(torch.autograd.Function):
         if bias_parts is not None:                                      # rides in the grouped slab sum below
             s_b = slab_job(bias_parts)
             gemm_group([j for j in (j_w, j_x) if j is not None], [s_b])
-            return (j_x.out if j_x else None), g_w, s_b.out.view(-1), None, None
+            return (j_x.out if j_x else None), g_w, s_b.out.view(-1), None, None, None
         gemm_group([j for j in (j_w, j_x, j_b) if j is not None])
-        return (j_x.out if j_x else None), g_w, (j_b.out.view(-1) if j_b else None), None, None
+        return (j_x.out if j_x else None), g_w, (j_b.out.view(-1) if j_b else None), None, None, None
 
 
-def gcn_conv(x, weight, bias, graph, relu=False):
+class GateLink(object):
+    """Hand-over between a ReLU layer (`relu='gated_downstream'`) and the one consumer of its output (`gate_input=True`): the
+    consumer's backward pass leaves the column sums of the masked gradient here (partial rows [W, 1, d]) for the layer's."""
+    __slots__ = ('parts',)
+
+    def __init__(self):
+        self.parts = None
+
+
+def gcn_conv(x, weight, bias, graph, relu=False, link=None):
     """x = None means identity features."""
-    return _GCNConv.apply(x, weight, bias, graph, relu)
+    return _GCNConv.apply(x, weight, bias, graph, relu, link)
 
 
 class _GCNConvAggFirst(torch.autograd.Function):
@@ -1640,16 +1672,18 @@ class _GCNConvAggFirst(torch.autograd.Function):
     gather -- 1 + 2 launches where transform-first took 2 + 3 (src/layers.py:392-394)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, graph, relu):
+    def forward(ctx, x, weight, bias, graph, relu, gate_input=False, link=None):
+        """gate_input: x is the ReLU output of a layer called with relu='gated_downstream' -- dx is masked with (x > 0), and
+        the column sums of the masked dx go to `link.parts`, in the epilogue of the transposed aggregation."""
         x = _f32c(x)
         agg, out = gather_sum_lin(graph.fwd, x, weight, bias, relu, row_scale=graph.scale)
-        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
-        ctx.save_for_backward(agg, weight, out if relu else None)
+        ctx.graph, ctx.relu, ctx.has_bias, ctx.gate_input, ctx.link = graph, relu, bias is not None, gate_input, link
+        ctx.save_for_backward(agg, weight, out if relu else None, x if gate_input else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        agg, weight, out = ctx.saved_tensors
+        agg, weight, out, x_in = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g).contiguous()
         if ctx.relu:
@@ -1675,12 +1709,22 @@ class _GCNConvAggFirst(torch.autograd.Function):
         g_x = None
         if j_x is not None:
             gw = j_x.out if graph.scale is None else rows_affine(j_x.out, row_mul=graph.scale)
-            g_x = gather_sum(graph.bwd, gw, riders=riders)
-        return g_x, g_w, (j_b.out.view(-1) if j_b is not None else None), None, None
+            if ctx.gate_input and gather_sum_epilogue_supported(graph.bwd, gw.shape[1]):
+                # the producer's ReLU backward and the partial rows of ITS bias gradient in this launch's epilogue
+                want = ctx.link is not None
+                res = gather_sum(graph.bwd, gw, riders=riders, gate=x_in, colsum=want)
+                g_x = res[0] if want else res
+                if want:
+                    ctx.link.parts = res[1]
+            else:
+                g_x = gather_sum(graph.bwd, gw, riders=riders)
+                if ctx.gate_input:
+                    g_x = rows_affine(g_x, gate=x_in)
+        return g_x, g_w, (j_b.out.view(-1) if j_b is not None else None), None, None, None, None
 
 
-def gcn_conv_agg_first(x, weight, bias, graph, relu=False):
-    return _GCNConvAggFirst.apply(x, weight, bias, graph, relu)
+def gcn_conv_agg_first(x, weight, bias, graph, relu=False, gate_input=False, link=None):
+    return _GCNConvAggFirst.apply(x, weight, bias, graph, relu, gate_input, link)
 
 
 class _DistMult(torch.autograd.Function):

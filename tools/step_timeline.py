@@ -4,7 +4,7 @@ import csv, glob, os, sys
 root = sys.argv[1]
 f = sorted(glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-ANCHOR = sys.argv[2] if len(sys.argv) > 2 else 'gate_colsum_kernel'   # a kernel that is launched once per step
+ANCHOR = sys.argv[2] if len(sys.argv) > 2 else 'drug_mix_gather_fwd_kernel'   # a kernel that is launched once per step
 fw = [i for i, r in enumerate(rows) if ANCHOR in r['Kernel_Name']]
 steps = [(a, b) for a, b in zip(fw, fw[1:]) if b - a > 10]          # skip the back-to-back launch timing loops
 per = {}
