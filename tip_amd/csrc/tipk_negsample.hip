@@ -128,7 +128,7 @@ template <typename OT>
 __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_unit_ptr,
     const int32_t* __restrict__ wg_units, int64_t n_nodes, uint64_t seed, uint64_t* __restrict__ call_counter, int advance,
-    const int64_t* __restrict__ pos_offset, OT* __restrict__ out_u, OT* __restrict__ out_v) {
+    const int64_t* __restrict__ pos_offset, OT* __restrict__ out_u, OT* __restrict__ out_v, int dbg) {
     extern __shared__ unsigned bm[];
     const uint64_t call_no = call_counter ? call_counter[0] : 0ull;
     const uint64_t key = call_counter ? call_key(call_counter[1], call_no) : seed;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
         const int64_t ub = wg_units[3 * ui + 1], ue = wg_units[3 * ui + 2];
         const int64_t a = rel_ptr[rel], b = rel_ptr[rel + 1];
         const int64_t off = pos_offset ? pos_offset[rel] : 0;
-        if (rel != have) {
+        if (rel != have && !TIPK_DBG(dbg & 2)) {           // (debug builds: 2 = no bitmap, 1 = no draws, 4 = no clear / barriers)
             __syncthreads();                               // the previous relation's tests are done
             for (int i = t; i < words; i += 1024) bm[i] = 0u;
             __syncthreads();
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
             __syncthreads();
             have = rel;
         }
+        if (!TIPK_DBG(dbg & 1))
         for (int64_t e = ub + t; e < ue; e += 1024) {
             // n^2 < 2^24 here (the bitmap fits LDS): the candidate mulhi64(x, n^2) is two 32 x 32 -> 64 products, and
             // (u, v) = (cand / n, cand % n) an exact float quotient with a one-step correction -- the same integers as
@@ -202,25 +203,26 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t bm_bytes = (((int64_t)n_nodes * n_nodes + 31) / 32) * 4;
+    const int dbg = TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG));
     if (wg_unit_ptr && wg_units && n_wg > 0 && n_wg <= 65535 && bm_bytes <= 150 * 1024 && n_nodes <= 4095) {
         if (idx_bytes == 8) {
             auto kern = neg_sample_bitmap_kernel<int64_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v, dbg);
         } else if (idx_bytes == 4) {
             auto kern = neg_sample_bitmap_kernel<int32_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v, dbg);
         } else if (idx_bytes == 2 && n_nodes <= 65535) {
             auto kern = neg_sample_bitmap_kernel<PackedOut>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u, dbg);
         } else {
             return TIPK_EINVAL;
         }
