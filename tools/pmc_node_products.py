@@ -15,8 +15,10 @@ for layer in (enc.rgcn1, enc.rgcn2):
     d, nb, r, n = layer.out_channels, layer.num_bases, layer.num_relations, graph.scale.numel()
     g = torch.randn(n, d, device=dev)
     att = torch.randn(r, nb, device=dev)
-    xb = torch.randn(nb, n, d, device=dev)
+    # the operands as the step hands them over: XB node-major (rows padded to 32 columns) through strides, and base-innermost
+    xb = torch.randn(n, nb, 32 if d <= 32 else d, device=dev).permute(1, 0, 2)[:, :, :d]
+    xbt = xb.permute(1, 2, 0).contiguous()
     for _ in range(3):
         dyc = ops.rel_stream_bwd(rs, g, row_scale=graph.scale)
-        ops.node_products(dyc, rs.compact, att, xb)
+        ops.node_products(dyc, rs.compact, att, xb, xbt)
 torch.cuda.synchronize()
