@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 15
+#define TIPK_ABI_VERSION 16
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -404,6 +404,39 @@ int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32
                             const float* att, int64_t ld_att, int n_bases,
                             const float* xb, int64_t xb_sb, int64_t xb_su, const float* xbt /* nullable */,
                             float* dxb, int64_t dxb_sb, int64_t dxb_su, float* datt_slabs, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 2e. The BACKWARD pass of the pair form 2c (autograd of src/layers.py:159-180 for graphs whose forward pass ran as
+ *     cells + tipk_pair_product): with g' = g / deg and the cells C the forward pass left in place,
+ *
+ *        dxb[b, u, c]     = sum_{v linked to u} C[u, v, b] * g'[v, c]
+ *        pg [slot(u, v)]  = XB[u] . g'[v]            one row of n_bases floats per LINKED (u, v): d C[u, v, :]
+ *        datt[r, :]       = sum over the pairs (u, v) that relation r links of pg[slot(u, v)]
+ *
+ *     -- no row of dY = A_r^T g' is ever formed (sections 2b / 2d), nothing is per relation until the last line, and on a
+ *     symmetric graph that line walks HALF the edges: datt[r] = sum_{u <= v} (pg[slot(u, v)] + pg[slot(v, u)]).
+ *     tipk_rgcn_pair_grads (the first two lines), plan arrays of tip_amd/plan.py `build_pair_bwd_plan`:
+ *       slots [n_slots][4]  { v, float bits of 1 / deg(v), cell line of (u, v), 0 }: the neighbours of a node in runs of
+ *          32 (n_slots % 32 == 0; pads carry a valid v / line and the factor 0.0f, so they add zeros -- g must be finite);
+ *          cell line L = the n_bases floats at cells + L * n_bases (a symmetric forward pass keeps (min, max) only);
+ *       node_desc [n_nodes][4]  { node u, its first slot, its tiles of 32 slots, 0 } by DECREASING tile count;
+ *       cells: n_lines lines of n_bases floats; xb [n_nodes][n_bases][32] as in 2c; g [n_nodes][ld_g]; dxb element
+ *       (b, u, c) at dxb[b * dxb_sb + u * dxb_su + c], written COMPLETE; pg [n_slots][n_bases] (pad rows are written too).
+ *     n_bases = 32, d in {16, 32} (`tipk_rgcn_pair_grads_supported`).  All sums in fixed order: bitwise reproducible.
+ *     tipk_stream_gather_parts (the last line) is tipk_stream_gather (1d) with a table PER WORKGROUP: the pairs are cut
+ *     into partitions of part_len rows that fit in LDS, row i of partition p = table[part_rows[p * part_len + i][0]] +
+ *     table[part_rows[..][1]] (table = pg with one more row of zeros for "no second term" and for pad rows), wg_part
+ *     [n_wg] = the partition a workgroup stages, ids = rows inside the partition, output rows = p * n_rel + r
+ *     (out [n_parts * n_rel][d], added over p in order by tipk_sum_slabs(_group)).  d = 32 (one 128-byte row per pair).
+ */
+int tipk_rgcn_pair_grads_supported(int n_bases, int d);
+int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const float* xb, const float* g, int64_t ld_g,
+                         int64_t n_nodes, int n_bases, int d, const int32_t* node_desc, const int32_t* slots,
+                         int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg, tipk_stream_t stream);
+int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, const int32_t* part_rows, int64_t part_len,
+                             const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr, const uint32_t* cells,
+                             const uint16_t* ids, int idx_unit, const int32_t* zero_ptr /* nullable */,
+                             const int32_t* zero_rows, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).

@@ -291,6 +291,81 @@ def test_node_products_compact(ops, R, N, d, nb):
     assert torch.equal(g_xb.cpu().double(), (ai.double().t() @ dyi).view(nb, N, d))
 
 
+def _random_dd_graph(N, R, per_rel, g, symmetric, hub=True):
+    """directed edge list of R relations over N nodes: (src, dst, rel); symmetric -> every pair in both directions;
+    a hub node linked to most others, nodes without any edge, a relation with one pair, duplicate-free inside a relation."""
+    src, dst, rel = [], [], []
+    for r in range(R):
+        m = 1 if r == R - 1 else int(torch.randint(1, per_rel, (1,), generator=g))
+        u = torch.randint(0, max(2, (2 * N) // 3), (m,), generator=g)
+        v = torch.randint(0, max(2, (2 * N) // 3), (m,), generator=g)
+        if hub and r % 3 == 0:
+            u[: m // 2] = 1
+        k = u != v
+        u, v = u[k], v[k]
+        if symmetric:
+            key = torch.unique(torch.minimum(u, v) * N + torch.maximum(u, v))
+            a, b = key // N, key % N
+            u, v = torch.cat([a, b]), torch.cat([b, a])
+        else:
+            key = torch.unique(u * N + v)
+            u, v = key // N, key % N
+        src.append(u); dst.append(v); rel.append(torch.full((u.numel(),), r))
+    return torch.cat(src), torch.cat(dst), torch.cat(rel)
+
+
+@pytest.mark.parametrize('R,N,d,symmetric,per_rel', [(1097, 645, 32, True, 1200), (1097, 645, 16, True, 1200), (40, 100, 32, False, 300),
+                                                     (33, 129, 16, False, 200), (7, 31, 32, True, 60), (200, 77, 16, True, 90)])
+def test_pair_grads_backward(ops, R, N, d, symmetric, per_rel):
+    """tipk_rgcn_pair_grads + tipk_stream_gather_parts (tipk.h section 2e): the backward pass of the pair form from the cells
+    the forward pass left (half of them on a symmetric graph) == the dense definition in fp64 (d XB complete, d att over
+    every directed edge), reproducible bit for bit, exact on integers; hub node, nodes without edges, one-pair relation."""
+    from tip_amd.plan import build_pair_bwd_plan
+    nb = 32
+    g = torch.Generator().manual_seed(R + N + d)
+    src, dst, rel = _random_dd_graph(N, R, per_rel, g, symmetric)
+    scale = 1.0 / torch.bincount(dst, minlength=N).clamp(min=1).float()
+    plan = build_pair_bwd_plan(src, dst, rel, N, R, scale, symmetric, 32, nb // 4, ops.rel_stream_piece()).to(DEV)
+    n_pad = -(-N // 8) * 8
+
+    def run(att, xb, gz):
+        # the buffers as the forward pass leaves them: cells C[u, v, :] (u <= v only on a symmetric graph) + trailing zeros,
+        # XB node-major with rows padded to 32 columns
+        C = torch.zeros(N * N, nb, dtype=torch.float64)
+        C.index_add_(0, src * N + dst, att.double()[rel])
+        want_xb = torch.einsum('uvb,vc->buc', C.view(N, N, nb), gz.double() * scale.double().unsqueeze(1))
+        want_att = torch.zeros(R, nb, dtype=torch.float64)
+        want_att.index_add_(0, rel, torch.einsum('ebc,ec->eb', xb.double()[src], (gz.double() * scale.double().unsqueeze(1))[dst]))
+        flat = torch.zeros(n_pad * N * nb + 64)
+        cm = C.float().view(N, N, nb).clone()
+        if symmetric:
+            cm[~torch.triu(torch.ones(N, N, dtype=torch.bool))] = float('nan')     # never read: the mirrored half does not exist
+        flat[:N * N * nb] = cm.view(-1)
+        xb_pad = torch.zeros(n_pad, nb, 32)
+        xb_pad[:N, :, :d] = xb
+        flat, xb_pad = flat.to(DEV), xb_pad.to(DEV)
+        cells = flat[:n_pad * N * nb].view(n_pad, N, nb)
+        job, g_xb = ops.pair_grads(plan, cells, xb_pad[:, :, :d], gz.to(DEV))
+        ops.gemm_group([], [job])
+        job2, g_xb2 = ops.pair_grads(plan, cells, xb_pad[:, :, :d], gz.to(DEV))
+        ops.gemm_group([], [job2])
+        assert torch.equal(job2.out, job.out) and torch.equal(g_xb2, g_xb)
+        return job.out, g_xb, want_att, want_xb
+
+    att, xb, gz = torch.randn(R, nb, generator=g), torch.randn(N, nb, d, generator=g), torch.randn(N, d, generator=g)
+    g_att, g_xb, want_att, want_xb = run(att, xb, gz)
+    close(g_att, want_att, rtol=2e-5, atol=2e-5 * float(want_att.abs().max()))
+    close(g_xb, want_xb, rtol=2e-5, atol=2e-5 * float(want_xb.abs().max()))
+    # exact on integers (1 / deg = a power of two everywhere: every product and every summation order is exact)
+    scale = torch.full((N,), 0.5)
+    plan = build_pair_bwd_plan(src, dst, rel, N, R, scale, symmetric, 32, nb // 4, ops.rel_stream_piece()).to(DEV)
+    ai = torch.randint(-3, 4, (R, nb), generator=g).float()
+    xi = torch.randint(-3, 4, (N, nb, d), generator=g).float()
+    gi = torch.randint(-3, 4, (N, d), generator=g).float()
+    g_att, g_xb, want_att, want_xb = run(ai, xi, gi)
+    assert torch.equal(g_att.cpu().double(), want_att) and torch.equal(g_xb.cpu().double(), want_xb)
+
+
 @pytest.mark.parametrize('R,N,d', [(70, 645, 32), (33, 100, 16), (1097, 37, 8)])
 def test_unwritten_rows_masked_end_to_end(ops, R, N, d):
     """Rows (relation, node) without edges: the wave-stream gather with write_zeros=False leaves them untouched

@@ -662,3 +662,47 @@ def test_gcn_rows_subset_plans_and_compact_hierarchy_graph():
     gm = torch.randn(n_t, d, generator=g, dtype=torch.float64)
     torch.testing.assert_close(execute_plan_reference(hc.bwd, gm), execute_plan_reference(hg.bwd, gm)[rows], rtol=1e-12, atol=1e-12)
     assert float(execute_plan_reference(hg.bwd, gm).abs().sum() - execute_plan_reference(hg.bwd, gm)[rows].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('symmetric,part_rows', [(True, 40), (False, 64), (True, 1008)])
+def test_pair_bwd_plan_reference(symmetric, part_rows):
+    """`build_pair_bwd_plan` (include/tipk.h section 2e), interpreted in torch exactly as the two kernels walk it: slots,
+    tiles, cell lines (half the cells on a symmetric graph), partitions of the (symmetrised) pair-gradient table, the merged
+    wave-stream plan (every (partition, relation) row written once, by a wavefront of that partition) == the definition."""
+    from tip_amd.plan import build_pair_bwd_plan, execute_pair_bwd_reference
+    g = torch.Generator().manual_seed(7 + part_rows)
+    N, R, nb, d = 41, 13, 32, 16
+    src, dst, rel = [], [], []
+    for r in range(R):
+        m = 1 if r == 3 else int(torch.randint(2, 70, (1,), generator=g))
+        u, v = torch.randint(0, 30, (m,), generator=g), torch.randint(0, 30, (m,), generator=g)
+        k = u != v
+        u, v = u[k], v[k]
+        if symmetric:
+            key = torch.unique(torch.minimum(u, v) * N + torch.maximum(u, v))
+            u, v = torch.cat([key // N, key % N]), torch.cat([key % N, key // N])
+        else:
+            key = torch.unique(u * N + v)
+            u, v = key // N, key % N
+        src.append(u); dst.append(v); rel.append(torch.full((u.numel(),), r))
+    src, dst, rel = torch.cat(src), torch.cat(dst), torch.cat(rel)
+    scale = (1.0 / torch.bincount(dst, minlength=N).clamp(min=1).double()).float()
+    plan = build_pair_bwd_plan(src, dst, rel, N, R, scale, symmetric, n_wg=6, part_rows_max=part_rows)
+    assert plan.n_slots % 32 == 0 and plan.part_rows.shape == (plan.n_parts * plan.part_len, 2)
+    assert int(plan.node_desc[:, 2].sum()) * 32 == plan.n_slots and bool((plan.node_desc[:-1, 2] >= plan.node_desc[1:, 2]).all())
+    att = torch.randn(R, nb, generator=g, dtype=torch.float64)
+    xb = torch.randn(N, nb, d, generator=g, dtype=torch.float64)
+    gz = torch.randn(N, d, generator=g, dtype=torch.float64)
+    C = torch.zeros(N * N, nb, dtype=torch.float64)
+    C.index_add_(0, src * N + dst, att[rel])
+    cells = C.clone().view(N, N, nb)
+    if symmetric:
+        cells[~torch.triu(torch.ones(N, N, dtype=torch.bool))] = float('nan')        # never read
+    dxb, pg, datt = execute_pair_bwd_reference(plan, cells.view(N * N, nb), xb, gz, nb)
+    gp = gz * scale.double().unsqueeze(1)
+    want_xb = torch.einsum('uvb,vc->buc', C.view(N, N, nb), gp)
+    want_att = torch.zeros(R, nb, dtype=torch.float64)
+    want_att.index_add_(0, rel, torch.einsum('ebc,ec->eb', xb[src], gp[dst]))
+    torch.testing.assert_close(dxb, want_xb, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(datt, want_att, rtol=1e-12, atol=1e-12)
+    assert not bool(torch.isnan(pg).any())

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class TipkError(RuntimeError):
@@ -78,6 +78,9 @@ SIGNATURES = {
     'tipk_rel_gather_chunk': (_I, [_L, _I, _I]),
     'tipk_pair_product_supported': (_I, [_I, _I]),
     'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'tipk_rgcn_pair_grads_supported': (_I, [_I, _I]),
+    'tipk_rgcn_pair_grads': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _L, _P, _L, _L, _P, _P]),
+    'tipk_stream_gather_parts': (_I, [_P, _L, _I, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
     'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),

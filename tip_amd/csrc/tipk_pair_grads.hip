@@ -1,0 +1,248 @@
+// The dense half of the pair-form D-D BACKWARD pass (include/tipk.h section 2e; autograd of src/layers.py:159-180).
+//
+// The forward pass (section 2c) is   agg[v] = sum_u C[u, v, :] . XB[u],   C[u, v, :] = sum of att[r, :] over the relations
+// linking u -> v.  Its two gradients, with g' = g / deg:
+//
+//     dXB[b, u, c]  = sum_{v linked to u} C[u, v, b] * g'[v, c]                      (uses the cells the forward pass left)
+//     dC [u, v, b]  = sum_c XB[u][b][c] * g'[v, c]      for the LINKED pairs only     ("pair gradient", one 128-byte row)
+//
+// and d att[r, :] = sum over the pairs r links of dC -- a wave-stream gather of those rows (tipk_stream_gather_parts).
+// Round 3/4 went through dY = A_r^T g' (one row per (relation, source node), 329 188 rows = 42 MB at BioSNAP layer 1, a
+// gather over all 8.3 M directed edges) and two products on it, of which the d att one multiplied 53 % zero rows
+// (tipk_rgcn_node_products: 31 us + a 28 us gather).  Here nothing is per relation: a drug pair is one K-step.
+//
+// One workgroup per source node u (heaviest first), its linked pairs in tiles of 32 SLOTS (a slot = one neighbour v_j,
+// plan: tip_amd/plan.py `build_pair_bwd_plan`), a wave takes every 4th tile.  Per tile, with v_mfma_f32_32x32x2_f32
+// (d = 32) / v_mfma_f32_16x16x4_f32 (the d XB product at d = 16: no half-empty 32-column tile):
+//   * g' rows of the 32 neighbours: lane (j, half) loads 64 (32) contiguous bytes of row v_j, scales by 1 / deg(v_j) (kept in
+//     the slot) = the A operand of the dC product as it lies in registers; B = XB[u] (loaded once per node);
+//     the [32 slots x 32 bases] result leaves as 16 stores of two full 128-byte lines each;
+//   * the same g' tile, transposed through a wave-private LDS tile (no barrier: LDS operations of a wave complete in
+//     order), is the B operand of the dXB product; A = the neighbours' cell lines, one dword per lane and K-step, two full
+//     lines per load (lane = base);  K runs over LINKED pairs only.
+// Two tiles in flight per wave in statically named register sets, slot words requested one tile further ahead and in
+// front of that step's loads (vector-memory operations retire in order).  The 4 waves' dXB tiles are added through LDS in
+// wave order: bitwise reproducible.
+#include <stdlib.h>
+#include "tipk_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+
+constexpr int PG_WAVES = 4;
+constexpr int PG_THREADS = PG_WAVES * 64;
+
+struct PgArgs {
+    const float* cells;                 // [..][n_bases = 32] lines, addressed by slot.line
+    const float* xb;                    // [n_nodes][32 bases][32]  (rows padded to 32 columns)
+    const float* g; int ld_g;           // [n_nodes][d]
+    const int4* node_desc;              // [n_nodes] {u, first slot, tiles, 0}, heaviest first
+    const int4* slots;                  // [n_slots] {v, bits of 1 / deg(v) (0 for a pad), cell line of (u, v), 0}
+    float* dxb; int64_t dxb_sb, dxb_su;
+    float* pg;                          // [n_slots][32]
+};
+
+__device__ __forceinline__ float pg_ldg(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float4 pg_ldg4(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// LDS accesses of ONE wave complete in issue order; what has to be stopped is the compiler moving a read of the tile in
+// front of the other lanes' writes
+__device__ __forceinline__ void pg_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void pair_grads_kernel(PgArgs a) {
+    static_assert(D == 16 || D == 32, "d = 16 | 32");
+    constexpr int H = D / 2;                               // columns of g' per lane half (dC product)
+    constexpr int LDT = D + 4;                             // floats per row of the wave's g' tile: 16-byte aligned rows,
+                                                           // neighbouring rows start 4 banks apart
+    constexpr int NA = 16;                                 // cell dwords per lane and tile (both widths)
+    __shared__ __attribute__((aligned(16))) float lds[PG_WAVES * 1024 > PG_WAVES * 32 * LDT ? PG_WAVES * 1024 : PG_WAVES * 32 * LDT];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n = lane & 31, kh = lane >> 5;               // 32x32x2 operands: row / column, k half
+    const int m16 = lane & 15, q16 = lane >> 4;            // 16x16x4 operands: row / column, k quarter
+    const int4 nd = a.node_desc[blockIdx.x];               // uniform index: one scalar load
+    const int u = __builtin_amdgcn_readfirstlane(nd.x);
+    const int s_first = __builtin_amdgcn_readfirstlane(nd.y);
+    const int n_tiles = __builtin_amdgcn_readfirstlane(nd.z);
+    float* tile = lds + w * 32 * LDT;
+    const u32 ldg4 = (u32)a.ld_g * 4u;
+
+    // XB[u] as the B operand of the dC product: lane (base n, half kh) holds columns H kh .. H kh + H - 1
+    float xbf[H];
+    {
+        const u32 off = ((u32)u * 1024u + (u32)n * 32u + (u32)(H * kh)) * 4u;
+#pragma unroll
+        for (int i = 0; i < H / 4; ++i) {
+            const float4 x = pg_ldg4(a.xb, off + 16u * i);
+            xbf[4 * i] = x.x; xbf[4 * i + 1] = x.y; xbf[4 * i + 2] = x.z; xbf[4 * i + 3] = x.w;
+        }
+    }
+    f32x16 acc;                                            // d = 32: dXB[:, u, :] as one 32 x 32 tile
+    f32x4 acc_lo, acc_hi;                                  // d = 16: bases 0-15 / 16-31 x 16 columns
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc_lo[i] = 0.f; acc_hi[i] = 0.f; }
+
+    auto getslot = [&](int tl) {
+        tl = tl < n_tiles ? tl : n_tiles - 1;
+        return a.slots[s_first + tl * 32 + n];
+    };
+    // operands of tile `tl` (clamped: a tile past the end re-reads the last one and is never multiplied)
+    auto load = [&](const int4& s, float (&cv)[NA], float (&gk)[H], float& ss) {
+        if constexpr (D == 32) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int lj = __shfl(s.z, 2 * kk + kh, 64);
+                cv[kk] = pg_ldg(a.cells, (u32)lj * 128u + (u32)n * 4u);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int lj = __shfl(s.z, 4 * ks + q16, 64);
+                cv[2 * ks] = pg_ldg(a.cells, (u32)lj * 128u + (u32)m16 * 4u);
+                cv[2 * ks + 1] = pg_ldg(a.cells, (u32)lj * 128u + (u32)(16 + m16) * 4u);
+            }
+        }
+        const u32 goff = (u32)s.x * ldg4 + (u32)(H * kh) * 4u;
+#pragma unroll
+        for (int i = 0; i < H / 4; ++i) {
+            const float4 x = pg_ldg4(a.g, goff + 16u * i);
+            gk[4 * i] = x.x; gk[4 * i + 1] = x.y; gk[4 * i + 2] = x.z; gk[4 * i + 3] = x.w;
+        }
+        ss = __int_as_float(s.y);
+    };
+    auto compute = [&](int tl, const float (&cv)[NA], const float (&gk)[H], float ss) {
+        float gs[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) gs[i] = gk[i] * ss;                     // g'[v_j][H kh + i]
+        pg_wave_sync();                                                     // (the previous tile's reads are issued)
+#pragma unroll
+        for (int i = 0; i < H / 4; ++i)
+            tipk_st4(tile + n * LDT + H * kh + 4 * i, make_float4(gs[4 * i], gs[4 * i + 1], gs[4 * i + 2], gs[4 * i + 3]));
+        // dC tile [32 slots x 32 bases] = g' tile (A: lane = slot) . XB[u]^T (B: lane = base), K = d
+        f32x16 pc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pc[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < H; ++i) pc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[i], xbf[i], pc, 0, 0, 0);
+        pg_wave_sync();
+        // dXB += cells^T (A: lane = base) . g' tile (B: lane = column), K = the tile's 32 slots
+        if constexpr (D == 32) {
+            float bv[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) bv[kk] = tile[(2 * kk + kh) * LDT + n];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cv[kk], bv[kk], acc, 0, 0, 0);
+        } else {
+            float bv[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) bv[ks] = tile[(4 * ks + q16) * LDT + m16];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                acc_lo = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[2 * ks], bv[ks], acc_lo, 0, 0, 0);
+                acc_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[2 * ks + 1], bv[ks], acc_hi, 0, 0, 0);
+            }
+        }
+        // rows of dC: C/D layout of the 32x32 MFMA -- column = lane & 31 (base), row = (reg & 3) + 8 (reg >> 2) + 4 kh (slot)
+        float* o = a.pg + ((int64_t)(s_first + tl * 32)) * 32 + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32] = pc[r];
+    };
+
+    if (n_tiles > 0) {
+        float cX[NA], gX[H], cY[NA], gY[H];
+        float sX = 0.f, sY = 0.f;
+        int tl = w;
+        int4 slX = getslot(tl), slY = getslot(tl + PG_WAVES);
+        load(slX, cX, gX, sX);
+        for (; tl < n_tiles; tl += 2 * PG_WAVES) {
+            slX = getslot(tl + 2 * PG_WAVES);
+            load(slY, cY, gY, sY);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(tl, cX, gX, sX);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tl + PG_WAVES < n_tiles) {                                  // (uniform)
+                slY = getslot(tl + 3 * PG_WAVES);
+                load(slX, cX, gX, sX);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(tl + PG_WAVES, cY, gY, sY);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // the waves' tiles -> one, in wave order
+    __syncthreads();
+    float* red = lds;
+    float* o = a.dxb + (int64_t)u * a.dxb_su;
+    if constexpr (D == 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * 1024 + r * 64 + lane] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 1024 / PG_THREADS; ++j) {
+            const int e = t + j * PG_THREADS;
+            float s = red[e];
+#pragma unroll
+            for (int q = 1; q < PG_WAVES; ++q) s += red[q * 1024 + e];
+            const int r = e >> 6, l = e & 63;
+            o[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * a.dxb_sb + (l & 31)] = s;
+        }
+    } else {
+        // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { red[w * 512 + i * 64 + lane] = acc_lo[i]; red[w * 512 + (4 + i) * 64 + lane] = acc_hi[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 512 / PG_THREADS; ++j) {
+            const int e = t + j * PG_THREADS;
+            float s = red[e];
+#pragma unroll
+            for (int q = 1; q < PG_WAVES; ++q) s += red[q * 512 + e];
+            const int r = e >> 6, l = e & 63;
+            o[(int64_t)(16 * (r >> 2) + 4 * (l >> 4) + (r & 3)) * a.dxb_sb + (l & 15)] = s;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tipk_rgcn_pair_grads_supported(int n_bases, int d) {
+    return n_bases == 32 && (d == 16 || d == 32);
+}
+
+extern "C" int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const float* xb, const float* g, int64_t ld_g,
+                                    int64_t n_nodes, int n_bases, int d, const int32_t* node_desc, const int32_t* slots,
+                                    int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg,
+                                    tipk_stream_t stream) {
+    if (!tipk_rgcn_pair_grads_supported(n_bases, d)) return TIPK_EUNSUPPORTED;
+    if (!cells || !xb || !g || !node_desc || !slots || !dxb || !pg || n_nodes <= 0 || n_slots <= 0 || n_slots % 32 != 0 ||
+        ld_g < d || ld_g % 4 != 0)
+        return TIPK_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(cells) & 15) || (reinterpret_cast<uintptr_t>(xb) & 15) || (reinterpret_cast<uintptr_t>(g) & 15) ||
+        (reinterpret_cast<uintptr_t>(node_desc) & 15) || (reinterpret_cast<uintptr_t>(slots) & 15))
+        return TIPK_EINVAL;
+    // 32-bit byte offsets into cells, xb and g
+    if (n_lines <= 0 || n_lines * 128 >= (1LL << 32) || n_nodes * 4096 >= (1LL << 32) || n_nodes * ld_g * 4 >= (1LL << 32) ||
+        n_nodes > 0x7fffffffLL)
+        return TIPK_EUNSUPPORTED;
+    PgArgs a;
+    a.cells = cells; a.xb = xb; a.g = g; a.ld_g = (int)ld_g;
+    a.node_desc = reinterpret_cast<const int4*>(node_desc); a.slots = reinterpret_cast<const int4*>(slots);
+    a.dxb = dxb; a.dxb_sb = dxb_sb; a.dxb_su = dxb_su; a.pg = pg;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 32) hipLaunchKernelGGL(pair_grads_kernel<32>, dim3((unsigned)n_nodes), dim3(PG_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(pair_grads_kernel<16>, dim3((unsigned)n_nodes), dim3(PG_THREADS), 0, st, a);
+    TIPK_RETURN_LAUNCH();
+}

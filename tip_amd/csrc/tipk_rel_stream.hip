@@ -55,6 +55,10 @@ struct RsArgs {
     const float* out_scale;
     const float* bias;
     int relu;
+    // KIND 2 (tipk_stream_gather_parts): every workgroup stages ITS partition of a table that exists only as sums of two
+    // rows of `table`: LDS row i of partition p = table[part_rows[p * n_nodes + i].x] + table[...y]
+    const int2* part_rows;
+    const int32_t* wg_part;            // [n_wg] partition of a workgroup
 };
 
 // a lane's piece of a row: float4 (16-byte rows and wider) or float2 (8-byte rows: tables of up to 19 000 nodes)
@@ -80,7 +84,8 @@ template <> struct RsVec<2> {
     static __device__ __forceinline__ void relu(T& a) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); }
 };
 
-// KIND only names the launch in profiles (0: rows = (relation, node), the transposed pass; 1: rows = node pairs)
+// KIND 0 / 1 only name the launch in profiles (0: rows = (relation, node), the transposed pass; 1: rows = node pairs);
+// KIND 2: the table is per workgroup -- a partition of the symmetrised pair gradients (tipk_stream_gather_parts)
 template <int L, bool UNIT, int KIND, int VW = 4>
 __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tab[];        // [n_nodes + 1][dc], last row = 0 (the pad id's row)
@@ -129,6 +134,36 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     }
     const int total4 = n_nodes * q4;
     if (t < dc) tab[(int64_t)n_nodes * dc + t] = 0.f;
+    if constexpr (KIND == 2) {
+        // the partition in ONE batch of requests: row pairs first (8 lanes share one), then both rows of every piece
+        constexpr int PSTAGE = 8;
+        const int part = __builtin_amdgcn_readfirstlane(a.wg_part[blockIdx.x]);
+        const int2* rows = a.part_rows + (int64_t)part * n_nodes;
+        for (int base = 0; base < total4; base += 1024 * PSTAGE) {
+            int2 rr[PSTAGE];
+#pragma unroll
+            for (int u = 0; u < PSTAGE; ++u) {
+                int i = base + u * 1024 + t;
+                i = i < total4 ? i : total4 - 1;
+                rr[u] = rows[i / q4];
+            }
+            vec_t ga[PSTAGE], gb[PSTAGE];
+#pragma unroll
+            for (int u = 0; u < PSTAGE; ++u) {
+                int i = base + u * 1024 + t;
+                i = i < total4 ? i : total4 - 1;
+                const int c = (i % q4) * VW;
+                ga[u] = *reinterpret_cast<const vec_t*>(table + (int64_t)rr[u].x * a.ld_t + c);
+                gb[u] = *reinterpret_cast<const vec_t*>(table + (int64_t)rr[u].y * a.ld_t + c);
+            }
+#pragma unroll
+            for (int u = 0; u < PSTAGE; ++u) {
+                const int i = base + u * 1024 + t;
+                V::add(ga[u], gb[u]);
+                if (i < total4) *reinterpret_cast<vec_t*>(tab + (i / q4) * dc + (i % q4) * VW) = ga[u];
+            }
+        }
+    } else
     // the whole table in ONE round trip: up to RS_STAGE float4 per thread are requested before the first is stored
     // (the LDS holds at most 10 112 float4; a loop of 4-deep batches cost a dependent round trip per 64 KB)
     for (int base = 0; base < total4; base += 1024 * RS_STAGE) {
@@ -249,8 +284,11 @@ inline int rel_stream_split(int64_t n_nodes, int d, int max_split) {
 template <int L, int VW = 4>
 int launch_rs(const RsArgs& a, int n_wg, int split, int kind, hipStream_t st) {
     const size_t lds = (size_t)(a.n_nodes + 1) * a.dc * 4;
-    auto kern = kind ? (a.idx_mul == 1 ? stream_gather_kernel<L, true, 1, VW> : stream_gather_kernel<L, false, 1, VW>)
-                     : (a.idx_mul == 1 ? stream_gather_kernel<L, true, 0, VW> : stream_gather_kernel<L, false, 0, VW>);
+    void (*kern)(RsArgs) = kind ? (a.idx_mul == 1 ? stream_gather_kernel<L, true, 1, VW> : stream_gather_kernel<L, false, 1, VW>)
+                                : (a.idx_mul == 1 ? stream_gather_kernel<L, true, 0, VW> : stream_gather_kernel<L, false, 0, VW>);
+    if constexpr (L == 8 && VW == 4) {                                 // per-workgroup tables: 128-byte rows only
+        if (kind == 2) kern = a.idx_mul == 1 ? stream_gather_kernel<L, true, 2, VW> : stream_gather_kernel<L, false, 2, VW>;
+    }
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return tipk_hip_status(e);
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)split), dim3(1024), lds, st, a);
@@ -291,6 +329,7 @@ extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t 
     a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
     a.out = out; a.ld_out = ld_out; a.row_scale = row_scale;
     a.out_scale = out_scale; a.bias = bias; a.relu = relu;
+    a.part_rows = nullptr; a.wg_part = nullptr;
     if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || (int64_t)n_nodes * idx_unit > 65535) return TIPK_EINVAL;
     a.idx_mul = a.dc * 4 / idx_unit;
     hipStream_t st = (hipStream_t)stream;
@@ -302,4 +341,29 @@ extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t 
         case 8: return launch_rs<8>(a, (int)n_wg, split, kind != 0, st);
         default: return launch_rs<16>(a, (int)n_wg, split, kind != 0, st);
     }
+}
+
+// d att of the pair-form backward pass (include/tipk.h section 2e): out[p * n_rel + r] = sum over the pairs of partition p
+// that relation r links of (table[a] + table[b]), (a, b) = part_rows of the pair.  A partition's sums are staged in LDS by
+// each of its workgroups (wg_part); everything else is tipk_stream_gather.
+extern "C" int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, const int32_t* part_rows, int64_t part_len,
+                                         const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr, const uint32_t* cells,
+                                         const uint16_t* ids, int idx_unit, const int32_t* zero_ptr, const int32_t* zero_rows,
+                                         float* out, int64_t ld_out, tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table || !part_rows || !wg_part || !wave_ptr || !cells || !ids || (zero_ptr && !zero_rows) ||
+        !out || (reinterpret_cast<uintptr_t>(ids) & 15) || (reinterpret_cast<uintptr_t>(part_rows) & 7))
+        return TIPK_EINVAL;
+    if (d != 32) return TIPK_EUNSUPPORTED;                             // one 128-byte row per pair (n_bases = 32)
+    if (part_len <= 0 || (part_len + 1) * d * 4 > RS_LDS_LIMIT) return TIPK_EUNSUPPORTED;
+    if (ld_table % 4 != 0 || ld_out % 4 != 0 || (reinterpret_cast<uintptr_t>(table) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return TIPK_EINVAL;
+    RsArgs a;
+    a.table = table; a.ld_t = ld_table; a.n_nodes = (int)part_len; a.dc = d;
+    a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
+    a.out = out; a.ld_out = ld_out; a.row_scale = nullptr;
+    a.out_scale = nullptr; a.bias = nullptr; a.relu = 0;
+    a.part_rows = reinterpret_cast<const int2*>(part_rows); a.wg_part = wg_part;
+    if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || part_len * idx_unit > 65535) return TIPK_EINVAL;
+    a.idx_mul = a.dc * 4 / idx_unit;
+    return launch_rs<8>(a, (int)n_wg, 1, 2, (hipStream_t)stream);
 }

@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import (build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
+from .plan import (build_pair_bwd_plan, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
                    relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
@@ -372,6 +372,22 @@ def relation_of_edges(range_list, n_edges, device):
     return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
 
 
+_PAIR_BWD_PLANS = []          # [(key, plan)], most recent first: the R-GCN layers of a model run on the same graph
+
+
+def _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg, lanes):
+    """`build_pair_bwd_plan`, cached on what the plan depends on (edge list, relation of every edge, 1 / deg, launch shape)."""
+    key = (src.data_ptr(), dst.data_ptr(), int(src.numel()), int(n_nodes), int(n_rel), bool(symmetric), int(n_wg), int(lanes),
+           str(src.device), int(src.sum()), int((dst * (rel + 1)).sum()), float(scale.double().sum()))
+    for k, plan in _PAIR_BWD_PLANS:
+        if k == key:
+            return plan
+    plan = build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg, lanes, ops.rel_stream_piece())
+    _PAIR_BWD_PLANS.insert(0, (key, plan))
+    del _PAIR_BWD_PLANS[4:]
+    return plan
+
+
 def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
     scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `in_degree`: [N]
@@ -386,7 +402,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     else:
         assert in_degree.numel() == n_nodes
         deg = in_degree.to(src.device).to(torch.float32).clamp_(min=1)
-    rl_fwd = rl_bwd = rs_bwd = pair_fwd = None
+    rl_fwd = rl_bwd = rs_bwd = pair_fwd = pair_bwd = None
     if n_nodes <= 1024 and n_rel > 0 and src.numel() > 0:
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
@@ -423,11 +439,19 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             pair_fwd.live = (tiles.long() << torch.arange(8, device=src.device).view(1, 8, 1)).sum(1).to(torch.uint8).contiguous()
         # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
         split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
+        if pair_fwd is not None and ops.pair_grads_supported(n_bases, d_out):
+            # backward pass in pair form as well (round 5): the cells of the forward pass + one 128-byte gradient row per
+            # linked pair; d att walks half the edges of a symmetric graph.  The plan does not depend on the layer's width:
+            # the layers of a model share it
+            sym, lanes_p = pair_fwd.symmetric, (n_bases // split_p) // 4
+            pair_bwd = lambda: _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, 1.0 / deg, sym, n_cu, lanes_p)
         if split_s:
-            # compact node-major rows when the products of dY can run on them (tipk_rgcn_node_products)
+            # compact node-major rows when the products of dY can run on them (tipk_rgcn_node_products); with the pair-form
+            # backward pass the plan is only built if some pass asks for it (a forward pass on the Y route of a sharded run)
             compact = bool(n_bases) and ops.node_products_slabs(n_nodes, d_out, n_rel, n_bases) > 0
-            rs_bwd = build_stream_plan(src, dst, rel, n_nodes, n_rel, n_cu, (d_out // split_s) // 4, ops.rel_stream_piece(),
-                                       compact=compact)
+            lanes_s = (d_out // split_s) // 4
+            build_rs = lambda: build_stream_plan(src, dst, rel, n_nodes, n_rel, n_cu, lanes_s, ops.rel_stream_piece(), compact=compact)
+            rs_bwd = build_rs if pair_bwd is not None else build_rs()
         else:
             rl_bwd = lambda: build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
     def fwd_plan():
@@ -445,7 +469,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd,
                         csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'), rs_bwd=rs_bwd,
-                        pair_fwd=pair_fwd)
+                        pair_fwd=pair_fwd, pair_bwd=pair_bwd)
 
 
 class _RGCNBase(nn.Module):

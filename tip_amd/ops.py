@@ -471,6 +471,38 @@ def node_products(dyc, cr, att, xb, xbt=None):
     return slab_job(datt_slabs), dxb
 
 
+def pair_grads_supported(nb, d):
+    return bool(lib().tipk_rgcn_pair_grads_supported(int(nb), int(d))) and not os.environ.get('TIPK_NO_PAIR_BWD')
+
+
+def pair_grads(pb, cells, xb_pad, g):
+    """The pair-form backward pass of an R-GCN layer (include/tipk.h section 2e) on plan `pb` (plan.PairBwdPlan):
+    cells = the cell buffer the forward pass filled ([N_pad, N, bases] + its trailing zeros, contiguous), xb_pad
+    [N_pad, bases, 32] = the node-major XB buffer of the pair product, g [N, d] (1 / deg is in the plan's slots).
+    -> (pending slab sum of d att [R, bases], d XB [bases, N, d] complete)."""
+    g = _f32c(g)
+    require_device(cells, xb_pad, g, pb.slots)
+    n, d = g.shape
+    nb = cells.shape[-1]
+    assert pb.n_nodes == n and g.stride(1) == 1 and cells.is_contiguous() and xb_pad.stride()[-2:] == (32, 1) and xb_pad.shape[1] == nb
+    dev = g.device
+    pg = pb.pg.get(str(dev))
+    if pg is None:                                    # kept on the plan: the zero row is written once, every call rewrites the rest
+        pg = pb.pg[str(dev)] = torch.zeros((pb.n_slots + 1, nb), dtype=torch.float32, device=dev)
+    dxb = torch.empty((nb, n, d), dtype=torch.float32, device=dev)
+    with _timed('pair_grads[%dx%dx%d,slots=%d]' % (n, nb, d, pb.n_slots)):
+        check(lib().tipk_rgcn_pair_grads(ptr(cells), cells.numel() // nb, ptr(xb_pad), ptr(g), g.stride(0), n, nb, d,
+                                         ptr(pb.node_desc), ptr(pb.slots), pb.n_slots, ptr(dxb), dxb.stride(0), dxb.stride(1),
+                                         ptr(pg), stream_ptr(dev)), 'tipk_rgcn_pair_grads')
+    gp = pb.gather
+    slabs = torch.empty((pb.n_parts, pb.n_rel, nb), dtype=torch.float32, device=dev)
+    with _timed('pair_att_gather[parts=%d,edges=%d]' % (pb.n_parts, gp.n_edges)):
+        check(lib().tipk_stream_gather_parts(ptr(pg), nb, nb, ptr(pb.part_rows), pb.part_len, ptr(pb.wg_part), gp.n_wg,
+                                             ptr(gp.wave_ptr), ptr(gp.cells), ptr(gp.ids), gp.idx_unit, ptr(gp.zero_ptr),
+                                             ptr(gp.zero_rows), ptr(slabs), nb, stream_ptr(dev)), 'tipk_stream_gather_parts')
+    return slab_job(slabs), dxb
+
+
 class SlabJob(object):
     """An ordered slab sum with the fused epilogue of `sum_slabs`, prepared for a grouped launch."""
     __slots__ = ('desc', 'out', 'keep')
@@ -999,7 +1031,7 @@ class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
     def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None,
-                 pair_fwd=None):
+                 pair_fwd=None, pair_bwd=None):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
         generic D-D plans are only needed where the relation-local kernel does not apply).
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
@@ -1007,11 +1039,27 @@ class AggGraph(object):
         self._csr_bwd = csr_bwd
         self._rl_fwd, self._rl_bwd = rl_fwd, rl_bwd        # relation-local (LDS) plans of a D-D graph: plans, or callables
                                                            # that build them on first use (fallback routes only)
-        self.rs_bwd = rs_bwd                               # wave-stream plan of the transposed pass (LDS-resident g')
+        self._rs_bwd = rs_bwd                              # wave-stream plan of the transposed pass (LDS-resident g'), or a
+                                                           # callable that builds it on first use (the pair-form backward
+                                                           # pass never needs it)
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
+        self._pair_bwd = pair_bwd                          # plan.PairBwdPlan of the pair-form backward pass (or a callable)
+        self.pair_stamp = 0                                # bumped by every pass that rewrites the pair buffers
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
         self.fwd_route = {}                                # sharded layers: timed choice pair form | Y route (ops._fwd_route)
+
+    @property
+    def rs_bwd(self):
+        if callable(self._rs_bwd):
+            self._rs_bwd = self._rs_bwd()
+        return self._rs_bwd
+
+    @property
+    def pair_bwd(self):
+        if callable(self._pair_bwd):
+            self._pair_bwd = self._pair_bwd()
+        return self._pair_bwd
 
     @property
     def rl_fwd(self):
@@ -1170,35 +1218,46 @@ def _fwd_route(graph, x, basis, att, pair, shard):
                stream, 3 runs each after a warm-up -- the times are SUMMED OVER THE RANKS (one all-reduce of two floats) and
                every rank takes the route with the smaller sum: one decision for the whole job, recorded on the graph
                (bench.py prints it as `config.forward_routes`).  A first call under graph capture cannot time anything and
-               uses the rule."""
+               uses the rule.
+
+    EVERY rank of a sharded layer calls this, with pair = None when it cannot take the pair form itself (no relations, an
+    att table beyond the LDS, a plan of another shape): in 'timed' mode the all-reduce below is part of the layer's
+    collective sequence, so whether it happens must not depend on a rank's own shard -- such a rank adds +inf to the pair
+    form's sum (the job takes the Y route) and the time of its own Y route (0 without relations)."""
     n = x.shape[0]
     nb, _, d_out = basis.shape
     r = att.shape[0]
-    key = (int(n), int(nb), int(d_out), int(r))
+    key = (int(n), int(nb), int(d_out))
     hit = graph.fwd_route.get(key)
     if hit is not None:
-        return hit[0]
+        return hit[0] if pair is not None else 'y'
     mode = FWD_ROUTE_MODE
     if mode in ('pair', 'y'):
-        return mode
+        return mode if pair is not None else 'y'
     rule = 'y' if shard.world >= PAIR_FWD_MAX_WORLD else 'pair'
     if mode != 'timed' or torch.cuda.is_current_stream_capturing() or _TIMING is not None:
-        return rule
+        return rule if pair is not None else 'y'
     with torch.no_grad():
-        cells, xb_nb, _ = graph.pair_buffers(n, nb, d_out, x.device)
-        xb = gemm(x, basis)
-        gemm(x, basis, out=xb_nb[:n].permute(1, 0, 2))
+        routes = []
+        if r > 0:
+            xb = gemm(x, basis)
+            use_rl = rel_gather_usable(graph.rl_fwd, n, d_out, False)
 
-        def pair_route():
-            stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
-            return sum_slabs(pair_product(cells, xb_nb, symmetric=pair.symmetric).view(-1, n, d_out))
-        use_rl = rel_gather_usable(graph.rl_fwd, n, d_out, False)
+            def y_route():
+                y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out)
+                return sum_slabs(rel_gather(graph.rl_fwd, y, backward=False, reduce=False)) if use_rl else gather_sum(graph.fwd, y)
+            routes.append(('y', y_route))
+        if pair is not None:
+            cells, xb_nb, _ = graph.pair_buffers(n, nb, d_out, x.device)
+            gemm(x, basis, out=xb_nb[:n].permute(1, 0, 2))
+            graph.pair_stamp += 1                                 # (the pair buffers are rewritten here)
 
-        def y_route():
-            y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out)
-            return sum_slabs(rel_gather(graph.rl_fwd, y, backward=False, reduce=False)) if use_rl else gather_sum(graph.fwd, y)
-        times = {}
-        for name, fn in (('pair', pair_route), ('y', y_route)):
+            def pair_route():
+                stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
+                return sum_slabs(pair_product(cells, xb_nb, symmetric=pair.symmetric).view(-1, n, d_out))
+            routes.append(('pair', pair_route))
+        times = {'pair': float('inf'), 'y': 0.0}
+        for name, fn in routes:
             fn()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -1207,12 +1266,12 @@ def _fwd_route(graph, x, basis, att, pair, shard):
             b.record()
             torch.cuda.synchronize(x.device)
             times[name] = a.elapsed_time(b) / 3 * 1e3
-        total = torch.tensor([times['pair'], times['y']], dtype=torch.float32, device=x.device)
+        total = torch.tensor([min(times['pair'], 1e30), times['y']], dtype=torch.float32, device=x.device)
         shard.all_reduce(total)                                   # the same two sums on every rank -> the same decision
         total = total.tolist()
     choice = 'pair' if total[0] <= total[1] else 'y'
     graph.fwd_route[key] = (choice, times, {'pair': total[0], 'y': total[1]})
-    return choice
+    return choice if pair is not None else 'y'
 
 
 class _RGCN(torch.autograd.Function):
@@ -1245,10 +1304,11 @@ class _RGCN(torch.autograd.Function):
         if pair is not None and not (pair.n_table == r and pair.n_rows == n * n and stream_gather_split(r, nb)
                                      and (nb // stream_gather_split(r, nb)) // 4 == pair.lanes):
             pair = None
-        if pair is not None and shard is not None and shard.world > 1:
+        if shard is not None and shard.world > 1:
             # the pair form's dense product reads the whole N x N cell matrix on EVERY rank (16 us at BioSNAP, whatever
             # the rank's share of the relations); the Y route (Y = att . XB + unit gather) scales with the share.  One
-            # decision for the whole job, the same from run to run unless timing is asked for (`_fwd_route`)
+            # decision for the whole job, the same from run to run unless timing is asked for; every rank asks, whether or
+            # not it could take the pair form itself (`_fwd_route`: the timed mode's all-reduce is a collective)
             if _fwd_route(graph, x, basis, att, pair, shard) == 'y':
                 pair = None
         if pair is not None:
@@ -1261,8 +1321,19 @@ class _RGCN(torch.autograd.Function):
             # 16 KB contiguous per operand tile (destination-major cells made every tile 128 separate 128-byte rows:
             # 2.5 TB/s); the u range is padded to a multiple of PAIR_KGROUP with cells / XB rows that stay zero
             cells, xb_nb, zeros = graph.pair_buffers(n, nb, d_out, x.device)
-            rs = graph.rs_bwd
-            if rs is not None and rs.compact is not None and any(ctx.needs_input_grad[:3]):
+            need_grad = any(ctx.needs_input_grad[:3])
+            ctx.pair_bwd = need_grad and pair_grads_supported(nb, d_out) and graph.pair_bwd is not None
+            rs = None if (ctx.pair_bwd or not need_grad) else graph.rs_bwd
+            # every pass through here rewrites the graph's cell / XB buffers: a backward pass that finds another stamp than
+            # its own forward pass left knows they are no longer its operands
+            graph.pair_stamp += 1
+            if ctx.pair_bwd:
+                # PAIR-FORM BACKWARD (round 5; include/tipk.h section 2e): the backward pass reads the cells and the node-major
+                # XB this pass leaves in the graph's buffers -- nothing else is saved, nothing is transposed
+                _, xroot = gemm_group([gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+                xb, xbt = None, None
+                ctx.xb_stamp = graph.pair_stamp
+            elif rs is not None and rs.compact is not None:
                 # XB is computed ONCE, into the node-major buffer the pair product reads; the backward pass
                 # (`node_products` on the compact dY) takes the same buffer through strides -- a node's 32 rows are one
                 # 4-KB block there.  The buffer belongs to the graph and the next forward pass rewrites it: the stamp tells
@@ -1272,7 +1343,6 @@ class _RGCN(torch.autograd.Function):
                 # [N, out, bases]: what the d att product of the backward pass reads (`node_products` xbt)
                 xbt = graph.xbt_buffer(n, nb, d_out, x.device)
                 xb = xb_nb[:n].permute(1, 0, 2)
-                graph.pair_stamp = getattr(graph, 'pair_stamp', 0) + 1
                 ctx.xb_stamp = graph.pair_stamp
             else:
                 xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
@@ -1288,7 +1358,7 @@ class _RGCN(torch.autograd.Function):
             ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
             ctx.save_for_backward(x, basis, att, root, xb if ctx.xb_stamp is None else None, out if relu is True else None)
             return out
-        ctx.xb_stamp = None
+        ctx.xb_stamp, ctx.pair_bwd = None, False
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)   # (the unit plan is built here, on first use)
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
@@ -1331,17 +1401,30 @@ class _RGCN(torch.autograd.Function):
         nb, _, d_out = basis.shape
         r = att.shape[0]
         xbt = None
-        if ctx.xb_stamp is not None:                                     # XB lives in the graph's node-major buffer (forward)
-            if getattr(graph, 'pair_stamp', 0) == ctx.xb_stamp:
+        j_att = None
+        if ctx.pair_bwd and r > 0:
+            cells, xb_nb, _ = graph.pair_buffers(n, nb, d_out, x.device)
+            if graph.pair_stamp != ctx.xb_stamp:
+                # another forward pass has rewritten the graph's buffers: the same values again -- and a new stamp, so that
+                # THAT pass's backward pass recomputes its own as well
+                pair = graph.pair_fwd
+                gemm(x, basis, out=xb_nb[:n].permute(1, 0, 2))
+                stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
+                graph.pair_stamp += 1
+                ctx.xb_stamp = graph.pair_stamp
+            j_att, g_xb = pair_grads(graph.pair_bwd, cells, xb_nb, g)
+        elif ctx.xb_stamp is not None:                                   # XB lives in the graph's node-major buffer (forward)
+            if graph.pair_stamp == ctx.xb_stamp:
                 xb = graph.pair_buffers(n, nb, d_out, x.device)[1][:n].permute(1, 0, 2)
                 xbt = graph.xbt_buffer(n, nb, d_out, x.device)
             else:                                                        # another forward pass has rewritten it: same values again
                 xb = gemm(x, basis)
-        xb2 = xb.view(nb, n * d_out) if xb.is_contiguous() else None
-        if r > 0:
+        xb2 = xb.view(nb, n * d_out) if (xb is not None and xb.is_contiguous()) else None
+        if j_att is not None:
+            pass
+        elif r > 0:
             rs = graph.rs_bwd
             used = None
-            j_att = None
             if rs is not None and rs.compact is not None:
                 assert rel_stream_split(n, d_out) and (d_out // rel_stream_split(n, d_out)) // 4 == rs.lanes and rs.n_rel == r
                 # dY_r = A_r^T (D^-1 g) in COMPACT node-major form: only the (relation, source) rows that have an edge
@@ -1368,7 +1451,6 @@ class _RGCN(torch.autograd.Function):
                 g_att, g_xb = dy_products(g_y, att, xb2, used, n)
                 g_xb = g_xb.view(nb, n, d_out)
         else:
-            j_att = None
             g_att = torch.zeros((0, nb), dtype=torch.float32, device=x.device)
             g_xb = torch.zeros((nb, n, d_out), dtype=torch.float32, device=x.device)
         extra = [] if j_att is None else [j_att]                         # the d att slabs ride in this layer's grouped slab sum

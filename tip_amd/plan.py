@@ -866,3 +866,206 @@ def execute_rel_plan_reference(plan, table, backward):
         return res.view(R * n, d)
     assert int(written.max()) <= 1
     return res.sum(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# pair-form BACKWARD pass (include/tipk.h section 2e)
+# ---------------------------------------------------------------------------------------------
+PAIR_PART_ROWS = 1008       # pairs per partition of the d att gather: (rows + 1) x 128 B of LDS, 16-bit pre-scaled ids
+PAIR_PART_EDGES_PER_WG = 16384
+
+
+class PairBwdPlan(object):
+    """Device arrays of `tipk_rgcn_pair_grads` + `tipk_stream_gather_parts` (layout: include/tipk.h section 2e).
+
+    slots [n_slots, 4] int32 {v, bits of 1 / deg(v), cell line, 0}, node_desc [N, 4] int32 {u, first slot, tiles, 0};
+    part_rows [n_parts * part_len, 2] int32 (rows of pg, n_slots = the zero row), wg_part [n_wg] int32, and the merged
+    wave-stream arrays of the partitions (`gather`: a StreamPlan whose rows are p * n_rel + r, ids = rows inside a partition)."""
+
+    def __init__(self, n_nodes, n_rel, n_slots, slots, node_desc, n_parts, part_len, part_rows, wg_part, gather, symmetric,
+                 slot_of_pair=None):
+        self.n_nodes, self.n_rel, self.n_slots = int(n_nodes), int(n_rel), int(n_slots)
+        self.slots, self.node_desc = slots, node_desc
+        self.n_parts, self.part_len, self.part_rows, self.wg_part, self.gather = int(n_parts), int(part_len), part_rows, wg_part, gather
+        self.symmetric = bool(symmetric)
+        self.slot_of_pair = slot_of_pair          # (tests) int64 [n_directed_pairs, 3] = (u, v, slot)
+        self.pg = {}                              # device -> the pair-gradient buffer [n_slots + 1, n_bases] (last row = zeros)
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return PairBwdPlan(self.n_nodes, self.n_rel, self.n_slots, mv(self.slots), mv(self.node_desc), self.n_parts,
+                           self.part_len, mv(self.part_rows), mv(self.wg_part), self.gather.to(device), self.symmetric,
+                           mv(self.slot_of_pair))
+
+
+def build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg=256, lanes=8, piece=4,
+                        part_rows_max=PAIR_PART_ROWS, line_stride=None):
+    """Plan of the pair-form backward pass of a D-D graph (src -> dst edges of relation rel; `scale` [N] = 1 / in-degree as
+    the layer applies it).  symmetric: every relation links u -> v iff v -> u, and the forward pass kept the cells with
+    u <= v only (`rgcn_graph`): a cell is read at line min * N + max, and the d att gather walks the edges with u <= v over
+    the sums pg[slot(u, v)] + pg[slot(v, u)].  Otherwise: line u * N + v, all edges, one term.
+    line_stride: nodes per row of the cell matrix (default n_nodes)."""
+    dev = src.device
+    N, R = int(n_nodes), int(n_rel)
+    ls = N if line_stride is None else int(line_stride)
+    src, dst, rel = src.to(torch.int64), dst.to(torch.int64), rel.to(torch.int64)
+    # ---- directed pairs, grouped by source node, neighbours ascending; 32 slots per tile
+    key = torch.unique(src * N + dst)                                    # sorted
+    pu, pv = key // N, key % N
+    n_dp = int(key.numel())
+    deg = torch.bincount(pu, minlength=N)
+    tiles = (deg + 31) // 32
+    first_tile = torch.cumsum(tiles, 0) - tiles
+    n_slots = int(tiles.sum()) * 32
+    first_pair = torch.cumsum(deg, 0) - deg
+    slot = first_tile[pu] * 32 + (torch.arange(n_dp, device=dev) - first_pair[pu])
+    line = torch.where(pu <= pv, pu * ls + pv, pv * ls + pu) if symmetric else pu * ls + pv
+    assert n_slots > 0 and int(line.max()) < 2 ** 24
+    # pads: the node's own first neighbour / line with the factor 0 (they add zeros; their pg rows are never read)
+    slot_node = torch.repeat_interleave(torch.arange(N, device=dev), tiles * 32)
+    sl_v = pv[first_pair.clamp(max=max(n_dp - 1, 0))][slot_node].clone()
+    sl_line = line[first_pair.clamp(max=max(n_dp - 1, 0))][slot_node].clone()
+    sl_scale = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+    sl_v[slot], sl_line[slot] = pv, line
+    sl_scale[slot] = scale.to(dev).to(torch.float32)[pv]
+    slots = torch.stack([sl_v.to(torch.int32), sl_scale.view(torch.int32), sl_line.to(torch.int32),
+                         torch.zeros(n_slots, dtype=torch.int32, device=dev)], dim=1).contiguous()
+    order = torch.sort(tiles, descending=True, stable=True).indices
+    node_desc = torch.stack([order, first_tile[order] * 32, tiles[order], torch.zeros_like(order)], dim=1).to(torch.int32).contiguous()
+    # ---- the d att gather: rows of the (symmetrised) pair-gradient table, cut into partitions that fit in LDS
+    if symmetric:
+        keep = pu <= pv
+        tu, tv = pu[keep], pv[keep]
+        row_a = slot[keep]
+        # slot of the mirrored pair (v, u); a self pair has one term only
+        mk = tv * N + tu
+        pos = torch.searchsorted(key, mk)
+        assert bool((key[pos.clamp(max=n_dp - 1)] == mk).all()), 'graph is not symmetric'
+        row_b = torch.where(tu == tv, torch.full_like(pos, n_slots), slot[pos.clamp(max=n_dp - 1)])
+        ek = src <= dst
+        e_key, e_rel = (src * N + dst)[ek], rel[ek]
+    else:
+        tu, tv, row_a = pu, pv, slot
+        row_b = torch.full_like(slot, n_slots)
+        e_key, e_rel = src * N + dst, rel
+    t_key = tu * N + tv                                                   # ascending
+    n_t = int(t_key.numel())
+    n_parts = max(1, -(-n_t // int(part_rows_max)))
+    part_len = -(-n_t // n_parts)
+    part_len = -(-part_len // 8) * 8
+    assert (part_len + 1) * lanes * 16 <= 158 * 1024
+    e_row = torch.searchsorted(t_key, e_key)                              # table row of every edge walked
+    e_part, e_local = e_row // part_len, e_row % part_len
+    part_rows = torch.full((n_parts * part_len, 2), n_slots, dtype=torch.int64, device=dev)
+    part_rows[:n_t, 0], part_rows[:n_t, 1] = row_a, row_b
+    # workgroups per partition in proportion to the edges it walks
+    E = int(e_key.numel())
+    e_cnt = torch.bincount(e_part, minlength=n_parts).cpu().tolist()
+    n_wg = int(max(n_parts, min(int(n_wg), -(-E // PAIR_PART_EDGES_PER_WG) if E else 1)))
+    wgs = [1] * n_parts
+    spare = n_wg - n_parts
+    if spare > 0 and E > 0:
+        want = [c * n_wg / float(E) for c in e_cnt]
+        for _ in range(spare):
+            p = max(range(n_parts), key=lambda q: want[q] / wgs[q])
+            wgs[p] += 1
+    n_wg = sum(wgs)
+    # ---- one wave-stream plan per partition, concatenated
+    wave_ptr, cells, ids, zero_ptr, zero_rows, wg_part = [], [], [], [], [], []
+    band0 = z0 = 0
+    idx_unit = None
+    o_part = torch.sort(e_part, stable=True).indices
+    p_first = [0]
+    for c in e_cnt:
+        p_first.append(p_first[-1] + c)
+    for p in range(n_parts):
+        sel = o_part[p_first[p]:p_first[p + 1]]
+        sp = build_stream_plan_rows(e_rel[sel], e_local[sel], R, part_len, wgs[p], lanes, piece)
+        assert idx_unit in (None, sp.idx_unit)
+        idx_unit = sp.idx_unit
+        c = sp.cells.to(torch.int64) & 0xffffffff
+        c = torch.where(c != 0, c + p * R, c)                             # output row = p * R + relation (24-bit field)
+        cells.append(torch.where(c >= 2 ** 31, c - 2 ** 32, c).to(torch.int32))
+        ids.append(sp.ids[:sp.n_bands * piece * (64 // lanes) * 8])
+        wave_ptr.append(sp.wave_ptr[:-1].to(torch.int64) + band0)
+        zr = sp.zero_rows[:int(sp.zero_ptr[-1])].to(torch.int64) + p * R
+        zero_rows.append(zr)
+        zero_ptr.append(sp.zero_ptr[:-1].to(torch.int64) + z0)
+        band0 += sp.n_bands
+        z0 += int(zr.numel())
+        wg_part += [p] * wgs[p]
+    assert n_parts * R < 2 ** 24
+    S = 64 // lanes
+    gather = StreamPlan(n_parts * R, part_len, n_wg, lanes, piece,
+                        torch.cat(wave_ptr + [torch.tensor([band0], device=dev)]).to(torch.int32).contiguous(),
+                        torch.cat(cells).view(-1, S).contiguous(),
+                        (torch.cat(ids) if band0 else torch.full((piece * S * 8,), part_len * idx_unit, dtype=torch.int32, device=dev).to(torch.uint16)).contiguous(),
+                        torch.cat(zero_ptr + [torch.tensor([z0], device=dev)]).to(torch.int32).contiguous(),
+                        (torch.cat(zero_rows) if z0 else torch.zeros(1, dtype=torch.int64, device=dev)).to(torch.int32).contiguous(),
+                        idx_unit)
+    gather.n_edges = E
+    plan = PairBwdPlan(N, R, n_slots, slots, node_desc, n_parts, part_len, part_rows.to(torch.int32).contiguous(),
+                       torch.tensor(wg_part, dtype=torch.int32, device=dev), gather, symmetric,
+                       torch.stack([pu, pv, slot], dim=1))
+    return plan
+
+
+def execute_pair_bwd_reference(plan, cells_flat, xb, g, n_bases):
+    """Pure-torch interpretation of a pair-backward plan (CPU unit tests): cells_flat [n_lines, n_bases], xb [N, n_bases, d],
+    g [N, d] -> (dxb [n_bases, N, d], pg [n_slots + 1, n_bases], datt [n_rel, n_bases]) exactly as the two kernels sum them
+    (up to the order inside a tile)."""
+    N, d = g.shape
+    sl = plan.slots.to(torch.int64)
+    v, line = sl[:, 0], sl[:, 2]
+    sc = plan.slots[:, 1].contiguous().view(torch.float32).to(g.dtype)
+    gp = g[v] * sc.unsqueeze(1)                                           # [n_slots, d]
+    nd = plan.node_desc.to(torch.int64)
+    node_of_slot = torch.empty(plan.n_slots, dtype=torch.int64)
+    for u, s0, nt, _ in nd.tolist():
+        node_of_slot[s0:s0 + 32 * nt] = u
+    dxb = torch.zeros((N, n_bases, d), dtype=g.dtype)
+    dxb.index_add_(0, node_of_slot, cells_flat[line].unsqueeze(2) * gp.unsqueeze(1))
+    pg = torch.zeros((plan.n_slots + 1, n_bases), dtype=g.dtype)
+    pg[:plan.n_slots] = torch.einsum('sbc,sc->sb', xb[node_of_slot], gp)
+    pr = plan.part_rows.to(torch.int64)
+    table = (pg[pr[:, 0]] + pg[pr[:, 1]]).view(plan.n_parts, plan.part_len, n_bases)
+    # the gather, partition by partition, on the merged stream plan
+    gp_ = plan.gather
+    S, P = 64 // gp_.lanes, gp_.piece
+    ids = (gp_.ids.to(torch.int64) // gp_.idx_unit).view(-1, P, S, 8)
+    cw = gp_.cells.to(torch.int64) & 0xffffffff
+    out = torch.zeros((gp_.n_rows, n_bases), dtype=g.dtype)
+    written = torch.zeros(gp_.n_rows, dtype=torch.long)
+    wp, zp = gp_.wave_ptr.tolist(), gp_.zero_ptr.tolist()
+    wg_part = plan.wg_part.tolist()
+    assert len(wp) == gp_.n_wg * 16 + 1 and wp[-1] == gp_.n_bands
+    for w in range(gp_.n_wg * 16):
+        tab = torch.cat([table[wg_part[w // 16]], torch.zeros((1, n_bases), dtype=g.dtype)])
+        acc = torch.zeros((S, n_bases), dtype=g.dtype)
+        for b in range(wp[w], wp[w + 1]):
+            klogs, lasts = [0] * S, []
+            for s_ in range(S):
+                c = int(cw[b, s_])
+                if c == 0:
+                    continue
+                row, ln, first, last, klogs[s_] = c & 0xffffff, (c >> 24) & 15, (c >> 28) & 1, (c >> 29) & 1, (c >> 30) & 3
+                if first:
+                    acc[s_] = 0
+                rows = ids[b, :ln, s_].reshape(-1)
+                acc[s_] += tab[rows].sum(0)
+                if last:
+                    lasts.append((s_, row))
+            if any(klogs):
+                for jj in range(3):
+                    for s_ in range(S):
+                        if klogs[s_] > jj and s_ % (2 << jj) == 0 and s_ + (1 << jj) < S:
+                            acc[s_] = acc[s_] + acc[s_ + (1 << jj)]
+            for s_, row in lasts:
+                assert row // plan.n_rel == wg_part[w // 16], 'a wavefront writes rows of its own partition only'
+                out[row] = acc[s_]
+                written[row] += 1
+        for z in range(zp[w], zp[w + 1]):
+            written[int(gp_.zero_rows[z])] += 1
+    assert bool((written == 1).all()), 'every (partition, relation) row is written exactly once'
+    datt = out.view(plan.n_parts, plan.n_rel, n_bases).sum(0)
+    return dxb.permute(1, 0, 2).contiguous(), pg, datt
