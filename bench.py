@@ -243,10 +243,31 @@ def dd_launches(enc, dev):
         y = None
         g = torch.randn(n, d, device=dev)
         nb = layer.num_bases
+        pair_ok = graph.pair_fwd is not None and graph.pair_fwd.n_table == r and bool(ops.stream_gather_split(r, nb))
+        # the backward pass the step takes behind a pair-form forward pass (ops._RGCN): pair form as well
+        pair_bwd = graph.pair_bwd if (pair_ok and ops.pair_grads_supported(nb, d) and 'y' not in
+                                      [v[0] for v in graph.fwd_route.values()]) else None
         for bwd in (False, True):
-            rs = graph.rs_bwd if bwd else None
-            pair = None if bwd or os.environ.get('TIPK_NO_PAIR_FWD') else graph.pair_fwd
-            if pair is not None and pair.n_table == r and ops.stream_gather_split(r, nb):
+            rs = graph.rs_bwd if (bwd and pair_bwd is None) else None
+            pair = None if bwd else graph.pair_fwd
+            if bwd and pair_bwd is not None:
+                pb = pair_bwd
+                cells, xb_nb, _zeros = graph.pair_buffers(n, nb, d, dev)
+                n_dp = int(pb.slot_of_pair.shape[0])
+                pg_box = []
+
+                def grads(pb=pb, cells=cells, xb_nb=xb_nb, g=g, pg_box=pg_box):
+                    pg_box[:] = [ops.pair_grads(pb, cells, xb_nb, g)[0]]
+                grads()
+                add('pair_grads[dd.bwd,d=%d]' % d, 'pair_grads_kernel<%d>' % d, None, 'mfma', 2 * 2.0 * n_dp * nb * d, grads,
+                    pairs=n_dp, hbm_bytes=4.0 * nb * (n_dp + pb.n_slots),
+                    note='algorithmic flops = the two products of the pair form over the %d linked (source, neighbour) pairs: '
+                         'd XB += cells^T g\' and d C = XB g\', 2 x 2 x pairs x bases x d' % n_dp)
+                add('pair_att_gather[dd.bwd,d=%d]' % d, 'stream_gather_kernel<8, %s, 2' % ('true' if pb.gather.idx_unit == nb * 4 else 'false'),
+                    '%dx1x1' % (pb.gather.n_wg * 1024), 'lds', pb.gather.n_edges * (4 + 4 * nb),
+                    lambda pb=pb, pg_box=pg_box: ops.pair_att_gather(pb, pg_box[0]), edges=pb.gather.n_edges, row_floats=nb,
+                    aggregation=True)
+            elif pair is not None and pair_ok:
                 # forward in pair form: per edge one id + one att row (nb floats) from LDS, then the dense product
                 split = ops.stream_gather_split(r, nb)
                 key = 'stream_gather_kernel<%d, %s, 1' % (nb // split // 4, 'true' if pair.idx_unit == nb // split * 4 else 'false')
@@ -293,7 +314,7 @@ def dd_launches(enc, dev):
                     lanes *= 2
                 if y is None and not bwd:
                     y = torch.randn(r * n, d, device=dev)
-                if bwd and d % 4 == 0 and 8 <= d <= 256 and not os.environ.get('TIPK_NO_CSR'):
+                if bwd and d % 4 == 0 and 8 <= d <= 256:
                     csr = graph.csr_bwd                        # the path _RGCN.backward takes on large graphs
                     lanes = max(lanes, 2)
                     rp = lanes - 1 if lanes <= 16 else 16
@@ -309,8 +330,8 @@ def dd_launches(enc, dev):
                 add('gather_sum[dd.%s,d=%d]' % ('bwd' if bwd else 'fwd', d), 'gather_sum_kernel<4, %d' % lanes,
                     '%dx1x1' % (-(-waves // 4) * 256), 'hbm', plan.n_edges * (4 + 4 * d), fn, edges=plan.n_edges, row_floats=d,
                     aggregation=True)
-        rs = graph.rs_bwd
-        if (rs is None or rs.compact is None) and ops.dy_products_fused(r, n * d, nb):
+        rs = graph.rs_bwd if pair_bwd is None else None
+        if pair_bwd is None and (rs is None or rs.compact is None) and ops.dy_products_fused(r, n * d, nb):
             g_y = torch.randn(r, n * d, device=dev)
             att = torch.randn(r, nb, device=dev)
             xb2 = torch.randn(nb, n * d, device=dev)
@@ -372,6 +393,9 @@ def measure_pmc_in_run(args):
     tmp = tempfile.mkdtemp(prefix='tipk_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp', TIPK_BENCH_CHILD='1')
     steps, warm = 3, 1
+    # full-size steps the child runs: prepare() (the plan-building first step) + warm-up + timed; a --step-only child runs
+    # no toy-graph step (main: `init_s`), so every libtipk launch it records belongs to one of them
+    steps_run = steps + warm + 1
     try:
         per = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -394,18 +418,30 @@ def measure_pmc_in_run(args):
                     acc['%s grid=%s' % (short(row['Kernel_Name']), shape.get(row['Dispatch_Id'], '?'))].append(float(row['Counter_Value']))
             for k, v in acc.items():
                 per.setdefault(k, {})[counter] = (sum(v) / len(v), len(v))
-        kernels, total = {}, 0.0
-        for k, d in per.items():
-            f_kb, n_f = d.get('FETCH_SIZE', (0.0, 0))
-            w_kb, n_w = d.get('WRITE_SIZE', (0.0, 0))
-            kernels[k] = (2.0 * f_kb + w_kb) * 1024.0
-            if not (k.startswith('at::') or k.startswith('rocprim') or 'elementwise' in k or k.startswith('__amd_rocclr')):
-                total += kernels[k] * max(n_f, n_w)
-        return {'kernels': kernels, 'step_hbm_bytes': total / (steps + warm)}
+        return pmc_summary(per, steps_run)
     except Exception:                                                      # noqa: BLE001
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_summary(per, steps_run):
+    """per: {kernel + grid: {'FETCH_SIZE': (mean KB per launch, launches), 'WRITE_SIZE': (..)}} of a run of `steps_run` full-size
+    steps -> per-launch HBM bytes of every kernel, corrected as MI355X_MICROARCH.md's HBM section prescribes for gfx950
+    (2 x FETCH_SIZE + WRITE_SIZE: FETCH_SIZE counts half of a wide streaming read) AND uncorrected (FETCH_SIZE + WRITE_SIZE:
+    the factor is stated for wide coalesced reads, a row-per-lane gather may not need it -- the truth lies between), and
+    the bytes of ONE step = sum over libtipk's kernels of bytes per launch x launches / steps_run."""
+    kernels, raw, total, total_raw = {}, {}, 0.0, 0.0
+    for k, d in per.items():
+        f_kb, n_f = d.get('FETCH_SIZE', (0.0, 0))
+        w_kb, n_w = d.get('WRITE_SIZE', (0.0, 0))
+        kernels[k] = (2.0 * f_kb + w_kb) * 1024.0
+        raw[k] = (f_kb + w_kb) * 1024.0
+        if not (k.startswith('at::') or k.startswith('rocprim') or 'elementwise' in k or k.startswith('__amd_rocclr')):
+            total += kernels[k] * max(n_f, n_w)
+            total_raw += raw[k] * max(n_f, n_w)
+    return {'kernels': kernels, 'kernels_uncorrected': raw, 'step_hbm_bytes': total / steps_run,
+            'step_hbm_bytes_uncorrected': total_raw / steps_run, 'steps_run': steps_run}
 
 
 def pmc_traffic(key_prefix, grid, build_id):
@@ -422,9 +458,10 @@ def pmc_traffic(key_prefix, grid, build_id):
     def match(name):
         return name.startswith(key_prefix) and (grid is None or name.endswith('grid=' + grid))
     if _LIVE_PMC is not None:
-        hits = [b for name, b in _LIVE_PMC['kernels'].items() if match(name)]
-        if hits:                                       # (the toy graph of `init_s` launches the same kernels on a small grid)
-            return max(hits), None, 'this run'
+        hits = [(b, name) for name, b in _LIVE_PMC['kernels'].items() if match(name)]
+        if hits:
+            b, name = max(hits)
+            return b, None, 'this run', _LIVE_PMC.get('kernels_uncorrected', {}).get(name)
     try:
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
             doc = json.load(open(fn))
@@ -444,7 +481,7 @@ def pmc_traffic(key_prefix, grid, build_id):
                 break
     except Exception:
         pass
-    return traffic, trace_us, src
+    return traffic, trace_us, src, None
 
 
 def step_hbm_bytes(build_id):
@@ -452,12 +489,12 @@ def step_hbm_bytes(build_id):
     (tools/summarize_prof.py: all libtipk launches of `bench.py --step-only` / (steps + warmup))."""
     import glob
     if _LIVE_PMC is not None and _LIVE_PMC.get('step_hbm_bytes'):
-        return float(_LIVE_PMC['step_hbm_bytes']), 'this run'
+        return float(_LIVE_PMC['step_hbm_bytes']), 'this run', _LIVE_PMC.get('step_hbm_bytes_uncorrected')
     try:
         for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
             doc = json.load(open(fn))
             if doc.get('build_id') == build_id and doc.get('step_hbm_bytes'):
-                return float(doc['step_hbm_bytes']), os.path.basename(fn)
+                return float(doc['step_hbm_bytes']), os.path.basename(fn), doc.get('step_hbm_bytes_uncorrected')
     except Exception:
         pass
     return None
@@ -473,6 +510,8 @@ def roofline_of(rec, us, build_id):
         achieved = rec['work'] / (us * 1e-6) / 1e12
         roof = {'bound': 'mfma', 'kernel': rec['label'], 'achieved': achieved, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': achieved * 1e12 / MFMA_F32_PEAK, 'launch_us': us, 'algorithmic_flops_per_launch': rec['work']}
+        if rec.get('note'):
+            roof['note'] = rec['note']
         if rec.get('flops_dense_form'):
             roof['frac_dense_form'] = rec['flops_dense_form'] / (us * 1e-6) / MFMA_F32_PEAK
             roof['note'] = ('algorithmic flops = both products of dY over the %d (relation, source) rows that have an edge; '
@@ -488,8 +527,10 @@ def roofline_of(rec, us, build_id):
                             'rate; HBM only carries the ids and the output rows')
     roof['grid'] = rec['grid']
     roof['timing'] = 'HIP events on the launch stream around a hipGraph of 20 back-to-back launches'
-    traffic, trace_us, src = pmc_traffic(rec['key'], rec['grid'], build_id)
+    traffic, trace_us, src, traffic_raw = pmc_traffic(rec['key'], rec['grid'], build_id)
     roof['traffic'] = traffic
+    if traffic_raw is not None:
+        roof['traffic_uncorrected'] = traffic_raw          # FETCH_SIZE + WRITE_SIZE without the gfx950 factor 2 on FETCH_SIZE
     if traffic is not None:
         roof['hbm_traffic_frac'] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
         roof['traffic_source'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (child processes, eager launches)'
@@ -529,17 +570,12 @@ def step_floor(launch_us, launches, kern, pp_edges, dims, pp_rows_edges=None):
                 t = n_e * (4 + 4 * dcol) / (L2_GATHER_GBS * 1e9) * 1e6              # the 2.4 MB table is L2-resident
                 parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
                 pp += kern[label][0] // passes
-            elif label.startswith('pp_stream['):                                    # round 3: rows out of LDS (8-byte rows)
-                dcol = int(label.split('d=')[1].split(']')[0])
-                t = pp_edges * 4 * dcol / (LDS_PEAK_GBS * 1e9) * 1e6
-                parts[label] = max(t, LAUNCH_FLOOR_US) * (kern[label][0] // passes)
-                pp += kern[label][0] // passes
         rest = max(0, n_launches - modelled - pp)
         parts['%d other launches x %.1f us' % (rest, LAUNCH_FLOOR_US)] = rest * LAUNCH_FLOOR_US
     return {'us': sum(parts.values()), 'launches_per_step': n_launches, 'parts_us': {k: round(v, 2) for k, v in parts.items()},
             'note': 'sum over the launches of one step of max(kernel roofline time, %.1f us launch floor): D-D gathers at the LDS '
                     'ds_read_b128 peak, products at the fp32 MFMA peak (pair product: or its one pass over the cell matrix at 8 TB/s), '
-                    'P-P gathers at the LDS peak (wave streams over 2-column blocks; `gather_sum` route: the L2 gather rate, 18.8 TB/s), '
+                    'P-P gathers (`gather_sum`: rows of a 2.4 MB table out of the L2 of the XCD) at the L2 gather rate, 18.8 TB/s, '
                     'every other launch at the floor' % LAUNCH_FLOOR_US}
 
 
@@ -857,7 +893,7 @@ def main():
     # cumsum ... -- and of libtipk's code objects: ~0.4 s of lazy loading on a fresh process), timed on a toy graph and
     # reported as `init_s`; `preprocess_s` is then the plan build of the REAL graph (the first step)
     init_s = None
-    if not sharded:
+    if not sharded and not args.step_only:                     # (a --step-only child is a PMC pass: full-size steps only)
         from tip_amd.data import synthetic_data_dict
         t0 = time.perf_counter()
         toy = synthetic_data_dict(n_drug=96, n_rel=6, n_edges=6000, seed=1, with_protein_graph=True, n_prot=128, pp_edges=2048, dp_edges=256)
@@ -970,7 +1006,8 @@ def main():
             out['step_floor'] = fl
             hb = step_hbm_bytes(bid)
             if hb is not None:
-                out['step_hbm'] = {'bytes_measured': hb[0], 'frac_of_8TBps': hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                out['step_hbm'] = {'bytes_measured': hb[0], 'bytes_measured_uncorrected': hb[2],
+                                   'frac_of_8TBps': hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    'source': 'rocprofv3 --pmc passes of this run' if hb[1] == 'this run' else 'profiles/' + hb[1] + ' (same build id)'}
         if kern:
             out['kernels_eager_ms'] = {

@@ -416,26 +416,29 @@ int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32
  *     -- no row of dY = A_r^T g' is ever formed (sections 2b / 2d), nothing is per relation until the last line, and on a
  *     symmetric graph that line walks HALF the edges: datt[r] = sum_{u <= v} (pg[slot(u, v)] + pg[slot(v, u)]).
  *     tipk_rgcn_pair_grads (the first two lines), plan arrays of tip_amd/plan.py `build_pair_bwd_plan`:
- *       slots [n_slots][4]  { v, float bits of 1 / deg(v), cell line of (u, v), 0 }: the neighbours of a node in runs of
- *          32 (n_slots % 32 == 0; pads carry a valid v / line and the factor 0.0f, so they add zeros -- g must be finite);
- *          cell line L = the n_bases floats at cells + L * n_bases (a symmetric forward pass keeps (min, max) only);
+ *       slots [n_slots][4]  { v, float bits of 1 / deg(v), cell line of (u, v), row of pg }: the neighbours of a node in runs
+ *          of 32 (n_slots % 32 == 0; pads carry a valid v / line, the factor 0.0f and a dump row, so they add zeros -- g must
+ *          be finite); cell line L = the n_bases floats at cells + L * n_bases (a symmetric forward pass keeps (min, max) only);
  *       node_desc [n_nodes][4]  { node u, its first slot, its tiles of 32 slots, 0 } by DECREASING tile count;
  *       cells: n_lines lines of n_bases floats; xb [n_nodes][n_bases][32] as in 2c; g [n_nodes][ld_g]; dxb element
- *       (b, u, c) at dxb[b * dxb_sb + u * dxb_su + c], written COMPLETE; pg [n_slots][n_bases] (pad rows are written too).
+ *       (b, u, c) at dxb[b * dxb_sb + u * dxb_su + c], written COMPLETE; pg [pg_rows][n_bases]: the gradient row of a slot
+ *       is written to row slots[..][3] -- the place the gather below stages it from, so pg needs no index on the way out.
  *     n_bases = 32, d in {16, 32} (`tipk_rgcn_pair_grads_supported`).  All sums in fixed order: bitwise reproducible.
- *     tipk_stream_gather_parts (the last line) is tipk_stream_gather (1d) with a table PER WORKGROUP: the pairs are cut
- *     into partitions of part_len rows that fit in LDS, row i of partition p = table[part_rows[p * part_len + i][0]] +
- *     table[part_rows[..][1]] (table = pg with one more row of zeros for "no second term" and for pad rows), wg_part
- *     [n_wg] = the partition a workgroup stages, ids = rows inside the partition, output rows = p * n_rel + r
- *     (out [n_parts * n_rel][d], added over p in order by tipk_sum_slabs(_group)).  d = 32 (one 128-byte row per pair).
+ *     tipk_stream_gather_parts (the last line) is tipk_stream_gather (1d) with a table PER WORKGROUP: the pairs (sorted) are
+ *     cut into partitions of at most part_len consecutive rows that fit in LDS, row i of partition p = table[part_first[p] + i]
+ *     + table[second + part_first[p] + i] (table = pg: first half = the rows of (u, v), u <= v, second half = the rows of
+ *     their mirrors; rows nobody writes hold zeros), wg_part [n_wg] = the partition a workgroup stages, ids = rows counted
+ *     from the partition's first, output rows = p * n_rel + r (out [n_parts * n_rel][d], added over p in order by
+ *     tipk_sum_slabs(_group)).  d = 32 (one 128-byte row per pair); every partition is staged part_len rows long.
  */
 int tipk_rgcn_pair_grads_supported(int n_bases, int d);
 int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const float* xb, const float* g, int64_t ld_g,
                          int64_t n_nodes, int n_bases, int d, const int32_t* node_desc, const int32_t* slots,
-                         int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg, tipk_stream_t stream);
-int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, const int32_t* part_rows, int64_t part_len,
-                             const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr, const uint32_t* cells,
-                             const uint16_t* ids, int idx_unit, const int32_t* zero_ptr /* nullable */,
+                         int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg, int64_t pg_rows,
+                         tipk_stream_t stream);
+int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, int64_t second, const int32_t* part_first,
+                             int64_t part_len, const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr,
+                             const uint32_t* cells, const uint16_t* ids, int idx_unit, const int32_t* zero_ptr /* nullable */,
                              const int32_t* zero_rows, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

@@ -345,9 +345,9 @@ def test_pair_grads_backward(ops, R, N, d, symmetric, per_rel):
         xb_pad[:N, :, :d] = xb
         flat, xb_pad = flat.to(DEV), xb_pad.to(DEV)
         cells = flat[:n_pad * N * nb].view(n_pad, N, nb)
-        job, g_xb = ops.pair_grads(plan, cells, xb_pad[:, :, :d], gz.to(DEV))
+        job, g_xb = ops.pair_backward(plan, cells, xb_pad[:, :, :d], gz.to(DEV))
         ops.gemm_group([], [job])
-        job2, g_xb2 = ops.pair_grads(plan, cells, xb_pad[:, :, :d], gz.to(DEV))
+        job2, g_xb2 = ops.pair_backward(plan, cells, xb_pad[:, :, :d], gz.to(DEV))
         ops.gemm_group([], [job2])
         assert torch.equal(job2.out, job.out) and torch.equal(g_xb2, g_xb)
         return job.out, g_xb, want_att, want_xb

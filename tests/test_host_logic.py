@@ -551,10 +551,30 @@ def test_bench_roofline_helpers(tmp_path, monkeypatch):
     (prof / 'r09_pmc_traffic.json').write_text(js.dumps(doc))
     (prof / 'r09_kernel_by_grid.csv').write_text('# x\nkernel_and_grid,calls,avg_ns,min_ns,max_ns\n"node_products_kernel<1> grid=294144x1x1",5,40500,1,2\n')
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
-    assert bench.pmc_traffic('node_products_kernel', None, 'bbbb') == (None, None, None)          # other build: dropped
-    t, us, src = bench.pmc_traffic('node_products_kernel', None, 'aaaa')
+    assert bench.pmc_traffic('node_products_kernel', None, 'bbbb') == (None, None, None, None)    # other build: dropped
+    t, us, src, _raw = bench.pmc_traffic('node_products_kernel', None, 'aaaa')
     assert t == 1.0e8 and abs(us - 40.5) < 1e-9 and src == 'r09_pmc_traffic.json'
     assert bench.step_hbm_bytes('bbbb') is None and bench.step_hbm_bytes('aaaa')[0] == 9.0e8
+    # the run's own PMC passes: a child runs prepare() + warm-up + steps FULL-SIZE steps and nothing else;
+    # bytes of one step = sum over libtipk's kernels of bytes per launch x launches / that count -- torch's kernels excluded --
+    # and every figure exists corrected (2 x FETCH_SIZE + WRITE_SIZE) and uncorrected
+    per = {'pair_grads_kernel<32> grid=165120x1x1': {'FETCH_SIZE': (10.0, 5), 'WRITE_SIZE': (20.0, 5)},
+           'gather_sum_kernel<4> grid=1024x1x1': {'FETCH_SIZE': (1.0, 10), 'WRITE_SIZE': (0.5, 10)},
+           'at::native::vectorized_elementwise_kernel<4> grid=64x1x1': {'FETCH_SIZE': (100.0, 50), 'WRITE_SIZE': (100.0, 50)}}
+    live = bench.pmc_summary(per, 5)
+    k = 'pair_grads_kernel<32> grid=165120x1x1'
+    assert live['kernels'][k] == 40.0 * 1024 and live['kernels_uncorrected'][k] == 30.0 * 1024 and live['steps_run'] == 5
+    assert live['step_hbm_bytes'] == (40.0 * 5 + 2.5 * 10) * 1024 / 5
+    assert live['step_hbm_bytes'] == sum(live['kernels'][q] * n for q, n in ((k, 5), ('gather_sum_kernel<4> grid=1024x1x1', 10))) / 5
+    assert live['step_hbm_bytes_uncorrected'] == (30.0 * 5 + 1.5 * 10) * 1024 / 5
+    monkeypatch.setattr(bench, '_LIVE_PMC', live)
+    t, us, src, raw = bench.pmc_traffic('pair_grads_kernel<32>', None, 'zzzz')
+    assert (t, us, src, raw) == (40.0 * 1024, None, 'this run', 30.0 * 1024)
+    assert bench.step_hbm_bytes('zzzz') == (live['step_hbm_bytes'], 'this run', live['step_hbm_bytes_uncorrected'])
+    roof = bench.roofline_of({'label': 'pair_grads[dd.bwd,d=32]', 'key': 'pair_grads_kernel<32>', 'grid': None, 'bound': 'mfma',
+                              'work': 5.2e8, 'note': 'n'}, 10.0, 'zzzz')
+    assert roof['traffic'] == 40.0 * 1024 and roof['traffic_uncorrected'] == 30.0 * 1024 and roof['note'] == 'n'
+    monkeypatch.setattr(bench, '_LIVE_PMC', None)
     rec = {'label': 'node_products[dd.bwd,d=32]', 'key': 'node_products_kernel', 'grid': None, 'bound': 'mfma', 'work': 1.35e9,
            'rows': 329188, 'flops_dense_form': 2.9e9}
     roof = bench.roofline_of(rec, 40.0, 'aaaa')
@@ -688,7 +708,7 @@ def test_pair_bwd_plan_reference(symmetric, part_rows):
     src, dst, rel = torch.cat(src), torch.cat(dst), torch.cat(rel)
     scale = (1.0 / torch.bincount(dst, minlength=N).clamp(min=1).double()).float()
     plan = build_pair_bwd_plan(src, dst, rel, N, R, scale, symmetric, n_wg=6, part_rows_max=part_rows)
-    assert plan.n_slots % 32 == 0 and plan.part_rows.shape == (plan.n_parts * plan.part_len, 2)
+    assert plan.n_slots % 32 == 0 and plan.part_first.shape == (plan.n_parts,) and int(plan.part_first[0]) == 0
     assert int(plan.node_desc[:, 2].sum()) * 32 == plan.n_slots and bool((plan.node_desc[:-1, 2] >= plan.node_desc[1:, 2]).all())
     att = torch.randn(R, nb, generator=g, dtype=torch.float64)
     xb = torch.randn(N, nb, d, generator=g, dtype=torch.float64)

@@ -40,9 +40,9 @@ struct PgArgs {
     const float* xb;                    // [n_nodes][32 bases][32]  (rows padded to 32 columns)
     const float* g; int ld_g;           // [n_nodes][d]
     const int4* node_desc;              // [n_nodes] {u, first slot, tiles, 0}, heaviest first
-    const int4* slots;                  // [n_slots] {v, bits of 1 / deg(v) (0 for a pad), cell line of (u, v), 0}
+    const int4* slots;                  // [n_slots] {v, bits of 1 / deg(v) (0 for a pad), cell line of (u, v), row of pg}
     float* dxb; int64_t dxb_sb, dxb_su;
-    float* pg;                          // [n_slots][32]
+    float* pg;                          // [..][32]: slot s writes row slots[s].w
 };
 
 __device__ __forceinline__ float pg_ldg(const float* base, u32 byte_off) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         return a.slots[s_first + tl * 32 + n];
     };
     // operands of tile `tl` (clamped: a tile past the end re-reads the last one and is never multiplied)
-    auto load = [&](const int4& s, float (&cv)[NA], float (&gk)[H], float& ss) {
+    auto load = [&](const int4& s, float (&cv)[NA], float (&gk)[H], float& ss, int& dest) {
         if constexpr (D == 32) {
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
@@ -122,8 +122,9 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             gk[4 * i] = x.x; gk[4 * i + 1] = x.y; gk[4 * i + 2] = x.z; gk[4 * i + 3] = x.w;
         }
         ss = __int_as_float(s.y);
+        dest = s.w;
     };
-    auto compute = [&](int tl, const float (&cv)[NA], const float (&gk)[H], float ss) {
+    auto compute = [&](const int dest, const float (&cv)[NA], const float (&gk)[H], float ss) {
         float gs[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) gs[i] = gk[i] * ss;                     // g'[v_j][H kh + i]
@@ -155,29 +156,33 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 acc_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[2 * ks + 1], bv[ks], acc_hi, 0, 0, 0);
             }
         }
-        // rows of dC: C/D layout of the 32x32 MFMA -- column = lane & 31 (base), row = (reg & 3) + 8 (reg >> 2) + 4 kh (slot)
-        float* o = a.pg + ((int64_t)(s_first + tl * 32)) * 32 + n;
+        // rows of dC: C/D layout of the 32x32 MFMA -- column = lane & 31 (base), row = (reg & 3) + 8 (reg >> 2) + 4 kh (slot);
+        // every row goes where the d att gather stages it from (the slot's own word): two full 128-byte lines per store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32] = pc[r];
+        for (int r = 0; r < 16; ++r) {
+            const int dj = __shfl(dest, (r & 3) + 8 * (r >> 2) + 4 * kh, 64);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(a.pg) + ((u32)dj * 128u + (u32)n * 4u)) = pc[r];
+        }
     };
 
     if (n_tiles > 0) {
         float cX[NA], gX[H], cY[NA], gY[H];
         float sX = 0.f, sY = 0.f;
+        int dX = 0, dY = 0;
         int tl = w;
         int4 slX = getslot(tl), slY = getslot(tl + PG_WAVES);
-        load(slX, cX, gX, sX);
+        load(slX, cX, gX, sX, dX);
         for (; tl < n_tiles; tl += 2 * PG_WAVES) {
             slX = getslot(tl + 2 * PG_WAVES);
-            load(slY, cY, gY, sY);
+            load(slY, cY, gY, sY, dY);
             __builtin_amdgcn_sched_barrier(0);
-            compute(tl, cX, gX, sX);
+            compute(dX, cX, gX, sX);
             __builtin_amdgcn_sched_barrier(0);
             if (tl + PG_WAVES < n_tiles) {                                  // (uniform)
                 slY = getslot(tl + 3 * PG_WAVES);
-                load(slX, cX, gX, sX);
+                load(slX, cX, gX, sX, dX);
                 __builtin_amdgcn_sched_barrier(0);
-                compute(tl + PG_WAVES, cY, gY, sY);
+                compute(dY, cY, gY, sY);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -224,7 +229,7 @@ extern "C" int tipk_rgcn_pair_grads_supported(int n_bases, int d) {
 
 extern "C" int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const float* xb, const float* g, int64_t ld_g,
                                     int64_t n_nodes, int n_bases, int d, const int32_t* node_desc, const int32_t* slots,
-                                    int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg,
+                                    int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg, int64_t pg_rows,
                                     tipk_stream_t stream) {
     if (!tipk_rgcn_pair_grads_supported(n_bases, d)) return TIPK_EUNSUPPORTED;
     if (!cells || !xb || !g || !node_desc || !slots || !dxb || !pg || n_nodes <= 0 || n_slots <= 0 || n_slots % 32 != 0 ||
@@ -234,7 +239,7 @@ extern "C" int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const f
         (reinterpret_cast<uintptr_t>(node_desc) & 15) || (reinterpret_cast<uintptr_t>(slots) & 15))
         return TIPK_EINVAL;
     // 32-bit byte offsets into cells, xb and g
-    if (n_lines <= 0 || n_lines * 128 >= (1LL << 32) || n_nodes * 4096 >= (1LL << 32) || n_nodes * ld_g * 4 >= (1LL << 32) ||
+    if (pg_rows <= 0 || pg_rows * 128 >= (1LL << 32) || n_lines <= 0 || n_lines * 128 >= (1LL << 32) || n_nodes * 4096 >= (1LL << 32) || n_nodes * ld_g * 4 >= (1LL << 32) ||
         n_nodes > 0x7fffffffLL)
         return TIPK_EUNSUPPORTED;
     PgArgs a;

@@ -55,10 +55,11 @@ struct RsArgs {
     const float* out_scale;
     const float* bias;
     int relu;
-    // KIND 2 (tipk_stream_gather_parts): every workgroup stages ITS partition of a table that exists only as sums of two
-    // rows of `table`: LDS row i of partition p = table[part_rows[p * n_nodes + i].x] + table[...y]
-    const int2* part_rows;
+    // KIND 2 (tipk_stream_gather_parts): every workgroup stages ITS partition of a table that exists as two halves:
+    // LDS row i of partition p = table[part_first[p] + i] + table[second + part_first[p] + i]
+    const int32_t* part_first;         // [n_parts] first table row of a partition
     const int32_t* wg_part;            // [n_wg] partition of a workgroup
+    int64_t second;                    // rows between the two halves
 };
 
 // a lane's piece of a row: float4 (16-byte rows and wider) or float2 (8-byte rows: tables of up to 19 000 nodes)
@@ -135,26 +136,20 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     const int total4 = n_nodes * q4;
     if (t < dc) tab[(int64_t)n_nodes * dc + t] = 0.f;
     if constexpr (KIND == 2) {
-        // the partition in ONE batch of requests: row pairs first (8 lanes share one), then both rows of every piece
+        // the partition in ONE batch of requests: both halves of every piece, two contiguous streams
         constexpr int PSTAGE = 8;
         const int part = __builtin_amdgcn_readfirstlane(a.wg_part[blockIdx.x]);
-        const int2* rows = a.part_rows + (int64_t)part * n_nodes;
+        const float* ta = table + (int64_t)__builtin_amdgcn_readfirstlane(a.part_first[part]) * a.ld_t;
+        const float* tb = ta + a.second * a.ld_t;
         for (int base = 0; base < total4; base += 1024 * PSTAGE) {
-            int2 rr[PSTAGE];
-#pragma unroll
-            for (int u = 0; u < PSTAGE; ++u) {
-                int i = base + u * 1024 + t;
-                i = i < total4 ? i : total4 - 1;
-                rr[u] = rows[i / q4];
-            }
             vec_t ga[PSTAGE], gb[PSTAGE];
 #pragma unroll
             for (int u = 0; u < PSTAGE; ++u) {
                 int i = base + u * 1024 + t;
                 i = i < total4 ? i : total4 - 1;
-                const int c = (i % q4) * VW;
-                ga[u] = *reinterpret_cast<const vec_t*>(table + (int64_t)rr[u].x * a.ld_t + c);
-                gb[u] = *reinterpret_cast<const vec_t*>(table + (int64_t)rr[u].y * a.ld_t + c);
+                const int64_t off = (int64_t)(i / q4) * a.ld_t + (i % q4) * VW;
+                ga[u] = *reinterpret_cast<const vec_t*>(ta + off);
+                gb[u] = *reinterpret_cast<const vec_t*>(tb + off);
             }
 #pragma unroll
             for (int u = 0; u < PSTAGE; ++u) {
@@ -329,7 +324,7 @@ extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t 
     a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
     a.out = out; a.ld_out = ld_out; a.row_scale = row_scale;
     a.out_scale = out_scale; a.bias = bias; a.relu = relu;
-    a.part_rows = nullptr; a.wg_part = nullptr;
+    a.part_first = nullptr; a.wg_part = nullptr; a.second = 0;
     if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || (int64_t)n_nodes * idx_unit > 65535) return TIPK_EINVAL;
     a.idx_mul = a.dc * 4 / idx_unit;
     hipStream_t st = (hipStream_t)stream;
@@ -343,15 +338,15 @@ extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t 
     }
 }
 
-// d att of the pair-form backward pass (include/tipk.h section 2e): out[p * n_rel + r] = sum over the pairs of partition p
-// that relation r links of (table[a] + table[b]), (a, b) = part_rows of the pair.  A partition's sums are staged in LDS by
-// each of its workgroups (wg_part); everything else is tipk_stream_gather.
-extern "C" int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, const int32_t* part_rows, int64_t part_len,
-                                         const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr, const uint32_t* cells,
-                                         const uint16_t* ids, int idx_unit, const int32_t* zero_ptr, const int32_t* zero_rows,
-                                         float* out, int64_t ld_out, tipk_stream_t stream) {
-    if (n_wg <= 0 || n_wg > 65535 || !table || !part_rows || !wg_part || !wave_ptr || !cells || !ids || (zero_ptr && !zero_rows) ||
-        !out || (reinterpret_cast<uintptr_t>(ids) & 15) || (reinterpret_cast<uintptr_t>(part_rows) & 7))
+// d att of the pair-form backward pass (include/tipk.h section 2e): out[p * n_rel + r] = sum over the pairs t of partition p
+// that relation r links of (table[t] + table[second + t]).  A partition's sums are staged in LDS by each of its
+// workgroups (wg_part); everything else is tipk_stream_gather.
+extern "C" int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, int64_t second, const int32_t* part_first,
+                                         int64_t part_len, const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr,
+                                         const uint32_t* cells, const uint16_t* ids, int idx_unit, const int32_t* zero_ptr,
+                                         const int32_t* zero_rows, float* out, int64_t ld_out, tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table || !part_first || !wg_part || !wave_ptr || !cells || !ids || (zero_ptr && !zero_rows) ||
+        !out || (reinterpret_cast<uintptr_t>(ids) & 15) || second < 0)
         return TIPK_EINVAL;
     if (d != 32) return TIPK_EUNSUPPORTED;                             // one 128-byte row per pair (n_bases = 32)
     if (part_len <= 0 || (part_len + 1) * d * 4 > RS_LDS_LIMIT) return TIPK_EUNSUPPORTED;
@@ -362,7 +357,7 @@ extern "C" int tipk_stream_gather_parts(const float* table, int64_t ld_table, in
     a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
     a.out = out; a.ld_out = ld_out; a.row_scale = nullptr;
     a.out_scale = nullptr; a.bias = nullptr; a.relu = 0;
-    a.part_rows = reinterpret_cast<const int2*>(part_rows); a.wg_part = wg_part;
+    a.part_first = part_first; a.wg_part = wg_part; a.second = second;
     if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || part_len * idx_unit > 65535) return TIPK_EINVAL;
     a.idx_mul = a.dc * 4 / idx_unit;
     return launch_rs<8>(a, (int)n_wg, 1, 2, (hipStream_t)stream);

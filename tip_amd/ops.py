@@ -476,10 +476,11 @@ def pair_grads_supported(nb, d):
 
 
 def pair_grads(pb, cells, xb_pad, g):
-    """The pair-form backward pass of an R-GCN layer (include/tipk.h section 2e) on plan `pb` (plan.PairBwdPlan):
-    cells = the cell buffer the forward pass filled ([N_pad, N, bases] + its trailing zeros, contiguous), xb_pad
-    [N_pad, bases, 32] = the node-major XB buffer of the pair product, g [N, d] (1 / deg is in the plan's slots).
-    -> (pending slab sum of d att [R, bases], d XB [bases, N, d] complete)."""
+    """The dense half of the pair-form backward pass of an R-GCN layer (include/tipk.h section 2e) on plan `pb`
+    (plan.PairBwdPlan): cells = the cell buffer the forward pass filled ([N_pad, N, bases] + its trailing zeros, contiguous),
+    xb_pad [N_pad, bases, 32] = the node-major XB buffer of the pair product, g [N, d] (1 / deg is in the plan's slots).
+    -> (pg [2 n_alloc + 1, bases]: the gradient row of every linked pair at the place `pair_att_gather` stages it from,
+    d XB [bases, N, d] complete)."""
     g = _f32c(g)
     require_device(cells, xb_pad, g, pb.slots)
     n, d = g.shape
@@ -487,20 +488,35 @@ def pair_grads(pb, cells, xb_pad, g):
     assert pb.n_nodes == n and g.stride(1) == 1 and cells.is_contiguous() and xb_pad.stride()[-2:] == (32, 1) and xb_pad.shape[1] == nb
     dev = g.device
     pg = pb.pg.get(str(dev))
-    if pg is None:                                    # kept on the plan: the zero row is written once, every call rewrites the rest
-        pg = pb.pg[str(dev)] = torch.zeros((pb.n_slots + 1, nb), dtype=torch.float32, device=dev)
+    if pg is None:                                    # kept on the plan, zeroed ONCE: a call rewrites the rows of the linked pairs,
+        pg = pb.pg[str(dev)] = torch.zeros((2 * pb.n_alloc + 1, nb), dtype=torch.float32, device=dev)   # the others stay zero
     dxb = torch.empty((nb, n, d), dtype=torch.float32, device=dev)
     with _timed('pair_grads[%dx%dx%d,slots=%d]' % (n, nb, d, pb.n_slots)):
         check(lib().tipk_rgcn_pair_grads(ptr(cells), cells.numel() // nb, ptr(xb_pad), ptr(g), g.stride(0), n, nb, d,
                                          ptr(pb.node_desc), ptr(pb.slots), pb.n_slots, ptr(dxb), dxb.stride(0), dxb.stride(1),
-                                         ptr(pg), stream_ptr(dev)), 'tipk_rgcn_pair_grads')
+                                         ptr(pg), pg.shape[0], stream_ptr(dev)), 'tipk_rgcn_pair_grads')
+    return pg, dxb
+
+
+def pair_att_gather(pb, pg):
+    """d att of the pair-form backward pass: per partition of the pairs one slab [R, bases] of sums of (symmetrised) rows of
+    pg over the pairs each relation links (`tipk_stream_gather_parts`) -> the pending ordered slab sum (`slab_job`)."""
+    require_device(pg, pb.part_first)
+    nb = pg.shape[1]
+    assert pg.shape[0] == 2 * pb.n_alloc + 1 and pg.is_contiguous()
     gp = pb.gather
-    slabs = torch.empty((pb.n_parts, pb.n_rel, nb), dtype=torch.float32, device=dev)
+    slabs = torch.empty((pb.n_parts, pb.n_rel, nb), dtype=torch.float32, device=pg.device)
     with _timed('pair_att_gather[parts=%d,edges=%d]' % (pb.n_parts, gp.n_edges)):
-        check(lib().tipk_stream_gather_parts(ptr(pg), nb, nb, ptr(pb.part_rows), pb.part_len, ptr(pb.wg_part), gp.n_wg,
+        check(lib().tipk_stream_gather_parts(ptr(pg), nb, nb, pb.n_alloc, ptr(pb.part_first), pb.part_len, ptr(pb.wg_part), gp.n_wg,
                                              ptr(gp.wave_ptr), ptr(gp.cells), ptr(gp.ids), gp.idx_unit, ptr(gp.zero_ptr),
-                                             ptr(gp.zero_rows), ptr(slabs), nb, stream_ptr(dev)), 'tipk_stream_gather_parts')
-    return slab_job(slabs), dxb
+                                             ptr(gp.zero_rows), ptr(slabs), nb, stream_ptr(pg.device)), 'tipk_stream_gather_parts')
+    return slab_job(slabs)
+
+
+def pair_backward(pb, cells, xb_pad, g):
+    """(pending slab sum of d att [R, bases], d XB [bases, N, d]): `pair_grads` + `pair_att_gather`."""
+    pg, dxb = pair_grads(pb, cells, xb_pad, g)
+    return pair_att_gather(pb, pg), dxb
 
 
 class SlabJob(object):
@@ -1412,7 +1428,7 @@ class _RGCN(torch.autograd.Function):
                 stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
                 graph.pair_stamp += 1
                 ctx.xb_stamp = graph.pair_stamp
-            j_att, g_xb = pair_grads(graph.pair_bwd, cells, xb_nb, g)
+            j_att, g_xb = pair_backward(graph.pair_bwd, cells, xb_nb, g)
         elif ctx.xb_stamp is not None:                                   # XB lives in the graph's node-major buffer (forward)
             if graph.pair_stamp == ctx.xb_stamp:
                 xb = graph.pair_buffers(n, nb, d_out, x.device)[1][:n].permute(1, 0, 2)

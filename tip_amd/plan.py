@@ -871,31 +871,35 @@ def execute_rel_plan_reference(plan, table, backward):
 # ---------------------------------------------------------------------------------------------
 # pair-form BACKWARD pass (include/tipk.h section 2e)
 # ---------------------------------------------------------------------------------------------
-PAIR_PART_ROWS = 1008       # pairs per partition of the d att gather: (rows + 1) x 128 B of LDS, 16-bit pre-scaled ids
+PAIR_PART_ROWS = 1016       # most pairs of one partition of the d att gather: (rows + 1) x 128 B of LDS, 16-bit ids x 64
+PAIR_PART_WGS = 4           # workgroups that share a partition (each stages it)
 PAIR_PART_EDGES_PER_WG = 16384
 
 
 class PairBwdPlan(object):
     """Device arrays of `tipk_rgcn_pair_grads` + `tipk_stream_gather_parts` (layout: include/tipk.h section 2e).
 
-    slots [n_slots, 4] int32 {v, bits of 1 / deg(v), cell line, 0}, node_desc [N, 4] int32 {u, first slot, tiles, 0};
-    part_rows [n_parts * part_len, 2] int32 (rows of pg, n_slots = the zero row), wg_part [n_wg] int32, and the merged
-    wave-stream arrays of the partitions (`gather`: a StreamPlan whose rows are p * n_rel + r, ids = rows inside a partition)."""
+    slots [n_slots, 4] int32 {v, bits of 1 / deg(v), cell line, row of pg the slot's gradient row is written to},
+    node_desc [N, 4] int32 {u, first slot, tiles, 0}; pg = two tables of n_alloc rows + one dump row: row t of the first
+    table = the gradient row of pair t = (u, v), of the second = that of the mirrored pair (v, u) (symmetric graphs; zeros
+    otherwise); part_first [n_parts] int32 = first pair of a partition, wg_part [n_wg] int32, and the merged wave-stream
+    arrays of the partitions (`gather`: a StreamPlan whose rows are p * n_rel + r, ids = pairs counted from the partition's
+    first)."""
 
-    def __init__(self, n_nodes, n_rel, n_slots, slots, node_desc, n_parts, part_len, part_rows, wg_part, gather, symmetric,
-                 slot_of_pair=None):
+    def __init__(self, n_nodes, n_rel, n_slots, slots, node_desc, n_parts, part_len, part_first, wg_part, gather, symmetric,
+                 n_alloc, slot_of_pair=None):
         self.n_nodes, self.n_rel, self.n_slots = int(n_nodes), int(n_rel), int(n_slots)
         self.slots, self.node_desc = slots, node_desc
-        self.n_parts, self.part_len, self.part_rows, self.wg_part, self.gather = int(n_parts), int(part_len), part_rows, wg_part, gather
-        self.symmetric = bool(symmetric)
+        self.n_parts, self.part_len, self.part_first, self.wg_part, self.gather = int(n_parts), int(part_len), part_first, wg_part, gather
+        self.symmetric, self.n_alloc = bool(symmetric), int(n_alloc)
         self.slot_of_pair = slot_of_pair          # (tests) int64 [n_directed_pairs, 3] = (u, v, slot)
-        self.pg = {}                              # device -> the pair-gradient buffer [n_slots + 1, n_bases] (last row = zeros)
+        self.pg = {}                              # device -> the pair-gradient buffer [2 * n_alloc + 1, n_bases], zeroed ONCE
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
         return PairBwdPlan(self.n_nodes, self.n_rel, self.n_slots, mv(self.slots), mv(self.node_desc), self.n_parts,
-                           self.part_len, mv(self.part_rows), mv(self.wg_part), self.gather.to(device), self.symmetric,
-                           mv(self.slot_of_pair))
+                           self.part_len, mv(self.part_first), mv(self.wg_part), self.gather.to(device), self.symmetric,
+                           self.n_alloc, mv(self.slot_of_pair))
 
 
 def build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg=256, lanes=8, piece=4,
@@ -903,8 +907,12 @@ def build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg=25
     """Plan of the pair-form backward pass of a D-D graph (src -> dst edges of relation rel; `scale` [N] = 1 / in-degree as
     the layer applies it).  symmetric: every relation links u -> v iff v -> u, and the forward pass kept the cells with
     u <= v only (`rgcn_graph`): a cell is read at line min * N + max, and the d att gather walks the edges with u <= v over
-    the sums pg[slot(u, v)] + pg[slot(v, u)].  Otherwise: line u * N + v, all edges, one term.
-    line_stride: nodes per row of the cell matrix (default n_nodes)."""
+    the sums of the two gradient rows of a pair.  Otherwise: line u * N + v, all edges, one term.
+    line_stride: nodes per row of the cell matrix (default n_nodes).
+
+    The pairs the gather walks are dealt to partitions that fit in LDS, with equal numbers of pairs and of EDGES (a pair is
+    linked by 1 ... 475 relations at BioSNAP); PAIR_PART_WGS workgroups share a partition, the relations' runs inside it are
+    dealt to their wavefronts by `build_stream_plan_rows`."""
     dev = src.device
     N, R = int(n_nodes), int(n_rel)
     ls = N if line_stride is None else int(line_stride)
@@ -921,58 +929,70 @@ def build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg=25
     slot = first_tile[pu] * 32 + (torch.arange(n_dp, device=dev) - first_pair[pu])
     line = torch.where(pu <= pv, pu * ls + pv, pv * ls + pu) if symmetric else pu * ls + pv
     assert n_slots > 0 and int(line.max()) < 2 ** 24
-    # pads: the node's own first neighbour / line with the factor 0 (they add zeros; their pg rows are never read)
-    slot_node = torch.repeat_interleave(torch.arange(N, device=dev), tiles * 32)
-    sl_v = pv[first_pair.clamp(max=max(n_dp - 1, 0))][slot_node].clone()
-    sl_line = line[first_pair.clamp(max=max(n_dp - 1, 0))][slot_node].clone()
-    sl_scale = torch.zeros(n_slots, dtype=torch.float32, device=dev)
-    sl_v[slot], sl_line[slot] = pv, line
-    sl_scale[slot] = scale.to(dev).to(torch.float32)[pv]
-    slots = torch.stack([sl_v.to(torch.int32), sl_scale.view(torch.int32), sl_line.to(torch.int32),
-                         torch.zeros(n_slots, dtype=torch.int32, device=dev)], dim=1).contiguous()
-    order = torch.sort(tiles, descending=True, stable=True).indices
-    node_desc = torch.stack([order, first_tile[order] * 32, tiles[order], torch.zeros_like(order)], dim=1).to(torch.int32).contiguous()
-    # ---- the d att gather: rows of the (symmetrised) pair-gradient table, cut into partitions that fit in LDS
+    # ---- the table of the d att gather: one row per pair walked
     if symmetric:
         keep = pu <= pv
-        tu, tv = pu[keep], pv[keep]
-        row_a = slot[keep]
-        # slot of the mirrored pair (v, u); a self pair has one term only
-        mk = tv * N + tu
-        pos = torch.searchsorted(key, mk)
-        assert bool((key[pos.clamp(max=n_dp - 1)] == mk).all()), 'graph is not symmetric'
-        row_b = torch.where(tu == tv, torch.full_like(pos, n_slots), slot[pos.clamp(max=n_dp - 1)])
+        t_key = key[keep]                                                 # ascending (u, v), u <= v
         ek = src <= dst
         e_key, e_rel = (src * N + dst)[ek], rel[ek]
+        lo, hi = torch.minimum(pu, pv), torch.maximum(pu, pv)
+        row_of = torch.searchsorted(t_key, lo * N + hi)                   # pair (u, v) and its mirror share a row
+        assert bool((t_key[row_of.clamp(max=t_key.numel() - 1)] == lo * N + hi).all()), 'graph is not symmetric'
     else:
-        tu, tv, row_a = pu, pv, slot
-        row_b = torch.full_like(slot, n_slots)
+        t_key = key
         e_key, e_rel = src * N + dst, rel
-    t_key = tu * N + tv                                                   # ascending
+        row_of = torch.arange(n_dp, device=dev)
     n_t = int(t_key.numel())
-    n_parts = max(1, -(-n_t // int(part_rows_max)))
-    part_len = -(-n_t // n_parts)
-    part_len = -(-part_len // 8) * 8
-    assert (part_len + 1) * lanes * 16 <= 158 * 1024
-    e_row = torch.searchsorted(t_key, e_key)                              # table row of every edge walked
-    e_part, e_local = e_row // part_len, e_row % part_len
-    part_rows = torch.full((n_parts * part_len, 2), n_slots, dtype=torch.int64, device=dev)
-    part_rows[:n_t, 0], part_rows[:n_t, 1] = row_a, row_b
-    # workgroups per partition in proportion to the edges it walks
     E = int(e_key.numel())
+    e_row = torch.searchsorted(t_key, e_key)                              # table row of every edge walked
+    # ---- partitions: equal numbers of rows AND of edges.  Where a pair's row sits in the table is free (the slots carry it),
+    # so the pairs are dealt to the partitions like cards, heaviest first, back and forth (BioSNAP: 1 ... 475 relations per
+    # pair, and 43 k ... 89 k edges per 1 000 consecutive pairs: consecutive blocks were 20 % apart)
+    cap = int(part_rows_max)
+    assert (cap + 1) * lanes * 16 <= 158 * 1024
+    n_parts = max(1, -(-n_t // cap))
+    if E >= 2 * PAIR_PART_WGS * PAIR_PART_EDGES_PER_WG:
+        n_parts = max(n_parts, min(int(n_wg) // PAIR_PART_WGS, -(-E // (PAIR_PART_WGS * PAIR_PART_EDGES_PER_WG))))
+    part_len = -(-(-(-n_t // n_parts)) // 8) * 8
+    row_edges = torch.bincount(e_row, minlength=n_t)
+    by_load = torch.sort(row_edges, descending=True, stable=True).indices
+    i = torch.arange(n_t, device=dev)
+    k, j = i // n_parts, i % n_parts
+    part_of = torch.empty(n_t, dtype=torch.int64, device=dev)
+    part_of[by_load] = torch.where(k % 2 == 0, j, n_parts - 1 - j)
+    # inside a partition the pairs keep their (u, v) order: a node's gradient rows land near each other
+    o_p = torch.sort(part_of, stable=True).indices
+    p_cnt = torch.bincount(part_of, minlength=n_parts)
+    p_start = torch.cumsum(p_cnt, 0) - p_cnt
+    new_row = torch.empty(n_t, dtype=torch.int64, device=dev)
+    new_row[o_p] = part_of[o_p] * part_len + (torch.arange(n_t, device=dev) - p_start[part_of[o_p]])
+    e_row, row_of = new_row[e_row], new_row[row_of]
+    part_first = torch.arange(n_parts, device=dev) * part_len
+    n_alloc = n_parts * part_len
+    e_part, e_local = e_row // part_len, e_row % part_len
+    # ---- slots: {v, 1 / deg(v), cell line, destination row of the gradient row}
+    # pads: the node's own first neighbour / line with the factor 0 (they add zeros); their gradient rows go to the dump row
+    slot_node = torch.repeat_interleave(torch.arange(N, device=dev), tiles * 32)
+    fp = first_pair.clamp(max=max(n_dp - 1, 0))
+    sl_v, sl_line = pv[fp][slot_node].clone(), line[fp][slot_node].clone()
+    sl_scale = torch.zeros(n_slots, dtype=torch.float32, device=dev)
+    sl_dest = torch.full((n_slots,), 2 * n_alloc, dtype=torch.int64, device=dev)
+    sl_v[slot], sl_line[slot] = pv, line
+    sl_scale[slot] = scale.to(dev).to(torch.float32)[pv]
+    sl_dest[slot] = torch.where(pu <= pv, row_of, n_alloc + row_of) if symmetric else row_of
+    assert 2 * n_alloc + 1 < 2 ** 25
+    slots = torch.stack([sl_v.to(torch.int32), sl_scale.view(torch.int32), sl_line.to(torch.int32), sl_dest.to(torch.int32)],
+                        dim=1).contiguous()
+    order = torch.sort(tiles, descending=True, stable=True).indices
+    node_desc = torch.stack([order, first_tile[order] * 32, tiles[order], torch.zeros_like(order)], dim=1).to(torch.int32).contiguous()
+    # ---- workgroups per partition
     e_cnt = torch.bincount(e_part, minlength=n_parts).cpu().tolist()
-    n_wg = int(max(n_parts, min(int(n_wg), -(-E // PAIR_PART_EDGES_PER_WG) if E else 1)))
-    wgs = [1] * n_parts
-    spare = n_wg - n_parts
-    if spare > 0 and E > 0:
-        want = [c * n_wg / float(E) for c in e_cnt]
-        for _ in range(spare):
-            p = max(range(n_parts), key=lambda q: want[q] / wgs[q])
-            wgs[p] += 1
+    per = max(1, min(int(n_wg) // n_parts, -(-E // (n_parts * PAIR_PART_EDGES_PER_WG)) if E else 1))
+    wgs = [per] * n_parts                                                 # (equal loads: equal shares)
     n_wg = sum(wgs)
-    # ---- one wave-stream plan per partition, concatenated
-    wave_ptr, cells, ids, zero_ptr, zero_rows, wg_part = [], [], [], [], [], []
-    band0 = z0 = 0
+    # ---- one wave-stream plan per partition, cut into its workgroups' pieces ...
+    S = 64 // lanes
+    pieces = {}                                                           # (partition, workgroup of it) -> its arrays
     idx_unit = None
     o_part = torch.sort(e_part, stable=True).indices
     p_first = [0]
@@ -985,17 +1005,38 @@ def build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg=25
         idx_unit = sp.idx_unit
         c = sp.cells.to(torch.int64) & 0xffffffff
         c = torch.where(c != 0, c + p * R, c)                             # output row = p * R + relation (24-bit field)
-        cells.append(torch.where(c >= 2 ** 31, c - 2 ** 32, c).to(torch.int32))
-        ids.append(sp.ids[:sp.n_bands * piece * (64 // lanes) * 8])
-        wave_ptr.append(sp.wave_ptr[:-1].to(torch.int64) + band0)
-        zr = sp.zero_rows[:int(sp.zero_ptr[-1])].to(torch.int64) + p * R
-        zero_rows.append(zr)
-        zero_ptr.append(sp.zero_ptr[:-1].to(torch.int64) + z0)
-        band0 += sp.n_bands
-        z0 += int(zr.numel())
-        wg_part += [p] * wgs[p]
+        c = torch.where(c >= 2 ** 31, c - 2 ** 32, c).to(torch.int32)
+        wp, zp = sp.wave_ptr.to(torch.int64), sp.zero_ptr.to(torch.int64)
+        idw = sp.ids.view(-1, piece * S * 8)                              # one row per band
+        for q in range(wgs[p]):
+            b0, b1 = int(wp[16 * q]), int(wp[16 * q + 16])
+            y0, y1 = int(zp[16 * q]), int(zp[16 * q + 16])
+            pieces[(p, q)] = (wp[16 * q:16 * q + 16] - b0, c[b0:b1], idw[b0:b1], zp[16 * q:16 * q + 16] - y0,
+                              sp.zero_rows[y0:y1].to(torch.int64) + p * R)
+    # ... laid out in LAUNCH order: workgroup b runs on XCD b mod 8, and the workgroups that stage the same partition should
+    # share an XCD -- then its rows cross the fabric once and the other three read them out of that XCD's L2 (in partition
+    # order the four sat on four XCDs: 66 MB instead of 17 MB out of the Infinity Cache per launch)
+    n_xcd = 8
+    per_xcd = [[(p, q) for p in range(x, n_parts, n_xcd) for q in range(wgs[p])] for x in range(n_xcd)]
+    order = []
+    while any(per_xcd):
+        for x in range(n_xcd):
+            src_l = per_xcd[x] if per_xcd[x] else max(per_xcd, key=len)
+            if src_l:
+                order.append(src_l.pop(0))
+    wave_ptr, cells, ids, zero_ptr, zero_rows, wg_part = [], [], [], [], [], []
+    band0 = z0 = 0
+    for (p, q) in order:
+        w_, c_, i_, z_, zr_ = pieces[(p, q)]
+        wave_ptr.append(w_ + band0)
+        zero_ptr.append(z_ + z0)
+        cells.append(c_)
+        ids.append(i_.reshape(-1))
+        zero_rows.append(zr_)
+        band0 += int(c_.shape[0])
+        z0 += int(zr_.numel())
+        wg_part.append(p)
     assert n_parts * R < 2 ** 24
-    S = 64 // lanes
     gather = StreamPlan(n_parts * R, part_len, n_wg, lanes, piece,
                         torch.cat(wave_ptr + [torch.tensor([band0], device=dev)]).to(torch.int32).contiguous(),
                         torch.cat(cells).view(-1, S).contiguous(),
@@ -1004,19 +1045,18 @@ def build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg=25
                         (torch.cat(zero_rows) if z0 else torch.zeros(1, dtype=torch.int64, device=dev)).to(torch.int32).contiguous(),
                         idx_unit)
     gather.n_edges = E
-    plan = PairBwdPlan(N, R, n_slots, slots, node_desc, n_parts, part_len, part_rows.to(torch.int32).contiguous(),
-                       torch.tensor(wg_part, dtype=torch.int32, device=dev), gather, symmetric,
+    return PairBwdPlan(N, R, n_slots, slots, node_desc, n_parts, part_len, part_first.to(torch.int32).contiguous(),
+                       torch.tensor(wg_part, dtype=torch.int32, device=dev), gather, symmetric, n_alloc,
                        torch.stack([pu, pv, slot], dim=1))
-    return plan
 
 
 def execute_pair_bwd_reference(plan, cells_flat, xb, g, n_bases):
     """Pure-torch interpretation of a pair-backward plan (CPU unit tests): cells_flat [n_lines, n_bases], xb [N, n_bases, d],
-    g [N, d] -> (dxb [n_bases, N, d], pg [n_slots + 1, n_bases], datt [n_rel, n_bases]) exactly as the two kernels sum them
+    g [N, d] -> (dxb [n_bases, N, d], pg [2 * n_alloc + 1, n_bases], datt [n_rel, n_bases]) exactly as the two kernels sum them
     (up to the order inside a tile)."""
     N, d = g.shape
     sl = plan.slots.to(torch.int64)
-    v, line = sl[:, 0], sl[:, 2]
+    v, line, dest = sl[:, 0], sl[:, 2], sl[:, 3]
     sc = plan.slots[:, 1].contiguous().view(torch.float32).to(g.dtype)
     gp = g[v] * sc.unsqueeze(1)                                           # [n_slots, d]
     nd = plan.node_desc.to(torch.int64)
@@ -1025,10 +1065,12 @@ def execute_pair_bwd_reference(plan, cells_flat, xb, g, n_bases):
         node_of_slot[s0:s0 + 32 * nt] = u
     dxb = torch.zeros((N, n_bases, d), dtype=g.dtype)
     dxb.index_add_(0, node_of_slot, cells_flat[line].unsqueeze(2) * gp.unsqueeze(1))
-    pg = torch.zeros((plan.n_slots + 1, n_bases), dtype=g.dtype)
-    pg[:plan.n_slots] = torch.einsum('sbc,sc->sb', xb[node_of_slot], gp)
-    pr = plan.part_rows.to(torch.int64)
-    table = (pg[pr[:, 0]] + pg[pr[:, 1]]).view(plan.n_parts, plan.part_len, n_bases)
+    pg = torch.zeros((2 * plan.n_alloc + 1, n_bases), dtype=g.dtype)
+    real = dest < 2 * plan.n_alloc
+    assert int(torch.unique(dest[real]).numel()) == int(real.sum()), 'every gradient row has a place of its own'
+    pg[dest] = torch.einsum('sbc,sc->sb', xb[node_of_slot], gp)           # (pads all land in the dump row)
+    pg[2 * plan.n_alloc] = 0
+    both = pg[:plan.n_alloc] + pg[plan.n_alloc:2 * plan.n_alloc]
     # the gather, partition by partition, on the merged stream plan
     gp_ = plan.gather
     S, P = 64 // gp_.lanes, gp_.piece
@@ -1037,10 +1079,11 @@ def execute_pair_bwd_reference(plan, cells_flat, xb, g, n_bases):
     out = torch.zeros((gp_.n_rows, n_bases), dtype=g.dtype)
     written = torch.zeros(gp_.n_rows, dtype=torch.long)
     wp, zp = gp_.wave_ptr.tolist(), gp_.zero_ptr.tolist()
-    wg_part = plan.wg_part.tolist()
+    wg_part, part_first = plan.wg_part.tolist(), plan.part_first.tolist()
     assert len(wp) == gp_.n_wg * 16 + 1 and wp[-1] == gp_.n_bands
     for w in range(gp_.n_wg * 16):
-        tab = torch.cat([table[wg_part[w // 16]], torch.zeros((1, n_bases), dtype=g.dtype)])
+        r0 = part_first[wg_part[w // 16]]
+        tab = torch.cat([both[r0:r0 + plan.part_len], torch.zeros((1, n_bases), dtype=g.dtype)])
         acc = torch.zeros((S, n_bases), dtype=g.dtype)
         for b in range(wp[w], wp[w + 1]):
             klogs, lasts = [0] * S, []
