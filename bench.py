@@ -766,14 +766,14 @@ def measure_config(workload, mod, dev, steps=20, warmup=5):
     return rec
 
 
-def train_step_record(dev, epochs=20):
+def train_step_record(dev, epochs=20, decoder='distmult'):
     """The whole graphed training epoch of tip.py:24-30 (sampler + encoder + fused objective + backward + fused Adam)
-    on BASELINE config 2: ms per epoch."""
+    on BASELINE config 2: ms per epoch.  decoder = 'nn': the same epoch with the NNDecoder (model/ddm-nn.py:65-102)."""
     import torch
     from tip_amd.layers import TIP, Setting
     from tip_amd.train import GraphedTrainStep
     torch.manual_seed(1111)
-    model = TIP(Setting(), dev)
+    model = TIP(Setting(), dev, decoder=decoder)
     from tip_amd.optim import Adam
     opt = Adam(model.parameters(), lr=0.01)                        # tipk_adam_step: one launch, device-side step count
     step = GraphedTrainStep(model, opt)
@@ -788,8 +788,9 @@ def train_step_record(dev, epochs=20):
     E = int(model.data.dd_train_idx.shape[1])
     loss = float(step())
     rec = {'ms_per_epoch': ms, 'edges_per_s': E / (ms * 1e-3), 'epochs_timed': epochs, 'loss_after': loss,
-           'what': 'hipGraph replay of zero_grad + typed negative sampling + encoder + fused DistMult objective + backward + '
-                   'Adam in one launch (tip_amd/optim.py, tip_amd/train.py), TIP-cat BioSNAP R=%d' % model.data.n_dd_et}
+           'what': 'hipGraph replay of zero_grad + typed negative sampling + encoder + fused %s objective + backward + '
+                   'Adam in one launch (tip_amd/optim.py, tip_amd/train.py), TIP-cat BioSNAP R=%d'
+                   % ('DistMult' if decoder == 'distmult' else 'NNDecoder (score tables)', model.data.n_dd_et)}
     del step, opt, model
     release()
     return rec
@@ -990,21 +991,27 @@ def main():
             out['dd_launches_us'] = {k: round(v, 2) for k, v in launch_us.items()}
         per_edge = sum(2 * (8 + 4 * dims[k]) for k in ('n_hid1', 'n_hid2'))     # 416 / 2080 B per edge
         if args.workload.startswith('synthetic'):
+            # the HBM yardstick of SURVEY 8(d) against the roofline of ALL the GPUs of the job (N x 8 TB/s)
             out['whole_step'] = {'alg_bytes': E * per_edge, 'bytes_per_edge': per_edge, 'GBps': E * per_edge / (ms * 1e-3) / 1e9,
-                                 'frac_of_8TBps': E * per_edge / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                 'n_gpus': world, 'peak_GBps': world * HBM_PEAK_GBS,
+                                 'frac_of_roofline': E * per_edge / (ms * 1e-3) / 1e9 / (world * HBM_PEAK_GBS)}
             if world == 1:
                 fl = dense_route_floor(dd['n_dd_et'], dd['n_drug'], E, dims)
                 fl['frac'] = fl['us'] / (ms * 1e3)
                 out['step_floor'] = fl
-        elif launch_us and world == 1:
+        elif launch_us:
+            # (N > 1: rank 0's own launches on ITS shard of the relations -- the floor of one rank's step, collectives at the
+            # launch floor like every launch that is not modelled)
             pp_edges = int(dd['pp_train_indices'].shape[1]) + dd['n_prot']
             rows_graph = getattr(getattr(getattr(enc, 'pp_encoder', None), 'conv2', None), '_cache_rows', None)
             rows_graph = rows_graph.value if rows_graph is not None else None
             fl = step_floor(launch_us, launches, kern, pp_edges, dims,
                             pp_rows_edges=int(rows_graph.fwd.n_edges) if rows_graph is not None else None)
             fl['frac'] = fl['us'] / (ms * 1e3)
+            if world > 1:
+                fl['of'] = 'rank 0 (its shard of the relations; the step time is the max over the ranks)'
             out['step_floor'] = fl
-            hb = step_hbm_bytes(bid)
+            hb = step_hbm_bytes(bid) if world == 1 else None
             if hb is not None:
                 out['step_hbm'] = {'bytes_measured': hb[0], 'bytes_measured_uncorrected': hb[2],
                                    'frac_of_8TBps': hb[0] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1039,10 +1046,12 @@ def main():
                 except Exception as exc:                           # noqa: BLE001 -- never lose the headline line
                     out['other_configs'][key] = {'error': repr(exc)}
                     release()
-            try:
-                out['train_step'] = train_step_record(dev)
-            except Exception as exc:                               # noqa: BLE001
-                out['train_step'] = {'error': repr(exc)}
+            for key, dec in (('train_step', 'distmult'), ('train_step_nn_decoder', 'nn')):
+                try:
+                    out[key] = train_step_record(dev, decoder=dec)
+                except Exception as exc:                           # noqa: BLE001
+                    out[key] = {'error': repr(exc)}
+                    release()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -16,7 +16,10 @@
  *     -(1000 + hipError_t) when a HIP runtime call failed; `tipk_strerror` names it;
  *   - workspaces (`partial`, slabs) are supplied by the caller; the library borrows pointers for the
  *     duration of the call only;
- *   - thread safety: re-entrant per (device, stream); one process per GPU for multi-GPU jobs.
+ *   - thread safety: the launch entry points are re-entrant per (device, stream); one process per GPU for multi-GPU jobs.
+ *     Two pieces of state are PROCESS-WIDE (plain globals, read at launch time, no locking): the options of section 0
+ *     (`tipk_set_option`) and the flag-wait budget of section 8 (`tipk_peer_set_timeout_ms`) -- set them before launching
+ *     from other threads; every exchange of the process shares the one budget.
  */
 #ifndef TIPK_H
 #define TIPK_H
@@ -346,7 +349,7 @@ int tipk_gemm_wg_group(const tipk_wg_gemm_desc* descs /* host, [count <= TIPK_WG
  *     and the gather only built the cells with u <= v (half the edges); cell (u, v) with v < u is read at (v, u).
  *     live (nullable): uint8 [n_src / group][ceil(n_dst / 32)], bit q = "some pair (group's node q, one of the tile's 32
  *     destinations) is linked": tiles without a link are not fetched (their cells are zeros by construction; `zeros` =
- *     >= 64 bytes of zeros, 16-byte aligned, read in their place).
+ *     >= n_bases * 4 bytes of zeros (128 B at n_bases = 32), 16-byte aligned, read in their place).
  *     xbt (nullable, [n_dst][d][n_bases], 16-byte aligned): XB of the first n_dst source nodes written back with the bases
  *     innermost -- the operand layout of the backward pass (tipk_rgcn_node_products xbt), from the LDS stage of this kernel.
  */
@@ -577,6 +580,19 @@ int tipk_pair_table_bwd(const float* g_score, const float* score, int64_t ld,
                         const void* idx_u, const void* idx_v, int idx_bytes,
                         const void* edge_type, int et_bytes, int64_t n_triples,
                         int sigmoid, float* g_s1, float* g_s2, tipk_stream_t stream);
+/*     The fused TIP objective on the tables (src/layers.py:335-340 with this decoder, model/ddm-nn.py:65-102):
+ *        loss = -mean log(sigma(x_pos) + eps) - mean log(1 - sigma(x_neg) + eps),  x = S1[u, r] + S2[v, r]
+ *     on TRANSPOSED tables s1t / s2t [n_rel][ld] (row r = every node's score under relation r: w_l2 . relu(z w_l1)^T from
+ *     tipk_gemm_f32).  pos_pairs / neg_pairs [n_positions]: u | v << 16 per triple (n_nodes <= 65 535), both grouped by
+ *     relation with the SAME blocks rel_ptr [n_rel + 1] (the sampler's layout); order [n_rel]: the relations by decreasing
+ *     block size (launch order of the per-relation workgroups).  Outputs: loss_parts [n_rel][2] (double) = a relation's
+ *     sums of log(sigma_pos + eps) and log(1 - sigma_neg + eps): loss = -(sum of all) / n_positions; g_s1t / g_s2t
+ *     [n_rel][ld] (both or neither; columns < n_nodes of EVERY row are written) = d loss / d S1^T, d S2^T, accumulated in
+ *     LDS as 64-bit fixed point: no atomics on global memory, bitwise reproducible. */
+int tipk_pair_table_loss(const float* s1t, const float* s2t, int64_t ld, int64_t n_nodes, int64_t n_rel,
+                         const uint32_t* pos_pairs, const uint32_t* neg_pairs, const int64_t* rel_ptr,
+                         const int32_t* order, int64_t n_positions, float eps, double* loss_parts,
+                         float* g_s1t /* nullable */, float* g_s2t /* nullable */, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 5. Typed negative sampling on device -- replaces typed_negative_sampling / negative_sampling,
@@ -680,7 +696,9 @@ int tipk_peer_allreduce(float* data, int64_t n, void* const* mailboxes /* host [
  *      (missing rank + 1) << 16 | chunk} in the ERROR WORD of its own mailbox (first record wins) and finishes with
  *      whatever the slots hold.  tipk_peer_status copies that word to the host (0 = every wait was served; a synchronous
  *      8-byte copy: call it where the host synchronises anyway, never inside a capture); the caller must treat a
- *      non-zero word as fatal for the process group.  tipk_peer_set_timeout_ms: the budget of later launches (1 ... 600 000). */
+ *      non-zero word as fatal for the process group.  tipk_peer_set_timeout_ms: the budget of later launches (1 ... 600 000),
+ *      ONE value for every exchange of the process (a short budget for a self-test, then a production budget that outlasts
+ *      the host-side skew between ranks: tip_amd/dist.py leaves 60 000 ms behind). */
 int tipk_peer_set_timeout_ms(int64_t ms);
 int tipk_peer_status(void* mailbox, int world, int64_t max_floats, uint64_t* error_word /* host */);
 

@@ -5,12 +5,22 @@ This is not a restatement of the reference (its sampler draws from numpy's globa
 that one for distribution checks).  It pins `tipk_typed_negative_sampling` (include/tipk.h
 section 5) so the HIP kernel can be tested for exact equality:
 
-  position e of relation r, attempt a = 0, 1, ...:
-      (x0, x1, x2, x3) = Philox4x32-10(counter = (e & 0xffffffff, e >> 32, a, 0),
-                                       key = (seed & 0xffffffff, seed >> 32))
-      cand = (x0 | x1 << 32) * n^2 >> 64
-      accept the first cand that is not a positive key u*n+v of relation r (at most 64 attempts,
-      the 64th is kept regardless);  u = cand // n, v = cand % n.
+  position e of relation r (counter c = e + pos_offset[r]), attempt a = 0, 1, ...:
+
+  n^2 < 2^32 (every graph whose node ids fit 16 bits; round 5) -- ONE Philox call serves FOUR positions:
+      (x0, x1, x2, x3) = Philox4x32-10(counter = (q & 0xffffffff, q >> 32, a, 0), q = c >> 2,
+                                       key = (seed & 0xffffffff, seed >> 32));   x = x[c & 3]
+      m = x * n^2 (64 bits);  cand = m >> 32;  lo = m & 0xffffffff
+      the draw is REJECTED if lo < (2^32 - n^2) mod n^2   (Lemire's test: what is left is exactly uniform on [0, n^2),
+                                                           p(reject) < n^2 / 2^32 = 1e-4 at BioSNAP)
+      or if cand is a positive key u*n+v of relation r; the first draw that is not rejected is kept (at most 64
+      attempts, the 64th is kept regardless);  u = cand // n, v = cand % n.
+      (Round 3 drew one 64-bit candidate per call: 20 wide multiplies per position, two thirds of the sampler's issue
+      slots; now 5 + 1.)
+
+  n^2 >= 2^32:
+      (x0, x1, x2, x3) = Philox4x32-10(counter = (c & 0xffffffff, c >> 32, a, 0), key as above)
+      cand = (x0 | x1 << 32) * n^2 >> 64,  rejected while it is a positive key of relation r, as above.
 """
 import numpy as np
 
@@ -71,12 +81,23 @@ def typed_negative_sampling_spec(pos_edge_index, num_nodes, rel_ptr, seed, pos_o
         keys = np.unique(pos[0, a:b] * n + pos[1, a:b]).astype(np.uint64)
         todo = np.arange(a, b, dtype=np.uint64)
         off = np.uint64(0 if pos_offset is None else int(pos_offset[r]))
+        nn = n * n
+        thresh = np.uint64(((1 << 32) - nn) % nn) if nn < (1 << 32) else None
         for attempt in range(MAX_ATTEMPTS):
             ctr = todo + off
-            x0, x1, _, _ = philox4x32_10(ctr & MASK32, ctr >> np.uint64(32), np.full(todo.size, attempt), 0, k0, k1)
-            cand = _mulhi64(x0 | (x1 << np.uint64(32)), n * n)
+            if thresh is not None:
+                q = ctr >> np.uint64(2)
+                xs = philox4x32_10(q & MASK32, q >> np.uint64(32), np.full(todo.size, attempt), 0, k0, k1)
+                x = np.choose((ctr & np.uint64(3)).astype(np.int64), xs)
+                m = x * np.uint64(nn)
+                cand = m >> np.uint64(32)
+                bad = (m & MASK32) < thresh
+            else:
+                x0, x1, _, _ = philox4x32_10(ctr & MASK32, ctr >> np.uint64(32), np.full(todo.size, attempt), 0, k0, k1)
+                cand = _mulhi64(x0 | (x1 << np.uint64(32)), nn)
+                bad = np.zeros(todo.size, dtype=bool)
             out[todo.astype(np.int64)] = cand
-            bad = np.isin(cand, keys)
+            bad = bad | np.isin(cand, keys)
             todo = todo[bad]
             if todo.size == 0:
                 break

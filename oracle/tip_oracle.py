@@ -290,6 +290,29 @@ def nn_decoder_fwd(z, edge_index, edge_type, w1_l1, w1_l2, w2_l1, w2_l2):
     return torch.sigmoid((d1 * w1_l2[edge_type]).sum(dim=1) + (d2 * w2_l2[edge_type]).sum(dim=1))
 
 
+def nn_decoder_bwd(g_score, z, edge_index, edge_type, w1_l1, w1_l2, w2_l1, w2_l2, chunk=1 << 20):
+    """Explicit (autograd-free) backward of `nn_decoder_fwd` (src/layers.py:620-631 under autograd), in chunks of triples:
+    -> (g_z, g_w1_l1, g_w1_l2, g_w2_l1, g_w2_l2) for the upstream gradient g_score of the sigmoid scores."""
+    g_z = torch.zeros_like(z)
+    g = [torch.zeros_like(w) for w in (w1_l1, w1_l2, w2_l1, w2_l2)]
+    for b in range(0, edge_index.shape[1], chunk):
+        u, v, et = edge_index[0, b:b + chunk], edge_index[1, b:b + chunk], edge_type[b:b + chunk]
+        zu, zv = z[u], z[v]
+        a1, a2 = zu @ w1_l1, zv @ w2_l1
+        d1, d2 = torch.relu(a1), torch.relu(a2)
+        s = torch.sigmoid((d1 * w1_l2[et]).sum(dim=1) + (d2 * w2_l2[et]).sum(dim=1))
+        gx = (g_score[b:b + chunk] * s * (1 - s)).unsqueeze(1)
+        g[1].index_add_(0, et, gx * d1)
+        g[3].index_add_(0, et, gx * d2)
+        ga1 = gx * w1_l2[et] * (a1 > 0)
+        ga2 = gx * w2_l2[et] * (a2 > 0)
+        g[0] += zu.t() @ ga1
+        g[2] += zv.t() @ ga2
+        g_z.index_add_(0, u, ga1 @ w1_l1.t())
+        g_z.index_add_(0, v, ga2 @ w2_l1.t())
+    return (g_z,) + tuple(g)
+
+
 def tip_loss(pos_score, neg_score):
     """-mean log(pos + eps) - mean log(1 - neg + eps)   (src/layers.py:338-340)."""
     return -torch.log(pos_score + EPS).mean() - torch.log(1 - neg_score + EPS).mean()

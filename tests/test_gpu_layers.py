@@ -653,10 +653,62 @@ def test_rgcn_backward_after_another_forward_recomputes_xb():
         layer.zero_grad()
         x.grad = None
         out = layer(x, ei, et, rg)
-        if disturb:
-            layer(x2, ei, et, rg)                                         # rewrites the graph's XB buffer
+        if disturb == 'grad':
+            layer(x2, ei, et, rg)                                         # rewrites the graph's cell / XB buffers
+        elif disturb == 'no_grad':                                        # ... as does a pass that saves nothing:
+            with torch.no_grad():                                         # other x AND other att -> other cells
+                keep = layer.att.data.clone()
+                layer.att.data.mul_(-2.0)
+                layer(x2, ei, et, rg)
+                layer.att.data.copy_(keep)
         out.backward(gup)
         return [x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
-    clean, mixed = grads(x1, False), grads(x1, True)
-    for a, b in zip(clean, mixed):
-        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    clean = grads(x1, None)
+    for mode in ('grad', 'no_grad'):
+        for a, b in zip(clean, grads(x1, mode)):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_nn_decoder_objective_biosnap_size():
+    """NNDecoder as a TRAINING decoder (src/layers.py:598-637 as the objective of model/ddm-nn.py:65-102) at
+    BioSNAP size: the fused objective on the transposed tables (`tipk_pair_table_loss`) == the oracle's literal forward +
+    explicit backward over all 8.3 M positive and 8.3 M negative triples (loss and all five gradients), == the unfused path
+    (scores + torch ops), and is reproducible bit for bit."""
+    from tip_amd.data import build_data_dict
+    from tip_amd.layers import NNDecoder
+    from tip_amd.neg_sampling import typed_negative_sampling
+    dd = build_data_dict()
+    n, R = dd['n_drug'], dd['n_dd_et']
+    g = torch.Generator().manual_seed(17)
+    z_c = torch.randn(n, 16, generator=g) * 0.5
+    m = NNDecoder(16, R, l1_dim=16)
+    for prm in m.parameters():
+        prm.data = torch.randn(prm.shape, generator=g) * 0.3
+    w = {k: v.detach().clone() for k, v in m.named_parameters()}
+    m = m.to(DEV)
+    pos, et, rg = dd['dd_train_idx'].to(DEV), dd['dd_train_et'].to(DEV), dd['dd_train_range'].to(DEV)
+    neg = typed_negative_sampling(pos, n, rg, seed=5)
+
+    def run():
+        m.zero_grad()
+        z = z_c.to(DEV).requires_grad_(True)
+        loss = m.objective(z, pos, neg, et)
+        loss.backward()
+        return loss.detach(), [z.grad.clone()] + [getattr(m, k).grad.clone() for k in ('w1_l1', 'w1_l2', 'w2_l1', 'w2_l2')]
+    loss, grads = run()
+    loss2, grads2 = run()
+    assert torch.equal(loss, loss2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    # oracle: literal forward, the loss of src/layers.py:335-340, explicit backward
+    posc, negc, etc = dd['dd_train_idx'], neg.cpu(), dd['dd_train_et']
+    args = (w['w1_l1'], w['w1_l2'], w['w2_l1'], w['w2_l2'])
+    ps, ns = O.nn_decoder_fwd(z_c, posc, etc, *args), O.nn_decoder_fwd(z_c, negc, etc, *args)
+    close(loss, O.tip_loss(ps, ns).view(1), rtol=2e-5, atol=1e-6)
+    gp, gn = O.tip_loss_bwd(ps, ns)
+    want = [a + b for a, b in zip(O.nn_decoder_bwd(gp, z_c, posc, etc, *args), O.nn_decoder_bwd(gn, z_c, negc, etc, *args))]
+    for got, ref in zip(grads, want):
+        close(got, ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+    # the unfused path of the module (forward() scores + torch ops) agrees
+    z = z_c.to(DEV)
+    unf = -torch.log(m(z, pos, et) + 1e-13).mean() - torch.log(1 - m(z, neg, et) + 1e-13).mean()
+    close(unf.view(1), loss, rtol=2e-5, atol=1e-6)

@@ -259,3 +259,25 @@ def test_bench_eight_ranks_oversubscribed_auto_collective():
     rp = rec['replicated']
     assert rp['replicated_us'] > 10 and rp['amdahl_ceiling'] > 1.0
     assert rec['config']['rccl_ranks'] == 0                                # gloo here; 8 on a real node
+
+
+@pytest.mark.timeout(900)
+def test_bench_one_rank_rccl_in_the_captured_step():
+    """RCCL under the driver: `TIPK_FORCE_SHARD=1 python bench.py --gpus 1` runs the relation-SHARDED
+    step on one rank -- `init_process_group('nccl', device_id=...)`, every all-reduce of the step issued through RCCL and
+    captured into the step's hipGraph (no silent eager fallback), fd 1 kept clean of RCCL's banner -- and the replayed
+    graph's outputs equal the oracle's (`parity_in_bench`)."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['TIPK_FORCE_SHARD'] = '1'
+    env.pop('TIPK_COLLECTIVE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2',
+                          '--no-extras', '--no-pmc', '--cpu-seconds', '2'], env=env, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]         # ONE JSON line, no banner on stdout
+    rec = json.loads(lines[0])
+    assert rec['config']['rccl_ranks'] == 1 and rec['config']['collective'] == 'nccl'
+    assert rec['config']['launch'].startswith('hipGraph'), rec['config']['launch']
+    assert rec['parity_in_bench']['ok'] and rec['parity_in_bench']['what'].endswith('hipGraph')
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and 'replicated' in rec

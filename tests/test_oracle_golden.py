@@ -192,3 +192,8 @@ def test_nn_decoder_restatement():
     g = load_golden('nn_decoder')
     s = O.nn_decoder_fwd(g['z'], g['dd_idx'], g['dd_et'], g['w1_l1'], g['w1_l2'], g['w2_l1'], g['w2_l2'])
     close(s, g['score'])
+    # the explicit backward against the reference's autograd gradients (upstream = the golden's weights of the scores)
+    gs = O.nn_decoder_bwd(g['upstream'], g['z'], g['dd_idx'], g['dd_et'], g['w1_l1'], g['w1_l2'], g['w2_l1'], g['w2_l2'], chunk=7)
+    close(gs[0], g['grad_z'], atol=1e-6)
+    for got, k in zip(gs[1:], ('w1_l1', 'w1_l2', 'w2_l1', 'w2_l2')):
+        close(got, g['grad.' + k], atol=1e-6)

@@ -1,8 +1,8 @@
 // Typed negative sampling on device (include/tipk.h section 5; reference src/neg_sampling.py:5-26).
-// One thread per positive position: counter-based Philox4x32-10 (no state, replayable), candidate
-// pair = mulhi64(random64, n^2), rejected while it is a positive of the SAME relation (binary search
-// in that relation's sorted keys, which stay L2-resident).  Bit-exact specification:
-// oracle/philox_sampler.py.
+// Counter-based Philox4x32-10 (no state, replayable); a candidate pair is uniform on [0, n^2) and rejected while it is a
+// positive of the SAME relation.  n^2 < 2^32 (round 5): one Philox call serves FOUR positions, a candidate is the high
+// word of x * n^2 with Lemire's rejection of the low word (exactly uniform); larger node sets: one 64-bit candidate per
+// call, mulhi64(random64, n^2).  Bit-exact specification: oracle/philox_sampler.py.
 #include <type_traits>
 #include "tipk_common.h"
 
@@ -20,7 +20,9 @@ __device__ __forceinline__ uint64_t mul_wide(uint32_t m, uint32_t x) {
     return r;
 }
 
-__device__ __forceinline__ uint64_t philox64(uint64_t ctr, uint32_t attempt, uint32_t k0, uint32_t k1) {
+struct Philox4 { uint32_t x[4]; };
+
+__device__ __forceinline__ Philox4 philox4(uint64_t ctr, uint32_t attempt, uint32_t k0, uint32_t k1) {
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = attempt, c3 = 0u;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
@@ -31,7 +33,21 @@ __device__ __forceinline__ uint64_t philox64(uint64_t ctr, uint32_t attempt, uin
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += PHILOX_W0; k1 += PHILOX_W1;
     }
-    return (uint64_t)c0 | ((uint64_t)c1 << 32);
+    Philox4 r;
+    r.x[0] = c0; r.x[1] = c1; r.x[2] = c2; r.x[3] = c3;
+    return r;
+}
+
+__device__ __forceinline__ uint64_t philox64(uint64_t ctr, uint32_t attempt, uint32_t k0, uint32_t k1) {
+    const Philox4 r = philox4(ctr, attempt, k0, k1);
+    return (uint64_t)r.x[0] | ((uint64_t)r.x[1] << 32);
+}
+
+// word (c & 3) of the Philox call of counter c >> 2 (constant indices: no scratch array)
+__device__ __forceinline__ uint32_t philox_word(uint64_t c, uint32_t attempt, uint32_t k0, uint32_t k1) {
+    const Philox4 r = philox4(c >> 2, attempt, k0, k1);
+    const uint32_t w = (uint32_t)c & 3u;
+    return w == 0u ? r.x[0] : (w == 1u ? r.x[1] : (w == 2u ? r.x[2] : r.x[3]));
 }
 
 // Philox key of call n of a sampler stream: splitmix64(seed + (n + 1) * golden) -- the same function
@@ -104,9 +120,17 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(const int64_t* __restri
     const int64_t a = rel_ptr[lo], b = rel_ptr[lo + 1];
     const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
     const uint64_t ctr = (uint64_t)(e + (pos_offset ? pos_offset[lo] : 0));      // the position's number in the WHOLE triple list
+    const bool narrow = nn < (1ull << 32);                                       // four positions per Philox call (spec)
+    const uint32_t nn32 = (uint32_t)nn, thresh = narrow ? (uint32_t)(((1ull << 32) - nn) % nn) : 0u;
     uint64_t cand = 0;
     for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
-        cand = __umul64hi(philox64(ctr, (uint32_t)attempt, k0, k1), nn);
+        if (narrow) {
+            const uint64_t m = mul_wide(nn32, philox_word(ctr, (uint32_t)attempt, k0, k1));
+            cand = m >> 32;
+            if ((uint32_t)m < thresh && attempt + 1 < MAX_ATTEMPTS) continue;
+        } else {
+            cand = __umul64hi(philox64(ctr, (uint32_t)attempt, k0, k1), nn);
+        }
         int64_t l = a, h = b;                       // lower_bound(keys[a:b], cand)
         while (l < h) {
             const int64_t mid = (l + h) >> 1;
@@ -136,6 +160,7 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const uint64_t nn = (uint64_t)n_nodes * (uint64_t)n_nodes;
     const int words = (int)((nn + 31) >> 5);
     const uint32_t nn32 = (uint32_t)nn, n32 = (uint32_t)n_nodes;
+    const uint32_t thresh = (uint32_t)(((1ull << 32) - nn) % nn);
     const float inv_n = 1.0f / (float)n32;
     const int t = threadIdx.x;
     int have = -1;                                         // relation whose bitmap is in LDS
@@ -158,25 +183,34 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
             __syncthreads();
             have = rel;
         }
-        if (!TIPK_DBG(dbg & 1))
-        for (int64_t e = ub + t; e < ue; e += 1024) {
-            // n^2 < 2^24 here (the bitmap fits LDS): the candidate mulhi64(x, n^2) is two 32 x 32 -> 64 products, and
-            // (u, v) = (cand / n, cand % n) an exact float quotient with a one-step correction -- the same integers as
-            // the generic 64-bit forms of neg_sample_kernel (a 64 x 64 high product and a 32-bit division are ~60 issue
-            // slots per attempt, a quarter of the Philox rounds themselves)
-            uint32_t cand = 0;
-            for (int attempt = 0; attempt < MAX_ATTEMPTS; ++attempt) {
-                const uint64_t x = philox64((uint64_t)(e + off), (uint32_t)attempt, k0, k1);
-                const uint64_t p0 = mul_wide(nn32, (uint32_t)x);
-                cand = (uint32_t)((mul_wide(nn32, (uint32_t)(x >> 32)) + (p0 >> 32)) >> 32);
-                if (!((bm[cand >> 5] >> (cand & 31)) & 1u)) break;
+        if (!TIPK_DBG(dbg & 1)) {
+        // A lane takes the FOUR positions of one Philox counter (c >> 2 = Q): one call of 20 wide multiplies draws all four
+        // first attempts (round 3: one call per position -- the Philox rounds were two thirds of the sampler's issue slots).
+        // n^2 < 2^24 here (the bitmap fits LDS): a candidate is the high word of x * n^2, rejected (exact uniformity:
+        // Lemire) when the low word is below (2^32 - n^2) mod n^2, or when its bit is set; (u, v) = (cand / n, cand % n) is
+        // an exact float quotient with a one-step correction.  A rejected position (p < 1e-3) draws again on its own.
+        const int64_t q_first = (ub + off) >> 2, q_last = (ue - 1 + off) >> 2;
+        for (int64_t Q = q_first + t; Q <= q_last; Q += 1024) {
+            const Philox4 first = philox4((uint64_t)Q, 0u, k0, k1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t e = 4 * Q + j - off;
+                if (e < ub || e >= ue) continue;
+                uint64_t m = mul_wide(nn32, first.x[j]);
+                uint32_t cand = (uint32_t)(m >> 32);
+                for (int attempt = 1; attempt < MAX_ATTEMPTS; ++attempt) {
+                    if ((uint32_t)m >= thresh && !((bm[cand >> 5] >> (cand & 31)) & 1u)) break;
+                    m = mul_wide(nn32, philox_word((uint64_t)(4 * Q + j), (uint32_t)attempt, k0, k1));
+                    cand = (uint32_t)(m >> 32);
+                }
+                uint32_t q = (uint32_t)((float)cand * inv_n);
+                int32_t r = (int32_t)(cand - __umul24(q, n32));
+                if (r < 0) { --q; r += (int32_t)n32; }
+                else if (r >= (int32_t)n32) { ++q; r -= (int32_t)n32; }
+                if constexpr (std::is_same<OT, PackedOut>::value) out_u[e].w = q | ((uint32_t)r << 16);
+                else { out_u[e] = (OT)q; out_v[e] = (OT)r; }
             }
-            uint32_t q = (uint32_t)((float)cand * inv_n);
-            int32_t r = (int32_t)(cand - __umul24(q, n32));
-            if (r < 0) { --q; r += (int32_t)n32; }
-            else if (r >= (int32_t)n32) { ++q; r -= (int32_t)n32; }
-            if constexpr (std::is_same<OT, PackedOut>::value) out_u[e].w = q | ((uint32_t)r << 16);
-            else { out_u[e] = (OT)q; out_v[e] = (OT)r; }
+        }
         }
     }
     stream_advance(call_counter, advance, call_no);

@@ -32,7 +32,7 @@ struct PpArgs {
     int row_tiles, n_groups;           // row_tiles: tiles of 128 destination rows
     int symmetric;                     // cells hold only source <= destination: C[u][v] for v < u is read at C[v][u]
     const uint8_t* live;               // nullable: [n_groups][ceil(n_dst / 32)] bit q = some cell (u0 + q, the 32 rows) is linked
-    const float* zeros;                // >= 64 bytes of zeros (read in place of the cells of a tile without links)
+    const float* zeros;                // >= NB * 4 bytes of zeros (read in place of the cells of a tile without links)
     float* xbt;                        // nullable: [n_dst][d][NB] -- XB written back base-innermost (by the row-tile-0 workgroups)
 };
 

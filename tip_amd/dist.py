@@ -28,7 +28,10 @@ the 2-ranks-on-one-GPU tests.
 import torch
 import torch.distributed as dist
 
+import os
+
 LOCAL_ROWS = ('encoder.rgcn1.att', 'encoder.rgcn2.att', 'decoder.weight')     # parameters held as shard-local rows
+PEER_WAIT_MS = int(os.environ.get('TIPK_PEER_TIMEOUT_MS', '60000'))           # flag-wait budget of the one-shot exchange after its self-test
 
 
 def partition_relations(sizes, world):
@@ -120,7 +123,9 @@ class RelationShard(object):
             torch.cuda.synchronize(device)
             ok = ex.error_word() == 0 and bool((x == float(self.world * (self.world + 1) // 2)).all())
             why = '' if ok else 'self-test: wrong sum or a wait ran out (error word %#x)' % ex.error_word()
-            ex.set_timeout_ms(2000)
+            # production budget: ranks reach the first exchanges of a step behind host-side work of data-dependent length
+            # (plan builds take seconds); a healthy run must not record a timeout there -- RCCL / gloo would simply wait
+            ex.set_timeout_ms(PEER_WAIT_MS)
         except Exception as exc:                                            # noqa: BLE001
             ok, why = False, 'self-test: %r' % (exc,)
         if not self._all_ok(ok, device):
@@ -130,14 +135,59 @@ class RelationShard(object):
         self.direct = ex
         return ex
 
-    def choose_collective(self, sizes, device, reps=20):
-        """Time the process group's all-reduce and the one-shot exchange for every message size of the step (floats) --
-        `reps` calls each after 3 warm-up calls, host-synchronised, the MAX over the ranks -- and keep the faster per size
-        (the same decision on every rank).  Call before any capture.  -> the report (also `self.collective_report`)."""
+    def _time_collective_us(self, fn, device, reps):
+        """us per call of `fn` the way the step issues it -- `reps` calls captured into ONE hipGraph and replayed, HIP events on
+        the replay stream -- or, if this build cannot capture the call on some rank, `reps` eager calls, host-synchronised
+        (every rank takes the same branch: the verdict travels through the process group).  -> (us, how)."""
         import time
+        graph, ok = None, True
+        try:
+            if dist.get_backend(self.group) != 'nccl':                      # (a host-side backend cannot be captured; its step
+                raise RuntimeError('eager backend')                         #  runs eagerly as well: bench.py `launch`)
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                for _ in range(reps):
+                    fn()
+        except Exception:                                                   # noqa: BLE001
+            ok, graph = False, None
+            torch.cuda.synchronize(device)
+        if self._all_ok(ok, device):
+            graph.replay()
+            torch.cuda.synchronize(device)
+            dist.barrier(group=self.group)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                graph.replay()
+            b.record()
+            torch.cuda.synchronize(device)
+            return a.elapsed_time(b) * 1e3 / (3 * reps), 'hipGraph replay'
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / reps * 1e6, 'eager calls, host-synchronised'
+
+    def choose_collective(self, sizes, device, reps=20):
+        """Time the process group's all-reduce and the one-shot exchange for every message size of the step (floats) the way
+        the step uses them -- inside a captured hipGraph (`_time_collective_us`), the MAX over the ranks -- and keep the
+        faster per size (the same decision on every rank).  Call before the step is captured.  -> the report (also
+        `self.collective_report`)."""
         assert self.direct is not None
         rep = {}
         use = {}
+        how = set()
         on_dev = dist.get_backend(self.group) == 'nccl'
         for n in sorted(set(int(s_) for s_ in sizes)):
             if n <= 0 or n > self.direct.max_floats:
@@ -147,15 +197,8 @@ class RelationShard(object):
             for name in ('group', 'direct'):
                 fn = (lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)) if name == 'group' else \
                     (lambda: self.direct.all_reduce(x))
-                for _ in range(3):
-                    fn()
-                torch.cuda.synchronize(device)
-                dist.barrier(group=self.group)
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    fn()
-                torch.cuda.synchronize(device)
-                t[name] = (time.perf_counter() - t0) / reps * 1e6
+                t[name], h = self._time_collective_us(fn, device, reps)
+                how.add(h)
             tt = torch.tensor([t['group'], t['direct']], dtype=torch.float32, device=device if on_dev else 'cpu')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
             g_us, d_us = [float(v) for v in tt.tolist()]
@@ -164,7 +207,7 @@ class RelationShard(object):
         self.direct.check()
         self.direct_sizes = use
         self.collective_report = {'per_size': rep, 'group_backend': dist.get_backend(self.group),
-                                  'how': 'eager calls, host-synchronised, max over ranks'}
+                                  'how': ' / '.join(sorted(how)) + ', max over ranks'}
         return self.collective_report
 
     @property
@@ -261,7 +304,8 @@ class DirectExchange(object):
         return flat
 
     def set_timeout_ms(self, ms):
-        """Wall-clock budget of the flag wait of later exchanges (default 2 000 ms)."""
+        """Wall-clock budget of the flag wait of later exchanges (PROCESS-WIDE in libtipk: include/tipk.h section 8; the
+        library's own default is 2 000 ms, `try_direct_exchange` leaves PEER_WAIT_MS behind)."""
         from ._lib import lib, check
         check(lib().tipk_peer_set_timeout_ms(int(ms)), 'tipk_peer_set_timeout_ms')
 

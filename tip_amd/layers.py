@@ -684,6 +684,17 @@ class NNDecoder(nn.Module):
         s2 = ops.matmul(q, self.w2_l2.t())
         return ops.pair_table_score(s1, s2, edge_index, edge_type, sigmoid=True)
 
+    def objective(self, z, pos_index, neg_index, edge_type):
+        """-mean log(sigma(pos)+eps) - mean log(1-sigma(neg)+eps) (src/layers.py:335-340 with this decoder as
+        model/ddm-nn.py:65-102 trains it), fused: the tables are formed TRANSPOSED ([R, N]: a relation's scores are one
+        contiguous row), one launch evaluates every positive and negative triple and leaves both table gradients
+        (`tipk_pair_table_loss`); the four weight gradients and d z follow through the four small products."""
+        p = torch.relu(ops.matmul(z, self.w1_l1))
+        q = torch.relu(ops.matmul(z, self.w2_l1))
+        s1t = ops.matmul(self.w1_l2, p.t())                      # [R, N]
+        s2t = ops.matmul(self.w2_l2, q.t())
+        return ops.pair_table_objective(s1t, s2t, pos_index, neg_index, edge_type)
+
 
 # ---------------------------------------------------------------------------------------------
 # A9  training framework   (src/layers.py:260-375)
@@ -705,13 +716,17 @@ class TIP(nn.Module):
     torch ops on the decoder scores exactly as `src/layers.py:335-340` spells it."""
 
     def __init__(self, settings, device, mod='cat', data_path='./data/data_dict.pkl', data=None, fused_loss=True,
-                 shard=None):
+                 shard=None, decoder='distmult'):
         """shard (extension): a `tip_amd.dist.RelationShard` -- this process holds only its relations'
-        edges, `rgcn*.att` rows and `decoder.weight` rows; see tip_amd/dist.py."""
+        edges, `rgcn*.att` rows and `decoder.weight` rows; see tip_amd/dist.py.
+        decoder (extension): 'distmult' (tip.py, src/layers.py:581-595) | 'nn' -- the NNDecoder of src/layers.py:598-637 in
+        the same training framework, as the reference's model/ddm-nn.py:65-102 trains it (l1_dim = 16)."""
         super().__init__()
-        assert mod in {'cat', 'add'}
+        assert mod in {'cat', 'add'} and decoder in {'distmult', 'nn'}
+        if decoder == 'nn' and shard is not None:
+            raise NotImplementedError('the relation-sharded step holds decoder.weight rows only (tip_amd/dist.py)')
         self.mod, self.device, self.settings, self.fused_loss = mod, device, settings, fused_loss
-        self.shard = shard
+        self.shard, self.decoder_kind = shard, decoder
         self.data = self.__prepare_data(data_path, settings.sp_rate, data).to(device)
         self.__prepare_model()
 
@@ -770,7 +785,10 @@ class TIP(nn.Module):
             attach_shard(self.encoder, self.shard)
         with torch.no_grad():                            # initial pass (:319, with self.device); it only
             self.embeddings = self.__encode()            # fills .embeddings and the plan caches
-        self.decoder = MultiInnerProductDecoder(s.n_hid2, d.n_dd_et).to(self.device)
+        if self.decoder_kind == 'nn':
+            self.decoder = NNDecoder(s.n_hid2, d.n_dd_et, l1_dim=16).to(self.device)
+        else:
+            self.decoder = MultiInnerProductDecoder(s.n_hid2, d.n_dd_et).to(self.device)
 
     def forward(self, neg_index=None):
         """One full-batch training objective (:328-342).  `neg_index` (extension) injects fixed

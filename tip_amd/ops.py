@@ -1933,5 +1933,61 @@ class _PairTable(torch.autograd.Function):
         return g1, g2, None, None, None
 
 
+class _PairTableLoss(torch.autograd.Function):
+    """The fused TIP objective on the TRANSPOSED score tables of the NNDecoder (`tipk_pair_table_loss`): loss and both table
+    gradients in one launch, reproducible bit for bit."""
+
+    @staticmethod
+    def forward(ctx, s1t, s2t, pos_index, neg_index, edge_type):
+        s1t, s2t = _f32c(s1t).contiguous(), _f32c(s2t).contiguous()
+        require_device(s1t, s2t, pos_index, neg_index, edge_type)
+        r, n = s1t.shape
+        assert s2t.shape == (r, n) and n <= 65535
+        validate_triples(pos_index, edge_type, n, r)
+        facts = _facts(edge_type)
+        blocks = facts.get('rel_blocks')
+        if blocks is None:
+            rels, counts = torch.unique_consecutive(edge_type, return_counts=True)
+            if torch.unique(rels).numel() != rels.numel():
+                raise _lib.TipkError('the fused objective needs the triples grouped by relation (src/utils.py:35-65)')
+            cnt = torch.zeros(r, dtype=torch.int64, device=edge_type.device)
+            cnt[rels.to(torch.int64)] = counts
+            rel_ptr = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).contiguous()
+            order = torch.sort(cnt, descending=True, stable=True).indices.to(torch.int32).contiguous()
+            blocks = facts['rel_blocks'] = (rel_ptr, order)
+        rel_ptr, order = blocks
+        pp = packed_pairs(pos_index, n)
+        if getattr(neg_index, '_tipk_packed_pairs', False):
+            npk = neg_index
+            if not getattr(neg_index, '_tipk_sampled', False):
+                validate_triples(unpack_pairs(neg_index), None, n, r)
+        else:
+            if not getattr(neg_index, '_tipk_sampled', False):
+                validate_triples(neg_index, None, n, r)
+            w = neg_index[0].to(torch.int64) | (neg_index[1].to(torch.int64) << 16)
+            npk = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+        assert npk.numel() == pp.numel()
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        parts = torch.empty((r, 2), dtype=torch.float64, device=s1t.device)
+        g1 = torch.empty_like(s1t) if need else None
+        g2 = torch.empty_like(s2t) if need else None
+        with _timed('pair_table_loss[%dx%d,positions=%d]' % (r, n, pp.numel())):
+            check(lib().tipk_pair_table_loss(ptr(s1t), ptr(s2t), s1t.stride(0), n, r, ptr(pp), ptr(npk), ptr(rel_ptr), ptr(order),
+                                             pp.numel(), 1e-13, ptr(parts), ptr(g1), ptr(g2), stream_ptr(s1t.device)),
+                  'tipk_pair_table_loss')
+        ctx.save_for_backward(g1, g2)
+        return (parts.sum() * (-1.0 / pp.numel())).to(torch.float32).view(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g1, g2 = ctx.saved_tensors
+        return g1 * g, g2 * g, None, None, None
+
+
+def pair_table_objective(s1t, s2t, pos_index, neg_index, edge_type):
+    """loss [1] of the fused objective on the transposed score tables s1t / s2t [R, N] (include/tipk.h section 4b)."""
+    return _PairTableLoss.apply(s1t, s2t, pos_index, neg_index, edge_type)
+
+
 def pair_table_score(s1, s2, edge_index, edge_type, sigmoid=True):
     return _PairTable.apply(s1, s2, edge_index, edge_type, sigmoid)
