@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 16
+#define TIPK_ABI_VERSION 17
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -445,6 +445,24 @@ int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, int64_
                              const int32_t* zero_rows, float* out, int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 2f. Forward aggregation of an R-GCN layer on LARGE node sets without Y = att . XB (src/layers.py:159-180 with
+ *     W_r = sum_b att[r, b] basis_b):   agg[v] = sum_b T[b, v, :] basis_b,
+ *
+ *        T[b, v, i] = sum_{e -> v} att[r_e, b] * x[src_e, i]          one matrix product per DESTINATION, K = its edges
+ *
+ *     -- 164 MB instead of the 10 GB of Y at config 5 (N = 10 000, R = 2 000, d = 128); the second product is a
+ *     batch-reduced tipk_gemm_f32.  edges [E]: uint32 rel | src << bits, grouped by destination (bits = the return value of
+ *     `tipk_rgcn_dest_products_supported`, 0 = shape not supported: n_bases > 32, or ids that do not fit 32 bits);
+ *     node_desc [n_nodes][4] { node v, its first edge, its edges, 0 } by DECREASING edge count (16-byte aligned);
+ *     T element (b, v, i) at t[b * t_sb + v * t_sv + i], every element written.  Sums in edge order per wave, the four
+ *     waves of a node in wave order: bitwise reproducible.
+ */
+int tipk_rgcn_dest_products_supported(int64_t n_nodes, int64_t n_rel, int n_bases, int d_in);
+int tipk_rgcn_dest_products(const float* x, int64_t ld_x, int d_in, const float* att, int64_t ld_att, int n_bases,
+                            int64_t n_nodes, int64_t n_rel, const int32_t* node_desc, const uint32_t* edges,
+                            float* t, int64_t t_sb, int64_t t_sv, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).
  */
 /* out[c, r] = in[r, c]  -- `lin(x)` for identity features is W^T (src/layers.py:392 with
@@ -600,11 +618,14 @@ int tipk_pair_table_loss(const float* s1t, const float* s2t, int64_t ld, int64_t
  *
  * For every positive position e of relation r (rel_ptr[r] <= e < rel_ptr[r+1]) draw a pair
  * uniformly from n_nodes^2 (with replacement, self pairs allowed, as np.random.choice does) and
- * redraw while it equals a positive pair OF THE SAME RELATION.  Randomness: Philox4x32-10,
- * counter = (e, attempt, 0, 0), key = (seed_lo, seed_hi); candidate = mulhi64(r0 | r1<<32, n^2)
- * -- specified bit-exactly in oracle/philox_sampler.py.  `pos_key_sorted` holds u*n+v of each
- * relation's positives sorted ascending within the relation (int64).  After 64 rejected attempts
- * the 64th candidate is kept (probability < density^64).
+ * redraw while it equals a positive pair OF THE SAME RELATION.  Randomness: Philox4x32-10, key = (seed_lo, seed_hi);
+ * n^2 < 2^32: ONE call (counter = (e >> 2, attempt, 0)) serves the four positions 4q .. 4q + 3, a candidate is the high
+ * word of x * n^2 and is redrawn when the low word is below (2^32 - n^2) mod n^2 (exactly uniform); larger node sets:
+ * counter = (e, attempt, 0), candidate = mulhi64(r0 | r1<<32, n^2) -- specified bit-exactly in
+ * oracle/philox_sampler.py.  `pos_key_sorted` holds u*n+v of each relation's positives sorted ascending within the
+ * relation (int64); `pos_key32` (nullable) the same keys as uint32, in any order inside a relation: what the bitmap
+ * route reads when given (half the bytes).  After 64 rejected attempts the 64th candidate is kept (probability <
+ * density^64).
  * wg_unit_ptr [n_wg + 1] / wg_units [n_units][3] (nullable, int32): edge-balanced deal of UNITS = (relation, first
  * position, end position) to n_wg workgroups -- the units tile [0, n_positions), a unit lies inside one relation (a
  * relation larger than a workgroup's share is cut into several units); with it and n_nodes^2 bits <= 150 KB each
@@ -624,7 +645,7 @@ int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* r
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
                                  uint64_t* call_counter /* nullable device uint64[2 or 3], see above */, int advance,
                                  const int32_t* wg_unit_ptr /* nullable */, const int32_t* wg_units, int64_t n_wg,
-                                 const int64_t* pos_offset /* nullable */,
+                                 const int64_t* pos_offset /* nullable */, const uint32_t* pos_key32 /* nullable */,
                                  void* out_u, void* out_v, int idx_bytes,
                                  int64_t n_positions /* = rel_ptr[n_rel], host copy */,
                                  tipk_stream_t stream);

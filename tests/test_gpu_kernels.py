@@ -366,6 +366,41 @@ def test_pair_grads_backward(ops, R, N, d, symmetric, per_rel):
     assert torch.equal(g_att.cpu().double(), want_att) and torch.equal(g_xb.cpu().double(), want_xb)
 
 
+@pytest.mark.parametrize('R,N,d_in,nb,E', [(200, 1000, 128, 32, 300000), (37, 50, 40, 7, 3000), (5, 31, 128, 32, 40), (2000, 300, 64, 32, 90000)])
+def test_dest_products_forward(ops, R, N, d_in, nb, E):
+    """tipk_rgcn_dest_products (tipk.h section 2f): T[b, v, :] = sum over the edges into v of att[r_e, b] x[src_e, :] == the
+    definition in fp64; together with the batch-reduced product over the bases == sum_r A_r X W_r (the aggregate the Y route
+    gathers); nodes without incoming edges, degrees that are no multiple of 32, bitwise repeat, exact on integers."""
+    from tip_amd.plan import build_dest_plan
+    g = torch.Generator().manual_seed(R + N + d_in)
+    rel = torch.sort(torch.randint(0, R, (E,), generator=g)).values
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, max(1, (3 * N) // 4), (E,), generator=g)          # a quarter of the nodes receive nothing
+    dst[: E // 5] = 1                                                      # a hub
+    bits = ops.dest_products_bits(N, R, nb, d_in)
+    assert bits > 0
+    dp = build_dest_plan(src, dst, rel, N, R, bits).to(DEV)
+
+    def run(x, att):
+        t = ops.dest_products(dp, x.to(DEV), att.to(DEV))
+        assert torch.equal(t, ops.dest_products(dp, x.to(DEV), att.to(DEV)))
+        want = torch.zeros(N, nb, d_in, dtype=torch.float64)
+        want.index_add_(0, dst, att.double()[rel].unsqueeze(2) * x.double()[src].unsqueeze(1))
+        return t, want.permute(1, 0, 2)
+    x, att = torch.randn(N, d_in, generator=g), torch.randn(R, nb, generator=g)
+    t, want = run(x, att)
+    close(t, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+    basis = torch.randn(nb, d_in, 16, generator=g)
+    agg = ops.gemm(t, basis.to(DEV), reduce_batch=True)
+    w_r = torch.einsum('rb,bio->rio', att.double(), basis.double())
+    ref = torch.zeros(N, 16, dtype=torch.float64)
+    ref.index_add_(0, dst, torch.einsum('ei,eio->eo', x.double()[src], w_r[rel]))
+    close(agg, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    xi, ai = torch.randint(-3, 4, (N, d_in), generator=g).float(), torch.randint(-3, 4, (R, nb), generator=g).float()
+    t, want = run(xi, ai)
+    assert torch.equal(t.cpu().double(), want)
+
+
 @pytest.mark.parametrize('R,N,d', [(70, 645, 32), (33, 100, 16), (1097, 37, 8)])
 def test_unwritten_rows_masked_end_to_end(ops, R, N, d):
     """Rows (relation, node) without edges: the wave-stream gather with write_zeros=False leaves them untouched

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class TipkError(RuntimeError):
@@ -81,6 +81,8 @@ SIGNATURES = {
     'tipk_rgcn_pair_grads_supported': (_I, [_I, _I]),
     'tipk_rgcn_pair_grads': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _L, _P, _L, _L, _P, _L, _P]),
     'tipk_stream_gather_parts': (_I, [_P, _L, _I, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
+    'tipk_rgcn_dest_products_supported': (_I, [_L, _L, _I, _I]),
+    'tipk_rgcn_dest_products': (_I, [_P, _L, _I, _P, _L, _I, _L, _L, _P, _P, _P, _L, _L, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
     'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),
@@ -113,7 +115,7 @@ SIGNATURES = {
     'tipk_pair_table_fwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_pair_table_bwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P]),
     'tipk_pair_table_loss': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _L, _F, _P, _P, _P, _P]),
-    'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _I, _P, _P, _L, _P, _P, _P, _I, _L, _P]),
+    'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _L, _P]),
     'tipk_counter_advance': (_I, [_P, _P]),
     'tipk_rank_metrics': (_I, [_P, _P, _P, _L, _L, _P, _P]),
     'tipk_peer_mailbox_bytes': (_L, [_I, _L]),

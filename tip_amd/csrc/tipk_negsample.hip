@@ -152,7 +152,8 @@ template <typename OT>
 __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
     const int64_t* __restrict__ keys, const int64_t* __restrict__ rel_ptr, const int32_t* __restrict__ wg_unit_ptr,
     const int32_t* __restrict__ wg_units, int64_t n_nodes, uint64_t seed, uint64_t* __restrict__ call_counter, int advance,
-    const int64_t* __restrict__ pos_offset, OT* __restrict__ out_u, OT* __restrict__ out_v, int dbg) {
+    const int64_t* __restrict__ pos_offset, const uint32_t* __restrict__ keys32, OT* __restrict__ out_u, OT* __restrict__ out_v,
+    int dbg) {
     extern __shared__ unsigned bm[];
     const uint64_t call_no = call_counter ? call_counter[0] : 0ull;
     const uint64_t key = call_counter ? call_key(call_counter[1], call_no) : seed;
@@ -176,9 +177,16 @@ __global__ __launch_bounds__(1024) void neg_sample_bitmap_kernel(
             __syncthreads();                               // the previous relation's tests are done
             for (int i = t; i < words; i += 1024) bm[i] = 0u;
             __syncthreads();
-            for (int64_t e = a + t; e < b; e += 1024) {
-                const uint64_t k = (uint64_t)keys[e];
-                atomicOr(&bm[k >> 5], 1u << (k & 31));
+            if (keys32) {                                  // (4 bytes per positive instead of 8)
+                for (int64_t e = a + t; e < b; e += 1024) {
+                    const uint32_t k = keys32[e];
+                    atomicOr(&bm[k >> 5], 1u << (k & 31));
+                }
+            } else {
+                for (int64_t e = a + t; e < b; e += 1024) {
+                    const uint64_t k = (uint64_t)keys[e];
+                    atomicOr(&bm[k >> 5], 1u << (k & 31));
+                }
             }
             __syncthreads();
             have = rel;
@@ -227,7 +235,7 @@ extern "C" int tipk_counter_advance(uint64_t* counter, tipk_stream_t stream) {
 extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr, int64_t n_rel,
                                             int64_t n_nodes, uint64_t seed, uint64_t* call_counter, int advance,
                                             const int32_t* wg_unit_ptr, const int32_t* wg_units, int64_t n_wg,
-                                            const int64_t* pos_offset,
+                                            const int64_t* pos_offset, const uint32_t* pos_key32,
                                             void* out_u, void* out_v, int idx_bytes, int64_t n_positions,
                                             tipk_stream_t stream) {
     if (n_rel < 0 || n_nodes <= 0 || n_positions < 0 || n_nodes > 0xffffffffLL) return TIPK_EINVAL;
@@ -244,19 +252,19 @@ extern "C" int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int64_t*)out_u, (int64_t*)out_v, dbg);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, pos_key32, (int64_t*)out_u, (int64_t*)out_v, dbg);
         } else if (idx_bytes == 4) {
             auto kern = neg_sample_bitmap_kernel<int32_t>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (int32_t*)out_u, (int32_t*)out_v, dbg);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, pos_key32, (int32_t*)out_u, (int32_t*)out_v, dbg);
         } else if (idx_bytes == 2 && n_nodes <= 65535) {
             auto kern = neg_sample_bitmap_kernel<PackedOut>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm_bytes);
             if (e != hipSuccess) return tipk_hip_status(e);
             hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), (size_t)bm_bytes, st, pos_key_sorted, rel_ptr,
-                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, (PackedOut*)out_u, (PackedOut*)out_u, dbg);
+                               wg_unit_ptr, wg_units, n_nodes, seed, call_counter, advance, pos_offset, pos_key32, (PackedOut*)out_u, (PackedOut*)out_u, dbg);
         } else {
             return TIPK_EINVAL;
         }

@@ -130,7 +130,9 @@ def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
         dev = pos_edge_index.device
         n_wg = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
         wg_ptr, wg_units = sampler_units(rel_ptr, n_wg)
-        hit = (keys, rel_ptr.to(dev), rel_ptr.numel() - 1, (wg_ptr.to(dev), wg_units.to(dev)), pos_edge_index)
+        # the same keys as 32-bit words (n^2 < 2^31): what the bitmap route sets its bits from -- half the bytes per step
+        keys32 = keys.to(torch.int32).contiguous() if int(num_nodes) ** 2 < 2 ** 31 and dev.type == 'cuda' else None
+        hit = (keys, rel_ptr.to(dev), rel_ptr.numel() - 1, (wg_ptr.to(dev), wg_units.to(dev)), (pos_edge_index, keys32))
         if len(_key_cache) > 8:
             _key_cache.clear()
         _key_cache[ident] = hit
@@ -145,16 +147,18 @@ def typed_negative_sampling(pos_edge_index, num_nodes, range_list, seed=None, _r
     packed (extension): return the SAME pairs as int32 [E] words u | v << 16 (num_nodes <= 65535) -- the form the fused
     objective reads (tip_amd/ops.py `distmult_loss`); `ops.unpack_pairs` gives the int64 [2, E] tensor back."""
     num_nodes = int(num_nodes)
-    keys, rel_ptr, n_rel, wg, _ = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
+    keys, rel_ptr, n_rel, wg, (_, keys32) = _cached_keys(pos_edge_index, num_nodes, range_list, _range_ident)
     if pos_offset is not None:
         pos_offset = pos_offset.to(pos_edge_index.device, torch.int64).contiguous()
         assert pos_offset.numel() == n_rel
     if seed is not None:                                     # explicit Philox key for this call
         return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, int(seed) & _MASK,
-                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg, pos_offset=pos_offset, packed=packed)
+                                                  pos_edge_index.shape[1], dtype=torch.int64, wg=wg, pos_offset=pos_offset, packed=packed,
+                                                  keys32=keys32)
     return ops.typed_negative_sampling_device(keys, rel_ptr, n_rel, num_nodes, _state['seed'],
                                               pos_edge_index.shape[1], dtype=torch.int64,
-                                              call_counter=_counter(pos_edge_index.device), wg=wg, pos_offset=pos_offset, packed=packed)
+                                              call_counter=_counter(pos_edge_index.device), wg=wg, pos_offset=pos_offset, packed=packed,
+                                              keys32=keys32)
 
 
 def negative_sampling(pos_edge_index, num_nodes, seed=None):

@@ -471,6 +471,29 @@ def node_products(dyc, cr, att, xb, xbt=None):
     return slab_job(datt_slabs), dxb
 
 
+def dest_products_bits(n_nodes, n_rel, nb, d_in):
+    """bits of the relation field of a destination-major edge word (`tipk_rgcn_dest_products`); 0 = shape not supported."""
+    if os.environ.get('TIPK_NO_DEST_FWD'):
+        return 0
+    return int(lib().tipk_rgcn_dest_products_supported(int(n_nodes), int(n_rel), int(nb), int(d_in)))
+
+
+def dest_products(dp, x, att):
+    """T[b, v, :] = sum over the edges e -> v of att[r_e, b] * x[src_e, :]  (include/tipk.h section 2f) on a `plan.DestPlan`:
+    x [N, d_in], att [R, bases] -> T [bases, N, d_in]."""
+    x, att = _f32c(x), _f32c(att)
+    require_device(x, att, dp.edges)
+    n, d_in = x.shape
+    r, nb = att.shape
+    assert dp.n_nodes == n and dp.n_rel == r
+    t = torch.empty((nb, n, d_in), dtype=torch.float32, device=x.device)
+    with _timed('dest_products[%dx%dx%d,edges=%d]' % (n, nb, d_in, dp.n_edges)):
+        check(lib().tipk_rgcn_dest_products(ptr(x), x.stride(0), d_in, ptr(att), att.stride(0), nb, n, r, ptr(dp.node_desc),
+                                            ptr(dp.edges), ptr(t), t.stride(0), t.stride(1), stream_ptr(x.device)),
+              'tipk_rgcn_dest_products')
+    return t
+
+
 def pair_grads_supported(nb, d):
     return bool(lib().tipk_rgcn_pair_grads_supported(int(nb), int(d))) and not os.environ.get('TIPK_NO_PAIR_BWD')
 
@@ -978,7 +1001,7 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
 
 
 def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed, n_positions, dtype=torch.int64,
-                                   call_counter=None, wg=None, pos_offset=None, packed=False):
+                                   call_counter=None, wg=None, pos_offset=None, packed=False, keys32=None):
     """pos_offset: optional int64 device tensor [n_rel]: Philox counter of position e of relation r = e + pos_offset[r]
     (relation-sharded runs: the position's number in the whole triple list).
     call_counter: optional int64 device tensor [2] = {position, seed} (the stream's state): the
@@ -995,14 +1018,14 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
         out = torch.empty((n_positions,), dtype=torch.int32, device=dev)
         check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed, ptr(call_counter), adv,
                                                  ptr(wg_ptr), ptr(wg_units), 0 if wg_ptr is None else wg_ptr.numel() - 1,
-                                                 ptr(pos_offset), ptr(out), None, 2, n_positions, st),
+                                                 ptr(pos_offset), ptr(keys32), ptr(out), None, 2, n_positions, st),
               'tipk_typed_negative_sampling')
         out._tipk_packed_pairs = True
     else:
         out = torch.empty((2, n_positions), dtype=dtype, device=dev)
         check(lib().tipk_typed_negative_sampling(ptr(pos_key_sorted), ptr(rel_ptr), n_rel, n_nodes, seed,
                                                  ptr(call_counter), adv, ptr(wg_ptr), ptr(wg_units),
-                                                 0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(pos_offset), ptr(out[0]), ptr(out[1]),
+                                                 0 if wg_ptr is None else wg_ptr.numel() - 1, ptr(pos_offset), ptr(keys32), ptr(out[0]), ptr(out[1]),
                                                  8 if dtype == torch.int64 else 4, n_positions, st),
               'tipk_typed_negative_sampling')
     if call_counter is not None and not adv:
@@ -1047,7 +1070,7 @@ class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
     def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None,
-                 pair_fwd=None, pair_bwd=None):
+                 pair_fwd=None, pair_bwd=None, dest_fwd=None):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
         generic D-D plans are only needed where the relation-local kernel does not apply).
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
@@ -1060,6 +1083,7 @@ class AggGraph(object):
                                                            # pass never needs it)
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
         self._pair_bwd = pair_bwd                          # plan.PairBwdPlan of the pair-form backward pass (or a callable)
+        self._dest_fwd = dest_fwd                          # plan.DestPlan of the forward pass of large graphs (or a callable)
         self.pair_stamp = 0                                # bumped by every pass that rewrites the pair buffers
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
@@ -1070,6 +1094,12 @@ class AggGraph(object):
         if callable(self._rs_bwd):
             self._rs_bwd = self._rs_bwd()
         return self._rs_bwd
+
+    @property
+    def dest_fwd(self):
+        if callable(self._dest_fwd):
+            self._dest_fwd = self._dest_fwd()
+        return self._dest_fwd
 
     @property
     def pair_bwd(self):
@@ -1381,6 +1411,17 @@ class _RGCN(torch.autograd.Function):
         elif r > 0:
             assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
         xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
+        # LARGE node sets (round 5; include/tipk.h section 2f): Y = att . XB [R N, out] is never formed -- per destination
+        # T[:, v, :] = sum_e att[r_e, :]^T (x) X[src_e] (a product over the node's incoming edges), then sum_b T_b basis_b
+        dest = graph.dest_fwd if (r > 0 and not use_rl) else None
+        if dest is not None:
+            agg = gemm(dest_products(dest, x, att), basis, reduce_batch=True)
+            if shard is not None:
+                shard.all_reduce(agg)
+            out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
+            ctx.graph, ctx.shard, ctx.relu, ctx.gate_input = graph, shard, relu, gate_input
+            ctx.save_for_backward(x, basis, att, root, xb, out if relu is True else None)
+            return out
         y = gemm(att, xb.view(nb, n * d_out)).view(r * n, d_out) if r > 0 else None     # [R N, out]
         if shard is None:
             if use_rl:

@@ -1112,3 +1112,35 @@ def execute_pair_bwd_reference(plan, cells_flat, xb, g, n_bases):
     assert bool((written == 1).all()), 'every (partition, relation) row is written exactly once'
     datt = out.view(plan.n_parts, plan.n_rel, n_bases).sum(0)
     return dxb.permute(1, 0, 2).contiguous(), pg, datt
+
+
+# ---------------------------------------------------------------------------------------------
+# destination-major edge list (include/tipk.h section 2f)
+# ---------------------------------------------------------------------------------------------
+class DestPlan(object):
+    """edges [E] int32 (uint32 words rel | src << bits) grouped by destination, node_desc [N, 4] int32 {v, first, count, 0} by
+    decreasing count."""
+
+    def __init__(self, n_nodes, n_rel, bits, edges, node_desc):
+        self.n_nodes, self.n_rel, self.bits, self.edges, self.node_desc = int(n_nodes), int(n_rel), int(bits), edges, node_desc
+        self.n_edges = int(edges.numel())
+
+    def to(self, device):
+        return DestPlan(self.n_nodes, self.n_rel, self.bits, self.edges.to(device), self.node_desc.to(device))
+
+
+def build_dest_plan(src, dst, rel, n_nodes, n_rel, bits):
+    """Edges sorted by destination (stable: relation-major order inside a node, as the edge list has it)."""
+    dev = src.device
+    src, dst, rel = src.to(torch.int64), dst.to(torch.int64), rel.to(torch.int64)
+    assert int(n_rel) <= (1 << bits) and int(n_nodes) <= (1 << (32 - bits))
+    order = torch.sort(dst, stable=True).indices
+    w = rel[order] | (src[order] << bits)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+    cnt = torch.bincount(dst, minlength=int(n_nodes))
+    first = torch.cumsum(cnt, 0) - cnt
+    by = torch.sort(cnt, descending=True, stable=True).indices
+    desc = torch.stack([by, first[by], cnt[by], torch.zeros_like(by)], dim=1).to(torch.int32).contiguous()
+    if w.numel() == 0:
+        w = torch.zeros(1, dtype=torch.int32, device=dev)
+    return DestPlan(n_nodes, n_rel, bits, w, desc)
