@@ -43,7 +43,8 @@ struct PgArgs {
     const int4* slots;                  // [n_slots] {v, bits of 1 / deg(v) (0 for a pad), cell line of (u, v), row of pg}
     float* dxb; int64_t dxb_sb, dxb_su;
     float* pg;                          // [..][32]: slot s writes row slots[s].w
-};
+    int dbg;                            // debug builds ("dp_debug"): 1 no dC stores, 2 no dC product, 4 no dXB product (cells unread),
+};                                      // 8 one tile per wave at most, 16 no g' loads, 32 no cell loads
 
 __device__ __forceinline__ float pg_ldg(const float* base, u32 byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
     const int4 nd = a.node_desc[blockIdx.x];               // uniform index: one scalar load
     const int u = __builtin_amdgcn_readfirstlane(nd.x);
     const int s_first = __builtin_amdgcn_readfirstlane(nd.y);
-    const int n_tiles = __builtin_amdgcn_readfirstlane(nd.z);
+    int n_tiles = __builtin_amdgcn_readfirstlane(nd.z);
+    if (TIPK_DBG(a.dbg & 8)) n_tiles = n_tiles < PG_WAVES ? n_tiles : PG_WAVES;
     float* tile = lds + w * 32 * LDT;
     const u32 ldg4 = (u32)a.ld_g * 4u;
 
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
     };
     // operands of tile `tl` (clamped: a tile past the end re-reads the last one and is never multiplied)
     auto load = [&](const int4& s, float (&cv)[NA], float (&gk)[H], float& ss, int& dest) {
-        if constexpr (D == 32) {
+        if (TIPK_DBG(a.dbg & 32)) {
+        } else if constexpr (D == 32) {
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int lj = __shfl(s.z, 2 * kk + kh, 64);
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         const u32 goff = (u32)s.x * ldg4 + (u32)(H * kh) * 4u;
 #pragma unroll
         for (int i = 0; i < H / 4; ++i) {
+            if (TIPK_DBG(a.dbg & 16)) break;
             const float4 x = pg_ldg4(a.g, goff + 16u * i);
             gk[4 * i] = x.x; gk[4 * i + 1] = x.y; gk[4 * i + 2] = x.z; gk[4 * i + 3] = x.w;
         }
@@ -136,11 +140,14 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         f32x16 pc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) pc[i] = 0.f;
+        if (!TIPK_DBG(a.dbg & 2)) {
 #pragma unroll
-        for (int i = 0; i < H; ++i) pc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[i], xbf[i], pc, 0, 0, 0);
+            for (int i = 0; i < H; ++i) pc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[i], xbf[i], pc, 0, 0, 0);
+        }
         pg_wave_sync();
         // dXB += cells^T (A: lane = base) . g' tile (B: lane = column), K = the tile's 32 slots
-        if constexpr (D == 32) {
+        if (TIPK_DBG(a.dbg & 4)) {
+        } else if constexpr (D == 32) {
             float bv[16];
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) bv[kk] = tile[(2 * kk + kh) * LDT + n];
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(PG_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         // every row goes where the d att gather stages it from (the slot's own word): two full 128-byte lines per store
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if (TIPK_DBG(a.dbg & 1)) break;
             const int dj = __shfl(dest, (r & 3) + 8 * (r >> 2) + 4 * kh, 64);
             *reinterpret_cast<float*>(reinterpret_cast<char*>(a.pg) + ((u32)dj * 128u + (u32)n * 4u)) = pc[r];
         }
@@ -246,6 +254,7 @@ extern "C" int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const f
     a.cells = cells; a.xb = xb; a.g = g; a.ld_g = (int)ld_g;
     a.node_desc = reinterpret_cast<const int4*>(node_desc); a.slots = reinterpret_cast<const int4*>(slots);
     a.dxb = dxb; a.dxb_sb = dxb_sb; a.dxb_su = dxb_su; a.pg = pg;
+    a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
     hipStream_t st = (hipStream_t)stream;
     if (d == 32) hipLaunchKernelGGL(pair_grads_kernel<32>, dim3((unsigned)n_nodes), dim3(PG_THREADS), 0, st, a);
     else hipLaunchKernelGGL(pair_grads_kernel<16>, dim3((unsigned)n_nodes), dim3(PG_THREADS), 0, st, a);
