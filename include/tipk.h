@@ -423,6 +423,7 @@ int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32
  *          of 32 (n_slots % 32 == 0; pads carry a valid v / line, the factor 0.0f and a dump row, so they add zeros -- g must
  *          be finite); cell line L = the n_bases floats at cells + L * n_bases (a symmetric forward pass keeps (min, max) only);
  *       node_desc [n_nodes][4]  { node u, its first slot, its tiles of 32 slots, 0 } by DECREASING tile count;
+ *       tile_node [n_slots / 32]  the node of every tile (the pair-gradient rows are computed one tile per wavefront);
  *       cells: n_lines lines of n_bases floats; xb [n_nodes][n_bases][32] as in 2c; g [n_nodes][ld_g]; dxb element
  *       (b, u, c) at dxb[b * dxb_sb + u * dxb_su + c], written COMPLETE; pg [pg_rows][n_bases]: the gradient row of a slot
  *       is written to row slots[..][3] -- the place the gather below stages it from, so pg needs no index on the way out.
@@ -437,7 +438,7 @@ int tipk_rgcn_node_products(const float* dyc, int64_t n_rows, int d, const int32
 int tipk_rgcn_pair_grads_supported(int n_bases, int d);
 int tipk_rgcn_pair_grads(const float* cells, int64_t n_lines, const float* xb, const float* g, int64_t ld_g,
                          int64_t n_nodes, int n_bases, int d, const int32_t* node_desc, const int32_t* slots,
-                         int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg, int64_t pg_rows,
+                         const int32_t* tile_node, int64_t n_slots, float* dxb, int64_t dxb_sb, int64_t dxb_su, float* pg, int64_t pg_rows,
                          tipk_stream_t stream);
 int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, int64_t second, const int32_t* part_first,
                              int64_t part_len, const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr,

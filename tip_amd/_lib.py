@@ -79,7 +79,7 @@ SIGNATURES = {
     'tipk_pair_product_supported': (_I, [_I, _I]),
     'tipk_pair_product': (_I, [_P, _P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'tipk_rgcn_pair_grads_supported': (_I, [_I, _I]),
-    'tipk_rgcn_pair_grads': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _L, _P, _L, _L, _P, _L, _P]),
+    'tipk_rgcn_pair_grads': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _P, _L, _L, _P, _L, _P]),
     'tipk_stream_gather_parts': (_I, [_P, _L, _I, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     'tipk_rgcn_dest_products_supported': (_I, [_L, _L, _I, _I]),
     'tipk_rgcn_dest_products': (_I, [_P, _L, _I, _P, _L, _I, _L, _L, _P, _P, _P, _L, _L, _P]),

@@ -516,7 +516,7 @@ def pair_grads(pb, cells, xb_pad, g):
     dxb = torch.empty((nb, n, d), dtype=torch.float32, device=dev)
     with _timed('pair_grads[%dx%dx%d,slots=%d]' % (n, nb, d, pb.n_slots)):
         check(lib().tipk_rgcn_pair_grads(ptr(cells), cells.numel() // nb, ptr(xb_pad), ptr(g), g.stride(0), n, nb, d,
-                                         ptr(pb.node_desc), ptr(pb.slots), pb.n_slots, ptr(dxb), dxb.stride(0), dxb.stride(1),
+                                         ptr(pb.node_desc), ptr(pb.slots), ptr(pb.tile_node), pb.n_slots, ptr(dxb), dxb.stride(0), dxb.stride(1),
                                          ptr(pg), pg.shape[0], stream_ptr(dev)), 'tipk_rgcn_pair_grads')
     return pg, dxb
 

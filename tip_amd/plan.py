@@ -890,6 +890,9 @@ class PairBwdPlan(object):
                  n_alloc, slot_of_pair=None):
         self.n_nodes, self.n_rel, self.n_slots = int(n_nodes), int(n_rel), int(n_slots)
         self.slots, self.node_desc = slots, node_desc
+        # node of every tile of 32 slots (role 2 of the launch computes the pair-gradient rows one tile per wavefront)
+        nd = node_desc.to(torch.int64)
+        self.tile_node = torch.repeat_interleave(nd[:, 0], nd[:, 2])[torch.argsort(torch.repeat_interleave(nd[:, 1], nd[:, 2]), stable=True)].to(torch.int32).contiguous()
         self.n_parts, self.part_len, self.part_first, self.wg_part, self.gather = int(n_parts), int(part_len), part_first, wg_part, gather
         self.symmetric, self.n_alloc = bool(symmetric), int(n_alloc)
         self.slot_of_pair = slot_of_pair          # (tests) int64 [n_directed_pairs, 3] = (u, v, slot)

@@ -24,9 +24,10 @@ for layer in (enc.rgcn1, enc.rgcn2):
     t_a = bench.time_launch_us(lambda: ops.pair_att_gather(pb, pg))
     print('d=%d  slots %d  pair_grads %.1f us   pair_att_gather %.1f us' % (d, pb.n_slots, t_g, t_a))
     if '+debug' in _lib.build_id():
-        for dbg, what in ((1, 'no dC stores'), (2, 'no dC product'), (3, 'no dC product, no stores'), (4, 'no dXB product (cells unread)'),
-                          (32, 'no cell loads'), (16, 'no g loads'), (48, 'no operand loads'), (8, 'at most one tile per wave'),
-                          (8 + 7, 'one tile per wave, no products, no stores'), (7 + 48, 'slot loads + reduce only')):
+        for dbg, what in ((64, 'role 1 alone (dXB per node)'), (128, 'role 2 alone (dC per tile)'), (1, 'no dC stores'), (2, 'no dC product'),
+                          (4, 'no dXB product (cells unread)'), (32, 'no cell loads'), (16 + 64, 'role 1, no g loads'),
+                          (8 + 64, 'role 1, at most one tile per wave'), (64 + 4 + 48, 'role 1: slot loads + reduce only'),
+                          (128 + 3, 'role 2: loads only')):
             _lib.set_option('dp_debug', dbg)
             print('   %-46s %.1f us' % (what, bench.time_launch_us(lambda: ops.pair_grads(pb, cells, xb_nb, g))))
         _lib.set_option('dp_debug', 0)
