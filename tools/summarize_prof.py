@@ -99,7 +99,7 @@ for n, d in pmc.items():
     f_kb, w_kb = d.get('FETCH_SIZE_KB_avg', 0.0), d.get('WRITE_SIZE_KB_avg', 0.0)
     d['hbm_bytes_per_launch'] = (2.0 * f_kb + w_kb) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 of wide reads
     d['hbm_bytes_per_launch_uncorrected'] = (f_kb + w_kb) * 1024.0
-step_bytes = None
+step_bytes = step_bytes_raw = None
 build_id = None
 try:                                                 # the build the counters were collected on (bench.py drops stale summaries)
     build_id = json.loads([l for l in open(os.path.join(src, 'bench_fetch.json')) if l.startswith('{')][-1]).get('build_id')
@@ -110,7 +110,13 @@ if pmc:
     try:
         line = [l for l in open(os.path.join(src, 'bench_fetch.json')) if l.startswith('{')][-1]
         meta = json.loads(line)
-        n_steps = int(meta['steps']) + int(meta['warmup'])
+        # full-size steps the pass ran: prepare() (the plan-building first step) + warm-up + timed; a --step-only run has no
+        # toy-graph step, so every libtipk launch of the pass belongs to one of them
+        n_steps = int(meta['steps']) + int(meta['warmup']) + 1
+        libtipk = lambda k: not (k.startswith('at::') or k.startswith('rocprim') or 'elementwise' in k or k.startswith('__amd_rocclr'))
+        tot_raw = sum(d['hbm_bytes_per_launch_uncorrected'] * max(d.get('launches_FETCH_SIZE', 0), d.get('launches_WRITE_SIZE', 0))
+                      for k, d in pmc.items() if libtipk(k))
+        step_bytes_raw = tot_raw / n_steps
         tot = sum(d['hbm_bytes_per_launch'] * max(d.get('launches_FETCH_SIZE', 0), d.get('launches_WRITE_SIZE', 0))
                   for k, d in pmc.items() if not (k.startswith('at::') or k.startswith('rocprim') or 'elementwise' in k
                                                   or k.startswith('__amd_rocclr')))          # setup copies / fills
@@ -123,14 +129,16 @@ if pmc:
     json.dump({'note': 'FETCH_SIZE/WRITE_SIZE in KB per launch (separate rocprofv3 --pmc passes of bench.py --launch eager); '
                        'hbm_bytes = (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md HBM section; keys = kernel + full grid XxYxZ '
                        '(joined from the kernel trace of the same pass by Dispatch_Id); step_hbm_bytes = all libtipk launches '
-                       'of the pass / (steps + warmup) of `bench.py --launch eager --step-only`',
-               'build_id': build_id, 'step_hbm_bytes': step_bytes, 'kernels': top},
+                       'of the pass / (steps + warmup + 1: the plan-building first step) of `bench.py --launch eager --step-only`; '
+                       '*_uncorrected = (FETCH + WRITE)*1024: the factor 2 is stated for wide streaming reads, a row-per-lane '
+                       'gather may not need it',
+               'build_id': build_id, 'step_hbm_bytes': step_bytes, 'step_hbm_bytes_uncorrected': step_bytes_raw, 'kernels': top},
               open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 
 lds = {}
 for sub in sorted(glob.glob(os.path.join(src, 'pmc_sq*'))):
     for key, cs in counters_by_launch(os.path.basename(sub)).items():
-        if not any(t in key for t in ('rel_gather', 'stream_gather', 'pair_product', 'gather_sum', 'dy_products', 'node_products', 'rgcn_')):
+        if not any(t in key for t in ('rel_gather', 'stream_gather', 'pair_product', 'pair_grads', 'gather_sum', 'dy_products', 'node_products', 'rgcn_')):
             continue
         for c, v in cs.items():
             lds.setdefault(key, {})[c] = sum(v) / len(v)
