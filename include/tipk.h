@@ -464,6 +464,19 @@ int tipk_rgcn_dest_products(const float* x, int64_t ld_x, int d_in, const float*
                             float* t, int64_t t_sb, int64_t t_sv, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * 2g. The hand-over between two R-GCN layers in one launch (src/layers.py:545-548): the ordered slab sum that ends a
+ *     layer's forward pass (the 16 slab lanes and the order of additions of tipk_sum_slabs_ex, epilogue relu?(row_scale * sum +
+ *     addend)) -> x [n_rows][32], and at once the next layer's row-local products: xb [row][n_bases][32] = x basis (node-major,
+ *     rows padded to 32 columns: the operand of 2c; columns >= d_out are not written) and xroot [n_rows][d_out] = x root.
+ *     slabs [n_slabs][n_rows][32] (slab_stride floats apart); basis [n_bases][32][d_out], root [32][d_out], contiguous.
+ *     d_in = 32 only (TIPK_EUNSUPPORTED otherwise: tipk_sum_slabs_ex + tipk_gemm_f32_group do the same).
+ */
+int tipk_sum_slabs_xb(const float* slabs, int64_t n_slabs, int64_t slab_stride, int64_t n_rows, int d_in,
+                      const float* row_scale /* nullable */, const float* addend /* nullable */, int relu, float* x,
+                      const float* basis, const float* root, int n_bases, int d_out, float* xb, float* xroot,
+                      tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).
  */
 /* out[c, r] = in[r, c]  -- `lin(x)` for identity features is W^T (src/layers.py:392 with

@@ -366,6 +366,34 @@ def test_pair_grads_backward(ops, R, N, d, symmetric, per_rel):
     assert torch.equal(g_att.cpu().double(), want_att) and torch.equal(g_xb.cpu().double(), want_xb)
 
 
+@pytest.mark.parametrize('S,N,nb,d_out', [(81, 645, 32, 16), (5, 7, 32, 32), (40, 130, 8, 16), (1, 2, 3, 5)])
+def test_sum_slabs_xb_layer_handover(ops, S, N, nb, d_out):
+    """tipk_sum_slabs_xb (tipk.h section 2g): the slab sum that ends a layer + the next layer's XB / X root products in one
+    launch == `sum_slabs` followed by the two products (fp64 references); the padding columns of the XB buffer stay
+    untouched; odd row counts; bitwise repeat."""
+    g = torch.Generator().manual_seed(S + N)
+    slabs = torch.randn(S, N, 32, generator=g).to(DEV)
+    scale = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    addend = torch.randn(N, 32, generator=g).to(DEV)
+    basis = torch.randn(nb, 32, d_out, generator=g).to(DEV)
+    root = torch.randn(32, d_out, generator=g).to(DEV)
+    n_pad = -(-N // 8) * 8
+    for relu in (True, False):
+        xb_pad = torch.full((n_pad, nb, 32), 7.0, device=DEV)
+        x = torch.empty(N, 32, device=DEV)
+        xroot = ops.sum_slabs_xb(slabs, scale, addend, relu, x, basis, root, xb_pad)
+        want_x = ops.sum_slabs(slabs, row_scale=scale, addend=addend, relu=relu)
+        close(x, want_x, rtol=1e-6, atol=1e-6)                       # (same lanes and order at 81 slabs; the compiler may fuse the epilogue differently)
+        ref = (slabs.double().sum(0) * scale.double().unsqueeze(1) + addend.double()).cpu()
+        close(x, torch.relu(ref) if relu else ref, rtol=2e-5, atol=2e-5)
+        close(xroot, x.double().cpu() @ root.double().cpu(), rtol=2e-5, atol=2e-5)
+        close(xb_pad[:N, :, :d_out], torch.einsum('ni,bio->nbo', x.double().cpu(), basis.double().cpu()), rtol=2e-5, atol=2e-5)
+        assert bool((xb_pad[:N, :, d_out:] == 7.0).all()) and bool((xb_pad[N:] == 7.0).all())
+        xb2 = torch.full((n_pad, nb, 32), 7.0, device=DEV)
+        x2 = torch.empty(N, 32, device=DEV)
+        assert torch.equal(ops.sum_slabs_xb(slabs, scale, addend, relu, x2, basis, root, xb2), xroot) and torch.equal(xb2, xb_pad)
+
+
 @pytest.mark.parametrize('R,N,d_in,nb,E', [(200, 1000, 128, 32, 300000), (37, 50, 40, 7, 3000), (5, 31, 128, 32, 40), (2000, 300, 64, 32, 90000)])
 def test_dest_products_forward(ops, R, N, d_in, nb, E):
     """tipk_rgcn_dest_products (tipk.h section 2f): T[b, v, :] = sum over the edges into v of att[r_e, b] x[src_e, :] == the

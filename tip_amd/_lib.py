@@ -83,6 +83,7 @@ SIGNATURES = {
     'tipk_stream_gather_parts': (_I, [_P, _L, _I, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     'tipk_rgcn_dest_products_supported': (_I, [_L, _L, _I, _I]),
     'tipk_rgcn_dest_products': (_I, [_P, _L, _I, _P, _L, _I, _L, _L, _P, _P, _P, _L, _L, _P]),
+    'tipk_sum_slabs_xb': (_I, [_P, _L, _L, _L, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
     'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),

@@ -509,13 +509,14 @@ class _RGCNBase(nn.Module):
         """in-degree over the relations of ALL ranks when this layer holds one shard of them."""
         return None if self.shard is None else self.shard.in_degree
 
-    def _run(self, x, graph, fuse_relu=False, gate_input=False):
+    def _run(self, x, graph, fuse_relu=False, gate_input=False, defer_output=False):
         if self.bias is not None:
             out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard) + self.bias
             if gate_input or fuse_relu == 'gated_downstream':
                 raise NotImplementedError('ReLU-mask hand-over between layers is only wired for bias=False')
             return torch.relu(out) if fuse_relu else out
-        return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu, gate_input=gate_input)
+        return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu, gate_input=gate_input,
+                        defer_output=defer_output)
 
     def __repr__(self):
         return '%s(%d, %d, num_relations=%d)' % (self.__class__.__name__, self.in_channels, self.out_channels,
@@ -526,10 +527,13 @@ class MyRGCNConv2(_RGCNBase):
     """Range-list variant (:102-193): relation r owns edges `range_list[r] = (start, end)`;
     `edge_type` is accepted and ignored, as in the reference."""
 
-    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False):
+    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False):
         """`fuse_relu` (extension): apply the ReLU that follows the layer in FMEncoder
         (src/layers.py:547) inside the layer's last kernel; 'gated_downstream' additionally leaves
-        the ReLU's backward mask to the one consumer, which is called with `gate_input=True`."""
+        the ReLU's backward mask to the one consumer, which is called with `gate_input=True`.
+        `defer_output` (extension, only with 'gated_downstream'): the layer's final slab sum may be left to that consumer --
+        an R-GCN layer of this package, which runs it in the launch of its own XB product; the returned tensor must not be
+        read by anything else."""
         n = x.shape[0]
 
         def build():
@@ -537,7 +541,7 @@ class MyRGCNConv2(_RGCNBase):
             return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
                               d_out=self.out_channels, n_bases=self.num_bases)
         graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
-        return self._run(x, graph, fuse_relu, gate_input)
+        return self._run(x, graph, fuse_relu, gate_input, defer_output)
 
 
 class MyRGCNConv(_RGCNBase):
@@ -583,7 +587,8 @@ class FMEncoder(nn.Module):
                 x_prot, pp_edge_index, dp_edge_index, dp_range_list):
         x0 = self.mixed_drug_features(x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list)
         # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
-        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream')
+        # ... and its final slab sum runs in rgcn2's first launch, together with rgcn2's XB / X root products
+        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream', defer_output=True)
         return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True)
 
     def mixed_drug_features(self, x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list):

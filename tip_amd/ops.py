@@ -494,6 +494,34 @@ def dest_products(dp, x, att):
     return t
 
 
+def sum_slabs_xb(slabs, row_scale, addend, relu, x_out, basis, root, xb_pad):
+    """x_out = relu?(row_scale * sum_s slabs[s] + addend) AND, in the same launch, the next layer's row-local products:
+    xb_pad[:N, :, :d_out] = x_out basis (node-major, rows padded to 32 columns) and the returned x_out root
+    (`tipk_sum_slabs_xb`, include/tipk.h section 2g).  slabs [S, N, 32], basis [bases, 32, d_out], root [32, d_out]."""
+    require_device(slabs, x_out, basis, root, xb_pad)
+    s_, n, d_in = slabs.shape
+    nb, _, d_out = basis.shape
+    assert slabs.is_contiguous() and x_out.is_contiguous() and x_out.shape == (n, d_in) and basis.is_contiguous() and root.is_contiguous()
+    assert xb_pad.stride()[-2:] == (32, 1) and xb_pad.shape[1] == nb and xb_pad.stride(0) == nb * 32 and xb_pad.shape[0] >= n
+    assert addend is None or (addend.is_contiguous() and addend.shape == (n, d_in))
+    xroot = torch.empty((n, d_out), dtype=torch.float32, device=slabs.device)
+    with _timed('sum_slabs_xb[%dx%d -> %dx%d]' % (s_, n * d_in, nb, d_out)):
+        check(lib().tipk_sum_slabs_xb(ptr(slabs), s_, n * d_in, n, d_in, ptr(row_scale), ptr(addend), int(bool(relu)), ptr(x_out),
+                                      ptr(basis), ptr(root), nb, d_out, ptr(xb_pad), ptr(xroot), stream_ptr(slabs.device)),
+              'tipk_sum_slabs_xb')
+    return xroot
+
+
+def sum_slabs_xb_supported(d_in, d_out):
+    return d_in == 32 and 1 <= d_out <= 32 and not os.environ.get('TIPK_NO_LAYER_HANDOVER')
+
+
+def _finish_pending(x, pend):
+    """Materialise a layer output whose final slab sum was left to its consumer (`_RGCN.forward(defer_output=True)`)."""
+    slabs, scale, addend, relu = pend
+    sum_slabs(slabs, out=x, row_scale=scale, addend=addend, relu=relu)
+
+
 def pair_grads_supported(nb, d):
     return bool(lib().tipk_rgcn_pair_grads_supported(int(nb), int(d))) and not os.environ.get('TIPK_NO_PAIR_BWD')
 
@@ -1335,7 +1363,7 @@ class _RGCN(torch.autograd.Function):
     into directly; d att rows are shard-local and never travel."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False):
+    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False, defer_output=False):
         """relu: False | True | 'gated_downstream' (ReLU applied here, its backward mask applied by the
         consumer, which must be the ONLY consumer and run with gate_input=True).
         gate_input: x is the ReLU output of the producing layer; dX is masked with (x > 0) while it is
@@ -1344,6 +1372,9 @@ class _RGCN(torch.autograd.Function):
         n, d_in = x.shape
         nb, _, d_out = basis.shape
         r = att.shape[0]
+        # x may be the output of the previous layer with its final slab sum still PENDING (`defer_output`): this layer then
+        # finishes it in the launch that computes its own XB / X root (`sum_slabs_xb`), or right here if it takes another route
+        pend = x.__dict__.pop('_tipk_pending', None) if hasattr(x, '__dict__') else None
         pair = graph.pair_fwd if r > 0 else None
         if pair is not None and pair.symmetric and not lib().tipk_pair_product_supported(nb, d_out):
             pair = None                                      # only the dedicated product kernel reads mirrored cells
@@ -1357,6 +1388,10 @@ class _RGCN(torch.autograd.Function):
             # not it could take the pair form itself (`_fwd_route`: the timed mode's all-reduce is a collective)
             if _fwd_route(graph, x, basis, att, pair, shard) == 'y':
                 pair = None
+        if pend is not None and not (pair is not None and shard is None and any(ctx.needs_input_grad[:3]) and pair_grads_supported(nb, d_out)
+                                     and graph.pair_bwd is not None and sum_slabs_xb_supported(d_in, d_out)):
+            _finish_pending(x, pend)
+            pend = None
         if pair is not None:
             # PAIR FORM.  sum_r A_r X W_r = sum_{(u -> v)} sum_b C[v, u, b] XB_b[u],  C[v, u, :] = sum of att[r, :] over
             # the relations r that link u -> v.  A BioSNAP drug pair is linked by 66 relations on average, so the
@@ -1376,7 +1411,11 @@ class _RGCN(torch.autograd.Function):
             if ctx.pair_bwd:
                 # PAIR-FORM BACKWARD (round 5; include/tipk.h section 2e): the backward pass reads the cells and the node-major
                 # XB this pass leaves in the graph's buffers -- nothing else is saved, nothing is transposed
-                _, xroot = gemm_group([gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
+                if pend is not None:                         # x itself + XB + X root in ONE launch (layer hand-over)
+                    xroot = sum_slabs_xb(pend[0], pend[1], pend[2], pend[3], x, basis, root, xb_nb)
+                    pend = None
+                else:
+                    _, xroot = gemm_group([gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
                 xb, xbt = None, None
                 ctx.xb_stamp = graph.pair_stamp
             elif rs is not None and rs.compact is not None:
@@ -1395,7 +1434,12 @@ class _RGCN(torch.autograd.Function):
                 ctx.xb_stamp, xbt = None, None
             stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
             slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, live=getattr(pair, 'live', None), zeros=zeros, xbt=xbt)
-            if shard is None:
+            if shard is None and defer_output and relu == 'gated_downstream' and d_out == 32:
+                # the ordered slab sum is left to the ONE consumer of this output (the next R-GCN layer, which runs it in the
+                # launch of its own XB product): until then `out` is storage only
+                out = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
+                out._tipk_pending = (slabs.view(-1, n, d_out), graph.scale, xroot, True)
+            elif shard is None:
                 out = sum_slabs(slabs.view(-1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
             else:
                 agg = sum_slabs(slabs.view(-1, n, d_out))
@@ -1535,7 +1579,7 @@ class _RGCN(torch.autograd.Function):
                     g_x = gemm(g, root.t(), out=g_x, c_in=g_x)           # replicated term, added once
                     if ctx.gate_input:
                         g_x = rows_affine(g_x, gate=x)
-                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None
+                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None, None
         j_root = gemm_job(x.t(), g)
         if shard is None:
             j_basis = gemm_job(x.t(), g_xb)                              # [B, in, out]
@@ -1567,11 +1611,11 @@ class _RGCN(torch.autograd.Function):
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
             if ctx.gate_input:
                 g_x = rows_affine(g_x, gate=x)
-        return g_x, g_basis, g_att, g_root, None, None, None, None
+        return g_x, g_basis, g_att, g_root, None, None, None, None, None
 
 
-def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False):
-    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input)
+def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False, defer_output=False):
+    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input, defer_output)
 
 
 class _DrugMix(torch.autograd.Function):

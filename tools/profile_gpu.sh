@@ -38,3 +38,6 @@ grep "ms/epoch" $OUT/train.log >> profiles/${TAG}_train_timeline.txt
 # 6. SQ / LDS counters of the fused objective (with and without gradients)
 if [ -z "$ARGS" ]; then bash tools/pmc_decoder.sh $TAG > $OUT/pmc_decoder.log 2>&1; fi
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
+# only the summaries and the logs travel back (gpurun merges at most 64 MiB of gpurun_out/): drop the raw rocprofv3 output
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq* $OUT/train gpurun_out/pmc_dm/grad* gpurun_out/pmc_dm/nograd*
+du -sh gpurun_out
