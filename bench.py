@@ -229,6 +229,24 @@ def dd_launches(enc, dev):
         rec = {'label': label, 'key': key, 'grid': grid, 'bound': bound, 'work': float(work), 'fn': fn}
         rec.update(extra)
         out.append(rec)
+    # both layers' pair cells in ONE launch (FMEncoder.forward: rgcn2's ride in rgcn1's cell launch)
+    cells_two = False
+    g1, g2 = enc.rgcn1._cache.value, enc.rgcn2._cache.value
+    if g1 is not None and g2 is not None and enc.rgcn1.shard is None and enc.rgcn2.shard is None:
+        n1 = g1.scale.numel()
+        a1, a2 = enc.rgcn1.att.detach(), enc.rgcn2.att.detach()
+        if ops.pair_cells_partner_ok(g1, a1, g2, a2, n1) and 'y' not in [v[0] for v in g1.fwd_route.values()]:
+            cells_two = True
+            nb1 = enc.rgcn1.num_bases
+            c1 = g1.pair_buffers(n1, nb1, enc.rgcn1.out_channels, dev)[0]
+            c2 = g2.pair_buffers(n1, nb1, enc.rgcn2.out_channels, dev)[0]
+            t1, t2 = torch.randn_like(a1), torch.randn_like(a2)
+            pf = g1.pair_fwd
+            add('pair_cells[dd.fwd,both layers]', 'stream_gather_kernel<%d, %s, 1' % (nb1 // 4, 'true' if pf.idx_unit == nb1 * 4 else 'false'),
+                '%dx2x1' % (pf.n_wg * 1024), 'lds', 2 * pf.n_edges * (4 + 4 * nb1),
+                lambda pf=pf, t1=t1, t2=t2, c1=c1, c2=c2, nb1=nb1, n1=n1: ops.stream_gather_two(
+                    pf, t1, t2, c1.view(-1, nb1)[:n1 * n1], c2.view(-1, nb1)[:n1 * n1]),
+                edges=2 * pf.n_edges, row_floats=nb1, aggregation=True)
     for layer in (enc.rgcn1, enc.rgcn2):
         graph = layer._cache.value
         if graph is None:
@@ -273,10 +291,11 @@ def dd_launches(enc, dev):
                 key = 'stream_gather_kernel<%d, %s, 1' % (nb // split // 4, 'true' if pair.idx_unit == nb // split * 4 else 'false')
                 att = torch.randn(r, nb, device=dev)
                 cells, xb_nb, _zeros = graph.pair_buffers(n, nb, d, dev)
-                add('pair_cells[dd.fwd,d=%d]' % d, key, '%dx%dx1' % (pair.n_wg * 1024, split), 'lds', pair.n_edges * (4 + 4 * nb),
-                    lambda pair=pair, att=att, cells=cells, nb=nb, n=n: ops.stream_gather(
-                        pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1),
-                    edges=pair.n_edges, row_floats=nb, aggregation=True)
+                if not cells_two:
+                    add('pair_cells[dd.fwd,d=%d]' % d, key, '%dx%dx1' % (pair.n_wg * 1024, split), 'lds', pair.n_edges * (4 + 4 * nb),
+                        lambda pair=pair, att=att, cells=cells, nb=nb, n=n: ops.stream_gather(
+                            pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], kind=1),
+                        edges=pair.n_edges, row_floats=nb, aggregation=True)
                 add('pair_product[dd.fwd,d=%d]' % d, 'pair_product_kernel', None, 'mfma', 2.0 * n * n * nb * d,
                     lambda cells=cells, xb_nb=xb_nb, pair=pair, z=_zeros: ops.pair_product(cells, xb_nb, symmetric=pair.symmetric,
                                                                                            live=pair.live, zeros=z),

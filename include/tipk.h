@@ -244,6 +244,12 @@ int tipk_rel_gather(int backward, const float* table, int64_t ld_table, int64_t 
  */
 /* column blocks of the launch (grid = n_wg x blocks); 0 = the table does not fit in LDS */
 int tipk_stream_gather_supported(int64_t n_table, int d, int max_split);
+/* two tables of the same shape on ONE plan in one launch (no zero rows, no scaling, no epilogue): out0 <- table0, out1 <- table1;
+ * the pair cells of both R-GCN layers of an encoder (they share the graph; the cells depend on the parameters only).  One column
+ * block only (tipk_stream_gather_supported(n_table, d, 1) == 1), d in {16, 32, 64}. */
+int tipk_stream_gather_two(const float* table0, const float* table1, int64_t ld_table, int64_t n_table, int d, int64_t n_wg,
+                           const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
+                           float* out0, float* out1, int64_t ld_out, tipk_stream_t stream);
 int tipk_stream_gather_piece(void);
 int tipk_stream_gather(const float* table, int64_t ld_table, int64_t n_table, int d, int64_t n_wg,
                         const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,

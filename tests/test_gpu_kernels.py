@@ -383,7 +383,7 @@ def test_sum_slabs_xb_layer_handover(ops, S, N, nb, d_out):
         x = torch.empty(N, 32, device=DEV)
         xroot = ops.sum_slabs_xb(slabs, scale, addend, relu, x, basis, root, xb_pad)
         want_x = ops.sum_slabs(slabs, row_scale=scale, addend=addend, relu=relu)
-        close(x, want_x, rtol=1e-6, atol=1e-6)                       # (same lanes and order at 81 slabs; the compiler may fuse the epilogue differently)
+        close(x, want_x.cpu(), rtol=1e-6, atol=1e-6)                       # (same lanes and order at 81 slabs; the compiler may fuse the epilogue differently)
         ref = (slabs.double().sum(0) * scale.double().unsqueeze(1) + addend.double()).cpu()
         close(x, torch.relu(ref) if relu else ref, rtol=2e-5, atol=2e-5)
         close(xroot, x.double().cpu() @ root.double().cpu(), rtol=2e-5, atol=2e-5)

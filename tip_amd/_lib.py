@@ -86,6 +86,7 @@ SIGNATURES = {
     'tipk_sum_slabs_xb': (_I, [_P, _L, _L, _L, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),
+    'tipk_stream_gather_two': (_I, [_P, _P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _L, _P]),
     'tipk_stream_gather': (_I, [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P]),
     'tipk_rel_gather': (_I, [_I, _P, _L, _L, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_gemm_f32': (_I, [C.POINTER(GemmDesc), _P]),

@@ -57,6 +57,8 @@ struct RsArgs {
     int relu;
     // KIND 2 (tipk_stream_gather_parts): every workgroup stages ITS partition of a table that exists as two halves:
     // LDS row i of partition p = table[part_first[p] + i] + table[second + part_first[p] + i]
+    // two tables in one launch (tipk_stream_gather_two): blockIdx.y = 1 gathers from table1 into out1 on the SAME plan
+    const float* table1; float* out1;
     const int32_t* part_first;         // [n_parts] first table row of a partition
     const int32_t* wg_part;            // [n_wg] partition of a workgroup
     int64_t second;                    // rows between the two halves
@@ -100,9 +102,10 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
 #endif
     const int n_nodes = a.n_nodes, dc = a.dc;
     const int slot = lane / L, c0 = (lane & (L - 1)) * VW;
-    const int col0 = blockIdx.y * dc;
-    const float* table = a.table + col0;
-    float* out = a.out + col0;
+    const bool second = a.table1 != nullptr && blockIdx.y == 1;        // (uniform)
+    const int col0 = second ? 0 : blockIdx.y * dc;
+    const float* table = second ? a.table1 : a.table + col0;
+    float* out = second ? a.out1 : a.out + col0;
     const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 16 + (t >> 6));
     int b = __builtin_amdgcn_readfirstlane(a.wave_ptr[gw]);
 #ifdef TIPK_DEBUG
@@ -324,7 +327,7 @@ extern "C" int tipk_stream_gather(const float* table, int64_t ld_table, int64_t 
     a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
     a.out = out; a.ld_out = ld_out; a.row_scale = row_scale;
     a.out_scale = out_scale; a.bias = bias; a.relu = relu;
-    a.part_first = nullptr; a.wg_part = nullptr; a.second = 0;
+    a.part_first = nullptr; a.wg_part = nullptr; a.second = 0; a.table1 = nullptr; a.out1 = nullptr;
     if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || (int64_t)n_nodes * idx_unit > 65535) return TIPK_EINVAL;
     a.idx_mul = a.dc * 4 / idx_unit;
     hipStream_t st = (hipStream_t)stream;
@@ -357,8 +360,37 @@ extern "C" int tipk_stream_gather_parts(const float* table, int64_t ld_table, in
     a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
     a.out = out; a.ld_out = ld_out; a.row_scale = nullptr;
     a.out_scale = nullptr; a.bias = nullptr; a.relu = 0;
-    a.part_first = part_first; a.wg_part = wg_part; a.second = second;
+    a.part_first = part_first; a.wg_part = wg_part; a.second = second; a.table1 = nullptr; a.out1 = nullptr;
     if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || part_len * idx_unit > 65535) return TIPK_EINVAL;
     a.idx_mul = a.dc * 4 / idx_unit;
     return launch_rs<8>(a, (int)n_wg, 1, 2, (hipStream_t)stream);
+}
+
+// The pair cells of BOTH R-GCN layers of an encoder in one launch (include/tipk.h section 1d): the layers share the graph,
+// hence the plan; a workgroup stages att of layer blockIdx.y.  (Two launches of 256 workgroups each left the chip idle
+// through two launch ramps and two tails; the cells depend on the parameters only, so they can lead the step.)
+extern "C" int tipk_stream_gather_two(const float* table0, const float* table1, int64_t ld_table, int64_t n_table, int d,
+                                       int64_t n_wg, const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids,
+                                       int idx_unit, float* out0, float* out1, int64_t ld_out, tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table0 || !table1 || !wave_ptr || !cells || !ids || !out0 || !out1 ||
+        (reinterpret_cast<uintptr_t>(ids) & 15))
+        return TIPK_EINVAL;
+    if (rel_stream_split(n_table, d, 1) != 1 || d < 16) return TIPK_EUNSUPPORTED;      // one column block, 16-byte lane pieces
+    if (ld_table % 4 != 0 || ld_out % 4 != 0 || ((reinterpret_cast<uintptr_t>(table0) | reinterpret_cast<uintptr_t>(table1) |
+                                                   reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1)) & 15))
+        return TIPK_EINVAL;
+    RsArgs a;
+    a.table = table0; a.ld_t = ld_table; a.n_nodes = (int)n_table; a.dc = d;
+    a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = nullptr; a.zero_rows = nullptr;
+    a.out = out0; a.ld_out = ld_out; a.row_scale = nullptr; a.out_scale = nullptr; a.bias = nullptr; a.relu = 0;
+    a.part_first = nullptr; a.wg_part = nullptr; a.second = 0; a.table1 = table1; a.out1 = out1;
+    if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || n_table * idx_unit > 65535) return TIPK_EINVAL;
+    a.idx_mul = a.dc * 4 / idx_unit;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.dc / 4) {
+        case 4: return launch_rs<4>(a, (int)n_wg, 2, 1, st);
+        case 8: return launch_rs<8>(a, (int)n_wg, 2, 1, st);
+        case 16: return launch_rs<16>(a, (int)n_wg, 2, 1, st);
+        default: return TIPK_EUNSUPPORTED;
+    }
 }

@@ -509,14 +509,14 @@ class _RGCNBase(nn.Module):
         """in-degree over the relations of ALL ranks when this layer holds one shard of them."""
         return None if self.shard is None else self.shard.in_degree
 
-    def _run(self, x, graph, fuse_relu=False, gate_input=False, defer_output=False):
+    def _run(self, x, graph, fuse_relu=False, gate_input=False, defer_output=False, partner=None):
         if self.bias is not None:
             out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard) + self.bias
             if gate_input or fuse_relu == 'gated_downstream':
                 raise NotImplementedError('ReLU-mask hand-over between layers is only wired for bias=False')
             return torch.relu(out) if fuse_relu else out
         return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu, gate_input=gate_input,
-                        defer_output=defer_output)
+                        defer_output=defer_output, partner=partner)
 
     def __repr__(self):
         return '%s(%d, %d, num_relations=%d)' % (self.__class__.__name__, self.in_channels, self.out_channels,
@@ -527,21 +527,30 @@ class MyRGCNConv2(_RGCNBase):
     """Range-list variant (:102-193): relation r owns edges `range_list[r] = (start, end)`;
     `edge_type` is accepted and ignored, as in the reference."""
 
-    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False):
+    def graph_for(self, n, edge_index, range_list):
+        """The layer's cached plans of this D-D graph over n nodes (built on first use)."""
+        def build():
+            rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
+            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
+                              d_out=self.out_channels, n_bases=self.num_bases)
+        return self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
+
+    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False, next_layer=None):
         """`fuse_relu` (extension): apply the ReLU that follows the layer in FMEncoder
         (src/layers.py:547) inside the layer's last kernel; 'gated_downstream' additionally leaves
         the ReLU's backward mask to the one consumer, which is called with `gate_input=True`.
         `defer_output` (extension, only with 'gated_downstream'): the layer's final slab sum may be left to that consumer --
         an R-GCN layer of this package, which runs it in the launch of its own XB product; the returned tensor must not be
-        read by anything else."""
+        read by anything else.
+        `next_layer` (extension): the R-GCN layer that follows on the SAME graph -- its pair cells (they depend on its `att`
+        alone) are gathered in this layer's cell launch."""
         n = x.shape[0]
-
-        def build():
-            rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
-            return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
-                              d_out=self.out_channels, n_bases=self.num_bases)
-        graph = self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
-        return self._run(x, graph, fuse_relu, gate_input, defer_output)
+        graph = self.graph_for(n, edge_index, range_list)
+        partner = None
+        if next_layer is not None and self.shard is None and next_layer.shard is None and next_layer.bias is None and \
+                next_layer.num_relations == self.num_relations and next_layer.num_bases == self.num_bases:
+            partner = (next_layer.att, next_layer.graph_for(n, edge_index, range_list), next_layer.out_channels)
+        return self._run(x, graph, fuse_relu, gate_input, defer_output, partner)
 
 
 class MyRGCNConv(_RGCNBase):
@@ -588,7 +597,9 @@ class FMEncoder(nn.Module):
         x0 = self.mixed_drug_features(x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list)
         # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
         # ... and its final slab sum runs in rgcn2's first launch, together with rgcn2's XB / X root products
-        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream', defer_output=True)
+        # rgcn2's pair cells ride in rgcn1's cell launch
+        x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream', defer_output=True,
+                        next_layer=self.rgcn2)
         return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True)
 
     def mixed_drug_features(self, x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list):

@@ -262,6 +262,35 @@ def stream_gather(sp, table, row_scale=None, write_zeros=True, out=None, label='
     return out
 
 
+def stream_gather_two(sp, table0, table1, out0, out1, label='pair_cells2[dd.fwd]'):
+    """out0[row] = sum of table0 rows, out1[row] = sum of table1 rows on ONE wave-stream plan in one launch
+    (`tipk_stream_gather_two`): the pair cells of both R-GCN layers of an encoder.  Rows without edges stay untouched."""
+    table0, table1 = _f32c(table0), _f32c(table1)
+    require_device(table0, table1, sp.ids, out0, out1)
+    d = table0.shape[1]
+    assert table0.shape == table1.shape == (sp.n_table, d) and table0.stride() == table1.stride() and table0.stride(1) == 1
+    assert out0.shape == out1.shape == (sp.n_rows, d) and out0.is_contiguous() and out1.is_contiguous()
+    assert stream_gather_split(sp.n_table, d, 1) == 1 and d * 4 == sp.row_bytes, 'plan was built for another launch shape'
+    with _timed('%s[d=%d]' % (label, d)):
+        check(lib().tipk_stream_gather_two(ptr(table0), ptr(table1), table0.stride(0), sp.n_table, d, sp.n_wg, ptr(sp.wave_ptr),
+                                           ptr(sp.cells), ptr(sp.ids), sp.idx_unit, ptr(out0), ptr(out1), d,
+                                           stream_ptr(table0.device)), 'tipk_stream_gather_two')
+
+
+def pair_cells_partner_ok(graph, att, graph2, att2, n):
+    """True when the pair cells of a second layer (graph2, att2) can be gathered in the launch that gathers (graph, att)'s:
+    the same plan shape (the layers share the D-D graph), att tables of one shape, one column block."""
+    if os.environ.get('TIPK_NO_CELLS_TWO'):
+        return False
+    p1, p2 = graph.pair_fwd, graph2.pair_fwd
+    if p1 is None or p2 is None or att.shape != att2.shape or att.stride() != att2.stride():
+        return False
+    r, nb = att.shape
+    return (p1.n_table == p2.n_table == r and p1.n_rows == p2.n_rows == n * n and p1.n_bands == p2.n_bands and p1.n_wg == p2.n_wg
+            and p1.lanes == p2.lanes and p1.idx_unit == p2.idx_unit and p1.symmetric == p2.symmetric
+            and stream_gather_split(r, nb, 1) == 1 and nb // 4 == p1.lanes and nb >= 16)
+
+
 def rel_stream_bwd(sp, table, row_scale=None, write_zeros=True):
     """Transposed D-D pass: table = g [N, d] -> dY (plan of `build_stream_plan`): [R * N, d], or -- compact plans --
     [n_rows + 1, d] node-major with a trailing zero row (a buffer kept ON THE PLAN per width: the zero row is written
@@ -1363,7 +1392,7 @@ class _RGCN(torch.autograd.Function):
     into directly; d att rows are shard-local and never travel."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False, defer_output=False):
+    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False, defer_output=False, partner=None):
         """relu: False | True | 'gated_downstream' (ReLU applied here, its backward mask applied by the
         consumer, which must be the ONLY consumer and run with gate_input=True).
         gate_input: x is the ReLU output of the producing layer; dX is masked with (x > 0) while it is
@@ -1432,7 +1461,21 @@ class _RGCN(torch.autograd.Function):
             else:
                 xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
                 ctx.xb_stamp, xbt = None, None
-            stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
+            tok = getattr(graph, 'cells_token', None)
+            graph.cells_token = None
+            if tok == (att.data_ptr(), att._version, graph.pair_stamp - 1):
+                pass                                         # this layer's cells were gathered with the previous layer's (below)
+            elif partner is not None and shard is None and pair_cells_partner_ok(graph, att, partner[1], partner[0], n):
+                # the cells depend on the parameters only: the NEXT layer's (same graph, its own att) are gathered in this
+                # launch too -- one launch ramp and one tail instead of two.  The partner's buffers are rewritten: its stamp
+                # moves on, and it is told for which att (object, version) and stamp its cells are current
+                att2, g2, d_out2 = partner[0].contiguous(), partner[1], partner[2]
+                cells2 = g2.pair_buffers(n, nb, d_out2, x.device)[0]
+                stream_gather_two(pair, att, att2, cells.view(-1, nb)[:n * n], cells2.view(-1, nb)[:n * n])
+                g2.pair_stamp += 1
+                g2.cells_token = (att2.data_ptr(), att2._version, g2.pair_stamp)
+            else:
+                stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
             slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, live=getattr(pair, 'live', None), zeros=zeros, xbt=xbt)
             if shard is None and defer_output and relu == 'gated_downstream' and d_out == 32:
                 # the ordered slab sum is left to the ONE consumer of this output (the next R-GCN layer, which runs it in the
@@ -1579,7 +1622,7 @@ class _RGCN(torch.autograd.Function):
                     g_x = gemm(g, root.t(), out=g_x, c_in=g_x)           # replicated term, added once
                     if ctx.gate_input:
                         g_x = rows_affine(g_x, gate=x)
-                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None, None
+                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None, None, None
         j_root = gemm_job(x.t(), g)
         if shard is None:
             j_basis = gemm_job(x.t(), g_xb)                              # [B, in, out]
@@ -1611,11 +1654,13 @@ class _RGCN(torch.autograd.Function):
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
             if ctx.gate_input:
                 g_x = rows_affine(g_x, gate=x)
-        return g_x, g_basis, g_att, g_root, None, None, None, None, None
+        return g_x, g_basis, g_att, g_root, None, None, None, None, None, None
 
 
-def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False, defer_output=False):
-    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input, defer_output)
+def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False, defer_output=False, partner=None):
+    """partner (optional): (att, graph, d_out) of the NEXT R-GCN layer on the same D-D graph -- its pair cells are gathered in
+    this layer's cell launch (`stream_gather_two`)."""
+    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input, defer_output, partner)
 
 
 class _DrugMix(torch.autograd.Function):
