@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 17
+#define TIPK_ABI_VERSION 18
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
