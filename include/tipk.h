@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 19
+#define TIPK_ABI_VERSION 18
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -599,27 +599,6 @@ int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const float* rel_
  * step; the bits are those of tipk_distmult_loss on zeroed outputs).  Only the workspace path can do that (its finalize
  * launch visits every output element): TIPK_EUNSUPPORTED otherwise, nothing launched. */
 int tipk_distmult_loss_store(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
-                             const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
-                             int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
-                             const int32_t* tasks, int64_t n_tasks,
-                             float* loss_out, float* g_z, float* g_w, void* workspace, tipk_stream_t stream);
-
-/* 4c. The positives' share of d z in PAIR-MAJOR order (k = 16, symmetric positive sets: every (u, v, r) has its (v, u, r)).
- *     The positives are the edges of the D-D graph, 66 relations per linked pair at BioSNAP: with p = z[u] o z[v] fixed per
- *     pair, W[u, v, :] = sum_{r links u-v} q_r D[r, :] (q_r = d loss / d score of the pair under r, weight 2 / n_triples: the
- *     triple and its mirror) is a wave-stream gather (section 1d; rows = pairs u * n_nodes + v with u <= v, ids = relations
- *     pre-scaled for 64-byte rows, plan built from the triples with u <= v) whose rows are weighted by a function of
- *     themselves, and g_z[u, :] = sum_{v linked to u} W[min, max, :] o z[v, :] one pass over the node's neighbours
- *     (nbr_ptr [n_nodes + 1], nbr [pairs][2] = {v, min * n_nodes + max}): no atomics.  wrows [n_nodes * n_nodes][16]: the
- *     rows of linked pairs are rewritten by every call.  g_z [n_nodes][16] is OVERWRITTEN.
- *     tipk_distmult_loss_negdz then = tipk_distmult_loss_store without the positives' d z scatter (a third of its LDS
- *     atomics): loss and g_w are overwritten, the negatives' d z terms are ADDED to g_z.  Packed pairs (idx_bytes = 2),
- *     workspace path only. */
-int tipk_distmult_pair_dz(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel, int64_t n_wg,
-                          const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
-                          float coef /* 2 / n_triples */, float* wrows, const int32_t* nbr_ptr, const int32_t* nbr,
-                          float* g_z, tipk_stream_t stream);
-int tipk_distmult_loss_negdz(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
                              const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
                              int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
                              const int32_t* tasks, int64_t n_tasks,

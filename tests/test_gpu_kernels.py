@@ -881,60 +881,12 @@ def test_distmult_fused_objective(ops):
         close(gwt, gwk.cpu(), rtol=1e-4, atol=1e-7)
 
 
-def test_distmult_positives_pair_major_dz(ops, monkeypatch):
-    """tipk_distmult_pair_dz + tipk_distmult_loss_negdz (tipk.h section 4c): the positives' d z in pair-major order (no
-    atomics), the objective kernel scattering the negatives only == the all-in-one objective (loss and d w bit for bit: that
-    part of the kernel is unchanged; d z up to rounding) == the oracle; reproducible bit for bit; a hub pair linked by many
-    relations (wide runs), a relation with one pair; an ASYMMETRIC positive list falls back to the all-in-one kernel."""
-    from tip_amd import neg_sampling as NS
-    g = torch.Generator().manual_seed(31)
-    n, r, k = 645, 60, 16
-    sizes = torch.randint(1, 3000, (r,), generator=g)
-    sizes[7] = 1
-    halves = []
-    for c in sizes.tolist():
-        h = torch.randint(0, n, (2, c), generator=g)
-        h[:, 0] = torch.tensor([3, 9])                                    # the pair (3, 9) is linked by every relation
-        halves.append(h)
-    pos = torch.cat([torch.cat([h, h.flip(0)], dim=1) for h in halves], dim=1).to(DEV)
-    et = torch.repeat_interleave(torch.arange(r), 2 * sizes).to(DEV)
-    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(2 * sizes, 0)])
-    rg = torch.stack([ptr[:-1], ptr[1:]], 1)
-    neg_p = NS.typed_negative_sampling(pos, n, rg, seed=5, packed=True)
-    z = (torch.randn(n, k, generator=g) * 0.7).to(DEV)
-    w = (torch.randn(r, k, generator=g) * 0.5).to(DEV)
-    assert ops.pos_pair_plan(pos, et, n, r) is not None
-    got = ops.distmult_loss(z, w, pos, neg_p, et)
-    again = ops.distmult_loss(z, w, pos, neg_p, et)
-    assert all(torch.equal(a, b) for a, b in zip(got, again))
-    monkeypatch.setenv('TIPK_NO_PAIR_DZ', '1')
-    want = ops.distmult_loss(z, w, pos, neg_p, et)
-    monkeypatch.delenv('TIPK_NO_PAIR_DZ')
-    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])
-    close(got[1], want[1].cpu(), rtol=1e-4, atol=2e-7)
-    posc, negc, etc = pos.cpu(), ops.unpack_pairs(neg_p).cpu(), et.cpu()
-    z64, w64 = z.double().cpu(), w.double().cpu()
-    ps, ns = O.distmult_fwd(z64, posc, etc, w64), O.distmult_fwd(z64, negc, etc, w64)
-    gp, gn = O.tip_loss_bwd(ps, ns)
-    gz1, _ = O.distmult_bwd(gp, z64, posc, etc, w64)
-    gz2, _ = O.distmult_bwd(gn, z64, negc, etc, w64)
-    close(got[1], gz1 + gz2, atol=2e-6)
-    # not symmetric: no plan, the all-in-one kernel
-    pos_a = pos.clone()
-    pos_a[0, 1] = (pos_a[0, 1] + 1) % n
-    assert ops.pos_pair_plan(pos_a, et, n, r) is None
-    la = ops.distmult_loss(z, w, pos_a, neg_p, et)
-    psa = O.distmult_fwd(z64, pos_a.cpu(), etc, w64)
-    close(la[0], O.tip_loss(psa, ns).view(1), rtol=2e-5)
-
-
 @pytest.mark.parametrize('k', [16, 8, 4])
-def test_distmult_fused_objective_packed_pairs_bit_identical(ops, k, monkeypatch):
+def test_distmult_fused_objective_packed_pairs_bit_identical(ops, k):
     """idx_bytes = 2 (include/tipk.h section 4): the pairs as one 32-bit word u | v << 16.  Same kernel, same order of
     operations -> loss, d z and d w are BIT-IDENTICAL to the int64-id call; the sampler's packed output holds exactly the
     pairs of its int64 output; shapes the packed kernel does not take fall back to plain ids with the same result."""
     from tip_amd import neg_sampling as NS
-    monkeypatch.setenv('TIPK_NO_PAIR_DZ', '1')        # (the pair-major d z of the packed path has its own test above)
     g = torch.Generator().manual_seed(21)
     n, r = 645, 37
     sizes = torch.randint(0, 3000, (r,), generator=g)

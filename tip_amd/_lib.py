@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 19
+ABI_VERSION = 18
 
 
 class TipkError(RuntimeError):
@@ -114,8 +114,6 @@ SIGNATURES = {
     'tipk_distmult_workspace_bytes': (_L, [_L, _I, _L]),
     'tipk_distmult_loss': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
     'tipk_distmult_loss_store': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
-    'tipk_distmult_loss_negdz': (_I, [_P, _L, _I, _P, _L, _P, _P, _P, _P, _I, _P, _I, _L, _P, _L, _P, _P, _P, _P, _P]),
-    'tipk_distmult_pair_dz': (_I, [_P, _L, _I, _P, _L, _L, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
     'tipk_pair_table_fwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_pair_table_bwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P]),
     'tipk_pair_table_loss': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _L, _F, _P, _P, _P, _P]),

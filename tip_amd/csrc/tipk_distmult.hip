@@ -484,9 +484,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
     const float* __restrict__ z, int n_nodes, const float* __restrict__ w, int n_rel,
     const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
     const IT* __restrict__ nu, const IT* __restrict__ nv, int64_t n_total, int want_grad,
-    unsigned long long* __restrict__ ws, int dbg, int pos_dz) {
-    // pos_dz = 0: the positives' d z terms are NOT scattered (tipk_distmult_pair_dz adds them, in pair-major order, without
-    // atomics); their loss terms and d w stay here
+    unsigned long long* __restrict__ ws, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
     const int t = threadIdx.x;
     constexpr int ld = K + 4, lg = K + 1;
@@ -593,7 +591,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         // twice the time, tools/bench_decoder.py) -- and keeps its column of d w.  What travels per position is its
         // coefficient and the BYTE OFFSETS of its two rows in the two images (multiplied once, by the position's lane):
         // an address is one add.  Positions that do not exist carry q = 0 and clamped ids: they add zeros, no branch.
-        auto scatter = [&](float q_mine, int u_mine, int v_mine, bool add_dz) {
+        auto scatter = [&](float q_mine, int u_mine, int v_mine) {
             const int zu_mine = u_mine * (ld * 4), zv_mine = v_mine * (ld * 4);
             const int gu_mine = u_mine * (lg * 8), gv_mine = v_mine * (lg * 8);
             pr_static_for<64 / G>([&](auto ic) {
@@ -615,7 +613,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
                 const float ua = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zu);
                 const float vb = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zv);
                 const float qs = q * wcs;
-                if (add_dz && !TIPK_DBG(dbg & 1)) {
+                if (!TIPK_DBG(dbg & 1)) {
                     const int tu = (int)rintf(qs * vb), tv = (int)rintf(qs * ua);     // |term * scale| < 2^30 by construction
                     __hip_atomic_fetch_add(reinterpret_cast<pr_lds_u64_t*>((uintptr_t)gu), (unsigned long long)(long long)tu,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -637,8 +635,8 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
                 qn = triple(id.nu, id.nv, true, 1.f);
             }
             if (want_grad) {
-                if (pos_w != 0) scatter(qp, id.pu, id.pv, pos_dz != 0);
-                scatter(qn, id.nu, id.nv, true);
+                if (pos_w != 0) scatter(qp, id.pu, id.pv);
+                scatter(qn, id.nu, id.nv);
             }
         }
         cur0 = nx0;
@@ -683,18 +681,16 @@ inline bool task_path_ok(int64_t n_nodes, int k, int64_t* lds_bytes) {
 // Converts, ADDS into the outputs (same contract as the float path) and zeroes the words again, so the caller's
 // workspace is reusable without a memset.
 // store != 0: the outputs are OVERWRITTEN (0 + value, the same bits as adding into zeroed outputs) -- no zero fills.
-// store bit 1 (= 2): g_z is ACCUMULATED whatever bit 0 says (it holds the positives' pair-major terms: tipk_distmult_pair_dz)
 __global__ __launch_bounds__(256) void det_finalize_kernel(unsigned long long* ws, int64_t n_z, int64_t n_w,
-                                                           float* loss_out, float* g_z, float* g_w, int store_flags) {
-    const int store = store_flags & 1, keep_z = store_flags & 2;
+                                                           float* loss_out, float* g_z, float* g_w, int store) {
     const double* sc = reinterpret_cast<const double*>(ws + n_z + n_w + 1);
     const double inv_z = 1.0 / sc[0], inv_w = 1.0 / sc[1], inv_l = 1.0 / sc[2];
     const int64_t total = n_z + n_w + 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const long long a = (long long)ws[i];
-        if (a == 0 && (!store || (keep_z && i < n_z))) continue;
+        if (a == 0 && !store) continue;
         if (a != 0) ws[i] = 0ull;
-        if (i < n_z) { if (g_z) g_z[i] = ((store && !keep_z) ? 0.0f : g_z[i]) + (float)((double)a * inv_z); }
+        if (i < n_z) { if (g_z) g_z[i] = (store ? 0.0f : g_z[i]) + (float)((double)a * inv_z); }
         else if (i < n_z + n_w) { if (g_w) g_w[i - n_z] = (store ? 0.0f : g_w[i - n_z]) + (float)((double)a * inv_w); }
         else loss_out[0] = (store ? 0.0f : loss_out[0]) + (float)((double)a * inv_l);
     }
@@ -739,7 +735,7 @@ int launch_objective(const float* z, int64_t n_nodes, int k, const float* w, int
         if (e != hipSuccess) return tipk_hip_status(e);                                                                  \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, st, z, (int)n_nodes, w, (int)n_rel, tasks,      \
                            (int)n_tasks, (const IT*)pu, (const IT*)pv, (const IT*)nu, (const IT*)nv, n_total,           \
-                           g_z != nullptr ? 1 : 0, ws, dbg, (store & 2) ? 0 : 1);                                        \
+                           g_z != nullptr ? 1 : 0, ws, dbg);                                                             \
     }
     if (idx_bytes == 8) { if (k == 4) OBJ(int64_t, 4) else if (k == 8) OBJ(int64_t, 8) else OBJ(int64_t, 16) }
     else if (idx_bytes == 4) { if (k == 4) OBJ(int32_t, 4) else if (k == 8) OBJ(int32_t, 8) else OBJ(int32_t, 16) }
@@ -904,18 +900,6 @@ extern "C" int tipk_distmult_loss(const float* z, int64_t n_nodes, int k, const 
                                   void* workspace, tipk_stream_t stream) {
     return distmult_loss_impl(z, n_nodes, k, rel_w, n_rel, pos_u, pos_v, neg_u, neg_v, idx_bytes, edge_type, et_bytes, n_triples,
                               tasks, n_tasks, loss_out, g_z, g_w, workspace, stream, 0);
-}
-
-// as tipk_distmult_loss_store, but the positives' d z terms are left to tipk_distmult_pair_dz: g_z must already hold them
-// (this call accumulates the negatives' terms on top); loss and g_w are overwritten.  Packed pairs + workspace path only.
-extern "C" int tipk_distmult_loss_negdz(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,
-                                        const void* pos_u, const void* pos_v, const void* neg_u, const void* neg_v,
-                                        int idx_bytes, const void* edge_type, int et_bytes, int64_t n_triples,
-                                        const int32_t* tasks, int64_t n_tasks, float* loss_out, float* g_z, float* g_w,
-                                        void* workspace, tipk_stream_t stream) {
-    if (idx_bytes != 2 || !workspace || !g_z || k != 16) return TIPK_EUNSUPPORTED;
-    return distmult_loss_impl(z, n_nodes, k, rel_w, n_rel, pos_u, pos_v, neg_u, neg_v, idx_bytes, edge_type, et_bytes, n_triples,
-                              tasks, n_tasks, loss_out, g_z, g_w, workspace, stream, 3);
 }
 
 extern "C" int tipk_distmult_loss_store(const float* z, int64_t n_nodes, int k, const float* rel_w, int64_t n_rel,

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256) void pair_product_kernel(PpArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     auto multiply = [&](const float (&av)[KH], int q) {
-        if (!((live >> q) & 1u)) return;                // (wave-uniform) a tile without a linked pair: its cells are zeros -- 16 MFMAs less
         const float* b = xbl + (q * NB + KH * kh) * 32 + row;
 #pragma unroll
         for (int kk = 0; kk < KH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b[kk * 32], acc, 0, 0, 0);

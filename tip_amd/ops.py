@@ -996,44 +996,6 @@ def unpack_pairs(packed):
     return out
 
 
-class _PosPairPlan(object):
-    """Plan of `tipk_distmult_pair_dz` for one (symmetric) positive triple list: the wave-stream plan of the pairs with u <= v
-    (ids = relations, 64-byte rows), the neighbour lists {v, line} per node and the W row buffer (zeroed once)."""
-    __slots__ = ('stream', 'nbr_ptr', 'nbr', 'wrows', 'n_triples')
-
-
-def pos_pair_plan(pos_index, edge_type, n_nodes, n_rel):
-    """`_PosPairPlan` of the positives, or None when the pair-major pass does not apply (asymmetric list, large node set,
-    TIPK_NO_PAIR_DZ=1).  Built once per tensor version and kept in the side table."""
-    if os.environ.get('TIPK_NO_PAIR_DZ') or n_nodes * n_nodes >= 2 ** 24 or n_nodes > 4095 or pos_index.shape[1] == 0:
-        return None
-    facts = _facts(pos_index)
-    hit = facts.get('pos_pair_plan')
-    if hit is not None:
-        return hit[0] if hit[1] == (edge_type.data_ptr(), edge_type._version) else None
-    from .plan import build_stream_plan_rows
-    src, dst, rel = pos_index[0].to(torch.int64), pos_index[1].to(torch.int64), edge_type.to(torch.int64)
-    n = int(n_nodes)
-    k_fw = torch.sort((rel * n + src) * n + dst).values
-    k_bw = torch.sort((rel * n + dst) * n + src).values
-    plan = None
-    if bool(torch.equal(k_fw, k_bw)) and (n_rel + 1) * 64 + n * 64 <= 158 * 1024:
-        keep = src <= dst
-        n_cu = torch.cuda.get_device_properties(pos_index.device).multi_processor_count
-        plan = _PosPairPlan()
-        plan.stream = build_stream_plan_rows(src[keep] * n + dst[keep], rel[keep], n * n, int(n_rel), n_cu, 4, rel_stream_piece())
-        key = torch.unique(src * n + dst)
-        pu, pv = key // n, key % n
-        cnt = torch.bincount(pu, minlength=n)
-        plan.nbr_ptr = torch.cat([cnt.new_zeros(1), torch.cumsum(cnt, 0)]).to(torch.int32).contiguous()
-        line = torch.where(pu <= pv, pu * n + pv, pv * n + pu)
-        plan.nbr = torch.stack([pv, line], dim=1).to(torch.int32).contiguous()
-        plan.wrows = torch.zeros((n * n, 16), dtype=torch.float32, device=pos_index.device)
-        plan.n_triples = int(pos_index.shape[1])
-    facts['pos_pair_plan'] = (plan, (edge_type.data_ptr(), edge_type._version))
-    return plan
-
-
 def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     """(loss [1], g_z, g_w) of the fused TIP objective (include/tipk.h section 4); bitwise reproducible
     (fixed-point cross-workgroup sums) unless TIPK_FLOAT_ATOMICS=1.
@@ -1058,25 +1020,6 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
         g_w = torch.empty_like(weight) if need_grad else None
         pp = packed_pairs(pos_index, z.shape[0])
         ws = _det_workspace(z.device, z.shape[0], z.shape[1], weight.shape[0])
-        ppl = pos_pair_plan(pos_index, et, z.shape[0], weight.shape[0]) if (need_grad and z.shape[1] == 16) else None
-        if ppl is not None:
-            # the positives' d z in pair-major order, without atomics (round 5; include/tipk.h section 4c): a third of the
-            # objective kernel's LDS atomics -- its floor -- disappear; it keeps the positives' loss and d w
-            sp = ppl.stream
-            with _timed('distmult_pair_dz[pairs=%d,edges=%d]' % (ppl.nbr.shape[0], sp.n_edges)):
-                st = lib().tipk_distmult_pair_dz(ptr(z), z.shape[0], 16, ptr(weight), weight.shape[0], sp.n_wg, ptr(sp.wave_ptr),
-                                                 ptr(sp.cells), ptr(sp.ids), sp.idx_unit, 2.0 / pp.numel(), ptr(ppl.wrows),
-                                                 ptr(ppl.nbr_ptr), ptr(ppl.nbr), ptr(g_z), stream_ptr(z.device))
-            if st == -2:
-                ppl = None
-            else:
-                check(st, 'tipk_distmult_pair_dz')
-                with _timed('distmult_objective[negdz,%d]' % pp.numel()):
-                    check(lib().tipk_distmult_loss_negdz(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pp), None,
-                                                         ptr(neg_index), None, 2, ptr(et), _idx_bytes(et), pp.numel(),
-                                                         ptr(tasks), tasks.shape[0], ptr(loss), ptr(g_z), ptr(g_w), ptr(ws),
-                                                         stream_ptr(z.device)), 'tipk_distmult_loss_negdz')
-                return loss, g_z, g_w
         st = lib().tipk_distmult_loss_store(ptr(z), z.shape[0], z.shape[1], ptr(weight), weight.shape[0], ptr(pp), None,
                                             ptr(neg_index), None, 2, ptr(et), _idx_bytes(et), pp.numel(),
                                             ptr(tasks), tasks.shape[0], ptr(loss), ptr(g_z), ptr(g_w), ptr(ws),
