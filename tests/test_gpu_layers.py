@@ -554,6 +554,14 @@ def test_graphed_train_step_matches_eager():
     # position): steps 3-5 draw the same negatives either way and the trajectories agree step by step
     assert all(1.0 < v < 1.45 for v in losses[0] + losses[1]), losses
     assert losses[0] == losses[1], losses                              # bit for bit: no float atomics anywhere in the step
+    # two epochs per replayed graph: after ONE replay the model stands where the one-epoch graph stands after two
+    torch.manual_seed(5)
+    model = TIP(st, torch.device(DEV), data=dd)
+    from tip_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=st.lr)
+    NS.manual_seed(123)
+    step2 = GraphedTrainStep(model, opt, warmup=2, steps_per_replay=2)
+    assert float(step2()) == losses[1][1]                              # epochs 3 and 4 of the trajectory: the loss of the 4th
 
 
 def test_whole_model_pickle_roundtrip_after_forward(tmp_path):

@@ -17,7 +17,9 @@ from . import ops
 
 
 class GraphedTrainStep(object):
-    def __init__(self, model, optimizer, warmup=2):
+    def __init__(self, model, optimizer, warmup=2, steps_per_replay=1):
+        """steps_per_replay (> 1): that many consecutive epochs per replayed graph -- the hand-over between two replays (~9 us on
+        MI355X) is paid once per replay; `__call__` then runs steps_per_replay epochs and returns the last one's loss."""
         for group in optimizer.param_groups:
             if not group.get('capturable', False):
                 raise ValueError('construct the optimizer with capturable=True (its step counter must live on the device)')
@@ -32,9 +34,12 @@ class GraphedTrainStep(object):
         # warm-up stream and would be reused (and synchronised with) inside the capture
         if hasattr(model, 'embeddings') and torch.is_tensor(model.embeddings):
             model.embeddings = model.embeddings.detach()
+        self.steps_per_replay = int(steps_per_replay)
+        assert self.steps_per_replay >= 1
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = self._step()
+            for _ in range(self.steps_per_replay):
+                self.loss = self._step()
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
