@@ -466,9 +466,23 @@ struct PackedPair { uint32_t w; };
 
 template <int I>
 __device__ __forceinline__ int pr_row_bcast(int x) {      // lane I of every 16-lane DPP row, broadcast to its row
-    // (no `old` value: every lane is written, and a mov_dpp without one folds into the VOP2 instruction that uses it)
-    return __builtin_amdgcn_mov_dpp(x, 0x150 + (I & 15), 0xf, 0xf, false);
+    // (bound_ctrl with every row and bank enabled: the combiner folds this move into the VOP2 instruction that uses it --
+    // v_add_u32_dpp / v_mul_f32_dpp; the plain mov_dpp builtin stays a separate v_mov_b32_dpp: 5 of the 20 VALU
+    // instructions of a scatter step in the round-4 kernel)
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + (I & 15), 0xf, 0xf, true);
 }
+// float -> int32, round to nearest (ties up: floor(x + 0.5)) in ONE instruction; rintf + the conversion are two
+__device__ __forceinline__ int pr_round_i32(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+template <int I>
+__device__ __forceinline__ void pr_fmac_row_bcast(float& acc, float x, float y) {   // acc += (lane I of the row's x) * y
+    // (the combiner folds a broadcast into v_add / v_mul but not into the tied-accumulator v_fmac)
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(I & 15));
+}
+typedef float pr_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float pr_lds_f32_t;
 typedef __attribute__((address_space(3))) unsigned long long pr_lds_u64_t;
 template <int N, int I = 0, typename F>
@@ -560,12 +574,10 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         fetch(task + gridDim.x, 0, nx0);                                  // the next task's ids (and this lane's column of
         fetch(task + gridDim.x, 1, nx1);                                  // its w row) travel during this one: nothing the
         nx_wcol = fetch_wcol(task + gridDim.x);                           // task itself uses comes from a vector load
-        float wr[K];
-#pragma unroll
-        for (int j = 0; j < K; j += 4) {
-            const float4 v = tipk_ld4(w + (int64_t)rel * K + j);
-            wr[j] = v.x; wr[j + 1] = v.y; wr[j + 2] = v.z; wr[j + 3] = v.w;
-        }
+        // (the task's w row is NOT loaded: column j sits in lane j of every 16-lane row -- `wcol`, prefetched a task ago --
+        // and enters the dot product as the broadcast operand of v_fmac_f32_dpp; the s_nop covers the DPP read-after-write
+        // hazard that the compiler does not see inside inline assembly)
+        asm volatile("s_nop 1" : "+v"(wcol));
         constexpr int G = 64 / K;                                         // positions one scatter instruction covers
         const int grp = (t & 63) / K;
         const float wcs = wcol * scale_f;                                 // (a power of two: the products round the same)
@@ -573,12 +585,12 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         // PHASE 1, one lane per position: score and the coefficient q of its gradient terms (0: nothing to add)
         auto triple = [&](int u, int v, bool negative, float weight) -> float {
             float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < K; j += 4) {
+            pr_static_for<K / 4>([&](auto jc) {
+                constexpr int j = 4 * decltype(jc)::value;
                 const float4 x = tipk_ld4(zl + u * ld + j), y = tipk_ld4(zl + v * ld + j);
-                d = fmaf(x.x * y.x, wr[j], d); d = fmaf(x.y * y.y, wr[j + 1], d);
-                d = fmaf(x.z * y.z, wr[j + 2], d); d = fmaf(x.w * y.w, wr[j + 3], d);
-            }
+                pr_fmac_row_bcast<j>(d, wcol, x.x * y.x); pr_fmac_row_bcast<j + 1>(d, wcol, x.y * y.y);
+                pr_fmac_row_bcast<j + 2>(d, wcol, x.z * y.z); pr_fmac_row_bcast<j + 3>(d, wcol, x.w * y.w);
+            });
             const float sg = fast_sigmoid(d);
             const float val = negative ? 1.f - sg : sg;
             loss -= weight * __logf(val + TIP_EPS);
@@ -591,36 +603,65 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
         // twice the time, tools/bench_decoder.py) -- and keeps its column of d w.  What travels per position is its
         // coefficient and the BYTE OFFSETS of its two rows in the two images (multiplied once, by the position's lane):
         // an address is one add.  Positions that do not exist carry q = 0 and clamped ids: they add zeros, no branch.
-        auto scatter = [&](float q_mine, int u_mine, int v_mine) {
-            const int zu_mine = u_mine * (ld * 4), zv_mine = v_mine * (ld * 4);
-            const int gu_mine = u_mine * (lg * 8), gv_mine = v_mine * (lg * 8);
-            pr_static_for<64 / G>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                float q;
-                unsigned zu, zv, gu, gv;
+        // The steps are software-pipelined: the two row reads of step i + 1 are issued BEFORE the two adds of step i (LDS
+        // operations complete in order, and the compiler will not move a read over an atomic it cannot prove disjoint):
+        // a wave waits for reads that have only its own previous reads in front of them, not for its adds to drain.
+        // NS streams (the positive's and the negative's terms) run through ONE pipeline of NS * 64 / G steps.
+        auto scatter = [&](auto ns_c, float q_a, int u_a, int v_a, float q_b, int u_b, int v_b) {
+            constexpr int NS = decltype(ns_c)::value, STEPS = 64 / G, TOTAL = NS * STEPS;
+            // (second registers with the coefficients: each broadcast then has ONE user and folds into it -- v_mul_f32_dpp
+            // for the scaled coefficient, v_fmac_f32_dpp for d w.  The s_nop: the hand-written DPP instruction reads them
+            // from other lanes and the hazard recognizer does not look inside inline assembly -- 2 wait states)
+            float q_a2 = q_a, q_b2 = q_b;
+            asm volatile("s_nop 1" : "+v"(q_a2), "+v"(q_b2));
+            const int zu_a = u_a * (ld * 4), zv_a = v_a * (ld * 4), gu_a = u_a * (lg * 8), gv_a = v_a * (lg * 8);
+            const int zu_b = u_b * (ld * 4), zv_b = v_b * (ld * 4), gu_b = u_b * (lg * 8), gv_b = v_b * (lg * 8);
+            float ua[TOTAL], vb[TOTAL];
+            auto issue_reads = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, i = j % STEPS;
+                constexpr bool second = j >= STEPS;
+                unsigned zu, zv;
                 if constexpr (K == 16) {
-                    // group = one DPP row of 16 lanes: lane i of every row is broadcast to its row (row_newbcast:i,
-                    // a full-rate VALU move) -- group g revisits the positions of lanes 16 g .. 16 g + 15
-                    q = __int_as_float(pr_row_bcast<i>(__float_as_int(q_mine)));
-                    zu = (unsigned)pr_row_bcast<i>(zu_mine) + c4; zv = (unsigned)pr_row_bcast<i>(zv_mine) + c4;
-                    gu = (unsigned)pr_row_bcast<i>(gu_mine) + c8; gv = (unsigned)pr_row_bcast<i>(gv_mine) + c8;
+                    zu = (unsigned)pr_row_bcast<i>(second ? zu_b : zu_a) + c4;
+                    zv = (unsigned)pr_row_bcast<i>(second ? zv_b : zv_a) + c4;
                 } else {
                     const int src = i * G + grp;
-                    q = __shfl(q_mine, src, 64);
-                    zu = (unsigned)__shfl(zu_mine, src, 64) + c4; zv = (unsigned)__shfl(zv_mine, src, 64) + c4;
-                    gu = (unsigned)__shfl(gu_mine, src, 64) + c8; gv = (unsigned)__shfl(gv_mine, src, 64) + c8;
+                    zu = (unsigned)__shfl(second ? zu_b : zu_a, src, 64) + c4;
+                    zv = (unsigned)__shfl(second ? zv_b : zv_a, src, 64) + c4;
                 }
-                const float ua = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zu);
-                const float vb = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zv);
-                const float qs = q * wcs;
+                ua[j] = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zu);
+                vb[j] = *reinterpret_cast<pr_lds_f32_t*>((uintptr_t)zv);
+            };
+            issue_reads(std::integral_constant<int, 0>{});
+            pr_static_for<TOTAL>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, i = j % STEPS;
+                constexpr bool second = j >= STEPS;
+                if constexpr (j + 1 < TOTAL) issue_reads(std::integral_constant<int, j + 1>{});
+                float qs, q = 0.f;
+                unsigned gu, gv;
+                if constexpr (K == 16) {
+                    // group = one DPP row of 16 lanes: lane i of every row is broadcast to its row (row_newbcast:i, folded
+                    // into the instruction that uses it) -- group g revisits the positions of lanes 16 g .. 16 g + 15
+                    qs = __int_as_float(pr_row_bcast<i>(__float_as_int(second ? q_b : q_a))) * wcs;
+                    gu = (unsigned)pr_row_bcast<i>(second ? gu_b : gu_a) + c8;
+                    gv = (unsigned)pr_row_bcast<i>(second ? gv_b : gv_a) + c8;
+                } else {
+                    const int src = i * G + grp;
+                    q = __shfl(second ? q_b : q_a, src, 64);
+                    qs = q * wcs;
+                    gu = (unsigned)__shfl(second ? gu_b : gu_a, src, 64) + c8;
+                    gv = (unsigned)__shfl(second ? gv_b : gv_a, src, 64) + c8;
+                }
                 if (!TIPK_DBG(dbg & 1)) {
-                    const int tu = (int)rintf(qs * vb), tv = (int)rintf(qs * ua);     // |term * scale| < 2^30 by construction
+                    const pr_f32x2 term = (pr_f32x2){vb[j], ua[j]} * (pr_f32x2){qs, qs};   // v_pk_mul_f32
+                    const int tu = pr_round_i32(term.x), tv = pr_round_i32(term.y);        // |term * scale| < 2^30 by construction
                     __hip_atomic_fetch_add(reinterpret_cast<pr_lds_u64_t*>((uintptr_t)gu), (unsigned long long)(long long)tu,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(reinterpret_cast<pr_lds_u64_t*>((uintptr_t)gv), (unsigned long long)(long long)tv,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                gwc = fmaf(q, ua * vb, gwc);
+                if constexpr (K == 16) pr_fmac_row_bcast<i>(gwc, second ? q_b2 : q_a2, ua[j] * vb[j]);
+                else gwc = fmaf(q, ua[j] * vb[j], gwc);
             });
         };
         const int cnt = te - tb;
@@ -629,32 +670,31 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
             const Ids& id = h ? cur1 : cur0;
             const bool valid = t + h * 1024 < cnt;
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;     // wave-uniform
-            float qp = 0.f, qn = 0.f;
-            if (valid) {
-                if (pos_w != 0) qp = triple(id.pu, id.pv, false, pw);
-                qn = triple(id.nu, id.nv, true, 1.f);
-            }
+            // (every lane evaluates -- the w row travels by DPP from lanes that must be active; a position that does not
+            // exist has clamped ids and weight 0: it adds 0 to the objective and its coefficient is 0)
+            float qp = 0.f, qn;
+            if (pos_w != 0) qp = triple(id.pu, id.pv, false, valid ? pw : 0.f);
+            qn = triple(id.nu, id.nv, true, valid ? 1.f : 0.f);
             if (want_grad) {
-                if (pos_w != 0) scatter(qp, id.pu, id.pv);
-                scatter(qn, id.nu, id.nv);
+                if (pos_w != 0) scatter(std::integral_constant<int, 2>{}, qp, id.pu, id.pv, qn, id.nu, id.nv);
+                else scatter(std::integral_constant<int, 1>{}, qn, id.nu, id.nv, 0.f, 0, 0);
             }
         }
         cur0 = nx0;
         cur1 = nx1;
         wcol = nx_wcol;
-        if (want_grad) {                                                  // d w[rel]: the wave's G groups, then 16 waves via LDS
+        if (want_grad) {
+            // d w[rel]: the wave's G groups by shuffles, then ONE fixed-point add per column and WAVE straight into the
+            // workspace.  No barrier anywhere in the task loop: the 16 waves of the workgroup drift apart, and the waves
+            // that are evaluating positions (VALU, transcendentals) overlap the waves that are scattering (LDS) -- with the
+            // per-task reduction through LDS (two barriers) every wave was in the same phase at the same time
 #pragma unroll
             for (int o = K; o < 64; o <<= 1) gwc += __shfl_xor(gwc, o, 64);
-            __syncthreads();                                              // red is free (previous task has been summed)
-            if (tipk_lane() < K) red[(t >> 6) * K + col] = gwc;
-            __syncthreads();
-            if (t < K) {
-                float tot = 0.f;
-                for (int wv = 0; wv < 16; ++wv) tot += red[wv * K + t];
-                atomicAdd(ws + (int64_t)n_nodes * K + (int64_t)rel * K + t, (unsigned long long)(long long)((double)tot * scale_w));
-            }
+            if (tipk_lane() < K)
+                atomicAdd(ws + (int64_t)n_nodes * K + (int64_t)rel * K + col, (unsigned long long)(long long)((double)gwc * scale_w));
         }
     }
+    __syncthreads();
     loss = block_sum_1024(loss, red, t);
     if (t == 0)
         atomicAdd(ws + (int64_t)n_nodes * K + (int64_t)n_rel * K, (unsigned long long)(long long)((double)(loss * inv_n) * scale_l));
