@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 18
+#define TIPK_ABI_VERSION 19
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -481,6 +481,32 @@ int tipk_sum_slabs_xb(const float* slabs, int64_t n_slabs, int64_t slab_stride, 
                       const float* row_scale /* nullable */, const float* addend /* nullable */, int relu, float* x,
                       const float* basis, const float* root, int n_bases, int d_out, float* xb, float* xroot,
                       tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 2h. LARGE node sets, both passes: the (relation, node) row sums are assembled in LDS and multiplied there -- neither
+ *     Y = att . XB nor dY = A_r^T g' exists in memory (src/layers.py:159-180 and its autograd):
+ *
+ *        S[(r, v), :] = sum_{e in (r, v)} table[other_e, :]
+ *        t[b, v, :]   = sum_r att[r, b] S[(r, v), :]               forward: table = X, rows by destination (agg = sum_b t_b basis_b);
+ *                                                                   backward: table = D^-1 g', rows by source (t = d XB)
+ *        d att[r, b]  = sum_v < S[(r, v), :], xb[b, v, :] >         only with xb != NULL: slab s of datt_slabs [n_slabs][n_rel][n_bases]
+ *                                                                   holds the partial sum of 8 nodes x 32 channels (sum the slabs)
+ *
+ *     entries [n_batches][2][16] int32: per (node, tile of 32 relations) batches of 16 words per HALF (half = rel & 1),
+ *     a half's list sorted by relation, word = inside << 24 | other << 8 | 4 * (rel % 32) with inside = 0 at the first word
+ *     of a (relation, node) row and 1 at its other words, padding word 128 (only at the end of a list); a node's batches are
+ *     consecutive, tile after tile; desc [n_nodes][ceil(n_rel / 32)][2] = { first batch, batches >= 1 }; `entries` ends with 8
+ *     batches of padding behind the last node's (the load pipeline runs 8 batches ahead of the sums).
+ *     channels % 32 == 0, n_bases <= 32, n_nodes <= 65 536 (`_supported`), ld_table % 64 == 0 and < 16 384;
+ *     t [n_bases][n_nodes * channels], every element written; n_slabs = `tipk_rgcn_row_products_slabs`.  Sums in entry
+ *     order: bitwise reproducible.
+ */
+int tipk_rgcn_row_products_supported(int64_t n_nodes, int64_t n_rel, int n_bases, int channels);
+int64_t tipk_rgcn_row_products_slabs(int64_t n_nodes, int channels);
+int tipk_rgcn_row_products(const float* table, int64_t ld_table, int64_t n_nodes, int channels, const float* att,
+                           int64_t ld_att, int64_t n_rel, int n_bases, const int32_t* entries, const int32_t* desc,
+                           const float* xb /* nullable */, int64_t ld_xb, float* t, float* datt_slabs /* nullable */,
+                           tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).

@@ -431,6 +431,58 @@ def test_dest_products_forward(ops, R, N, d_in, nb, E):
     assert torch.equal(t.cpu().double(), want)
 
 
+@pytest.mark.parametrize('R,N,ch,nb,E', [(70, 50, 32, 32, 4000), (33, 37, 64, 8, 900), (129, 21, 128, 32, 6000), (5, 16, 32, 3, 40)])
+def test_row_products_both_passes(ops, R, N, ch, nb, E):
+    """tipk_rgcn_row_products (tipk.h section 2h): the (relation, node) row sums assembled in LDS and multiplied there ==
+    the definition in fp64 -- T[b, v, :] = sum_r att[r, b] S[(r, v), :] (forward: with the batch-reduced product over the
+    bases == sum_r A_r X W_r) and, with XB, d att[r, b] = sum_v <S[(r, v)], XB[b, v]> (the transposed pass's two products of
+    dY).  Nodes without edges, a hub, relations without edges, R no multiple of 32, node counts no multiple of 16; bitwise
+    repeat; exact on integers; the plan interpreted in torch gives the same."""
+    from tip_amd.plan import build_row_stream_plan, execute_row_stream_reference
+    assert ops.row_products_supported(N, R, nb, ch)
+    g = torch.Generator().manual_seed(R + N + ch)
+    rel = torch.randint(0, R, (E,), generator=g)
+    rel[rel == R // 2] = 0                                                 # a relation without edges
+    key = torch.randint(0, max(1, (3 * N) // 4), (E,), generator=g)          # a quarter of the nodes own no row
+    key[: E // 5] = 1                                                      # a hub
+    other = torch.randint(0, N, (E,), generator=g)
+    rp = build_row_stream_plan(key, other, rel, N, R).to(DEV)
+
+    def want(table, att, xb):
+        s = torch.zeros(R * N, ch, dtype=torch.float64)
+        s.index_add_(0, rel * N + key, table.double()[other])
+        s = s.view(R, N, ch)
+        return torch.einsum('rb,rvc->bvc', att.double(), s), torch.einsum('rvc,bvc->rb', s, xb.double())
+
+    def run(table, att, xb):
+        t1 = ops.row_products(rp, table.to(DEV), att.to(DEV))
+        job, t2 = ops.row_products(rp, table.to(DEV), att.to(DEV), xb.to(DEV).view(nb, N * ch))
+        ops.gemm_group([], [job])
+        job_b, t3 = ops.row_products(rp, table.to(DEV), att.to(DEV), xb.to(DEV).view(nb, N * ch))
+        ops.gemm_group([], [job_b])
+        assert torch.equal(t1, t2) and torch.equal(t2, t3) and torch.equal(job.out, job_b.out)
+        return t1, job.out
+    table, att, xb = torch.randn(N, ch, generator=g), torch.randn(R, nb, generator=g), torch.randn(nb, N, ch, generator=g)
+    t, datt = run(table, att, xb)
+    wt, wa = want(table, att, xb)
+    close(t, wt, rtol=2e-5, atol=2e-5 * float(wt.abs().max()))
+    close(datt, wa, rtol=2e-5, atol=2e-5 * float(wa.abs().max()))
+    rt, ra = execute_row_stream_reference(rp, table, att, xb)
+    close(rt, wt, rtol=1e-12, atol=1e-12)
+    close(ra, wa, rtol=1e-12, atol=1e-10)
+    basis = torch.randn(nb, ch, 16, generator=g)
+    agg = ops.gemm(t, basis.to(DEV), reduce_batch=True)
+    w_r = torch.einsum('rb,bio->rio', att.double(), basis.double())
+    ref = torch.zeros(N, 16, dtype=torch.float64)
+    ref.index_add_(0, key, torch.einsum('ei,eio->eo', table.double()[other], w_r[rel]))
+    close(agg, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    ti, ai = torch.randint(-3, 4, (N, ch), generator=g).float(), torch.randint(-3, 4, (R, nb), generator=g).float()
+    xi = torch.randint(-2, 3, (nb, N, ch), generator=g).float()
+    t, datt = run(ti, ai, xi)
+    wt, wa = want(ti, ai, xi)
+    assert torch.equal(t.cpu().double(), wt) and torch.equal(datt.cpu().double(), wa)
+
+
 @pytest.mark.parametrize('R,N,d', [(70, 645, 32), (33, 100, 16), (1097, 37, 8)])
 def test_unwritten_rows_masked_end_to_end(ops, R, N, d):
     """Rows (relation, node) without edges: the wave-stream gather with write_zeros=False leaves them untouched

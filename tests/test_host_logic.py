@@ -684,6 +684,57 @@ def test_gcn_rows_subset_plans_and_compact_hierarchy_graph():
     assert float(execute_plan_reference(hg.bwd, gm).abs().sum() - execute_plan_reference(hg.bwd, gm)[rows].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('R,N,E', [(70, 23, 900), (5, 16, 40), (33, 9, 0)])
+def test_row_stream_plan_reference(R, N, E):
+    """`build_row_stream_plan` (include/tipk.h section 2h) interpreted in torch as the kernel walks it (batches of 16 words
+    per lane half, padding into the dump column) == the definition; every edge appears once, in its (node, tile, half)
+    list, rows in edge-list order."""
+    from tip_amd.plan import build_row_stream_plan, execute_row_stream_reference
+    g = torch.Generator().manual_seed(R + N)
+    rel = torch.randint(0, R, (E,), generator=g)
+    key = torch.randint(0, N, (E,), generator=g)
+    other = torch.randint(0, N, (E,), generator=g)
+    rp = build_row_stream_plan(key, other, rel, N, R)
+    assert rp.desc.shape == (N, (R + 31) // 32, 2) and rp.entries.dtype == torch.int32
+    words = rp.entries.view(-1)
+    real = words[words != 128].to(torch.int64)
+    assert real.numel() == E
+    nb, ch = 4, 8
+    table, att, xb = torch.randn(N, ch, generator=g), torch.randn(R, nb, generator=g), torch.randn(nb, N, ch, generator=g)
+    s = torch.zeros(R * N, ch, dtype=torch.float64)
+    if E:
+        s.index_add_(0, rel * N + key, table.double()[other])
+    s = s.view(R, N, ch)
+    t, datt = execute_row_stream_reference(rp, table, att, xb)
+    assert torch.allclose(t, torch.einsum('rb,rvc->bvc', att.double(), s), rtol=1e-12, atol=1e-12)
+    assert torch.allclose(datt, torch.einsum('rvc,bvc->rb', s, xb.double()), rtol=1e-12, atol=1e-12)
+    # `inside` (byte 3) is set exactly where the previous word of the half's list has the same row -- the kernel's running
+    # sum restarts at every other word; the halves of a (node, tile) hold disjoint rows and are balanced up to one row
+    w = rp.entries.to(torch.int64)
+    desc = rp.desc.to(torch.int64)
+    for v in range(N):
+        for tl in range(rp.n_tiles):
+            f, nb_ = int(desc[v, tl, 0]), int(desc[v, tl, 1])
+            seen = []
+            for h in range(2):
+                lst = w[f:f + nb_, h, :].reshape(-1)
+                real = lst[lst != 128]
+                assert bool((lst[real.numel():] == 128).all())                 # padding only at the end of a half's list
+                rows = real & 0xff
+                assert bool((rows[1:] >= rows[:-1]).all())
+                want_inside = torch.zeros_like(rows)
+                want_inside[1:] = (rows[1:] == rows[:-1]).to(torch.int64)
+                assert torch.equal(real >> 24, want_inside)
+                seen.append(rows)
+            assert not (set(seen[0].tolist()) & set(seen[1].tolist()))
+            n0, n1 = seen[0].numel(), seen[1].numel()
+            assert nb_ >= 1
+            if n0 + n1:
+                assert nb_ == max(1, (max(n0, n1) + 15) // 16)
+                longest_row = int(torch.bincount(torch.cat(seen) // 4).max())
+                assert abs(n0 - n1) <= longest_row
+
+
 @pytest.mark.parametrize('symmetric,part_rows', [(True, 40), (False, 64), (True, 1008)])
 def test_pair_bwd_plan_reference(symmetric, part_rows):
     """`build_pair_bwd_plan` (include/tipk.h section 2e), interpreted in torch exactly as the two kernels walk it: slots,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class TipkError(RuntimeError):
@@ -83,6 +83,9 @@ SIGNATURES = {
     'tipk_stream_gather_parts': (_I, [_P, _L, _I, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
     'tipk_rgcn_dest_products_supported': (_I, [_L, _L, _I, _I]),
     'tipk_rgcn_dest_products': (_I, [_P, _L, _I, _P, _L, _I, _L, _L, _P, _P, _P, _L, _L, _P]),
+    'tipk_rgcn_row_products_supported': (_I, [_L, _L, _I, _I]),
+    'tipk_rgcn_row_products_slabs': (_L, [_L, _I]),
+    'tipk_rgcn_row_products': (_I, [_P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _P, _L, _P, _P, _P]),
     'tipk_sum_slabs_xb': (_I, [_P, _L, _L, _L, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),

@@ -1,0 +1,312 @@
+// Large node sets (config 5: N = 10 000, R = 2 000, E = 50 M): the (relation, node) ROW SUMS of an R-GCN layer are
+// assembled in LDS and multiplied where they are -- they never exist in HBM (include/tipk.h section 2h).
+//
+//     S[(r, v), :]  = sum_{e in (r, v)} table[other_e, :]           (~2.5 edges per row at config 5)
+//     T[b, v, :]    = sum_r att[r, b] S[(r, v), :]                  forward: table = X, rows by destination  -> agg = sum_b T_b basis_b
+//                                                                   backward: table = D^-1 g', rows by source -> T = d XB
+//     d att[r, b]   = sum_v <S[(r, v), :], XB[b, v, :]>             backward only (P2)
+//
+// Round 4 wrote S (= dY, 10 GB) with a CSR gather (3.4 ms) and read it back for both products (`dy_products`, 3.8 ms);
+// the round-5 forward pass multiplied per EDGE (`dest_products`: 0.41 TFLOP, 4.2 ms).  Multiplying the row sums is
+// 0.16 TFLOP per product, and the sums cost LDS adds instead of HBM round trips.
+//
+// Workgroup = 8 waves = 8 nodes x ONE tile of 32 channels (launch order: channel tile major, so that the gathered
+// slices of the table -- N x 128 bytes -- stay inside an XCD's L2); TWO workgroups per CU: product 2's cross-wave sum
+// puts two barriers into every tile, so the waves of a workgroup gather at the same time and multiply at the same time --
+// the other workgroup of the CU is in another phase.  Wave w owns node v = 8 g + w and walks the relation
+// tiles r0 = 0, 32, ...:
+//   * the tile's edges come as batches of 16 ENTRY WORDS per lane half (half kh owns rows r0 + 2 kk + kh, the row
+//     split of the v_mfma_f32_32x32x2_f32 operands), sorted by row: word = inside << 24 | other << 8 | byte offset of the
+//     row inside the tile (128 = the unused 33rd column: padding; inside = 0 at the first entry of a row).  One coalesced
+//     load per batch; lane j of every 16-lane row holds entry j, and entry j reaches the half's lanes as the DPP row
+//     broadcast folded into the instruction that unpacks it;
+//   * per entry ONE 128-byte row piece per lane half is loaded (table[other, 32 channels]) and summed in a REGISTER per
+//     lane (acc = acc * inside + piece: v_cvt_f32_ubyte3 + v_fma), and the running sum is stored to the wave's private
+//     [32 channels][33] tile -- the last store of a row is its sum.  (ds_add_f32 into the tile: 45 ms instead of 4: LDS
+//     float atomics run lane by lane on this chip.)  Fixed order: the sums are reproducible;
+//   * the tile is the B operand of product 1 (lane = channel) and, read transposed, the A operand of product 2
+//     (lane = row); product 2's 8 partial tiles (one per node) are added through LDS in wave order.
+#include <stdlib.h>
+#include <type_traits>
+#include "tipk_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32;
+typedef __attribute__((address_space(3))) float rp_lds_f32_t;
+
+constexpr int RP_WAVES = 8;                             // nodes per workgroup: two workgroups share a CU (see the kernel's header)
+constexpr int RP_TLD = 33;                              // tile row stride: conflict-free both ways; column 32 = dump
+
+struct RpArgs {
+    const float* table; u32 ld_table_b; int n_nodes, ch;        // gathered rows [n_nodes][ld], ch channels (multiple of 32)
+    const float* att; u32 ld_att_b; int R, NB;
+    const float* xb; int64_t ld_xb;                             // P2: [NB][n_nodes * ch]
+    const int32_t* entries; const int32_t* desc; int n_tiles;   // desc[(node * n_tiles + tile) * 2] = {first batch, batches}
+    float* t_out;                                               // [NB][n_nodes * ch]
+    float* datt;                                                // P2 slabs: [gridDim.x][R][NB]
+    int n_groups;
+    int dbg;                                                    // TIPK_DP_DEBUG: 1 no table loads, 2 no LDS adds, 4 no products, 8 plain read-add-write
+};
+
+__device__ __forceinline__ float rp_ldg(const float* base, u32 byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float rp_and(float v, u32 mask) { return __uint_as_float(__float_as_uint(v) & mask); }
+template <int I>
+__device__ __forceinline__ u32 rp_row_bcast(u32 x) {      // lane I of every 16-lane DPP row, broadcast to its row
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + (I & 15), 0xf, 0xf, true);
+}
+template <int I>
+__device__ __forceinline__ void rp_fmac_row_bcast(float& d, float x, float y) {    // d += (lane I of the row's x) * y
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(d) : "v"(x), "v"(y), "n"(I & 15));
+}
+// LDS words written by one lane of the wave and read by another: LDS operations of a wave execute in order; the fences keep
+// the COMPILER from moving them across this point
+__device__ __forceinline__ void rp_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void rp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rp_static_for<N, I + 1>(f);
+    }
+}
+
+template <bool P2>
+__global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int row = lane & 31, kh = lane >> 5;
+    float* tile = lds + w * (32 * RP_TLD);              // wave-private: [channel][row of the relation tile], + dump column
+    float* red = lds + RP_WAVES * (32 * RP_TLD);        // P2: [waves][32 x 32] partial d att tiles
+    float* attl = red + RP_WAVES * 1024;                // P2: [2][32 rows][33] att tiles shared by the workgroup (see begin_tile)
+    const int ct = (int)blockIdx.x / a.n_groups, grp = (int)blockIdx.x - ct * a.n_groups;
+    const int node_raw = grp * RP_WAVES + w;
+    const bool wave_on = node_raw < a.n_nodes;          // the last group may have idle waves (they still join barriers)
+    const int node = wave_on ? node_raw : a.n_nodes - 1;
+    const int NB = a.NB, R = a.R;
+    const int64_t NC = (int64_t)a.n_nodes * a.ch;
+    const int64_t col = (int64_t)node * a.ch + ct * 32 + row;            // column of [NB][NC]
+    const u32 tcol_b = (u32)(ct * 32 + row) * 4u;                        // this lane's channel inside a table row
+    const u32 tile_c = (u32)(uintptr_t)(rp_lds_f32_t*)tile + (u32)row * (RP_TLD * 4u);   // LDS byte address of tile[row][0]
+    const u32 att_b = (u32)(row < NB ? row : NB - 1) * 4u;
+
+    float xbv[16];
+    if (P2) {                                           // B operand of product 2: XB[b = lane & 31][column c0 + 2 kk + kh]
+        const int64_t b_off = (int64_t)(row < NB ? row : NB - 1) * a.ld_xb + (int64_t)node * a.ch + ct * 32;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) xbv[kk] = rp_and(a.xb[b_off + 2 * kk + kh], (row < NB && wave_on) ? 0xffffffffu : 0u);
+    }
+    f32x16 acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+
+    // The node's batches are consecutive in `entries` (tile after tile) and every tile has at least one: ONE load pipeline
+    // over all of them, always two half batches (16 row pieces per lane half) in flight and the entry words eight batches ahead.
+    // Every wait for a load then has a FIXED number of younger loads behind it on every path (vmcnt counts in order, and the
+    // compiler must assume the path with the fewest): with tiles of zero batches, or loads issued under a condition, each
+    // tile's att operand cost a drain of the whole pipeline.  (The loads issued past the node's last batch fetch the next
+    // node's pieces -- the array ends with one batch of padding -- and are never used.)
+    const int32_t* dsc = a.desc + (int64_t)node * a.n_tiles * 2;
+    int b = dsc[0];
+    int nbat = dsc[1];                                  // (the scalar load of a tile's length travels a tile ahead)
+    int tl = 0;
+    const u32 word_lane = (u32)(kh * 16 + (lane & 15));
+    auto load_word = [&](int batch) { return (u32)a.entries[(int64_t)batch * 32 + word_lane]; };
+    const u32 ld_mul = a.ld_table_b >> 8;               // (entry & 0xffff00) * ld_mul = other * bytes per table row
+    float acc = 0.f;                                    // running sum of the current row of this lane's half
+    float atv[16];
+    // Lane j of a 16-lane row unpacks entry j ONCE per batch (row offset in the table, LDS offset, the 0.0 / 1.0 of byte 3);
+    // per entry the unpacked value reaches the half's lanes as the DPP row broadcast inside the instruction that uses it:
+    // v_add_u32_dpp (load address), v_fmac_f32_dpp (running sum), v_add_u32_dpp (LDS address) -- 3 VALU instructions.
+    constexpr int DEPTH = 8;                            // entries per buffer: a batch is consumed as two halves
+    auto issue = [&](auto lo_c, float (&val)[DEPTH], u32 wv) {
+        constexpr int LO = decltype(lo_c)::value;
+        const u32 rowb = __umul24(wv & 0x00ffff00u, ld_mul);
+        rp_static_for<DEPTH>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const u32 off = rp_row_bcast<LO + j>(rowb) + tcol_b;
+            val[j] = TIPK_DBG(a.dbg & 1) ? __uint_as_float(off) : rp_ldg(a.table, off);
+        });
+    };
+    auto consume = [&](auto lo_c, float (&val)[DEPTH], u32 wv) {
+        constexpr int LO = decltype(lo_c)::value;
+        float keep = (float)(wv >> 24);                 // v_cvt_f32_ubyte3: 0.0 at the first entry of a row (and padding), else 1.0
+        const u32 offl = wv & 0xffu;
+        asm volatile("s_nop 1" : "+v"(keep));           // (hand-written DPP below: 2 wait states after the VALU write)
+        rp_static_for<DEPTH>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            rp_fmac_row_bcast<LO + j>(val[j], keep, acc);   // val = inside * acc + piece
+            acc = val[j];
+            const u32 off = rp_row_bcast<LO + j>(offl) + tile_c;
+            if (!TIPK_DBG(a.dbg & 2)) *reinterpret_cast<rp_lds_f32_t*>((uintptr_t)off) = acc;   // the row's last write is its sum
+        });
+    };
+    // A operand of product 1 = att^T (lane = base).  Forward pass: 16 registers per tile, requested when the tile begins.
+    // P2 (no registers to spare; the waves meet at two barriers per tile anyway): ONE copy per workgroup in LDS, double
+    // buffered -- thread t fetches element (row t / 32, base t % 32) of the NEXT tile when a tile begins and stores it before
+    // the tile's first barrier; rows beyond R / bases beyond NB are stored as zeros.
+    constexpr int NT = RP_WAVES * 64, PER = 1024 / NT;  // elements of a 32 x 32 tile per thread
+    float att_next[PER];
+    auto att_elem = [&](int tile_i, int i) {
+        const int e = i * NT + t, r = tile_i * 32 + (e >> 5), bb = e & 31;
+        const float v = a.att[(int64_t)(r < R ? r : R - 1) * (a.ld_att_b >> 2) + (bb < NB ? bb : NB - 1)];
+        return rp_and(v, (r < R && bb < NB && tile_i < a.n_tiles) ? 0xffffffffu : 0u);
+    };
+    auto att_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) attl[buf * (32 * RP_TLD) + ((i * NT + t) >> 5) * RP_TLD + (t & 31)] = att_next[i];
+    };
+    if (P2) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) att_next[i] = att_elem(0, i);
+        att_store(0);
+        __syncthreads();
+    }
+    auto begin_tile = [&]() {
+        const int r0 = tl * 32;
+        if (P2) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) att_next[i] = att_elem(tl + 1 < a.n_tiles ? tl + 1 : tl, i);
+        } else {
+            const float* att_t = a.att + (int64_t)r0 * (a.ld_att_b >> 2);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int r = r0 + 2 * kk + kh;
+                atv[kk] = rp_ldg(att_t, (u32)((r < R ? r : R - 1) - r0) * a.ld_att_b + att_b);
+            }
+        }
+        // zero the tile (rows without edges): 4 x 64 float4 + the last 32 floats
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tipk_st4(tile + (i * 64 + lane) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        static_assert(32 * RP_TLD == 1024 + 32, "tile zeroing");
+        if (lane < 32) tile[1024 + lane] = 0.f;
+        rp_wave_sync();
+    };
+    auto finish_tile = [&]() {
+        const int r0 = tl * 32;
+        rp_wave_sync();
+        // (1) T += att^T . S : B operand lane = channel, k = row
+        if (!TIPK_DBG(a.dbg & 4))
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const u32 mk = (r0 + 2 * kk + kh < R && row < NB) ? 0xffffffffu : 0u;
+            const float av = P2 ? attl[(tl & 1) * (32 * RP_TLD) + (2 * kk + kh) * RP_TLD + row] : rp_and(atv[kk], mk);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tile[row * RP_TLD + 2 * kk + kh], acc1, 0, 0, 0);
+        }
+        if (P2) {
+            // (2) d att tile = S . XB^T : A operand lane = row r, k = channel
+            f32x16 acc2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(2 * kk + kh) * RP_TLD + row], xbv[kk], acc2, 0, 0, 0);
+            att_store((tl + 1) & 1);                        // (free: read two barriers ago)
+            __syncthreads();                                // red is free (previous tile has been summed)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                red[w * 1024 + rr * 32 + row] = acc2[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = i * NT + t;
+                float sum = red[e];
+#pragma unroll
+                for (int q = 1; q < RP_WAVES; ++q) sum += red[q * 1024 + e];
+                const int rr = r0 + (e >> 5), bb = e & 31;
+                if (rr < R && bb < NB) a.datt[((int64_t)blockIdx.x * R + rr) * NB + bb] = sum;
+            }
+        }
+    };
+    float va[DEPTH], vb[DEPTH];
+    constexpr std::integral_constant<int, 0> c0{};
+    constexpr std::integral_constant<int, 8> c8{};
+    constexpr int WQ = 6;                               // entry words on their way: batches b + 2 .. b + 1 + WQ
+    u32 wa = load_word(b), wb = load_word(b + 1), wq[WQ];
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) wq[q] = load_word(b + 2 + q);
+    issue(c0, va, wa);
+    issue(c8, vb, wa);
+    for (tl = 0; tl < a.n_tiles; ++tl) {
+        const int nbat_next = dsc[2 * (tl + 1 < a.n_tiles ? tl + 1 : tl) + 1];
+        begin_tile();
+        int i = 0;
+        do {                                            // (at least one batch: see above)
+            consume(c0, va, wa);
+            issue(c0, va, wb);
+            consume(c8, vb, wa);
+            issue(c8, vb, wb);
+            wa = wb; wb = wq[0];
+#pragma unroll
+            for (int q = 0; q + 1 < WQ; ++q) wq[q] = wq[q + 1];
+            wq[WQ - 1] = load_word(b + 2 + WQ);
+            ++b;
+        } while (++i < nbat);
+        finish_tile();
+        nbat = nbat_next;
+    }
+    // T: C layout col = lane & 31 (channel), rows = bases
+    if (wave_on) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (b < NB) a.t_out[(int64_t)b * NC + col] = acc1[r];
+        }
+    }
+}
+
+constexpr size_t RP_LDS_1 = (size_t)(RP_WAVES * 32 * RP_TLD) * sizeof(float);
+constexpr size_t RP_LDS_2 = (size_t)(RP_WAVES * 32 * RP_TLD + RP_WAVES * 1024 + 2 * 32 * RP_TLD) * sizeof(float);
+
+}  // namespace
+
+extern "C" int tipk_rgcn_row_products_supported(int64_t n_nodes, int64_t n_rel, int n_bases, int channels) {
+    if (n_nodes <= 0 || n_rel <= 0 || n_bases <= 0 || n_bases > 32 || channels <= 0 || channels % 32 != 0) return 0;
+    if (n_nodes > 65536 || n_rel > 0x7fffffffLL) return 0;                            // entry word: inside << 24 | other << 8 | row offset
+    const int64_t slabs = tipk_ceil_div(n_nodes, RP_WAVES) * (channels / 32);
+    if (slabs > 0x7fffffffLL) return 0;
+    return 1;
+}
+
+extern "C" int64_t tipk_rgcn_row_products_slabs(int64_t n_nodes, int channels) {
+    return tipk_ceil_div(n_nodes, RP_WAVES) * (channels / 32);
+}
+
+extern "C" int tipk_rgcn_row_products(const float* table, int64_t ld_table, int64_t n_nodes, int channels, const float* att,
+                                      int64_t ld_att, int64_t n_rel, int n_bases, const int32_t* entries, const int32_t* desc,
+                                      const float* xb, int64_t ld_xb, float* t_out, float* datt_slabs, tipk_stream_t stream) {
+    if (!tipk_rgcn_row_products_supported(n_nodes, n_rel, n_bases, channels)) return TIPK_EUNSUPPORTED;
+    if (!table || !att || !entries || !desc || !t_out || ld_table < channels || ld_att < n_bases) return TIPK_EINVAL;
+    if ((xb == nullptr) != (datt_slabs == nullptr) || (xb && ld_xb < n_nodes * channels)) return TIPK_EINVAL;
+    if (n_nodes * ld_table * 4 >= (1LL << 32) || 32 * ld_att * 4 >= (1LL << 31)) return TIPK_EUNSUPPORTED;   // 32-bit byte offsets
+    if (ld_table % 64 != 0 || ld_table * 4 / 256 >= 256) return TIPK_EUNSUPPORTED;     // (other << 8) * (row bytes / 256) in 24-bit arithmetic
+    RpArgs a;
+    a.table = table; a.ld_table_b = (u32)(ld_table * 4); a.n_nodes = (int)n_nodes; a.ch = channels;
+    a.att = att; a.ld_att_b = (u32)(ld_att * 4); a.R = (int)n_rel; a.NB = n_bases;
+    a.xb = xb; a.ld_xb = ld_xb;
+    a.entries = entries; a.desc = desc; a.n_tiles = (int)tipk_ceil_div(n_rel, 32);
+    a.t_out = t_out; a.datt = datt_slabs;
+    a.n_groups = (int)tipk_ceil_div(n_nodes, RP_WAVES);
+    a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
+    const unsigned blocks = (unsigned)(a.n_groups * (channels / 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (xb) {
+        hipError_t e = hipFuncSetAttribute((const void*)row_products_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RP_LDS_2);
+        if (e != hipSuccess) return tipk_hip_status(e);
+        hipLaunchKernelGGL(row_products_kernel<true>, dim3(blocks), dim3(RP_WAVES * 64), RP_LDS_2, st, a);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)row_products_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RP_LDS_1);
+        if (e != hipSuccess) return tipk_hip_status(e);
+        hipLaunchKernelGGL(row_products_kernel<false>, dim3(blocks), dim3(RP_WAVES * 64), RP_LDS_1, st, a);
+    }
+    TIPK_RETURN_LAUNCH();
+}

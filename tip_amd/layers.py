@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import (build_pair_bwd_plan, build_dest_plan, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
+from .plan import (build_pair_bwd_plan, build_dest_plan, build_row_stream_plan, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
                    relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
@@ -456,11 +456,16 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             rl_bwd = lambda: build_rel_plan(src, dst, rel, n_nodes, n_rel, wg_b, backward=True, lanes=lanes_b)
     # forward pass of LARGE node sets without Y (tipk_rgcn_dest_products): where Y = [R N, d_out] would not stay in the
     # Infinity Cache (config 5: 10 GB) and neither LDS route applies
-    dest_fwd = None
+    dest_fwd = row_fwd = row_bwd = None
     if src.is_cuda and d_out and n_bases and pair_fwd is None and n_rel * n_nodes * d_out * 4 > (192 << 20):
         bits = ops.dest_products_bits(n_nodes, n_rel, n_bases, 1)
         if bits:
             dest_fwd = lambda: build_dest_plan(src, dst, rel, n_nodes, n_rel, bits)
+        if n_nodes < (1 << 23):
+            # row sums assembled in LDS (tipk_rgcn_row_products): rows (relation, destination) <- sources for the forward pass,
+            # rows (relation, source) <- destinations for the transposed pass
+            row_fwd = lambda: build_row_stream_plan(dst, src, rel, n_nodes, n_rel)
+            row_bwd = lambda: build_row_stream_plan(src, dst, rel, n_nodes, n_rel)
 
     def fwd_plan():
         # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by
@@ -477,7 +482,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd,
                         csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'), rs_bwd=rs_bwd,
-                        pair_fwd=pair_fwd, pair_bwd=pair_bwd, dest_fwd=dest_fwd)
+                        pair_fwd=pair_fwd, pair_bwd=pair_bwd, dest_fwd=dest_fwd, row_fwd=row_fwd, row_bwd=row_bwd)
 
 
 class _RGCNBase(nn.Module):

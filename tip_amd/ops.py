@@ -523,6 +523,40 @@ def dest_products(dp, x, att):
     return t
 
 
+def row_products_supported(n_nodes, n_rel, nb, channels):
+    if os.environ.get('TIPK_NO_ROW_PRODUCTS'):
+        return False
+    return bool(lib().tipk_rgcn_row_products_supported(int(n_nodes), int(n_rel), int(nb), int(channels)))
+
+
+def row_products(rp, table, att, xb2=None):
+    """The (relation, node) row sums S = sum of table rows over a row's edges, assembled in LDS, and their products
+    (`tipk_rgcn_row_products`, include/tipk.h section 2h) on a `plan.RowStreamPlan`:
+    table [N, ch], att [R, bases] -> T [bases, N, ch] = sum_r att[r, b] S[(r, v)];  with xb2 [bases, N * ch] also the slab
+    job of d att [R, bases] = sum_v <S[(r, v)], XB[b, v]>  (returns (job, T); the caller's grouped slab sum finishes it)."""
+    table, att = _f32c(table), _f32c(att)
+    require_device(table, att, rp.entries)
+    n, ch = table.shape
+    r, nb = att.shape
+    assert rp.n_nodes == n and rp.n_rel == r and table.stride(1) == 1 and att.stride(1) == 1
+    if table.stride(0) % 64 != 0:                        # (the kernel multiplies `other << 8` by row bytes / 256: rows of 64 k floats)
+        wide = torch.empty((n, -(-ch // 64) * 64), dtype=torch.float32, device=table.device)
+        wide[:, :ch] = table
+        table = wide[:, :ch]
+    t = torch.empty((nb, n, ch), dtype=torch.float32, device=table.device)
+    slabs = None
+    if xb2 is not None:
+        assert xb2.shape == (nb, n * ch) and xb2.stride(1) == 1
+        slabs = torch.empty((int(lib().tipk_rgcn_row_products_slabs(n, ch)), r, nb), dtype=torch.float32, device=table.device)
+    with _timed('row_products[%dx%dx%d,edges=%d,%s]' % (n, nb, ch, rp.n_edges, 'T+datt' if slabs is not None else 'T')):
+        check(lib().tipk_rgcn_row_products(ptr(table), table.stride(0), n, ch, ptr(att), att.stride(0), r, nb, ptr(rp.entries),
+                                           ptr(rp.desc), ptr(xb2), xb2.stride(0) if xb2 is not None else 0, ptr(t), ptr(slabs),
+                                           stream_ptr(table.device)), 'tipk_rgcn_row_products')
+    if slabs is None:
+        return t
+    return slab_job(slabs), t
+
+
 def sum_slabs_xb(slabs, row_scale, addend, relu, x_out, basis, root, xb_pad):
     """x_out = relu?(row_scale * sum_s slabs[s] + addend) AND, in the same launch, the next layer's row-local products:
     xb_pad[:N, :, :d_out] = x_out basis (node-major, rows padded to 32 columns) and the returned x_out root
@@ -1127,7 +1161,7 @@ class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
     def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None,
-                 pair_fwd=None, pair_bwd=None, dest_fwd=None):
+                 pair_fwd=None, pair_bwd=None, dest_fwd=None, row_fwd=None, row_bwd=None):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
         generic D-D plans are only needed where the relation-local kernel does not apply).
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
@@ -1141,6 +1175,8 @@ class AggGraph(object):
         self.pair_fwd = pair_fwd                           # wave-stream plan of the forward pass in pair form (LDS-resident att)
         self._pair_bwd = pair_bwd                          # plan.PairBwdPlan of the pair-form backward pass (or a callable)
         self._dest_fwd = dest_fwd                          # plan.DestPlan of the forward pass of large graphs (or a callable)
+        self._row_fwd, self._row_bwd = row_fwd, row_bwd    # plan.RowStreamPlans of large graphs (rows by destination / by
+                                                           # source), or callables: tipk_rgcn_row_products
         self.pair_stamp = 0                                # bumped by every pass that rewrites the pair buffers
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
@@ -1151,6 +1187,18 @@ class AggGraph(object):
         if callable(self._rs_bwd):
             self._rs_bwd = self._rs_bwd()
         return self._rs_bwd
+
+    @property
+    def row_fwd(self):
+        if callable(self._row_fwd):
+            self._row_fwd = self._row_fwd()
+        return self._row_fwd
+
+    @property
+    def row_bwd(self):
+        if callable(self._row_bwd):
+            self._row_bwd = self._row_bwd()
+        return self._row_bwd
 
     @property
     def dest_fwd(self):
@@ -1500,9 +1548,12 @@ class _RGCN(torch.autograd.Function):
         xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
         # LARGE node sets (round 5; include/tipk.h section 2f): Y = att . XB [R N, out] is never formed -- per destination
         # T[:, v, :] = sum_e att[r_e, :]^T (x) X[src_e] (a product over the node's incoming edges), then sum_b T_b basis_b
-        dest = graph.dest_fwd if (r > 0 and not use_rl) else None
-        if dest is not None:
-            agg = gemm(dest_products(dest, x, att), basis, reduce_batch=True)
+        rows = graph.row_fwd if (r > 0 and not use_rl and row_products_supported(n, r, nb, d_in)) else None
+        dest = graph.dest_fwd if (r > 0 and not use_rl and rows is None) else None
+        if dest is not None or rows is not None:
+            # (row sums first: 0.16 TFLOP per layer at config 5 instead of the 0.41 of the per-edge product)
+            t_b = row_products(rows, x, att) if rows is not None else dest_products(dest, x, att)
+            agg = gemm(t_b, basis, reduce_batch=True)
             if shard is not None:
                 shard.all_reduce(agg)
             out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
@@ -1583,6 +1634,13 @@ class _RGCN(torch.autograd.Function):
                 used = rs.row_used if masked else None
             elif rel_gather_usable(graph.rl_bwd, n, d_out, True):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
+            elif (graph.row_bwd is not None and row_products_supported(n, r, nb, d_out) and xb2 is not None
+                  and n * d_out * 4 < 2 ** 32):
+                # LARGE node sets: dY = A_r^T (D^-1 g') is never written -- its rows are summed in LDS and multiplied there
+                gs = rows_affine(g, row_mul=graph.scale)
+                j_rows, g_xb = row_products(graph.row_bwd, gs, att, xb2)
+                gemm_group([], [j_rows])                                 # (thousands of slabs: a slab sum of its own, as dy_products')
+                g_att, g_y = j_rows.out, None
             else:
                 gs = rows_affine(g, row_mul=graph.scale)
                 csr = graph.csr_bwd if (d_out % 4 == 0 and 8 <= d_out <= 256 and gs.numel() * 4 < 2 ** 32) else None   # (32-bit row offsets)
@@ -1590,7 +1648,7 @@ class _RGCN(torch.autograd.Function):
                     g_y = gather_rows_csr(csr, gs).view(r, n * d_out)
                 else:
                     g_y = gather_sum(graph.bwd, gs).view(r, n * d_out)
-            if j_att is None:
+            if j_att is None and g_y is not None:
                 # both consumers of dY in one pass over it (+ one grouped slab sum)
                 g_att, g_xb = dy_products(g_y, att, xb2, used, n)
                 g_xb = g_xb.view(nb, n, d_out)

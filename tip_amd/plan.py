@@ -1147,3 +1147,96 @@ def build_dest_plan(src, dst, rel, n_nodes, n_rel, bits):
     if w.numel() == 0:
         w = torch.zeros(1, dtype=torch.int32, device=dev)
     return DestPlan(n_nodes, n_rel, bits, w, desc)
+
+
+class RowStreamPlan(object):
+    """Per (node, relation tile of 32) the edges of the node as batches of 16 entry words per lane half
+    (`tipk_rgcn_row_products`, include/tipk.h section 2h):
+
+        entries [n_batches, 2, 16] int32   word = inside << 24 | other << 8 | 4 * (rel % 32), sorted by row inside a half's
+                                           list; inside = 0 at the first entry of a (relation, node) row, 1 at the others;
+                                           padding = 128 (node 0 into the dump column), only at the end of a list; the two
+                                           halves of a (node, tile) hold disjoint sets of rows
+        desc    [n_nodes, n_tiles, 2] int32  {first batch, batches >= 1} of the tile; a node's batches are consecutive, and
+                                           the array ends with 8 batches of padding (the kernel's loads run 8 batches ahead)
+
+    `key` is the node that owns a row (destination for the forward pass, source for the transposed pass), `other` the
+    node whose table row is gathered."""
+
+    def __init__(self, n_nodes, n_rel, entries, desc, n_edges):
+        self.n_nodes, self.n_rel, self.entries, self.desc, self.n_edges = int(n_nodes), int(n_rel), entries, desc, int(n_edges)
+        self.n_tiles = (self.n_rel + 31) // 32
+
+    def to(self, device):
+        return RowStreamPlan(self.n_nodes, self.n_rel, self.entries.to(device), self.desc.to(device), self.n_edges)
+
+
+def build_row_stream_plan(key, other, rel, n_nodes, n_rel):
+    """Edges sorted by (key, relation) -- stable, so equal rows keep the edge list's order and the sums are a fixed
+    sequence.  The sorted list of a (node, tile) is cut in two at the row boundary nearest its middle: the first part is
+    walked by lanes 0-31, the second by lanes 32-63 (the rows of a tile meet in LDS, so any split by whole rows will do)."""
+    dev = key.device
+    n_nodes, n_rel = int(n_nodes), int(n_rel)
+    n_tiles = (n_rel + 31) // 32
+    key, other, rel = key.to(torch.int64), other.to(torch.int64), rel.to(torch.int64)
+    assert n_nodes <= (1 << 16)
+    e = int(key.numel())
+    n_seg = n_nodes * n_tiles
+    seg = key * n_tiles + rel // 32                                     # (node, tile) segment of every edge
+    row_key = key * n_rel + rel
+    order = torch.sort(row_key, stable=True).indices                   # (node, relation): segments in (node, tile) order
+    seg_s, row_s = seg[order], row_key[order]
+    n_in = torch.bincount(seg_s, minlength=n_seg)
+    cut = torch.zeros(n_seg, dtype=torch.int64, device=dev)
+    if e:
+        seg_first = torch.cumsum(n_in, 0) - n_in
+        idx = torch.arange(e, device=dev)
+        pos = idx - seg_first[seg_s]                                   # rank inside the segment's list
+        starts = torch.ones(e, dtype=torch.bool, device=dev)
+        starts[1:] = row_s[1:] != row_s[:-1]
+        row_start = pos[torch.cummax(torch.where(starts, idx, torch.zeros_like(idx)), 0).values]   # rank of the row's first entry
+        # the row start s that minimises max(s, n - s): the longer part decides the number of batches
+        cost = torch.maximum(row_start, n_in[seg_s] - row_start) * (1 << 20) + row_start
+        best = torch.full((n_seg,), (1 << 62), dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, seg_s[starts], cost[starts], 'amin', include_self=True)
+        cut = torch.where(n_in > 0, best % (1 << 20), torch.zeros_like(best))
+        half = (row_start >= cut[seg_s]).to(torch.int64)
+        rank = pos - half * cut[seg_s]
+    longer = torch.maximum(cut, n_in - cut)
+    nbat = torch.clamp((longer + 15) // 16, min=1)                     # every tile at least one batch (the kernel's load
+    first = torch.cumsum(nbat, 0) - nbat                               # pipeline never branches on a tile's length)
+    n_batches = int(nbat.sum())
+    entries = torch.full((n_batches + 8, 2, 16), 128, dtype=torch.int32, device=dev)   # + padding the pipeline runs into
+    if e:
+        inside = (~starts).to(torch.int64)
+        word = (inside << 24) | (other[order] << 8) | ((rel[order] % 32) * 4)
+        flat = ((first[seg_s] + rank // 16) * 2 + half) * 16 + rank % 16
+        entries.view(-1)[flat] = word.to(torch.int32)
+    desc = torch.stack([first, nbat], dim=1).to(torch.int32).view(n_nodes, n_tiles, 2).contiguous()
+    return RowStreamPlan(n_nodes, n_rel, entries.contiguous(), desc, e)
+
+
+def execute_row_stream_reference(plan, table, att, xb=None):
+    """What `tipk_rgcn_row_products` computes, from the plan alone (float64): T [nb, n, ch] and (with xb [nb, n, ch]) d att."""
+    n, r, nt = plan.n_nodes, plan.n_rel, plan.n_tiles
+    table = table.double().cpu()
+    att = att.double().cpu()
+    ent = plan.entries.cpu().to(torch.int64)
+    desc = plan.desc.cpu().to(torch.int64)
+    ch = table.shape[1]
+    s = torch.zeros((nt * 32 + 1, n, ch), dtype=torch.float64)          # row r of node v; the last row collects padding
+    for v in range(n):
+        for tl in range(nt):
+            f, nb_ = int(desc[v, tl, 0]), int(desc[v, tl, 1])
+            if nb_ == 0:
+                continue
+            w = ent[f:f + nb_].permute(1, 0, 2).reshape(2, -1)          # [half, entries]
+            for h in range(2):
+                oth, off = (w[h] >> 8) & 0xffff, (w[h] & 0xff) // 4
+                rows = torch.where(off < 32, tl * 32 + off, torch.full_like(off, nt * 32))
+                s[:, v].index_add_(0, rows, table[oth])
+    s = s[:r]
+    t = torch.einsum('rb,rvc->bvc', att, s)
+    if xb is None:
+        return t
+    return t, torch.einsum('rvc,bvc->rb', s, xb.double().cpu())
