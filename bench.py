@@ -265,6 +265,23 @@ def dd_launches(enc, dev):
         # the backward pass the step takes behind a pair-form forward pass (ops._RGCN): pair form as well
         pair_bwd = graph.pair_bwd if (pair_ok and ops.pair_grads_supported(nb, d) and 'y' not in
                                       [v[0] for v in graph.fwd_route.values()]) else None
+        d_in = layer.in_channels
+        if (not pair_ok and graph.row_fwd is not None and ops.row_products_supported(n, r, nb, d_in)
+                and ops.row_products_supported(n, r, nb, d)):
+            # LARGE node sets (config 5): both passes sum the (relation, node) rows in LDS and multiply them there
+            # (tipk_rgcn_row_products) -- algorithmic flops = the products of the row sums, 2 x R N ch bases each
+            x_in, att = torch.randn(n, d_in, device=dev), torch.randn(r, nb, device=dev)
+            xb2 = torch.randn(nb, n * d, device=dev)
+            rf, rb = graph.row_fwd, graph.row_bwd
+            add('row_products[dd.fwd,ch=%d]' % d_in, 'row_products_kernel<false>', None, 'mfma', 2.0 * r * n * d_in * nb,
+                lambda rf=rf, x_in=x_in, att=att: ops.row_products(rf, x_in, att), edges=rf.n_edges, row_floats=d_in,
+                gathered_bytes=rf.n_edges * (4.0 + 4 * d_in), batches=int(rf.entries.shape[0]),
+                note='T = att^T . S over the (relation, node) row sums S assembled in LDS from %d gathered rows' % rf.n_edges)
+            add('row_products[dd.bwd,ch=%d]' % d, 'row_products_kernel<true>', None, 'mfma', 2 * 2.0 * r * n * d * nb,
+                lambda rb=rb, g=g, att=att, xb2=xb2: ops.row_products(rb, g, att, xb2)[1], edges=rb.n_edges, row_floats=d,
+                gathered_bytes=rb.n_edges * (4.0 + 4 * d), batches=int(rb.entries.shape[0]),
+                note='d XB = att^T . S and d att = S . XB^T on the row sums of the transposed pass')
+            continue
         for bwd in (False, True):
             rs = graph.rs_bwd if (bwd and pair_bwd is None) else None
             pair = None if bwd else graph.pair_fwd
@@ -622,6 +639,23 @@ def dense_route_floor(r, n, e, dims, other_us=200.0):
                     'Infinity-Cache gather rate (8.6 TB/s), the gather of g\' rows out of L2 (18.8 TB/s)'}
 
 
+def row_route_floor(r, n, e, widths, nb, other_us=400.0):
+    """What bounds a step on the ROW-SUM route (round 5, config 5: `tipk_rgcn_row_products` -- neither Y nor dY exists): per
+    layer the forward launch (the product of the row sums with att at the fp32 MFMA peak, or E rows of X gathered out of L2)
+    and the transposed launch (both products, or E rows of g' out of L2); everything else (P-P / P->D stage, XB, T . basis, the
+    parameter-gradient products, the d att slab sums: `other_us`) as measured.  widths = [(d_in, d_out)] per layer."""
+    parts = {}
+    for li, (d_in, d_out) in enumerate(widths):
+        parts['forward row products [layer %d, ch=%d]' % (li + 1, d_in)] = max(2.0 * r * nb * n * d_in / MFMA_F32_PEAK,
+                                                                              e * (4 + 4.0 * d_in) / (L2_GATHER_GBS * 1e9)) * 1e6
+        parts['transposed row products [layer %d, ch=%d]' % (li + 1, d_out)] = max(2 * 2.0 * r * nb * n * d_out / MFMA_F32_PEAK,
+                                                                                  e * (4 + 4.0 * d_out) / (L2_GATHER_GBS * 1e9)) * 1e6
+    parts['everything else (measured)'] = other_us
+    return {'us': sum(parts.values()), 'parts_us': {k: round(v, 1) for k, v in parts.items()},
+            'note': 'row-sum route: the products of the (relation, node) row sums at the fp32 MFMA peak, or the gather of the '
+                    'E table rows they are summed from out of L2 (18.8 TB/s)'}
+
+
 # ---------------------------------------------------------------------------------------------
 # one configuration: build, capture, time
 # ---------------------------------------------------------------------------------------------
@@ -787,7 +821,16 @@ def measure_config(workload, mod, dev, steps=20, warmup=5):
         rec['mfma_side'] = {'flops_per_step': flops, 'ms_at_fp32_mfma_peak': flops / MFMA_F32_PEAK * 1e3,
                             'note': 'Y = att . XB forward and the two products of dY backward, per layer; the HBM side prices '
                                     '%d B per edge' % per_edge}
-        fl = dense_route_floor(r, n, E, dims)                            # what the route's own passes allow (composite)
+        rows_route = any(l['label'].startswith('row_products') for l in launches)
+        if rows_route:
+            widths = [(b.enc.rgcn1.in_channels, b.enc.rgcn1.out_channels), (b.enc.rgcn2.in_channels, b.enc.rgcn2.out_channels)]
+            flops = sum(2.0 * r * n * nb * (d_in + 2 * d_out) for d_in, d_out in widths)
+            rec['mfma_side'] = {'flops_per_step': flops, 'ms_at_fp32_mfma_peak': flops / MFMA_F32_PEAK * 1e3,
+                                'note': 'the products of the row sums: T = att^T . S forward, d XB = att^T . S\' and d att = '
+                                        'S\' . XB^T backward, per layer; the HBM side prices %d B per edge' % per_edge}
+            fl = row_route_floor(r, n, E, widths, nb)
+        else:
+            fl = dense_route_floor(r, n, E, dims)                        # what the route's own passes allow (composite)
         fl['frac'] = fl['us'] / (ms * 1e3)
         rec['step_floor'] = fl
     del launches, run, b
@@ -1040,7 +1083,12 @@ def main():
                                  'n_gpus': world, 'peak_GBps': world * HBM_PEAK_GBS,
                                  'frac_of_roofline': E * per_edge / (ms * 1e-3) / 1e9 / (world * HBM_PEAK_GBS)}
             if world == 1:
-                fl = dense_route_floor(dd['n_dd_et'], dd['n_drug'], E, dims)
+                if any(l['label'].startswith('row_products') for l in launches):
+                    fl = row_route_floor(dd['n_dd_et'], dd['n_drug'], E,
+                                         [(enc.rgcn1.in_channels, enc.rgcn1.out_channels), (enc.rgcn2.in_channels, enc.rgcn2.out_channels)],
+                                         dims['num_base'])
+                else:
+                    fl = dense_route_floor(dd['n_dd_et'], dd['n_drug'], E, dims)
                 fl['frac'] = fl['us'] / (ms * 1e3)
                 out['step_floor'] = fl
         elif launch_us:
