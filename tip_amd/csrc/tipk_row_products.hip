@@ -77,42 +77,56 @@ __device__ __forceinline__ void rp_static_for(F&& f) {
     }
 }
 
-template <bool P2>
+template <int CPL> struct RpGeom {
+    static constexpr int CW = 32 * CPL;                         // channels per wave
+    static constexpr int TS = CW + (CPL == 1 ? 1 : 2);          // tile row stride in floats (row 32 = padding's dump row)
+    static constexpr int TILE = (33 * TS + 3) / 4 * 4;          // floats per wave, 16-byte multiple
+};
+
+template <bool P2, int CPL>
 __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a) {
+    using G = RpGeom<CPL>;
+    constexpr int CW = G::CW, TS = G::TS;
+    typedef float vec_t __attribute__((ext_vector_type(CPL)));
+    typedef __attribute__((address_space(3))) vec_t lds_vec_t;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int row = lane & 31, kh = lane >> 5;
-    float* tile = lds + w * (32 * RP_TLD);              // wave-private: [channel][row of the relation tile], + dump column
-    float* red = lds + RP_WAVES * (32 * RP_TLD);        // P2: [waves][32 x 32] partial d att tiles
-    float* attl = red + RP_WAVES * 1024;                // P2: [2][32 rows][33] att tiles shared by the workgroup (see begin_tile)
-    const int ct = (int)blockIdx.x / a.n_groups, grp = (int)blockIdx.x - ct * a.n_groups;
+    float* tile = lds + w * G::TILE;                    // wave-private: [row of the relation tile (+ dump row)][TS channels]
+    float* attl = lds + RP_WAVES * G::TILE;             // P2: [2][32 rows][33] att tiles shared by the workgroup (see begin_tile)
+    const int cb = (int)blockIdx.x / a.n_groups, grp = (int)blockIdx.x - cb * a.n_groups;   // channel block, node group
     const int node_raw = grp * RP_WAVES + w;
     const bool wave_on = node_raw < a.n_nodes;          // the last group may have idle waves (they still join barriers)
     const int node = wave_on ? node_raw : a.n_nodes - 1;
     const int NB = a.NB, R = a.R;
     const int64_t NC = (int64_t)a.n_nodes * a.ch;
-    const int64_t col = (int64_t)node * a.ch + ct * 32 + row;            // column of [NB][NC]
-    const u32 tcol_b = (u32)(ct * 32 + row) * 4u;                        // this lane's channel inside a table row
-    const u32 tile_c = (u32)(uintptr_t)(rp_lds_f32_t*)tile + (u32)row * (RP_TLD * 4u);   // LDS byte address of tile[row][0]
+    const int64_t col0 = (int64_t)node * a.ch + cb * CW;                 // first column of [NB][NC] of this wave
+    const u32 tcol_b = (u32)(cb * CW + row * CPL) * 4u;                  // this lane's channels inside a table row
+    const u32 tile_c = (u32)(uintptr_t)(rp_lds_f32_t*)tile + (u32)row * (CPL * 4u);   // LDS byte address of tile[0][lane's channels]
     const u32 att_b = (u32)(row < NB ? row : NB - 1) * 4u;
 
-    float xbv[16];
-    if (P2) {                                           // B operand of product 2: XB[b = lane & 31][column c0 + 2 kk + kh]
-        const int64_t b_off = (int64_t)(row < NB ? row : NB - 1) * a.ld_xb + (int64_t)node * a.ch + ct * 32;
+    float xbv[CPL][16];
+    if (P2) {                                           // B operand of product 2: XB[b = lane & 31][channel 32 q + 2 kk + kh]
+        const int64_t b_off = (int64_t)(row < NB ? row : NB - 1) * a.ld_xb + col0;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) xbv[kk] = rp_and(a.xb[b_off + 2 * kk + kh], (row < NB && wave_on) ? 0xffffffffu : 0u);
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                xbv[q][kk] = rp_and(a.xb[b_off + 32 * q + 2 * kk + kh], (row < NB && wave_on) ? 0xffffffffu : 0u);
     }
-    f32x16 acc1;
+    f32x16 acc1[CPL];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+    for (int q = 0; q < CPL; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[q][i] = 0.f;
 
     // The node's batches are consecutive in `entries` (tile after tile) and every tile has at least one: ONE load pipeline
-    // over all of them, always two half batches (16 row pieces per lane half) in flight and the entry words eight batches ahead.
-    // Every wait for a load then has a FIXED number of younger loads behind it on every path (vmcnt counts in order, and the
-    // compiler must assume the path with the fewest): with tiles of zero batches, or loads issued under a condition, each
-    // tile's att operand cost a drain of the whole pipeline.  (The loads issued past the node's last batch fetch the next
-    // node's pieces -- the array ends with one batch of padding -- and are never used.)
+    // over all of them, always two parts of a batch in flight and the entry words some batches ahead.  Every wait for a load
+    // then has a FIXED number of younger loads behind it on every path (vmcnt counts in order, and the compiler must assume
+    // the path with the fewest): with tiles of zero batches, or loads issued under a condition, each tile's att operand cost
+    // a drain of the whole pipeline.  (The loads issued past the node's last batch fetch the next node's pieces -- the array
+    // ends with batches of padding -- and are never used.)
     const int32_t* dsc = a.desc + (int64_t)node * a.n_tiles * 2;
     int b = dsc[0];
     int nbat = dsc[1];                                  // (the scalar load of a tile's length travels a tile ahead)
@@ -120,38 +134,54 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a
     const u32 word_lane = (u32)(kh * 16 + (lane & 15));
     auto load_word = [&](int batch) { return (u32)a.entries[(int64_t)batch * 32 + word_lane]; };
     const u32 ld_mul = a.ld_table_b >> 8;               // (entry & 0xffff00) * ld_mul = other * bytes per table row
-    float acc = 0.f;                                    // running sum of the current row of this lane's half
+    float acc[CPL];                                     // running sum of the current row of this lane's half
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
     float atv[16];
     // Lane j of a 16-lane row unpacks entry j ONCE per batch (row offset in the table, LDS offset, the 0.0 / 1.0 of byte 3);
     // per entry the unpacked value reaches the half's lanes as the DPP row broadcast inside the instruction that uses it:
-    // v_add_u32_dpp (load address), v_fmac_f32_dpp (running sum), v_add_u32_dpp (LDS address) -- 3 VALU instructions.
-    constexpr int DEPTH = 8;                            // entries per buffer: a batch is consumed as two halves
-    auto issue = [&](auto lo_c, float (&val)[DEPTH], u32 wv) {
+    // v_add_u32_dpp (load address), v_fmac_f32_dpp per channel (running sum), v_add_u32_dpp (LDS address).
+    // A batch is consumed in 16 / DEPTH parts, part g through buffer g & 1.
+    constexpr int DEPTH = CPL == 2 ? 4 : 8, NQ = 16 / DEPTH;
+    auto issue = [&](auto lo_c, float (&val)[DEPTH][CPL], u32 wv) {
         constexpr int LO = decltype(lo_c)::value;
         const u32 rowb = __umul24(wv & 0x00ffff00u, ld_mul);
         rp_static_for<DEPTH>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const u32 off = rp_row_bcast<LO + j>(rowb) + tcol_b;
-            val[j] = TIPK_DBG(a.dbg & 1) ? __uint_as_float(off) : rp_ldg(a.table, off);
+            if (TIPK_DBG(a.dbg & 1)) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) val[j][c] = __uint_as_float(off);
+            } else {
+                const vec_t x = *reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(a.table) + off);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) val[j][c] = x[c];
+            }
         });
     };
-    auto consume = [&](auto lo_c, float (&val)[DEPTH], u32 wv) {
+    auto consume = [&](auto lo_c, float (&val)[DEPTH][CPL], u32 wv) {
         constexpr int LO = decltype(lo_c)::value;
         float keep = (float)(wv >> 24);                 // v_cvt_f32_ubyte3: 0.0 at the first entry of a row (and padding), else 1.0
-        const u32 offl = wv & 0xffu;
+        const u32 offl = __umul24(wv & 0xffu, (u32)TS); // 4 * row of the tile -> byte offset of that row
         asm volatile("s_nop 1" : "+v"(keep));           // (hand-written DPP below: 2 wait states after the VALU write)
         rp_static_for<DEPTH>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            rp_fmac_row_bcast<LO + j>(val[j], keep, acc);   // val = inside * acc + piece
-            acc = val[j];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                rp_fmac_row_bcast<LO + j>(val[j][c], keep, acc[c]);    // val = inside * acc + piece
+                acc[c] = val[j][c];
+            }
             const u32 off = rp_row_bcast<LO + j>(offl) + tile_c;
-            if (!TIPK_DBG(a.dbg & 2)) *reinterpret_cast<rp_lds_f32_t*>((uintptr_t)off) = acc;   // the row's last write is its sum
+            vec_t o;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) o[c] = acc[c];
+            if (!TIPK_DBG(a.dbg & 2)) *reinterpret_cast<lds_vec_t*>((uintptr_t)off) = o;     // the row's last write is its sum
         });
     };
     // A operand of product 1 = att^T (lane = base).  Forward pass: 16 registers per tile, requested when the tile begins.
     // P2 (no registers to spare; the waves meet at two barriers per tile anyway): ONE copy per workgroup in LDS, double
-    // buffered -- thread t fetches element (row t / 32, base t % 32) of the NEXT tile when a tile begins and stores it before
-    // the tile's first barrier; rows beyond R / bases beyond NB are stored as zeros.
+    // buffered -- thread t fetches elements of the NEXT tile when a tile begins and stores them before the tile's first
+    // barrier; rows beyond R / bases beyond NB are stored as zeros.
     constexpr int NT = RP_WAVES * 64, PER = 1024 / NT;  // elements of a 32 x 32 tile per thread
     float att_next[PER];
     auto att_elem = [&](int tile_i, int i) {
@@ -182,23 +212,26 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a
                 atv[kk] = rp_ldg(att_t, (u32)((r < R ? r : R - 1) - r0) * a.ld_att_b + att_b);
             }
         }
-        // zero the tile (rows without edges): 4 x 64 float4 + the last 32 floats
+        // zero rows 0 .. 31 of the tile (rows without edges): 32 * TS floats as float4
+        constexpr int N4 = 32 * TS / 4;
+        static_assert(32 * TS % 4 == 0, "tile zeroing");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tipk_st4(tile + (i * 64 + lane) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-        static_assert(32 * RP_TLD == 1024 + 32, "tile zeroing");
-        if (lane < 32) tile[1024 + lane] = 0.f;
+        for (int i = 0; i < (N4 + 63) / 64; ++i)
+            if (i * 64 + lane < N4) tipk_st4(tile + (i * 64 + lane) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
         rp_wave_sync();
     };
     auto finish_tile = [&]() {
         const int r0 = tl * 32;
         rp_wave_sync();
-        // (1) T += att^T . S : B operand lane = channel, k = row
+        // (1) T += att^T . S : B operand lane = channel 32 q + (lane & 31), k = row
         if (!TIPK_DBG(a.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const u32 mk = (r0 + 2 * kk + kh < R && row < NB) ? 0xffffffffu : 0u;
             const float av = P2 ? attl[(tl & 1) * (32 * RP_TLD) + (2 * kk + kh) * RP_TLD + row] : rp_and(atv[kk], mk);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tile[row * RP_TLD + 2 * kk + kh], acc1, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+                acc1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tile[(2 * kk + kh) * TS + 32 * q + row], acc1[q], 0, 0, 0);
         }
         if (P2) {
             // (2) d att tile = S . XB^T : A operand lane = row r, k = channel
@@ -206,45 +239,52 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(2 * kk + kh) * RP_TLD + row], xbv[kk], acc2, 0, 0, 0);
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[row * TS + 32 * q + 2 * kk + kh], xbv[q][kk], acc2, 0, 0, 0);
+            // the 8 waves' partial tiles are added through LDS in wave order: each wave puts its own where its tile of row
+            // sums was (read for the last time just above; zeroed again when the next tile begins, behind the second barrier)
             att_store((tl + 1) & 1);                        // (free: read two barriers ago)
-            __syncthreads();                                // red is free (previous tile has been summed)
+            rp_wave_sync();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                red[w * 1024 + rr * 32 + row] = acc2[r];
+                tile[rr * 32 + row] = acc2[r];
             }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = i * NT + t;
-                float sum = red[e];
+                float sum = lds[e];
 #pragma unroll
-                for (int q = 1; q < RP_WAVES; ++q) sum += red[q * 1024 + e];
+                for (int q = 1; q < RP_WAVES; ++q) sum += lds[q * G::TILE + e];
                 const int rr = r0 + (e >> 5), bb = e & 31;
                 if (rr < R && bb < NB) a.datt[((int64_t)blockIdx.x * R + rr) * NB + bb] = sum;
             }
+            __syncthreads();
         }
     };
-    float va[DEPTH], vb[DEPTH];
-    constexpr std::integral_constant<int, 0> c0{};
-    constexpr std::integral_constant<int, 8> c8{};
-    constexpr int WQ = 6;                               // entry words on their way: batches b + 2 .. b + 1 + WQ
+    float va[DEPTH][CPL], vb[DEPTH][CPL];
+    constexpr int WQ = 2;                               // entry words on their way: batches b + 2 .. b + 1 + WQ
     u32 wa = load_word(b), wb = load_word(b + 1), wq[WQ];
 #pragma unroll
     for (int q = 0; q < WQ; ++q) wq[q] = load_word(b + 2 + q);
-    issue(c0, va, wa);
-    issue(c8, vb, wa);
+    issue(std::integral_constant<int, 0>{}, va, wa);
+    issue(std::integral_constant<int, DEPTH>{}, vb, wa);
     for (tl = 0; tl < a.n_tiles; ++tl) {
         const int nbat_next = dsc[2 * (tl + 1 < a.n_tiles ? tl + 1 : tl) + 1];
         begin_tile();
         int i = 0;
         do {                                            // (at least one batch: see above)
-            consume(c0, va, wa);
-            issue(c0, va, wb);
-            consume(c8, vb, wa);
-            issue(c8, vb, wb);
+            rp_static_for<NQ>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;  // part g of this batch; part g + 2 takes its buffer
+                constexpr int nx = (g + 2) % NQ;
+                auto lo = std::integral_constant<int, g * DEPTH>{};
+                auto lo_nx = std::integral_constant<int, nx * DEPTH>{};
+                if constexpr ((g & 1) == 0) { consume(lo, va, wa); issue(lo_nx, va, g + 2 < NQ ? wa : wb); }
+                else { consume(lo, vb, wa); issue(lo_nx, vb, g + 2 < NQ ? wa : wb); }
+            });
             wa = wb; wb = wq[0];
 #pragma unroll
             for (int q = 0; q + 1 < WQ; ++q) wq[q] = wq[q + 1];
@@ -257,28 +297,44 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a
     // T: C layout col = lane & 31 (channel), rows = bases
     if (wave_on) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (b < NB) a.t_out[(int64_t)b * NC + col] = acc1[r];
-        }
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bb = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (bb < NB) a.t_out[(int64_t)bb * NC + col0 + 32 * q + row] = acc1[q][r];
+            }
     }
 }
 
-constexpr size_t RP_LDS_1 = (size_t)(RP_WAVES * 32 * RP_TLD) * sizeof(float);
-constexpr size_t RP_LDS_2 = (size_t)(RP_WAVES * 32 * RP_TLD + RP_WAVES * 1024 + 2 * 32 * RP_TLD) * sizeof(float);
+template <int CPL> constexpr size_t rp_lds_bytes(bool p2) {
+    return (size_t)(RP_WAVES * RpGeom<CPL>::TILE + (p2 ? 2 * 32 * RP_TLD : 0)) * sizeof(float);
+}
+
+template <bool P2, int CPL>
+int rp_launch(const RpArgs& a, unsigned blocks, hipStream_t st) {
+    const size_t lds = rp_lds_bytes<CPL>(P2);
+    hipError_t e = hipFuncSetAttribute((const void*)row_products_kernel<P2, CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return tipk_hip_status(e);
+    hipLaunchKernelGGL((row_products_kernel<P2, CPL>), dim3(blocks), dim3(RP_WAVES * 64), lds, st, a);
+    TIPK_RETURN_LAUNCH();
+}
+
+// channels per lane: two (64-channel blocks, 8-byte loads and LDS stores: half the instructions per gathered byte) where the
+// width allows
+inline int rp_cpl(int channels) { return channels % 64 == 0 ? 2 : 1; }
 
 }  // namespace
 
 extern "C" int tipk_rgcn_row_products_supported(int64_t n_nodes, int64_t n_rel, int n_bases, int channels) {
     if (n_nodes <= 0 || n_rel <= 0 || n_bases <= 0 || n_bases > 32 || channels <= 0 || channels % 32 != 0) return 0;
     if (n_nodes > 65536 || n_rel > 0x7fffffffLL) return 0;                            // entry word: inside << 24 | other << 8 | row offset
-    const int64_t slabs = tipk_ceil_div(n_nodes, RP_WAVES) * (channels / 32);
+    const int64_t slabs = tipk_ceil_div(n_nodes, RP_WAVES) * (channels / (32 * rp_cpl(channels)));
     if (slabs > 0x7fffffffLL) return 0;
     return 1;
 }
 
 extern "C" int64_t tipk_rgcn_row_products_slabs(int64_t n_nodes, int channels) {
-    return tipk_ceil_div(n_nodes, RP_WAVES) * (channels / 32);
+    return tipk_ceil_div(n_nodes, RP_WAVES) * (channels / (32 * rp_cpl(channels)));
 }
 
 extern "C" int tipk_rgcn_row_products(const float* table, int64_t ld_table, int64_t n_nodes, int channels, const float* att,
@@ -289,6 +345,7 @@ extern "C" int tipk_rgcn_row_products(const float* table, int64_t ld_table, int6
     if ((xb == nullptr) != (datt_slabs == nullptr) || (xb && ld_xb < n_nodes * channels)) return TIPK_EINVAL;
     if (n_nodes * ld_table * 4 >= (1LL << 32) || 32 * ld_att * 4 >= (1LL << 31)) return TIPK_EUNSUPPORTED;   // 32-bit byte offsets
     if (ld_table % 64 != 0 || ld_table * 4 / 256 >= 256) return TIPK_EUNSUPPORTED;     // (other << 8) * (row bytes / 256) in 24-bit arithmetic
+    if (reinterpret_cast<uintptr_t>(table) & 7) return TIPK_EINVAL;                    // 8-byte loads
     RpArgs a;
     a.table = table; a.ld_table_b = (u32)(ld_table * 4); a.n_nodes = (int)n_nodes; a.ch = channels;
     a.att = att; a.ld_att_b = (u32)(ld_att * 4); a.R = (int)n_rel; a.NB = n_bases;
@@ -297,16 +354,9 @@ extern "C" int tipk_rgcn_row_products(const float* table, int64_t ld_table, int6
     a.t_out = t_out; a.datt = datt_slabs;
     a.n_groups = (int)tipk_ceil_div(n_nodes, RP_WAVES);
     a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
-    const unsigned blocks = (unsigned)(a.n_groups * (channels / 32));
+    const int cpl = rp_cpl(channels);
+    const unsigned blocks = (unsigned)(a.n_groups * (channels / (32 * cpl)));
     hipStream_t st = (hipStream_t)stream;
-    if (xb) {
-        hipError_t e = hipFuncSetAttribute((const void*)row_products_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RP_LDS_2);
-        if (e != hipSuccess) return tipk_hip_status(e);
-        hipLaunchKernelGGL(row_products_kernel<true>, dim3(blocks), dim3(RP_WAVES * 64), RP_LDS_2, st, a);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)row_products_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RP_LDS_1);
-        if (e != hipSuccess) return tipk_hip_status(e);
-        hipLaunchKernelGGL(row_products_kernel<false>, dim3(blocks), dim3(RP_WAVES * 64), RP_LDS_1, st, a);
-    }
-    TIPK_RETURN_LAUNCH();
+    if (xb) return cpl == 2 ? rp_launch<true, 2>(a, blocks, st) : rp_launch<true, 1>(a, blocks, st);
+    return cpl == 2 ? rp_launch<false, 2>(a, blocks, st) : rp_launch<false, 1>(a, blocks, st);
 }
