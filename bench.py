@@ -863,9 +863,51 @@ def train_step_record(dev, epochs=20, decoder='distmult'):
            'what': 'hipGraph replay of zero_grad + typed negative sampling + encoder + fused %s objective + backward + '
                    'Adam in one launch (tip_amd/optim.py, tip_amd/train.py), TIP-cat BioSNAP R=%d'
                    % ('DistMult' if decoder == 'distmult' else 'NNDecoder (score tables)', model.data.n_dd_et)}
+    if decoder == 'distmult':
+        rec['roofline'] = train_step_rooflines(model, dev)
     del step, opt, model
     release()
     return rec
+
+
+def train_step_rooflines(model, dev):
+    """The two launches of the training epoch that the encoder's headline does not see -- the fused objective and the typed
+    negative sampler -- timed alone (HIP events around a hipGraph of back-to-back launches) on the epoch's own triple lists."""
+    import torch
+    from tip_amd import ops
+    from tip_amd.neg_sampling import typed_negative_sampling
+    d = model.data
+    pos, et, rg = d.dd_train_idx, d.dd_train_et, d.dd_train_range
+    n, k = d.n_drug, model.embeddings.shape[1] if torch.is_tensor(getattr(model, 'embeddings', None)) else 16
+    E = int(pos.shape[1])
+    z = torch.randn(n, k, device=dev) * 0.5
+    w = torch.randn(d.n_dd_et, k, device=dev) * 0.3
+    negp = typed_negative_sampling(pos, n, rg, packed=True)
+    obj_us = time_launch_us(lambda: ops.distmult_loss(z, w, pos, negp, et), reps=10, replays=3)
+    smp_us = time_launch_us(lambda: typed_negative_sampling(pos, n, rg, packed=True), reps=10, replays=3)
+    # objective: every term of d z is one LDS row-add (16 lanes x ds_add_u64 = 128 bytes of read-modify-write) and one 64-byte row
+    # read for the scatter; the evaluation reads both rows of a triple once more.  A symmetric relation's positives are
+    # evaluated once per undirected pair (weight 2): E / 2 positive + E negative triples.
+    triples = E // 2 + E
+    lds_bytes = triples * 2 * (128.0 + 64.0) + triples * 2 * 4.0 * k
+    atomics = triples * 2 / 4.0                                              # wave-level ds_add_u64: 4 rows per instruction
+    obj = {'kernel': 'distmult_objective_kernel<PackedPair,%d> (+ the finalize launch)' % k, 'bound': 'lds', 'launch_us': obj_us,
+           'achieved': lds_bytes / (obj_us * 1e-6) / 1e9, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',
+           'frac': lds_bytes / (obj_us * 1e-6) / 1e9 / LDS_PEAK_GBS, 'algorithmic_lds_bytes': lds_bytes, 'row_adds': triples * 2,
+           'atomic_floor_us': atomics * 8 / (256 * 2.4e9) * 1e6,
+           'note': 'LDS bytes the sums need (row-adds as 128-byte read-modify-writes, 64-byte row reads) against the ds_read_b128 '
+                   'rate; atomic_floor_us = the wave-level ds_add_u64 at their measured 8 cycles each (64 B/clk per CU) on 256 CUs'}
+    # sampler: one Philox4x32-10 call per 4 positions = 10 rounds x (2 mul_hi + 2 mul_lo + 4 xor / add) on quarter-rate
+    # multipliers; the floor below counts the 40 32-bit multiplies of a call at 16 lanes per cycle and SIMD
+    calls = E / 4.0
+    mul_cycles = calls * 40 / 64.0 * 16                                        # wave-instructions x 16 cycles (quarter rate)
+    smp = {'kernel': 'neg_sample_bitmap_kernel<PackedOut>', 'bound': 'valu', 'launch_us': smp_us,
+           'positions_per_s': E / (smp_us * 1e-6), 'philox_calls': calls,
+           'multiply_floor_us': mul_cycles / (1024 * 2.4e9) * 1e6,
+           'frac': mul_cycles / (1024 * 2.4e9) * 1e6 / smp_us,
+           'note': 'VALU issue: the 40 quarter-rate 32-bit multiplies of a Philox4x32-10 call alone, on 1 024 SIMDs at 2.4 GHz; '
+                   'the bitmap of a relation\'s positives (LDS) and the rejection loop come on top'}
+    return {'objective': obj, 'sampler': smp}
 
 
 def main():
