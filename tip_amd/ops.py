@@ -1541,15 +1541,18 @@ class _RGCN(torch.autograd.Function):
             return out
         ctx.xb_stamp, ctx.pair_bwd = None, False
         use_rl = r > 0 and rel_gather_usable(graph.rl_fwd, n, d_out, False)   # (the unit plan is built here, on first use)
-        if use_rl:
-            assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
-        elif r > 0:
-            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
-        xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
-        # LARGE node sets (round 5; include/tipk.h section 2f): Y = att . XB [R N, out] is never formed -- per destination
-        # T[:, v, :] = sum_e att[r_e, :]^T (x) X[src_e] (a product over the node's incoming edges), then sum_b T_b basis_b
+        # LARGE node sets (round 5; include/tipk.h sections 2h / 2f): Y = att . XB [R N, out] is never formed -- the (relation,
+        # node) row sums are multiplied where they are assembled, or per destination T[:, v, :] = sum_e att[r_e, :]^T (x) X[src_e]
+        # (a product over the node's incoming edges); then sum_b T_b basis_b
         rows = graph.row_fwd if (r > 0 and not use_rl and row_products_supported(n, r, nb, d_in)) else None
         dest = graph.dest_fwd if (r > 0 and not use_rl and rows is None) else None
+        if use_rl:
+            assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
+        elif rows is not None:
+            assert rows.n_nodes == n and rows.n_rel == r, 'graph/plan mismatch'
+        elif r > 0 and dest is None:                                         # (the generic plan is built here, on first use)
+            assert graph.fwd.n_out == n and graph.fwd.n_table == r * n, 'graph/plan mismatch'
+        xb, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, root)])      # XB and X root: one grouped launch
         if dest is not None or rows is not None:
             # (row sums first: 0.16 TFLOP per layer at config 5 instead of the 0.41 of the per-edge product)
             t_b = row_products(rows, x, att) if rows is not None else dest_products(dest, x, att)
