@@ -171,26 +171,36 @@ def cpu_baseline(dd, dims, mod, budget_s, weights, up):
     # reference-shaped flavour on the first relations (bounded: its cost grows ~ R * E because every
     # `x_j[start:end]` slice backward zero-fills an E x in gradient)
     try:
-        r_s = min(R, 24)
-        e_s = int(dd['dd_train_range'][r_s - 1, 1])
-        ei = dd['dd_train_idx'][:, :e_s]
-        rg = dd['dd_train_range'][:r_s]
         d_in = dims['n_embed'] + dims['prot_drug_dim'] if mod == 'cat' else dims['n_embed']
-        x = torch.randn(dd['n_drug'], d_in).requires_grad_(True)
-        prm = [p['rgcn1.basis'][:, :d_in].clone().requires_grad_(True), p['rgcn1.att'][:r_s].clone().requires_grad_(True),
-               p['rgcn1.root'][:d_in].clone().requires_grad_(True)]
-        g = torch.randn(dd['n_drug'], prm[0].shape[2])
-        t0 = time.perf_counter()
-        y = O.rgcn_fwd_reference_shaped(x, ei, rg, *prm)
-        y.backward(g)
-        dt_ref = time.perf_counter() - t0
+
+        def shaped(r_s):
+            e_s = int(dd['dd_train_range'][r_s - 1, 1])
+            ei = dd['dd_train_idx'][:, :e_s]
+            rg = dd['dd_train_range'][:r_s]
+            x = torch.randn(dd['n_drug'], d_in).requires_grad_(True)
+            prm = [p['rgcn1.basis'][:, :d_in].clone().requires_grad_(True), p['rgcn1.att'][:r_s].clone().requires_grad_(True),
+                   p['rgcn1.root'][:d_in].clone().requires_grad_(True)]
+            g = torch.randn(dd['n_drug'], prm[0].shape[2])
+            t0 = time.perf_counter()
+            y = O.rgcn_fwd_reference_shaped(x, ei, rg, *prm)
+            y.backward(g)
+            return e_s, time.perf_counter() - t0
+        # TWO samples: the second, 2.7 x as many relations, checks the cost model the full-size figure is extrapolated with
+        r_a, r_b = min(R, 24), min(R, 64)
+        e_a, dt_a = shaped(r_a)
+        e_b, dt_b = shaped(r_b) if r_b > r_a else (e_a, dt_a)
+        r_s, e_s, dt_ref = r_b, e_b, dt_b
         out['reference_shaped'] = {
             'value': e_s / dt_ref, 'unit': 'edges/s (one R-GCN layer fwd+bwd, on the SAMPLE)', 'cores': threads,
             'sample': 'first %d relations, %d edges, PyG op sequence under autograd, %.2f s' % (r_s, e_s, dt_ref),
             # time ~ c * R_s * E_s  ->  full graph: E / (c R E) = sample rate * R_s / R
             'full_size_estimate': e_s / dt_ref * r_s / R,
-            'full_size_estimate_note': 'sample rate x R_sample / R (cost model c*R*E of the slice backward; the survey '
-                                       'probe of the literal reference measured 0.020 M edges/s on 8 cores)'}
+            'cost_model_check': {'samples': [[r_a, e_a, round(dt_a, 3)], [r_b, e_b, round(dt_b, 3)]],
+                                 'time_ratio_measured': dt_b / dt_a,
+                                 'time_ratio_of_c_R_E': (r_b * e_b) / float(r_a * e_a)},
+            'full_size_estimate_note': 'sample rate x R_sample / R (cost model c*R*E of the slice backward, checked on two sample '
+                                       'sizes: cost_model_check; the survey probe of the literal reference measured 0.020 M '
+                                       'edges/s on 8 cores)'}
     except Exception as exc:                                   # never let the side leg kill the bench
         out['reference_shaped'] = {'error': repr(exc)}
     return out, zo, go
