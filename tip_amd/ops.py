@@ -368,7 +368,8 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     slab_mode = None                       # None | 'k' (split the k range) | 'q' (one slab per batch term) | 'g' (per group of terms)
     n_slabs = 0
     if kgroup:
-        assert reduce_batch and plain and c_in is None and z % kgroup == 0 and a.dim() == 3 and b.dim() == 3
+        # (c_in == out: the slab sum accumulates on top of what `out` holds, as in mode 'q')
+        assert reduce_batch and plain and z % kgroup == 0 and a.dim() == 3 and b.dim() == 3
         slab_mode, n_slabs = 'g', z // kgroup
     elif reduce_batch and plain and tiles * 2 <= 256 and z > 1:
         slab_mode, n_slabs = 'q', z
@@ -427,9 +428,15 @@ def gemm_job(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=Fals
     return job
 
 
-def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None):
+def large_kgroup(m, z):
+    """Batch-reduced products over a LARGE node set (config 5: [10 000 x 128] x [128 x 128] summed over 32 bases) have few
+    output tiles (314) and a reduction of 4 096: four slabs of 8 bases each fill the chip (255 -> 169 us)."""
+    return 8 if (m >= 4096 and z >= 16 and z % 8 == 0) else None
+
+
+def gemm(a, b, out=None, c_in=None, relu=False, alpha=1.0, reduce_batch=False, ksplit=None, kgroup=None):
     """out = relu?(alpha * a @ b + c_in): one product, launched now (see `gemm_job`)."""
-    job = gemm_job(a, b, out, c_in, relu, alpha, reduce_batch, ksplit)
+    job = gemm_job(a, b, out, c_in, relu, alpha, reduce_batch, ksplit, kgroup)
     st = stream_ptr(a.device)
     with _timed('gemm[%s]' % job.label):
         check(lib().tipk_gemm_f32(job.desc, st), 'tipk_gemm_f32')
@@ -1556,7 +1563,7 @@ class _RGCN(torch.autograd.Function):
         if dest is not None or rows is not None:
             # (row sums first: 0.16 TFLOP per layer at config 5 instead of the 0.41 of the per-edge product)
             t_b = row_products(rows, x, att) if rows is not None else dest_products(dest, x, att)
-            agg = gemm(t_b, basis, reduce_batch=True)
+            agg = gemm(t_b, basis, reduce_batch=True, kgroup=large_kgroup(n, nb))
             if shard is not None:
                 shard.all_reduce(agg)
             out = sum_slabs(agg.view(1, n, d_out), row_scale=graph.scale, addend=xroot, relu=bool(relu))
@@ -1689,7 +1696,7 @@ class _RGCN(torch.autograd.Function):
             j_basis = gemm_job(x.t(), g_xb)                              # [B, in, out]
             j_xr = gemm_job(g, root.t(), ksplit=1)                       # written by the GEMM launch itself: the
             g_x = j_xr.out                                               # basis half is summed on top of it afterwards
-            j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True)
+            j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, c_in=g_x, reduce_batch=True, kgroup=large_kgroup(n, nb))
             if j_xq.slabs is not None:                                   # summed on top of g root^T afterwards
                 if ctx.gate_input:
                     j_xq.gate = x                                        # ... and masked with (x > 0) in the same pass
@@ -1708,7 +1715,7 @@ class _RGCN(torch.autograd.Function):
             g_x = flat[:n * d_in].view(n, d_in)
             g_basis = flat[n * d_in:].view(nb, d_in, d_out)
             j_basis = gemm_job(x.t(), g_xb, out=g_basis)
-            j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, reduce_batch=True)   # partial over this shard
+            j_xq = gemm_job(g_xb, basis.transpose(1, 2), out=g_x, reduce_batch=True, kgroup=large_kgroup(n, nb))   # partial over this shard
             gemm_group([j_basis, j_root, j_xq], extra)
             g_root = j_root.out
             shard.all_reduce(flat)
