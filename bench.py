@@ -276,18 +276,20 @@ def dd_launches(enc, dev):
         pair_bwd = graph.pair_bwd if (pair_ok and ops.pair_grads_supported(nb, d) and 'y' not in
                                       [v[0] for v in graph.fwd_route.values()]) else None
         d_in = layer.in_channels
-        if (not pair_ok and graph.row_fwd is not None and ops.row_products_supported(n, r, nb, d_in)
-                and ops.row_products_supported(n, r, nb, d)):
+        wave_uniform = getattr(graph.row_fwd, 'ROW_BYTES', None) is not None if not pair_ok else False
+        rows_ok = ops.row_products_s_supported if wave_uniform else ops.row_products_supported
+        if not pair_ok and graph.row_fwd is not None and rows_ok(n, r, nb, d_in) and rows_ok(n, r, nb, d):
             # LARGE node sets (config 5): both passes sum the (relation, node) rows in LDS and multiply them there
             # (tipk_rgcn_row_products) -- algorithmic flops = the products of the row sums, 2 x R N ch bases each
             x_in, att = torch.randn(n, d_in, device=dev), torch.randn(r, nb, device=dev)
             xb2 = torch.randn(nb, n * d, device=dev)
             rf, rb = graph.row_fwd, graph.row_bwd
-            add('row_products[dd.fwd,ch=%d]' % d_in, 'row_products_kernel<false>', None, 'mfma', 2.0 * r * n * d_in * nb,
+            kname = 'row_products_s_kernel' if getattr(rf, 'ROW_BYTES', None) is not None else 'row_products_kernel'
+            add('row_products[dd.fwd,ch=%d]' % d_in, kname + '<false', None, 'mfma', 2.0 * r * n * d_in * nb,
                 lambda rf=rf, x_in=x_in, att=att: ops.row_products(rf, x_in, att), edges=rf.n_edges, row_floats=d_in,
                 gathered_bytes=rf.n_edges * (4.0 + 4 * d_in), batches=int(rf.entries.shape[0]),
                 note='T = att^T . S over the (relation, node) row sums S assembled in LDS from %d gathered rows' % rf.n_edges)
-            add('row_products[dd.bwd,ch=%d]' % d, 'row_products_kernel<true>', None, 'mfma', 2 * 2.0 * r * n * d * nb,
+            add('row_products[dd.bwd,ch=%d]' % d, kname + '<true', None, 'mfma', 2 * 2.0 * r * n * d * nb,
                 lambda rb=rb, g=g, att=att, xb2=xb2: ops.row_products(rb, g, att, xb2)[1], edges=rb.n_edges, row_floats=d,
                 gathered_bytes=rb.n_edges * (4.0 + 4 * d), batches=int(rb.entries.shape[0]),
                 note='d XB = att^T . S and d att = S . XB^T on the row sums of the transposed pass')

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 19
+#define TIPK_ABI_VERSION 20
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -507,6 +507,19 @@ int tipk_rgcn_row_products(const float* table, int64_t ld_table, int64_t n_nodes
                            int64_t ld_att, int64_t n_rel, int n_bases, const int32_t* entries, const int32_t* desc,
                            const float* xb /* nullable */, int64_t ld_xb, float* t, float* datt_slabs /* nullable */,
                            tipk_stream_t stream);
+
+/* The same two products with WAVE-UNIFORM entries (channels % 64 == 0; any node count whose table fits 2 GB): a wave =
+ * (node, 64 channels), one entry per step for the whole wave, so the entry's table offset, LDS row offset and inside-row flag
+ * are scalar operands (1 VALU instruction per entry; the fp32 MFMA and the VALU of a SIMD do not overlap on gfx950).
+ * entries [n_batches][2][16] int32: ONE list per (node, tile of 32 relations) sorted by relation and padded to 16 entries,
+ * plane 0 = BYTE offset of the gathered table row (other * ld_table * 4), plane 1 = 260 * (rel % 32) | 0x3f800000 at every entry
+ * of a (relation, node) row but its first (padding: 0 / 260 * 32); desc, padding batches at the end, t and datt_slabs as above
+ * (a slab = 8 nodes x 64 channels). */
+int tipk_rgcn_row_products_s_supported(int64_t n_nodes, int64_t n_rel, int n_bases, int channels);
+int tipk_rgcn_row_products_s(const float* table, int64_t ld_table, int64_t n_nodes, int channels, const float* att,
+                             int64_t ld_att, int64_t n_rel, int n_bases, const int32_t* entries, const int32_t* desc,
+                             const float* xb /* nullable */, int64_t ld_xb, float* t, float* datt_slabs /* nullable */,
+                             tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 3. Small row-wise glue (each replaces one or more torch elementwise/copy kernels, K3/K8).

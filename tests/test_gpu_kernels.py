@@ -483,6 +483,57 @@ def test_row_products_both_passes(ops, R, N, ch, nb, E):
     assert torch.equal(t.cpu().double(), wt) and torch.equal(datt.cpu().double(), wa)
 
 
+@pytest.mark.parametrize('R,N,ch,nb,E', [(70, 50, 64, 32, 4000), (33, 37, 128, 8, 900), (129, 21, 192, 32, 6000), (5, 16, 64, 3, 40)])
+def test_row_products_s_both_passes(ops, R, N, ch, nb, E):
+    """tipk_rgcn_row_products_s (wave-uniform entries: scalar entry words, buffer loads with a scalar offset, LDS stores
+    through M0) == the definition in fp64 and == `tipk_rgcn_row_products` on the same graph up to summation order; nodes
+    without edges, a hub, a relation without edges, R no multiple of 32, node counts no multiple of 8; bitwise repeat; exact
+    on integers."""
+    from tip_amd.plan import build_row_stream_plan_s, build_row_stream_plan
+    assert ops.row_products_s_supported(N, R, nb, ch)
+    g = torch.Generator().manual_seed(R + N + ch)
+    rel = torch.randint(0, R, (E,), generator=g)
+    rel[rel == R // 2] = 0
+    key = torch.randint(0, max(1, (3 * N) // 4), (E,), generator=g)
+    key[: E // 5] = 1
+    other = torch.randint(0, N, (E,), generator=g)
+    rp = build_row_stream_plan_s(key, other, rel, N, R).to(DEV)
+    rv = build_row_stream_plan(key, other, rel, N, R).to(DEV)
+
+    def want(table, att, xb):
+        s = torch.zeros(R * N, ch, dtype=torch.float64)
+        s.index_add_(0, rel * N + key, table.double()[other])
+        s = s.view(R, N, ch)
+        return torch.einsum('rb,rvc->bvc', att.double(), s), torch.einsum('rvc,bvc->rb', s, xb.double())
+
+    def run(plan, table, att, xb):
+        t1 = ops.row_products(plan, table.to(DEV), att.to(DEV))
+        job, t2 = ops.row_products(plan, table.to(DEV), att.to(DEV), xb.to(DEV).view(nb, N * ch))
+        ops.gemm_group([], [job])
+        job_b, t3 = ops.row_products(plan, table.to(DEV), att.to(DEV), xb.to(DEV).view(nb, N * ch))
+        ops.gemm_group([], [job_b])
+        assert torch.equal(t1, t2) and torch.equal(t2, t3) and torch.equal(job.out, job_b.out)
+        return t1, job.out
+    table, att, xb = torch.randn(N, ch, generator=g), torch.randn(R, nb, generator=g), torch.randn(nb, N, ch, generator=g)
+    t, datt = run(rp, table, att, xb)
+    wt, wa = want(table, att, xb)
+    close(t, wt, rtol=2e-5, atol=2e-5 * float(wt.abs().max()))
+    close(datt, wa, rtol=2e-5, atol=2e-5 * float(wa.abs().max()))
+    tv, dv = run(rv, table, att, xb)
+    close(t, tv.cpu().double(), rtol=2e-5, atol=2e-5 * float(wt.abs().max()))
+    close(datt, dv.cpu().double(), rtol=2e-5, atol=2e-5 * float(wa.abs().max()))
+    ti, ai = torch.randint(-3, 4, (N, ch), generator=g).float(), torch.randint(-3, 4, (R, nb), generator=g).float()
+    xi = torch.randint(-2, 3, (nb, N, ch), generator=g).float()
+    t, datt = run(rp, ti, ai, xi)
+    wt, wa = want(ti, ai, xi)
+    assert torch.equal(t.cpu().double(), wt) and torch.equal(datt.cpu().double(), wa)
+    # a table whose rows are longer than its channels (a view): the scalar offsets follow the stride
+    wide = torch.randn(N, ch + 64, generator=g)
+    t = ops.row_products(rp, wide.to(DEV)[:, :ch], att.to(DEV))
+    wt, _ = want(wide[:, :ch], att, xb)
+    close(t, wt, rtol=2e-5, atol=2e-5 * float(wt.abs().max()))
+
+
 @pytest.mark.parametrize('R,N,d', [(70, 645, 32), (33, 100, 16), (1097, 37, 8)])
 def test_unwritten_rows_masked_end_to_end(ops, R, N, d):
     """Rows (relation, node) without edges: the wave-stream gather with write_zeros=False leaves them untouched

@@ -735,6 +735,48 @@ def test_row_stream_plan_reference(R, N, E):
                 assert abs(n0 - n1) <= longest_row
 
 
+@pytest.mark.parametrize('R,N,E', [(70, 23, 900), (5, 16, 40), (33, 9, 0)])
+def test_row_stream_plan_s_reference(R, N, E):
+    """`build_row_stream_plan_s` (wave-uniform entries of `tipk_rgcn_row_products_s`) interpreted in torch == the definition;
+    one sorted list per (node, tile), `inside` exactly where the previous entry has the same row, padding only at the end."""
+    from tip_amd.plan import build_row_stream_plan_s, execute_row_stream_s_reference, RowStreamPlanS
+    g = torch.Generator().manual_seed(R + N)
+    rel = torch.randint(0, R, (E,), generator=g)
+    key = torch.randint(0, N, (E,), generator=g)
+    other = torch.randint(0, N, (E,), generator=g)
+    rp = build_row_stream_plan_s(key, other, rel, N, R)
+    assert rp.desc.shape == (N, (R + 31) // 32, 2) and rp.entries.dtype == torch.int32
+    nb, ch = 4, 8
+    table, att, xb = torch.randn(N, ch, generator=g), torch.randn(R, nb, generator=g), torch.randn(nb, N, ch, generator=g)
+    s = torch.zeros(R * N, ch, dtype=torch.float64)
+    if E:
+        s.index_add_(0, rel * N + key, table.double()[other])
+    s = s.view(R, N, ch)
+    t, datt = execute_row_stream_s_reference(rp, table, att, xb)
+    assert torch.allclose(t, torch.einsum('rb,rvc->bvc', att.double(), s), rtol=1e-12, atol=1e-12)
+    assert torch.allclose(datt, torch.einsum('rvc,bvc->rb', s, xb.double()), rtol=1e-12, atol=1e-12)
+    w = rp.entries.to(torch.int64)
+    desc = rp.desc.to(torch.int64)
+    pad = 32 * RowStreamPlanS.ROW_BYTES
+    n_real = 0
+    for v in range(N):
+        for tl in range(rp.n_tiles):
+            f, nb_ = int(desc[v, tl, 0]), int(desc[v, tl, 1])
+            assert nb_ >= 1
+            w1 = w[f:f + nb_, 1, :].reshape(-1)
+            real = w1[w1 != pad]
+            assert bool((w1[real.numel():] == pad).all()) and nb_ == max(1, (real.numel() + 15) // 16)
+            rows = real & 0xffff
+            assert bool((rows % RowStreamPlanS.ROW_BYTES == 0).all()) and bool((rows[1:] >= rows[:-1]).all())
+            want_inside = torch.zeros_like(rows)
+            want_inside[1:] = (rows[1:] == rows[:-1]).to(torch.int64) * 0x3f800000
+            assert torch.equal(real & 0x3f800000, want_inside)
+            n_real += real.numel()
+    assert n_real == E
+    e512 = rp.entries_for(512)
+    assert torch.equal(e512[:, 0, :], rp.entries[:, 0, :] * 512) and torch.equal(e512[:, 1, :], rp.entries[:, 1, :])
+
+
 @pytest.mark.parametrize('symmetric,part_rows', [(True, 40), (False, 64), (True, 1008)])
 def test_pair_bwd_plan_reference(symmetric, part_rows):
     """`build_pair_bwd_plan` (include/tipk.h section 2e), interpreted in torch exactly as the two kernels walk it: slots,

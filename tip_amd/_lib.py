@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class TipkError(RuntimeError):
@@ -86,6 +86,8 @@ SIGNATURES = {
     'tipk_rgcn_row_products_supported': (_I, [_L, _L, _I, _I]),
     'tipk_rgcn_row_products_slabs': (_L, [_L, _I]),
     'tipk_rgcn_row_products': (_I, [_P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _P, _L, _P, _P, _P]),
+    'tipk_rgcn_row_products_s_supported': (_I, [_L, _L, _I, _I]),
+    'tipk_rgcn_row_products_s': (_I, [_P, _L, _L, _I, _P, _L, _L, _I, _P, _P, _P, _L, _P, _P, _P]),
     'tipk_sum_slabs_xb': (_I, [_P, _L, _L, _L, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_stream_gather_supported': (_I, [_L, _I, _I]),
     'tipk_stream_gather_piece': (_I, []),

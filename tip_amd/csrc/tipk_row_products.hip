@@ -306,6 +306,214 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_kernel(RpArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// WAVE-UNIFORM entries (channels % 64 == 0).  The fp32 MFMA and the VALU instructions of a SIMD do not overlap on this chip
+// (tools/microbench/mfma_valu_overlap.hip): a launch costs at least MFMA busy + VALU busy, and the kernel above spends 2.5
+// VALU instructions per entry and 64 channels (address add, two running-sum fmacs, LDS address add for two entries a step).
+// Here ONE entry occupies the whole wave -- lane = channel of the 64-channel block -- so everything that depends on the
+// entry alone is SCALAR: the entry words come through s_load, the table row offset is the soffset of `buffer_load_dword`,
+// the LDS row offset goes into M0 for `ds_write_addtid_b32` (address = M0 + lane * 4) and the inside-row flag is an SGPR
+// operand of the one v_fma that is left: 1 VALU instruction per entry (+ 4 on the scalar port).
+// Entry format (plan.RowStreamPlan.scalar()): [batch][2][16] int32, plane 0 = byte offset of the table row (other * bytes
+// per row), plane 1 = byte offset of the tile row (4 * 65 * row; row 32 = padding's dump row) | 0x3f800000 inside a row;
+// one list per (node, tile), sorted by row, padded to 16; desc as above.
+constexpr int RPS_TS = 65;                              // tile row stride in floats (conflict-free operand reads both ways)
+constexpr int RPS_TILE = (33 * RPS_TS + 3) / 4 * 4;     // floats per wave
+
+template <bool P2>
+__global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_s_kernel(RpArgs a) {
+    constexpr int TS = RPS_TS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int row = lane & 31, kh = lane >> 5;
+    float* tile = lds + w * RPS_TILE;                   // wave-private: [row of the relation tile (+ dump row)][65]
+    float* attl = lds + RP_WAVES * RPS_TILE;            // P2: [2][32 rows][33] att tiles shared by the workgroup
+    const int cb = (int)blockIdx.x / a.n_groups, grp = (int)blockIdx.x - cb * a.n_groups;
+    const int node_raw = grp * RP_WAVES + w;
+    const bool wave_on = node_raw < a.n_nodes;
+    const int node = wave_on ? node_raw : a.n_nodes - 1;
+    const int NB = a.NB, R = a.R;
+    const int64_t NC = (int64_t)a.n_nodes * a.ch;
+    const int64_t col0 = (int64_t)node * a.ch + cb * 64;
+    const u32 voff = (u32)(cb * 64 + lane) * 4u;                         // this lane's channel inside a table row
+    u32 tile_base = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(rp_lds_f32_t*)tile);   // (not const: an asm operand inside a lambda)
+    const u32 att_b = (u32)(row < NB ? row : NB - 1) * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.table), 0,
+                                                                           (int)((u32)a.n_nodes * a.ld_table_b), 0x00020000);
+    float xbv[2][16];
+    if (P2) {
+        const int64_t b_off = (int64_t)(row < NB ? row : NB - 1) * a.ld_xb + col0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                xbv[q][kk] = rp_and(a.xb[b_off + 32 * q + 2 * kk + kh], (row < NB && wave_on) ? 0xffffffffu : 0u);
+    }
+    f32x16 acc1[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[q][i] = 0.f;
+    const int32_t* dsc = a.desc + (int64_t)node * a.n_tiles * 2;
+    int b = __builtin_amdgcn_readfirstlane(dsc[0]);
+    int nbat = __builtin_amdgcn_readfirstlane(dsc[1]);
+    int tl = 0;
+    float acc = 0.f;
+    float atv[16];
+    float va[8], vb[8];
+    int w1c[16], wn[32];                                // plane 1 of the current batch; both planes of the next one (SGPRs)
+    // (the constant address space makes these s_load_dwordx16: `entries` is read-only for the whole launch)
+    typedef const __attribute__((address_space(4))) int32_t* rp_const_i32_t;
+    const rp_const_i32_t entries_c = (rp_const_i32_t)(uintptr_t)a.entries;
+    auto load_words = [&](int batch, int (&dst)[32]) __attribute__((always_inline)) {
+        const rp_const_i32_t eb = entries_c + (int64_t)batch * 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dst[j] = eb[j];
+    };
+    auto issue = [&](auto lo_c, float (&val)[8], const int (&w0)[32]) __attribute__((always_inline)) {
+        constexpr int LO = decltype(lo_c)::value;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            val[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, w0[LO + j], 0));
+    };
+    auto consume = [&](auto lo_c, float (&val)[8], const int (&w1)[16]) __attribute__((always_inline)) {
+        constexpr int LO = decltype(lo_c)::value;
+        const u32 tb = tile_base;                       // (a generic lambda does not capture what only an asm operand names)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int wd = w1[LO + j];
+            const float keep = __int_as_float(wd & 0x3f800000);
+            acc = fmaf(acc, keep, val[j]);
+            // M0 = tile base + the entry's plane-1 word as it is: the inside-row bits (23 .. 29) sit above the LDS address
+            // bits the add-TID instruction looks at (tools/microbench/ds_addtid.hip); SALU write of M0 -> add-TID LDS
+            // instruction needs one wait state, which the compiler cannot see inside inline assembly
+            if (!TIPK_DBG(a.dbg & 2))
+                asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(acc), "s"(tb), "s"(wd) : "memory", "scc");
+        }
+    };
+    constexpr int NT = RP_WAVES * 64, PER = 1024 / NT;
+    float att_next[PER];
+    auto att_elem = [&](int tile_i, int i) __attribute__((always_inline)) {
+        const int e = i * NT + t, r = tile_i * 32 + (e >> 5), bb = e & 31;
+        const float v = a.att[(int64_t)(r < R ? r : R - 1) * (a.ld_att_b >> 2) + (bb < NB ? bb : NB - 1)];
+        return rp_and(v, (r < R && bb < NB && tile_i < a.n_tiles) ? 0xffffffffu : 0u);
+    };
+    auto att_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) attl[buf * (32 * RP_TLD) + ((i * NT + t) >> 5) * RP_TLD + (t & 31)] = att_next[i];
+    };
+    if (P2) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) att_next[i] = att_elem(0, i);
+        att_store(0);
+        __syncthreads();
+    }
+    auto begin_tile = [&]() __attribute__((always_inline)) {
+        const int r0 = tl * 32;
+        if (P2) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) att_next[i] = att_elem(tl + 1 < a.n_tiles ? tl + 1 : tl, i);
+        } else {
+            const float* att_t = a.att + (int64_t)r0 * (a.ld_att_b >> 2);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int r = r0 + 2 * kk + kh;
+                atv[kk] = rp_ldg(att_t, (u32)((r < R ? r : R - 1) - r0) * a.ld_att_b + att_b);
+            }
+        }
+        constexpr int N4 = 32 * TS / 4;                                  // rows 0 .. 31 as float4
+        static_assert(32 * TS % 4 == 0, "tile zeroing");
+#pragma unroll
+        for (int i = 0; i < (N4 + 63) / 64; ++i)
+            if (i * 64 + lane < N4) tipk_st4(tile + (i * 64 + lane) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        rp_wave_sync();
+    };
+    auto finish_tile = [&]() __attribute__((always_inline)) {
+        const int r0 = tl * 32;
+        rp_wave_sync();
+        if (!TIPK_DBG(a.dbg & 4))
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const u32 mk = (r0 + 2 * kk + kh < R && row < NB) ? 0xffffffffu : 0u;
+            const float av = P2 ? attl[(tl & 1) * (32 * RP_TLD) + (2 * kk + kh) * RP_TLD + row] : rp_and(atv[kk], mk);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                acc1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tile[(2 * kk + kh) * TS + 32 * q + row], acc1[q], 0, 0, 0);
+        }
+        if (P2) {
+            f32x16 acc2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[row * TS + 32 * q + 2 * kk + kh], xbv[q][kk], acc2, 0, 0, 0);
+            att_store((tl + 1) & 1);
+            rp_wave_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                tile[rr * 32 + row] = acc2[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = i * NT + t;
+                float sum = lds[e];
+#pragma unroll
+                for (int q = 1; q < RP_WAVES; ++q) sum += lds[q * RPS_TILE + e];
+                const int rr = r0 + (e >> 5), bb = e & 31;
+                if (rr < R && bb < NB) a.datt[((int64_t)blockIdx.x * R + rr) * NB + bb] = sum;
+            }
+            __syncthreads();
+        }
+    };
+    constexpr std::integral_constant<int, 0> c0{};
+    constexpr std::integral_constant<int, 8> c8{};
+    load_words(b, wn);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w1c[j] = wn[16 + j];
+    issue(c0, va, wn);
+    issue(c8, vb, wn);
+    for (tl = 0; tl < a.n_tiles; ++tl) {
+        const int nbat_next = __builtin_amdgcn_readfirstlane(dsc[2 * (tl + 1 < a.n_tiles ? tl + 1 : tl) + 1]);
+        begin_tile();
+        int i = 0;
+        do {                                            // (at least one batch per tile)
+            load_words(b + 1, wn);                      // (past the node's last batch: the next node's, or padding; unused)
+            consume(c0, va, w1c);
+            issue(c0, va, wn);
+            consume(c8, vb, w1c);
+            issue(c8, vb, wn);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w1c[j] = wn[16 + j];
+            ++b;
+        } while (++i < nbat);
+        finish_tile();
+        nbat = nbat_next;
+    }
+    if (wave_on) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int bb = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (bb < NB) a.t_out[(int64_t)bb * NC + col0 + 32 * q + row] = acc1[q][r];
+            }
+    }
+}
+
+template <bool P2>
+int rps_launch(const RpArgs& a, unsigned blocks, hipStream_t st) {
+    const size_t lds = (size_t)(RP_WAVES * RPS_TILE + (P2 ? 2 * 32 * RP_TLD : 0)) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)row_products_s_kernel<P2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return tipk_hip_status(e);
+    hipLaunchKernelGGL((row_products_s_kernel<P2>), dim3(blocks), dim3(RP_WAVES * 64), lds, st, a);
+    TIPK_RETURN_LAUNCH();
+}
+
 template <int CPL> constexpr size_t rp_lds_bytes(bool p2) {
     return (size_t)(RP_WAVES * RpGeom<CPL>::TILE + (p2 ? 2 * 32 * RP_TLD : 0)) * sizeof(float);
 }
@@ -359,4 +567,29 @@ extern "C" int tipk_rgcn_row_products(const float* table, int64_t ld_table, int6
     hipStream_t st = (hipStream_t)stream;
     if (xb) return cpl == 2 ? rp_launch<true, 2>(a, blocks, st) : rp_launch<true, 1>(a, blocks, st);
     return cpl == 2 ? rp_launch<false, 2>(a, blocks, st) : rp_launch<false, 1>(a, blocks, st);
+}
+
+extern "C" int tipk_rgcn_row_products_s_supported(int64_t n_nodes, int64_t n_rel, int n_bases, int channels) {
+    if (n_nodes <= 0 || n_rel <= 0 || n_bases <= 0 || n_bases > 32 || channels <= 0 || channels % 64 != 0) return 0;
+    if (n_rel > 0x7fffffffLL || tipk_ceil_div(n_nodes, RP_WAVES) * (channels / 64) > 0x7fffffffLL) return 0;
+    return 1;
+}
+
+extern "C" int tipk_rgcn_row_products_s(const float* table, int64_t ld_table, int64_t n_nodes, int channels, const float* att,
+                                        int64_t ld_att, int64_t n_rel, int n_bases, const int32_t* entries, const int32_t* desc,
+                                        const float* xb, int64_t ld_xb, float* t_out, float* datt_slabs, tipk_stream_t stream) {
+    if (!tipk_rgcn_row_products_s_supported(n_nodes, n_rel, n_bases, channels)) return TIPK_EUNSUPPORTED;
+    if (!table || !att || !entries || !desc || !t_out || ld_table < channels || ld_att < n_bases) return TIPK_EINVAL;
+    if ((xb == nullptr) != (datt_slabs == nullptr) || (xb && ld_xb < n_nodes * channels)) return TIPK_EINVAL;
+    if (n_nodes * ld_table * 4 >= (1LL << 31) || 32 * ld_att * 4 >= (1LL << 31)) return TIPK_EUNSUPPORTED;   // 32-bit byte offsets
+    RpArgs a;
+    a.table = table; a.ld_table_b = (u32)(ld_table * 4); a.n_nodes = (int)n_nodes; a.ch = channels;
+    a.att = att; a.ld_att_b = (u32)(ld_att * 4); a.R = (int)n_rel; a.NB = n_bases;
+    a.xb = xb; a.ld_xb = ld_xb;
+    a.entries = entries; a.desc = desc; a.n_tiles = (int)tipk_ceil_div(n_rel, 32);
+    a.t_out = t_out; a.datt = datt_slabs;
+    a.n_groups = (int)tipk_ceil_div(n_nodes, RP_WAVES);
+    a.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DP_DEBUG));
+    const unsigned blocks = (unsigned)(a.n_groups * (channels / 64));
+    return xb ? rps_launch<true>(a, blocks, (hipStream_t)stream) : rps_launch<false>(a, blocks, (hipStream_t)stream);
 }

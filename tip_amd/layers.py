@@ -22,7 +22,7 @@ from torch.nn import Parameter as Param
 from . import ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
-from .plan import (build_pair_bwd_plan, build_dest_plan, build_row_stream_plan, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
+from .plan import (build_pair_bwd_plan, build_dest_plan, build_row_stream_plan, build_row_stream_plan_s, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
                    relations_per_segment, DEFAULT_CHUNK)
 from .utils import process_edges, auprc_auroc_ap_by_range
 
@@ -464,8 +464,11 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         if n_nodes < (1 << 23):
             # row sums assembled in LDS (tipk_rgcn_row_products): rows (relation, destination) <- sources for the forward pass,
             # rows (relation, source) <- destinations for the transposed pass
-            row_fwd = lambda: build_row_stream_plan(dst, src, rel, n_nodes, n_rel)
-            row_bwd = lambda: build_row_stream_plan(src, dst, rel, n_nodes, n_rel)
+            # (widths that are multiples of 64: the wave-uniform form, tipk_rgcn_row_products_s)
+            wide = bool(d_out) and d_out % 64 == 0 and ops.row_products_s_supported(n_nodes, n_rel, n_bases, d_out)
+            build = build_row_stream_plan_s if wide else build_row_stream_plan
+            row_fwd = lambda: build(dst, src, rel, n_nodes, n_rel)
+            row_bwd = lambda: build(src, dst, rel, n_nodes, n_rel)
 
     def fwd_plan():
         # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by

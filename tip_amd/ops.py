@@ -536,7 +536,41 @@ def row_products_supported(n_nodes, n_rel, nb, channels):
     return bool(lib().tipk_rgcn_row_products_supported(int(n_nodes), int(n_rel), int(nb), int(channels)))
 
 
+def row_products_s_supported(n_nodes, n_rel, nb, channels):
+    if os.environ.get('TIPK_NO_ROW_PRODUCTS_S'):
+        return False
+    return bool(lib().tipk_rgcn_row_products_s_supported(int(n_nodes), int(n_rel), int(nb), int(channels)))
+
+
 def row_products(rp, table, att, xb2=None):
+    if getattr(rp, 'ROW_BYTES', None) is not None:
+        return _row_products_s(rp, table, att, xb2)
+    return _row_products_v(rp, table, att, xb2)
+
+
+def _row_products_s(rp, table, att, xb2=None):
+    """`tipk_rgcn_row_products_s` on a `plan.RowStreamPlanS` (wave-uniform entries): same results as the form below."""
+    table, att = _f32c(table), _f32c(att)
+    require_device(table, att, rp.entries)
+    n, ch = table.shape
+    r, nb = att.shape
+    assert rp.n_nodes == n and rp.n_rel == r and table.stride(1) == 1 and att.stride(1) == 1
+    entries = rp.entries_for(table.stride(0) * 4)
+    t = torch.empty((nb, n, ch), dtype=torch.float32, device=table.device)
+    slabs = None
+    if xb2 is not None:
+        assert xb2.shape == (nb, n * ch) and xb2.stride(1) == 1
+        slabs = torch.empty((-(-n // 8) * (ch // 64), r, nb), dtype=torch.float32, device=table.device)
+    with _timed('row_products_s[%dx%dx%d,edges=%d,%s]' % (n, nb, ch, rp.n_edges, 'T+datt' if slabs is not None else 'T')):
+        check(lib().tipk_rgcn_row_products_s(ptr(table), table.stride(0), n, ch, ptr(att), att.stride(0), r, nb, ptr(entries),
+                                             ptr(rp.desc), ptr(xb2), xb2.stride(0) if xb2 is not None else 0, ptr(t), ptr(slabs),
+                                             stream_ptr(table.device)), 'tipk_rgcn_row_products_s')
+    if slabs is None:
+        return t
+    return slab_job(slabs), t
+
+
+def _row_products_v(rp, table, att, xb2=None):
     """The (relation, node) row sums S = sum of table rows over a row's edges, assembled in LDS, and their products
     (`tipk_rgcn_row_products`, include/tipk.h section 2h) on a `plan.RowStreamPlan`:
     table [N, ch], att [R, bases] -> T [bases, N, ch] = sum_r att[r, b] S[(r, v)];  with xb2 [bases, N * ch] also the slab
@@ -1552,6 +1586,8 @@ class _RGCN(torch.autograd.Function):
         # node) row sums are multiplied where they are assembled, or per destination T[:, v, :] = sum_e att[r_e, :]^T (x) X[src_e]
         # (a product over the node's incoming edges); then sum_b T_b basis_b
         rows = graph.row_fwd if (r > 0 and not use_rl and row_products_supported(n, r, nb, d_in)) else None
+        if rows is not None and getattr(rows, 'ROW_BYTES', None) is not None and not row_products_s_supported(n, r, nb, d_in):
+            rows = None                                                      # (wave-uniform plan, width no multiple of 64)
         dest = graph.dest_fwd if (r > 0 and not use_rl and rows is None) else None
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
@@ -1645,7 +1681,8 @@ class _RGCN(torch.autograd.Function):
             elif rel_gather_usable(graph.rl_bwd, n, d_out, True):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
             elif (graph.row_bwd is not None and row_products_supported(n, r, nb, d_out) and xb2 is not None
-                  and n * d_out * 4 < 2 ** 32):
+                  and n * d_out * 4 < 2 ** 31
+                  and (getattr(graph.row_bwd, 'ROW_BYTES', None) is None or row_products_s_supported(n, r, nb, d_out))):
                 # LARGE node sets: dY = A_r^T (D^-1 g') is never written -- its rows are summed in LDS and multiplied there
                 gs = rows_affine(g, row_mul=graph.scale)
                 j_rows, g_xb = row_products(graph.row_bwd, gs, att, xb2)

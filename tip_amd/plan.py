@@ -1216,6 +1216,88 @@ def build_row_stream_plan(key, other, rel, n_nodes, n_rel):
     return RowStreamPlan(n_nodes, n_rel, entries.contiguous(), desc, e)
 
 
+class RowStreamPlanS(object):
+    """Wave-uniform form of the row-sum plan (`tipk_rgcn_row_products_s`, include/tipk.h section 2h): ONE list per (node, tile
+    of 32 relations), sorted by relation, padded to batches of 16 entries:
+
+        entries [n_batches, 2, 16] int32   plane 0 = `other` (the node whose table row is gathered; `entries_for(ld_bytes)`
+                                           multiplies it by the bytes of a table row: what the kernel's buffer loads take as
+                                           their scalar offset), plane 1 = 260 * row | 0x3f800000 inside a (relation, node)
+                                           row (260 = 4 * 65: the byte stride of the kernel's LDS tile; row 32 = padding)
+        desc    [n_nodes, n_tiles, 2] int32  {first batch, batches >= 1}; the array ends with 8 batches of padding"""
+    ROW_BYTES = 260
+
+    def __init__(self, n_nodes, n_rel, entries, desc, n_edges):
+        self.n_nodes, self.n_rel, self.entries, self.desc, self.n_edges = int(n_nodes), int(n_rel), entries, desc, int(n_edges)
+        self.n_tiles = (self.n_rel + 31) // 32
+        self._by_ld = {}
+
+    def to(self, device):
+        return RowStreamPlanS(self.n_nodes, self.n_rel, self.entries.to(device), self.desc.to(device), self.n_edges)
+
+    def entries_for(self, ld_bytes):
+        ld_bytes = int(ld_bytes)
+        if ld_bytes not in self._by_ld:
+            assert self.n_nodes * ld_bytes < 2 ** 31
+            e = self.entries.clone()
+            e[:, 0, :] *= ld_bytes
+            self._by_ld[ld_bytes] = e.contiguous()
+        return self._by_ld[ld_bytes]
+
+
+def build_row_stream_plan_s(key, other, rel, n_nodes, n_rel):
+    """Edges sorted by (key, relation), stable: the sums are a fixed sequence."""
+    dev = key.device
+    n_nodes, n_rel = int(n_nodes), int(n_rel)
+    n_tiles = (n_rel + 31) // 32
+    key, other, rel = key.to(torch.int64), other.to(torch.int64), rel.to(torch.int64)
+    e = int(key.numel())
+    n_seg = n_nodes * n_tiles
+    seg = key * n_tiles + rel // 32
+    row_key = key * n_rel + rel
+    order = torch.sort(row_key, stable=True).indices
+    seg_s, row_s = seg[order], row_key[order]
+    n_in = torch.bincount(seg_s, minlength=n_seg)
+    nbat = torch.clamp((n_in + 15) // 16, min=1)
+    first = torch.cumsum(nbat, 0) - nbat
+    n_batches = int(nbat.sum())
+    entries = torch.zeros((n_batches + 8, 2, 16), dtype=torch.int32, device=dev)
+    entries[:, 1, :] = 32 * RowStreamPlanS.ROW_BYTES                     # padding: row 0 of the table into the dump row
+    if e:
+        seg_first = torch.cumsum(n_in, 0) - n_in
+        pos = torch.arange(e, device=dev) - seg_first[seg_s]
+        inside = torch.zeros(e, dtype=torch.int64, device=dev)
+        inside[1:] = (row_s[1:] == row_s[:-1]).to(torch.int64)
+        flat0 = (first[seg_s] + pos // 16) * 32 + pos % 16
+        entries.view(-1)[flat0] = other[order].to(torch.int32)
+        entries.view(-1)[flat0 + 16] = ((rel[order] % 32) * RowStreamPlanS.ROW_BYTES + inside * 0x3f800000).to(torch.int32)
+    desc = torch.stack([first, nbat], dim=1).to(torch.int32).view(n_nodes, n_tiles, 2).contiguous()
+    return RowStreamPlanS(n_nodes, n_rel, entries.contiguous(), desc, e)
+
+
+def execute_row_stream_s_reference(plan, table, att, xb=None):
+    """What `tipk_rgcn_row_products_s` computes, from the plan alone (float64)."""
+    n, r, nt = plan.n_nodes, plan.n_rel, plan.n_tiles
+    table, att = table.double().cpu(), att.double().cpu()
+    ent = plan.entries.cpu().to(torch.int64)
+    desc = plan.desc.cpu().to(torch.int64)
+    ch = table.shape[1]
+    s = torch.zeros((nt * 32 + 1, n, ch), dtype=torch.float64)
+    for v in range(n):
+        for tl in range(nt):
+            f, nb_ = int(desc[v, tl, 0]), int(desc[v, tl, 1])
+            oth = ent[f:f + nb_, 0, :].reshape(-1)
+            w1 = ent[f:f + nb_, 1, :].reshape(-1)
+            row = (w1 & 0xffff) // RowStreamPlanS.ROW_BYTES
+            rows = torch.where(row < 32, tl * 32 + row, torch.full_like(row, nt * 32))
+            s[:, v].index_add_(0, rows, table[oth])
+    s = s[:r]
+    t = torch.einsum('rb,rvc->bvc', att, s)
+    if xb is None:
+        return t
+    return t, torch.einsum('rvc,bvc->rb', s, xb.double().cpu())
+
+
 def execute_row_stream_reference(plan, table, att, xb=None):
     """What `tipk_rgcn_row_products` computes, from the plan alone (float64): T [nb, n, ch] and (with xb [nb, n, ch]) d att."""
     n, r, nt = plan.n_nodes, plan.n_rel, plan.n_tiles

@@ -26,6 +26,12 @@ def t(f, reps=3):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+from tip_amd.plan import build_row_stream_plan_s
+rs = build_row_stream_plan_s(dst, src, rel, n, r)
+print('wave-uniform entries: %d batches, padding %.2f x' % (rs.entries.shape[0], rs.entries.shape[0] * 16 / max(1, rel.numel())))
+print('S forward  (T)        ms %.3f' % t(lambda: ops.row_products(rs, x, att)))
+print('S backward (T + datt) ms %.3f' % t(lambda: ops.row_products(rs, x, att, xb)))
+ts_ = ops.row_products(rs, x, att)
 print('forward  (T)        ms %.3f' % t(lambda: ops.row_products(rp, x, att)))
 print('backward (T + datt) ms %.3f' % t(lambda: ops.row_products(rp, x, att, xb)))
 if '+debug' in _lib.build_id():
@@ -35,6 +41,7 @@ if '+debug' in _lib.build_id():
     _lib.set_option('dp_debug', 0)
 # sampled check against the definition
 tt = ops.row_products(rp, x, att)
+print('S vs V: max |dT| / max |T| = %.2e' % float((ts_ - tt).abs().max() / tt.abs().max()))
 for v in (0, n // 2, n - 1):
     m = dst == v
     s = torch.zeros(r, ch, dtype=torch.float64, device=dev)
