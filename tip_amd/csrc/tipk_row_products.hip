@@ -421,6 +421,13 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_s_kernel(RpArgs
                 const int r = r0 + 2 * kk + kh;
                 atv[kk] = rp_ldg(att_t, (u32)((r < R ? r : R - 1) - r0) * a.ld_att_b + att_b);
             }
+            // rows beyond R / bases beyond NB are cleared HERE, and only in a tile that has any (the last one of a relation
+            // count that is no multiple of 32; fewer than 32 bases): per MFMA the masks were 64 of a tile's ~200 VALU instructions
+            if (r0 + 32 > R || NB < 32) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
+                    atv[kk] = rp_and(atv[kk], (r0 + 2 * kk + kh < R && row < NB) ? 0xffffffffu : 0u);
+            }
         }
         constexpr int N4 = 32 * TS / 4;                                  // rows 0 .. 31 as float4
         static_assert(32 * TS % 4 == 0, "tile zeroing");
@@ -435,8 +442,7 @@ __global__ __launch_bounds__(RP_WAVES * 64, 4) void row_products_s_kernel(RpArgs
         if (!TIPK_DBG(a.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const u32 mk = (r0 + 2 * kk + kh < R && row < NB) ? 0xffffffffu : 0u;
-            const float av = P2 ? attl[(tl & 1) * (32 * RP_TLD) + (2 * kk + kh) * RP_TLD + row] : rp_and(atv[kk], mk);
+            const float av = P2 ? attl[(tl & 1) * (32 * RP_TLD) + (2 * kk + kh) * RP_TLD + row] : atv[kk];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 acc1[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tile[(2 * kk + kh) * TS + 32 * q + row], acc1[q], 0, 0, 0);
