@@ -25,7 +25,7 @@ for f in glob.glob('gpurun_out/pmc_rp/p*/**/*counter_collection.csv', recursive=
         k = r['Kernel_Name']
         if 'row_products' not in k: continue
         import re
-        m = re.search(r'row_products_kernel<[^>]*>', k)
+        m = re.search(r'row_products(_s)?_kernel<[^>]*>', k)
         key = m.group(0) if m else k[:60]
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 with open('profiles/${TAG}_pmc_row_products.txt', 'w') as out:
