@@ -327,7 +327,7 @@ def dd_launches(enc, dev):
                         edges=pair.n_edges, row_floats=nb, aggregation=True)
                 add('pair_product[dd.fwd,d=%d]' % d, 'pair_product_kernel', None, 'mfma', 2.0 * n * n * nb * d,
                     lambda cells=cells, xb_nb=xb_nb, pair=pair, z=_zeros: ops.pair_product(cells, xb_nb, symmetric=pair.symmetric,
-                                                                                           live=pair.live, zeros=z),
+                                                                                           links=pair.links, zeros=z),
                     hbm_bytes=cells.numel() * 4.0 / (2 if pair.symmetric else 1))
             elif rs is not None and ops.rel_stream_split(n, d):
                 split = ops.rel_stream_split(n, d)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 20
+#define TIPK_ABI_VERSION 21
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -353,15 +353,15 @@ int tipk_gemm_wg_group(const tipk_wg_gemm_desc* descs /* host, [count <= TIPK_WG
  *     (`tipk_pair_product_supported`; otherwise tipk_gemm_f32 with kbatch = group does the same sums).
  *     symmetric != 0: every relation links u -> v iff it links v -> u (BioSNAP), so cells[u][v] == cells[v][u]
  *     and the gather only built the cells with u <= v (half the edges); cell (u, v) with v < u is read at (v, u).
- *     live (nullable): uint8 [n_src / group][ceil(n_dst / 32)], bit q = "some pair (group's node q, one of the tile's 32
- *     destinations) is linked": tiles without a link are not fetched (their cells are zeros by construction; `zeros` =
- *     >= n_bases * 4 bytes of zeros (128 B at n_bases = 32), 16-byte aligned, read in their place).
+ *     links (nullable): uint32 [n_src][ceil(n_dst / 32)], bit r of word (u, t) = "pair (u, 32 t + r) is linked" (rows of the
+ *     padding nodes zero; on a symmetric graph bit (u, v) == bit (v, u)): the cell of an unlinked pair is not fetched (it is
+ *     zero by construction; `zeros` = >= n_bases * 4 bytes of zeros (128 B at n_bases = 32), 16-byte aligned, read in its place).
  *     xbt (nullable, [n_dst][d][n_bases], 16-byte aligned): XB of the first n_dst source nodes written back with the bases
  *     innermost -- the operand layout of the backward pass (tipk_rgcn_node_products xbt), from the LDS stage of this kernel.
  */
 int tipk_pair_product_supported(int n_bases, int d);
 int tipk_pair_product(const float* cells, const float* xb, int64_t n_src, int64_t n_dst, int n_bases, int d,
-                      int group, int symmetric, const uint8_t* live, const float* zeros, float* xbt /* nullable */,
+                      int group, int symmetric, const uint32_t* links, const float* zeros, float* xbt /* nullable */,
                       float* slabs, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

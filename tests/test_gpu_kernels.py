@@ -850,23 +850,23 @@ def test_pair_product(ops, n, nb, d, monkeypatch):
     junk[:n][lower] = float('nan')
     got_s = ops.pair_product(junk.to(DEV), xb.to(DEV), symmetric=True)
     close(got_s, want_s, rtol=2e-5, atol=2e-5 * float(want_s.abs().max()))
-    # tiles without a linked pair are not fetched (`live`: bit q of [group][tile of 32 destinations]): cells of such tiles
-    # may hold anything -- the product reads zeros in their place -- and the result equals the product of the masked cells
+    # cells of unlinked pairs are not fetched (`links`: bit r of word (u, t) = pair (u, 32 t + r) is linked): such cells may
+    # hold anything -- the product reads zeros in their place -- and the result equals the product of the masked cells
     gl = torch.Generator().manual_seed(n + 1)
     n8, n32 = cells.shape[0], -(-n // 32) * 32
     link = torch.zeros(n8, n32, dtype=torch.bool)
     link[:n, :n] = torch.rand(n, n, generator=gl) < 0.08
     link[:n, :n] |= link[:n, :n].t().clone()                                         # symmetric links
-    tiles = link.view(n8 // 8, 8, n32 // 32, 32).any(-1)
-    live = (tiles.long() << torch.arange(8).view(1, 8, 1)).sum(1).to(torch.uint8).contiguous()
-    keep = tiles.unsqueeze(-1).expand(-1, -1, -1, 32).reshape(n8, n32)[:, :n]        # cell (u, v) lies in a live tile
+    w = (link.view(n8, n32 // 32, 32).to(torch.int64) << torch.arange(32).view(1, 1, 32)).sum(-1)
+    links = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+    keep = link[:, :n]                                                               # cell (u, v) is read iff the pair is linked
     masked = full * keep.unsqueeze(-1)
     want_l = torch.einsum('guvb,gubc->gvc', masked.double().view(-1, ops.PAIR_KGROUP, n, nb), xb.double().view(-1, ops.PAIR_KGROUP, nb, d))
     poison = sym.clone()
     never = ~(keep[:n] | keep[:n].t())                                               # (a stored cell serves (u, v) and (v, u))
     poison[:n][never] = float('nan')
     poison[:n][lower] = float('nan')
-    got_l = ops.pair_product(poison.to(DEV), xb.to(DEV), symmetric=True, live=live.to(DEV), zeros=torch.zeros(64, device=DEV))
+    got_l = ops.pair_product(poison.to(DEV), xb.to(DEV), symmetric=True, links=links.to(DEV), zeros=torch.zeros(64, device=DEV))
     close(got_l, want_l, rtol=2e-5, atol=2e-5 * float(want_s.abs().max()))
 
 

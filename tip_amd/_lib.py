@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class TipkError(RuntimeError):

@@ -18,6 +18,7 @@
 //                              columns (zeros beyond d), so a group's blocks are one contiguous 32 KB copy
 // (instruction kk multiplies base (NB / 2) * half + kk: a fixed permutation of the reduction index).
 #include <stdlib.h>
+#include <type_traits>
 #include "tipk_common.h"
 
 namespace {
@@ -31,8 +32,8 @@ struct PpArgs {
     int n_src, n_dst, d, group;        // n_src: multiple of group (padded blocks are zero)
     int row_tiles, n_groups;           // row_tiles: tiles of 128 destination rows
     int symmetric;                     // cells hold only source <= destination: C[u][v] for v < u is read at C[v][u]
-    const uint8_t* live;               // nullable: [n_groups][ceil(n_dst / 32)] bit q = some cell (u0 + q, the 32 rows) is linked
-    const float* zeros;                // >= NB * 4 bytes of zeros (read in place of the cells of a tile without links)
+    const uint32_t* links;             // nullable: [n_src][ceil(n_dst / 32)] bit r of word (u, t) = pair (u, 32 t + r) is linked
+    const float* zeros;                // >= NB * 4 bytes of zeros (read in place of the cell of an unlinked pair)
     float* xbt;                        // nullable: [n_dst][d][NB] -- XB written back base-innermost (by the row-tile-0 workgroups)
 };
 
@@ -44,6 +45,16 @@ __global__ __launch_bounds__(256) void pair_product_kernel(PpArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = (int)blockIdx.x / a.row_tiles, rt = (int)blockIdx.x - g * a.row_tiles;
     const int u0 = g * PP_GROUP;
+    // the link words of this wave's 32 destination rows, one per source node of the group (requested first: they steer the
+    // cell loads, and travel while XB is staged)
+    const int v0 = rt * 128 + wv * 32;
+    uint32_t lk[PP_GROUP];
+    {
+        const int lw = (a.n_dst + 31) >> 5;
+        const int tcol = v0 < a.n_dst ? (v0 >> 5) : 0;
+#pragma unroll
+        for (int q = 0; q < PP_GROUP; ++q) lk[q] = a.links ? a.links[(int64_t)(u0 + q) * lw + tcol] : 0xffffffffu;
+    }
     // stage XB[u0 .. u0 + PP_GROUP) : [node][base][d] -> LDS rows of 32 floats
     {
         // stage XB[u0 .. u0 + PP_GROUP): rows are stored padded to 32 columns, so the block IS the LDS image
@@ -70,22 +81,20 @@ __global__ __launch_bounds__(256) void pair_product_kernel(PpArgs a) {
             }
         }
     }
-    const int v0 = rt * 128 + wv * 32;
     if (v0 >= a.n_dst) return;
     const int v = v0 + row < a.n_dst ? v0 + row : a.n_dst - 1;                  // clamped: rows past the end are not stored
     const int64_t a_step = (int64_t)a.n_dst * NB;
     const float* ap = a.cells + ((int64_t)u0 * a.n_dst + v) * NB + KH * kh;     // cell (u0 + q, v): + q * a_step
     const float* at = a.cells + ((int64_t)v * a.n_dst + u0) * NB + KH * kh;     // mirrored cell (v, u0 + q): + q * NB
     float a0[KH], a1[KH], a2[KH];
-    // 19 % of the (32 destination rows, source node) tiles of BioSNAP hold no linked pair (30 % of the cells are linked):
-    // their 4 KB are not fetched -- every lane reads one shared block of zeros instead (no branch: the MFMAs run on zeros)
-    const unsigned live = a.live ? a.live[(int64_t)g * ((a.n_dst + 31) >> 5) + (v0 >> 5)] : 0xffu;
+    // 30 % of BioSNAP's drug pairs are linked: the cell of an UNLINKED pair is not fetched -- its lane reads one shared
+    // block of zeros instead (no branch: the MFMAs run on zeros).  Round 4 skipped whole (32 rows, source node) tiles
+    // without a link (19 % of them); per row the cell traffic falls from 43 MB to the 16 MB that hold data.
     const float* zp = a.zeros + KH * kh;
-    auto fetch = [&](float (&av)[KH], int q) {
-        q = q < PP_GROUP ? q : PP_GROUP - 1;
+    auto fetch = [&](float (&av)[KH], int q) __attribute__((always_inline)) {       // (q is a literal at every call)
         const bool mirrored = a.symmetric && v < u0 + q && u0 + q < a.n_dst;
         const float* p = mirrored ? at + q * NB : ap + q * a_step;
-        p = (live >> q) & 1u ? p : zp;
+        p = (lk[q] >> row) & 1u ? p : zp;
 #pragma unroll
         for (int i = 0; i < KH / 4; ++i) {
             const float4 x = tipk_ld4(p + 4 * i);
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void pair_product_kernel(PpArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    auto multiply = [&](const float (&av)[KH], int q) {
+    auto multiply = [&](const float (&av)[KH], int q) __attribute__((always_inline)) {
         const float* b = xbl + (q * NB + KH * kh) * 32 + row;
 #pragma unroll
         for (int kk = 0; kk < KH; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], b[kk * 32], acc, 0, 0, 0);
@@ -128,17 +137,17 @@ extern "C" int tipk_pair_product_supported(int n_bases, int d) {
 }
 
 extern "C" int tipk_pair_product(const float* cells, const float* xb, int64_t n_src, int64_t n_dst, int n_bases, int d,
-                                 int group, int symmetric, const uint8_t* live, const float* zeros, float* xbt,
+                                 int group, int symmetric, const uint32_t* links, const float* zeros, float* xbt,
                                  float* slabs, tipk_stream_t stream) {
     if (!cells || !xb || !slabs || n_src <= 0 || n_dst <= 0 || group != PP_GROUP || n_src % group != 0) return TIPK_EINVAL;
-    if (live && (!zeros || (reinterpret_cast<uintptr_t>(zeros) & 15))) return TIPK_EINVAL;
+    if (links && (!zeros || (reinterpret_cast<uintptr_t>(zeros) & 15))) return TIPK_EINVAL;
     if (xbt && ((reinterpret_cast<uintptr_t>(xbt) & 15) || n_src < n_dst)) return TIPK_EINVAL;   // (sources = destinations = the drugs)
     if (!tipk_pair_product_supported(n_bases, d)) return TIPK_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(cells) & 15) || (reinterpret_cast<uintptr_t>(xb) & 15) || n_src * n_dst * n_bases >= (1LL << 40)) return TIPK_EINVAL;
     PpArgs a;
     a.cells = cells; a.xb = xb; a.slabs = slabs;
     a.n_src = (int)n_src; a.n_dst = (int)n_dst; a.d = d; a.group = group; a.symmetric = symmetric != 0;
-    a.live = live; a.zeros = live ? zeros : cells; a.xbt = xbt;
+    a.links = links; a.zeros = links ? zeros : cells; a.xbt = xbt;
     a.row_tiles = (int)tipk_ceil_div(n_dst, 128);
     a.n_groups = (int)(n_src / group);
     const int64_t blocks = (int64_t)a.row_tiles * a.n_groups;

@@ -388,6 +388,15 @@ def _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg,
     return plan
 
 
+def pair_link_words(src, dst, n_nodes):
+    """uint32 words (as int32) [n_nodes padded to 8][ceil(n_nodes / 32)]: bit r of word (u, t) = some edge links u -> 32 t + r."""
+    n8, n32 = -(-n_nodes // 8) * 8, -(-n_nodes // 32) * 32
+    link = torch.zeros((n8, n32), dtype=torch.bool, device=src.device)
+    link[src, dst] = True
+    w = (link.view(n8, n32 // 32, 32).to(torch.int64) << torch.arange(32, device=src.device).view(1, 1, 32)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
 def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
     scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `in_degree`: [N]
@@ -430,13 +439,9 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             pair_fwd = build_stream_plan_rows(src[keep] * n_nodes + dst[keep], rel[keep], n_nodes * n_nodes, n_rel, n_cu,
                                               (n_bases // split_p) // 4, ops.rel_stream_piece())
             pair_fwd.symmetric = symmetric
-            # which (32 destinations, source node) tiles of the cell matrix hold a linked pair: the product does not fetch
-            # the others (uint8 [sources / 8][ceil(N / 32)], bit q = node 8 g + q; tipk.h section 2c `live`)
-            n8, n32 = -(-n_nodes // 8) * 8, -(-n_nodes // 32) * 32
-            link = torch.zeros((n8, n32), dtype=torch.bool, device=src.device)
-            link[src, dst] = True
-            tiles = link.view(n8 // 8, 8, n32 // 32, 32).any(-1)                        # [groups, 8, tiles]
-            pair_fwd.live = (tiles.long() << torch.arange(8, device=src.device).view(1, 8, 1)).sum(1).to(torch.uint8).contiguous()
+            # which pairs are linked at all, one bit per (source, destination): the product fetches only their cells
+            # (uint32 [sources padded to 8][ceil(N / 32)], bit r of word (u, t) = pair (u, 32 t + r); tipk.h section 2c `links`)
+            pair_fwd.links = pair_link_words(src, dst, n_nodes)
         # transposed pass: wave streams (no work units, no barriers) when g' fits in LDS, else relation-local units
         split_s = ops.rel_stream_split(n_nodes, d_out) if on_dev and n_rel * n_nodes < 2 ** 24 else 0
         if pair_fwd is not None and ops.pair_grads_supported(n_bases, d_out):

@@ -1173,10 +1173,12 @@ PAIR_FWD_MAX_WORLD = 4   # fallback rule when the forward routes cannot be timed
 PAIR_KGROUP = 8          # source nodes whose products are summed inside one wavefront of the pair-form product
 
 
-def pair_product(cells, xb_nb, symmetric=False, live=None, zeros=None, xbt=None):
+def pair_product(cells, xb_nb, symmetric=False, links=None, zeros=None, xbt=None):
     """slabs[g] = sum_{u in group g} cells[u] (N x bases) @ xb_nb[u] (bases x out)  (include/tipk.h section 2c):
     cells [N_pad, N, bases], xb_nb [N_pad, bases, out] -- or a column slice [..., :out] of a buffer whose rows are
     padded to 32 columns with zeros (what the dedicated kernel reads) -> [N_pad / PAIR_KGROUP, N, out].
+    links (optional, uint32 [N_pad, ceil(N / 32)] as int32): bit r of word (u, t) = pair (u, 32 t + r) is linked; the cells of the
+    other pairs are not read (they are zero).
     xbt (optional, [N, out, bases] contiguous): filled with XB of the N nodes, bases innermost (`node_products` reads it)."""
     n_pad, n, nb = cells.shape
     d = xb_nb.shape[2]
@@ -1193,7 +1195,7 @@ def pair_product(cells, xb_nb, symmetric=False, live=None, zeros=None, xbt=None)
     assert padded, 'tipk_pair_product reads XB rows padded to 32 columns (AggGraph.pair_buffers)'
     slabs = torch.empty((n_pad // PAIR_KGROUP, n, d), dtype=torch.float32, device=cells.device)
     with _timed('pair_product[%dx%dx%dx%d]' % (n_pad, n, nb, d)):
-        check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(live), ptr(zeros),
+        check(lib().tipk_pair_product(ptr(cells), ptr(xb_nb), n_pad, n, nb, d, PAIR_KGROUP, int(symmetric), ptr(links), ptr(zeros),
                                       ptr(xbt), ptr(slabs), stream_ptr(cells.device)), 'tipk_pair_product')
     return slabs
 
@@ -1565,7 +1567,7 @@ class _RGCN(torch.autograd.Function):
                 g2.cells_token = (att2.data_ptr(), att2._version, g2.pair_stamp)
             else:
                 stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
-            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, live=getattr(pair, 'live', None), zeros=zeros, xbt=xbt)
+            slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, links=getattr(pair, 'links', None), zeros=zeros, xbt=xbt)
             if shard is None and defer_output and relu == 'gated_downstream' and d_out == 32:
                 # the ordered slab sum is left to the ONE consumer of this output (the next R-GCN layer, which runs it in the
                 # launch of its own XB product): until then `out` is storage only

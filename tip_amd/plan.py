@@ -543,7 +543,7 @@ class StreamPlan(object):
         # the (relation, node) form of `build_stream_plan`: rows = relation * n_nodes + node
         self.row_used = row_used                  # int32 [ceil(R / 32), N] bit mask of the rows with edges (tipk.h section 2b)
         self.symmetric = False                    # pair-form plans: built from the edges with source <= destination only
-        self.live = None                          # pair-form plans: uint8 [sources / 8, ceil(N / 32)] tiles of the cell matrix with a linked pair
+        self.links = None                         # pair-form plans: link words [sources padded to 8, ceil(N / 32)] (layers.pair_link_words)
         self.n_edges = 0                          # edges the plan walks
         self.n_nodes, self.n_rel = n_nodes, n_rel
         self.compact = None                       # CompactRows: the rows are the node-major compact numbering (tipk.h section 2d)
@@ -556,7 +556,7 @@ class StreamPlan(object):
                         mv(self.ids), mv(self.zero_ptr), mv(self.zero_rows), self.idx_unit, mv(self.row_used),
                         self.n_nodes, self.n_rel)
         sp.symmetric, sp.n_edges, sp.row_bytes = self.symmetric, self.n_edges, self.row_bytes
-        sp.live = mv(self.live)
+        sp.links = mv(self.links)
         sp.compact = None if self.compact is None else self.compact.to(device)
         return sp
 

@@ -21,5 +21,5 @@ for layer in (enc.rgcn1, enc.rgcn2):
     graph = layer._cache.value
     cells, xb_nb, _zeros = graph.pair_buffers(n, layer.num_bases, layer.out_channels, dev)
     for _ in range(3):
-        ops.pair_product(cells, xb_nb, symmetric=graph.pair_fwd.symmetric, live=graph.pair_fwd.live, zeros=_zeros)
+        ops.pair_product(cells, xb_nb, symmetric=graph.pair_fwd.symmetric, links=graph.pair_fwd.links, zeros=_zeros)
 torch.cuda.synchronize()
