@@ -1,5 +1,7 @@
-import sys, torch
-sys.path.insert(0, '/root/repo')
+"""Config-5-shaped dense products (graph-free timing): T . basis with and without slabs of bases, XB, dX, d basis.
+   python tools/gemm_large_shapes.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tip_amd import ops
 dev='cuda:0'
 n, nb, d = 10000, 32, 128
