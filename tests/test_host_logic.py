@@ -735,6 +735,23 @@ def test_row_stream_plan_reference(R, N, E):
                 assert abs(n0 - n1) <= longest_row
 
 
+def test_pair_link_words_bit_layout():
+    """`layers.pair_link_words` (tipk.h section 2c `links`): bit r of word (u, t) = some edge u -> 32 t + r; rows padded to a
+    multiple of 8 nodes, columns to whole words; bit 31 lands in the sign of the int32 the words travel as."""
+    from tip_amd.layers import pair_link_words
+    g = torch.Generator().manual_seed(3)
+    n = 77
+    src, dst = torch.randint(0, n, (400,), generator=g), torch.randint(0, n, (400,), generator=g)
+    src = torch.cat([src, torch.tensor([5, 5])]); dst = torch.cat([dst, torch.tensor([31, 63])])      # sign bits of two words
+    w = pair_link_words(src, dst, n)
+    assert w.dtype == torch.int32 and tuple(w.shape) == (80, 3)
+    dense = torch.zeros(80, 96, dtype=torch.bool)
+    dense[src, dst] = True
+    bits = ((w.to(torch.int64) & 0xffffffff).unsqueeze(-1) >> torch.arange(32)) & 1
+    assert torch.equal(bits.view(80, 96).bool(), dense)
+    assert int(w[5, 0]) < 0 and int(w[5, 1]) < 0
+
+
 @pytest.mark.parametrize('R,N,E', [(70, 23, 900), (5, 16, 40), (33, 9, 0)])
 def test_row_stream_plan_s_reference(R, N, E):
     """`build_row_stream_plan_s` (wave-uniform entries of `tipk_rgcn_row_products_s`) interpreted in torch == the definition;
