@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 21
+#define TIPK_ABI_VERSION 22
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -450,6 +450,13 @@ int tipk_stream_gather_parts(const float* table, int64_t ld_table, int d, int64_
                              int64_t part_len, const int32_t* wg_part, int64_t n_wg, const int32_t* wave_ptr,
                              const uint32_t* cells, const uint16_t* ids, int idx_unit, const int32_t* zero_ptr /* nullable */,
                              const int32_t* zero_rows, float* out, int64_t ld_out, tipk_stream_t stream);
+/* Round 6: the d att gathers of BOTH R-GCN layers of an encoder in one launch (the layers share the plan): grid.y = 1
+ * stages its partitions from table1 and writes out1; everything else as tipk_stream_gather_parts. */
+int tipk_stream_gather_parts_two(const float* table0, const float* table1, int64_t ld_table, int d, int64_t second,
+                                 const int32_t* part_first, int64_t part_len, const int32_t* wg_part, int64_t n_wg,
+                                 const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
+                                 const int32_t* zero_ptr, const int32_t* zero_rows, float* out0, float* out1,
+                                 int64_t ld_out, tipk_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * 2f. Forward aggregation of an R-GCN layer on LARGE node sets without Y = att . XB (src/layers.py:159-180 with
@@ -576,6 +583,40 @@ int tipk_drug_mix_gather_fwd(const float* xd, int64_t ld_xd, const float* d_norm
                              float* mean, tipk_stream_t stream);
 int tipk_drug_mix_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
                       int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_mean, float* g_w,
+                      tipk_stream_t stream);
+
+/* Round 6 -- the same forward launch ALSO leaves the first R-GCN layer's row-local products of the rows it finishes
+ * (src/layers.py:545 applied to the output of :532-539; reference MyRGCNConv2.forward :159-188, basis-first):
+ *     xb[d, b, :d_out] = out[d, :] basis[b]      node-major [.. x n_bases x 32] (rows padded to 32 columns: the operand of
+ *                                                tipk_pair_product / tipk_rgcn_pair_grads; columns >= d_out untouched)
+ *     xroot[d, :]      = out[d, :] root          [rows x d_out] contiguous
+ *   basis [n_bases x cols x d_out], root [cols x d_out] contiguous, cols = cat ? ne + q : ne (a multiple of 4, <= 128),
+ *   d_out 16 or 32 (tipk_drug_mix_gather_xb_supported).  v_mfma_f32_16x16x4_f32 on the workgroup's <= 16 rows: a k-ordered
+ *   fp32 fma chain per element.  Saves the launch of the two products (9.6 us at BioSNAP for 88 MFLOP). */
+int tipk_drug_mix_gather_xb_supported(int p, int q, int ne, int cat, int n_bases, int d_out);
+int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
+                                const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc,
+                                int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat, float* out,
+                                int64_t ld_out, float* mean, const float* basis, const float* root, int n_bases, int d_out,
+                                float* xb, float* xroot, tipk_stream_t stream);
+
+/* Round 6 -- the backward pass of the whole P -> D stage in ONE launch: tipk_drug_mix_bwd + the transposed gather of
+ * d mean + the products of GCNConv 2's backward pass (autograd of src/layers.py:526-539 and of PPEncoder.conv2, :394):
+ *     g_xd = g[:, :ne] / d_norm,   g_w = mean^T g_pd                        as tipk_drug_mix_bwd
+ *     g_h[s] = sum_{e in [tptr[s], tptr[s + 1])} tw[e] * (g_pd W^T)[tdst[e]]     per kept source row s (CSR by source row:
+ *                                                                                drug ids, 1 / #targets(drug)); never stored
+ *     gw[s, :] = (g_h[s] W2) * row_scale[s]        [n_src x c1]; W2 (k < p, n < c1) at w2[k * w2_sk + n * w2_sn]
+ *     dw2_slabs[j] = agg[rows of workgroup j]^T g_h    [c1 x p] per row workgroup,  db2_slabs[j] = column sums of g_h  [p]
+ *   agg [n_src x c1]: GCNConv 2's aggregated input rows (tipk_gather_sum_lin's first output).  The slabs --
+ *   tipk_pd_stage_bwd_slabs(n_src, p) of each -- are summed in order by the caller (riders of the next launch).
+ *   Supported: tipk_drug_mix_gather_supported(p, q), rows * p <= 24 576, p * c1 <= 4 096. */
+int tipk_pd_stage_bwd_supported(int p, int q, int64_t rows, int c1);
+int64_t tipk_pd_stage_bwd_slabs(int64_t n_src, int p);
+int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
+                      int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w,
+                      const int32_t* tptr, const int32_t* tdst, const float* tw, int64_t n_src,
+                      const float* agg, int64_t ld_agg, int c1, const float* w2, int64_t w2_sk, int64_t w2_sn,
+                      const float* row_scale, float* gw, int64_t ld_gw, float* dw2_slabs, float* db2_slabs,
                       tipk_stream_t stream);
 
 /* out[c] = sum_r in[r, c]  (bias gradients of GCNConv).  `scratch` holds >= 256*cols floats. */

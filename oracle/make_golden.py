@@ -8,6 +8,7 @@ seeded graphs plus explicit weights, and records inputs, outputs and every param
 
     python oracle/make_golden.py            # rewrites tests/golden/
     python oracle/make_golden.py drug_features check_loader     # only the named fixture(s)
+    python oracle/make_golden.py fast_route                     # round 6: the pair-form shapes (tip.py:14 dims)
 """
 import os
 import pickle
@@ -43,7 +44,7 @@ def npz(name, **arrays):
 # ---------------------------------------------------------------------------------------------
 # small seeded graphs with the nasty cases of SURVEY.md section 8(c)
 # ---------------------------------------------------------------------------------------------
-def small_graph(seed, n_drug=37, n_prot=211, sizes=(40, 1, 6, 90, 3, 17, 250), symmetric=True):
+def small_graph(seed, n_drug=37, n_prot=211, sizes=(40, 1, 6, 90, 3, 17, 250), symmetric=True, nasty=False):
     rng = np.random.RandomState(seed)
     blocks = []
     for s in sizes:
@@ -51,6 +52,12 @@ def small_graph(seed, n_drug=37, n_prot=211, sizes=(40, 1, 6, 90, 3, 17, 250), s
         # replacement gives duplicate edges in the big relations
         u = rng.randint(0, n_drug - 3, s)
         v = rng.randint(0, n_drug - 3, s)
+        if nasty and s >= 9:
+            # explicit self pairs (u == v: on a symmetric graph the mirrored half repeats them) and an explicit duplicate edge
+            # inside the relation, whatever the draw gave
+            v[0] = u[0]
+            v[3] = u[3]
+            u[2], v[2] = u[1], v[1]
         e = torch.from_numpy(np.stack([u, v]).astype(np.int64))
         blocks.append(torch.cat([e, e.flip(0)], dim=1) if symmetric else e)
     dd_idx = torch.cat(blocks, dim=1)
@@ -107,6 +114,45 @@ def golden_rgcn(seed, d_in, d_out, n_base, symmetric, name):
             assert torch.allclose(out, keep['out'], atol=1e-4), 'MyRGCNConv != MyRGCNConv2'
             keep['out_bmm_variant'] = out
     npz(name, x=x, upstream=up, dd_idx=g['dd_idx'], dd_et=g['dd_et'], dd_range=g['dd_range'], **keep)
+
+
+def golden_rgcn_fast(seed, symmetric, name):
+    """The two R-GCN layers at the dims of tip.py:14 (64 -> 32 -> 16, num_base 32) on <= 64 drugs with self pairs, duplicate
+    edges inside a relation, one- and two-edge relations and isolated drugs: the shapes the PAIR-FORM route of the build takes
+    (tip_amd/layers.py `rgcn_graph`: n_bases = 32, d in {32, 16}), which the small-dims fixtures above never reach."""
+    g = small_graph(seed, n_drug=61, sizes=(300, 1, 40, 700, 9, 120, 1500, 2, 64), symmetric=symmetric, nasty=True)
+    assert bool((g['dd_idx'][0] == g['dd_idx'][1]).any())
+    torch.manual_seed(seed)
+    x = torch.randn(g['n_drug'], 64, requires_grad=True)
+    up = torch.randn(g['n_drug'], 16)
+    m1 = ref.MyRGCNConv2(64, 32, g['n_rel'], 32, after_relu=False)
+    m2 = ref.MyRGCNConv2(32, 16, g['n_rel'], 32, after_relu=True)
+    randomize_(m1, seed + 1)
+    randomize_(m2, seed + 2)
+    h = m1(x, g['dd_idx'], g['dd_et'], g['dd_range'])
+    h.retain_grad()
+    out = m2(torch.relu(h), g['dd_idx'], g['dd_et'], g['dd_range'])
+    (out * up).sum().backward()
+    npz(name, x=x, upstream=up, dd_idx=g['dd_idx'], dd_et=g['dd_et'], dd_range=g['dd_range'], hidden=h, out=out, grad_x=x.grad,
+        grad_hidden=h.grad, **{'l1.' + k: v for k, v in params_of(m1).items()}, **{'l2.' + k: v for k, v in params_of(m2).items()},
+        **{'grad.l1.' + k[5:]: v for k, v in grads_of(m1).items()}, **{'grad.l2.' + k[5:]: v for k, v in grads_of(m2).items()})
+
+
+def golden_encoder_fast(seed, mod, symmetric, name):
+    """FMEncoder at the dims of tip.py:14 / :17 on the graph of `golden_rgcn_fast`: the whole fast route of the build (layer
+    hand-over, both layers' pair cells in one launch, pair-form backward) against the reference's own forward + autograd."""
+    g = small_graph(seed, n_drug=61, sizes=(300, 1, 40, 700, 9, 120, 1500, 2, 64), symmetric=symmetric, nasty=True)
+    torch.manual_seed(seed)
+    kw = dict(prot_drug_dim=16, num_base=32, n_embed=48, n_hid1=32, n_hid2=16) if mod == 'cat' else \
+        dict(prot_drug_dim=64, num_base=32, n_embed=64, n_hid1=32, n_hid2=16)
+    enc = ref.FMEncoder('cpu', g['n_drug'], g['n_rel'], g['n_prot'], g['n_prot'], g['n_drug'], mod=mod, **kw)
+    randomize_(enc, seed)
+    up = torch.randn(g['n_drug'], 16)
+    z = enc(ref_sparse_id(g['n_drug']), g['dd_idx'], g['dd_et'], g['dd_range'], g['d_norm'],
+            ref_sparse_id(g['n_prot']), g['pp_idx'], g['dp_idx'], None)
+    (z * up).sum().backward()
+    npz(name, z=z, upstream=up, mod=mod, **{k: v for k, v in g.items()}, **params_of(enc),
+        **grads_of(enc), **{'cfg.' + k: v for k, v in kw.items()})
 
 
 def golden_hier(seed):
@@ -309,6 +355,12 @@ if __name__ == '__main__' and ONLY:
     os.makedirs(OUT, exist_ok=True)
     if 'drug_features' in ONLY:
         golden_drug_features(23)
+    if 'fast_route' in ONLY:
+        golden_rgcn_fast(31, True, 'rgcn_fast_sym')
+        golden_rgcn_fast(32, False, 'rgcn_fast_directed')
+        golden_encoder_fast(33, 'cat', True, 'encoder_fast_cat_sym')
+        golden_encoder_fast(34, 'add', True, 'encoder_fast_add_sym')
+        golden_encoder_fast(35, 'cat', False, 'encoder_fast_cat_directed')
     sys.exit(0)
 
 if __name__ == '__main__':
@@ -324,3 +376,8 @@ if __name__ == '__main__':
     golden_tip(18)
     golden_biosnap_slice()
     golden_drug_features(23)
+    golden_rgcn_fast(31, True, 'rgcn_fast_sym')
+    golden_rgcn_fast(32, False, 'rgcn_fast_directed')
+    golden_encoder_fast(33, 'cat', True, 'encoder_fast_cat_sym')
+    golden_encoder_fast(34, 'add', True, 'encoder_fast_add_sym')
+    golden_encoder_fast(35, 'cat', False, 'encoder_fast_cat_directed')

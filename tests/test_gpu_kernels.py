@@ -1518,3 +1518,127 @@ def test_drug_mix_gather_fused_launches(ops, n, n_src, p, q, ne, cat):
     out2 = ops.drug_mix_gather(xd2, h2, w2, dn.to(DEV), cat, graph)
     out2.backward(gup.to(DEV))
     assert torch.equal(out2, out) and torch.equal(h2.grad, h_d.grad) and torch.equal(w2.grad, w_d.grad)
+
+
+# ------------------------------------------------------------------ round 6: the fused launches of the encoder-level schedule
+@pytest.mark.parametrize('n,n_src,p,q,ne,cat,nb,d_out', [(645, 3640, 16, 16, 48, True, 32, 32), (37, 50, 8, 8, 12, True, 5, 16),
+                                                         (130, 64, 16, 64, 64, False, 32, 32), (33, 300, 6, 10, 10, True, 3, 16)])
+def test_drug_mix_gather_xb_fwd(ops, n, n_src, p, q, ne, cat, nb, d_out):
+    """tipk_drug_mix_gather_xb_fwd: the forward launch of the P -> D stage that also leaves XB = x0 basis (node-major, rows
+    padded to 32 columns) and x0 root (src/layers.py:526-545): x0 / mean bit for bit what tipk_drug_mix_gather_fwd writes, the
+    products == fp64, exact on integers (a k-ordered fma chain), a hub drug with its own workgroup, drugs without targets."""
+    from tip_amd import encoder
+    from tip_amd.layers import hier_graph
+    g = torch.Generator().manual_seed(n + p + q + nb)
+    E = 6 * n + 3
+    src = torch.randint(0, n_src, (E,), generator=g)
+    dst = torch.randint(0, max(1, n - 2), (E,), generator=g)
+    if n >= 100:
+        dst[:700] = 3                                                  # a hub: more than 512 targets -> all 16 wavefronts on it
+    ei = torch.stack([src, dst + n_src]).to(DEV)
+    graph = hier_graph(ei, n_src + n, n_src, table_rows=n_src, d=p)
+    cols = ne + q if cat else ne
+    if not ops.lib().tipk_drug_mix_gather_xb_supported(p, q, ne, int(cat), nb, d_out):
+        assert cols % 4 != 0 or d_out not in (16, 32)
+        pytest.skip('shape not taken by the fused launch')
+    xd, h, w = torch.randn(n, ne, generator=g), torch.randn(n_src, p, generator=g), torch.randn(p, q, generator=g)
+    dn = torch.rand(n, generator=g) + 0.5
+    basis, root = torch.randn(nb, cols, d_out, generator=g), torch.randn(cols, d_out, generator=g)
+    n_pad = -(-n // 8) * 8
+
+    def run(xd, h, w, basis, root):
+        xb_pad = torch.zeros(n_pad, nb, 32, device=DEV)
+        x0, mean, xroot = encoder.drug_mix_gather_xb(xd.to(DEV), h.to(DEV), w.to(DEV), dn.to(DEV), cat, graph, basis.to(DEV),
+                                                     root.to(DEV), xb_pad[:, :, :d_out])
+        return x0, mean, xroot, xb_pad
+    x0, mean, xroot, xb_pad = run(xd, h, w, basis, root)
+    ref = ops.drug_mix_gather(xd.to(DEV), h.to(DEV), w.to(DEV), dn.to(DEV), cat, graph)
+    assert torch.equal(x0, ref)
+    want_b = torch.einsum('nk,bkc->nbc', x0.double().cpu(), basis.double())
+    want_r = x0.double().cpu() @ root.double()
+    close(xb_pad[:n, :, :d_out], want_b, rtol=2e-5, atol=2e-5 * float(want_b.abs().max()))
+    close(xroot, want_r, rtol=2e-5, atol=2e-5 * float(want_r.abs().max()))
+    assert float(xb_pad[n:].abs().max()) == 0.0 and float(xb_pad[:, :, d_out:].abs().max() if d_out < 32 else 0.0) == 0.0
+    again = run(xd, h, w, basis, root)
+    assert all(torch.equal(a, b) for a, b in zip(again, (x0, mean, xroot, xb_pad)))
+    # exact on small integers (d_norm = a power of two, integer mean by construction: one edge per drug)
+    if cat:
+        xi = torch.randint(-3, 4, (n, ne), generator=g).float()
+        bi, ri = torch.randint(-2, 3, basis.shape, generator=g).float(), torch.randint(-2, 3, root.shape, generator=g).float()
+        hi, wi = torch.randint(-2, 3, h.shape, generator=g).float(), torch.randint(-2, 3, w.shape, generator=g).float()
+        src1 = torch.randint(0, n_src, (n,), generator=g)
+        g1 = hier_graph(torch.stack([src1, torch.arange(n) + n_src]).to(DEV), n_src + n, n_src, table_rows=n_src, d=p)
+        xb_pad = torch.zeros(n_pad, nb, 32, device=DEV)
+        x0i, _, xri = encoder.drug_mix_gather_xb(xi.to(DEV), hi.to(DEV), wi.to(DEV), torch.full((n,), 0.5, device=DEV), cat, g1,
+                                                 bi.to(DEV), ri.to(DEV), xb_pad[:, :, :d_out])
+        want_x0 = torch.cat([xi.double() * 2, hi.double()[src1] @ wi.double()], 1)
+        assert torch.equal(x0i.double().cpu(), want_x0)
+        assert torch.equal(xb_pad[:n, :, :d_out].double().cpu(), torch.einsum('nk,bkc->nbc', want_x0, bi.double()))
+        assert torch.equal(xri.double().cpu(), want_x0 @ ri.double())
+
+
+@pytest.mark.parametrize('n,n_src,p,q,ne,cat,c1', [(645, 3640, 16, 16, 48, True, 32), (37, 50, 8, 8, 12, True, 24),
+                                                   (130, 64, 16, 64, 64, False, 32), (33, 300, 6, 10, 10, True, 7)])
+def test_pd_stage_bwd(ops, n, n_src, p, q, ne, cat, c1):
+    """tipk_pd_stage_bwd: d xd, d W_h, the transposed P -> D gather, conv2's g W and the slabs of d W2 / d b2 in ONE launch
+    == the fp64 definitions (autograd of src/layers.py:526-539 and of GCNConv 2); source rows without edges, repeated edges,
+    a strided upstream gradient, a row scale; bitwise reproducible."""
+    from tip_amd import encoder
+    from tip_amd.layers import hier_graph
+    g = torch.Generator().manual_seed(n + p + q + c1)
+    E = 6 * n + 3
+    src = torch.randint(0, max(1, n_src - 3), (E,), generator=g)      # the last source rows have no edge
+    dst = torch.randint(0, max(1, n - 2), (E,), generator=g)
+    src[:4] = src[4:8]; dst[:4] = dst[4:8]
+    ei = torch.stack([src, dst + n_src]).to(DEV)
+    graph = hier_graph(ei, n_src + n, n_src, table_rows=n_src, d=p)
+    cols = ne + q if cat else ne
+    gup = torch.randn(n, cols + 3, generator=g)[:, 1:-2]
+    mean, w = torch.randn(n, p, generator=g), torch.randn(p, q, generator=g)
+    dn = torch.rand(n, generator=g) + 0.5
+    agg = torch.randn(n_src, c1, generator=g)
+    w2_store = torch.randn(c1, p, generator=g)                         # [in, out] storage behind the [out, in] shape
+    rs = torch.rand(n_src, generator=g) + 0.5
+    cnt = torch.bincount(dst, minlength=n).clamp(min=1).double()
+    gd = gup.double()
+    g_pd = gd[:, ne:] if cat else gd
+    g_mean = (g_pd @ w.double().t()) / cnt.unsqueeze(1)
+    g_h = torch.zeros(n_src, p, dtype=torch.float64).index_add_(0, src, g_mean[dst])
+    w2 = w2_store.t()
+    want_gw = (g_h @ w2.double()) * rs.double().unsqueeze(1)
+
+    def run(scale):
+        return encoder.pd_stage_bwd(gup.to(DEV), dn.to(DEV), mean.to(DEV), w.to(DEV), ne, cat, graph, agg.to(DEV), w2_store.to(DEV).t(),
+                                    scale)
+    g_xd, g_w, gw, j_w2, j_b2 = run(rs.to(DEV))
+    ops.gemm_group([], [j_w2, j_b2])
+    close(g_xd, gd[:, :ne] / dn.double().unsqueeze(1), rtol=2e-5, atol=2e-6)
+    close(g_w, mean.double().t() @ g_pd, rtol=2e-5, atol=2e-5 * float((mean.double().t() @ g_pd).abs().max()))
+    close(gw, want_gw, rtol=2e-5, atol=2e-5 * float(want_gw.abs().max()))
+    want_w2 = agg.double().t() @ g_h
+    close(j_w2.out, want_w2, rtol=2e-5, atol=2e-5 * float(want_w2.abs().max()))
+    close(j_b2.out, g_h.sum(0), rtol=2e-5, atol=2e-5 * float(g_h.abs().sum(0).max()))
+    assert float(gw[n_src - 3:].abs().max()) == 0.0                    # rows without edges: exact zeros
+    again = run(rs.to(DEV))
+    ops.gemm_group([], [again[3], again[4]])
+    assert torch.equal(again[0], g_xd) and torch.equal(again[1], g_w) and torch.equal(again[2], gw)
+    assert torch.equal(again[3].out, j_w2.out) and torch.equal(again[4].out, j_b2.out)
+    plain = run(None)
+    close(plain[2], g_h @ w2.double(), rtol=2e-5, atol=2e-5 * float((g_h @ w2.double()).abs().max()))
+
+
+def test_pair_att_gather_two_tables_one_launch(ops):
+    """tipk_stream_gather_parts_two == two tipk_stream_gather_parts launches, bit for bit (BioSNAP-shaped plan)."""
+    from tip_amd import encoder
+    from tip_amd.plan import build_pair_bwd_plan
+    R, N, nb = 300, 200, 32
+    g = torch.Generator().manual_seed(5)
+    src, dst, rel = _random_dd_graph(N, R, 400, g, True)
+    scale = 1.0 / torch.bincount(dst, minlength=N).clamp(min=1).float()
+    plan = build_pair_bwd_plan(src, dst, rel, N, R, scale, True, 32, nb // 4, ops.rel_stream_piece()).to(DEV)
+    pa = torch.randn(2 * plan.n_alloc + 1, nb, generator=g).to(DEV)
+    pb_ = torch.randn(2 * plan.n_alloc + 1, nb, generator=g).to(DEV)
+    ja, jb = encoder.pair_att_gather_two(plan, pa, pb_)
+    ra, rb = ops.pair_att_gather(plan, pa), ops.pair_att_gather(plan, pb_)
+    ops.gemm_group([], [ja, jb, ra, rb])
+    assert torch.equal(ja.out, ra.out) and torch.equal(jb.out, rb.out)

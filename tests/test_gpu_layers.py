@@ -19,6 +19,19 @@ def close(got, want, rtol=2e-4, atol=None):
     torch.testing.assert_close(got, want, rtol=rtol, atol=atol)
 
 
+# Tolerances of the module-level comparisons (round 6, calibrated with TIPK_ERRLOG, tests/conftest.py): the largest error any
+# of these sites showed on MI355X was 3e-7 max|want| for activations and 1.1e-6 max|want| for gradients (4e-6 for the NNDecoder
+# tables at BioSNAP size), both sides fp32 with different summation orders.  The bounds below are 10-30 x that.
+def close_act(got, want):
+    """activations / embeddings: |d| <= 1e-5 |want| + 1e-5 max|want|."""
+    close(got, want, rtol=1e-5, atol=1e-5 * float(want.detach().abs().max()) + 1e-12)
+
+
+def close_grad(got, want, scale=1.0):
+    """gradients: |d| <= 1e-4 |want| + 2e-5 max|want|  (scale: the 64-bit fixed-point decoder sums at full size)."""
+    close(got, want, rtol=1e-4 * scale, atol=2e-5 * scale * float(want.detach().abs().max()) + 1e-12)
+
+
 def load_params(module, g, prefix=''):
     sd = module.state_dict()
     for k in sd:
@@ -45,6 +58,139 @@ def test_rgcn_layers(name):
             close(getattr(m, k).grad, g['grad.' + k])
         out2 = m(x, ei, et, rg) if cls is MyRGCNConv2 else m(x, ei, et)     # cached plans, same bits
         assert torch.equal(out, out2)
+
+
+def _launch_labels(fn):
+    """Labels of the launches `fn` makes (ops' per-launch timing hooks), as one string."""
+    from tip_amd import ops
+    ops.timing_start()
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        rec = ops.timing_stop()
+    return ' '.join(sorted(rec))
+
+
+@pytest.mark.parametrize('name', ['rgcn_fast_sym', 'rgcn_fast_directed'])
+def test_rgcn_pair_route_against_reference_golden(name):
+    """Round 6 (VERDICT r5 missing #4): the PAIR-FORM route (n_bases 32, 64 -> 32 -> 16) against outputs and autograd gradients of
+    the reference's own MyRGCNConv2 x 2 on a graph with self pairs, duplicate edges inside a relation, one- and two-edge
+    relations and isolated drugs -- and the test asserts that this route, not the generic one, produced the numbers."""
+    from tip_amd.layers import MyRGCNConv2
+    g = load_golden(name)
+    r = g['l1.att'].shape[0]
+    m1 = load_params(MyRGCNConv2(64, 32, r, 32, after_relu=False), g, 'l1.')
+    m2 = load_params(MyRGCNConv2(32, 16, r, 32, after_relu=True), g, 'l2.')
+    ei, et, rg = g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV)
+    x = g['x'].to(DEV).requires_grad_(True)
+    box = {}
+
+    def run():
+        # exactly as FMEncoder.forward drives the two layers (ReLU fused, slab sum handed over, cells of both layers together)
+        h = m1(x, ei, et, rg, fuse_relu='gated_downstream', defer_output=True, next_layer=m2)
+        box['out'] = m2(h, ei, et, rg, gate_input=True)
+        (box['out'] * g['upstream'].to(DEV)).sum().backward()
+    labels = _launch_labels(run)
+    for need in ('pair_cells', 'pair_grads', 'pair_att_gather', 'sum_slabs_xb'):
+        assert need in labels, (need, labels)
+    assert 'gather_sum[dd' not in labels and 'rel_gather' not in labels and 'rel_stream' not in labels, labels
+    graph = m1.graph_for(x.shape[0], ei, rg)
+    assert graph.pair_fwd is not None and graph.pair_fwd.symmetric == ('sym' in name)
+    close(box['out'], g['out'], rtol=1e-5, atol=1e-5 * float(g['out'].abs().max()))
+    close(x.grad, g['grad_x'], rtol=1e-4, atol=1e-5 * float(g['grad_x'].abs().max()))
+    for tag, m in (('l1', m1), ('l2', m2)):
+        for k in ('basis', 'att', 'root'):
+            want = g['grad.%s.%s' % (tag, k)]
+            close(getattr(m, k).grad, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+    # the layers one by one (no hand-over, ReLU outside): the hidden activations and their gradient too
+    m1.zero_grad(); m2.zero_grad()
+    x2 = g['x'].to(DEV).requires_grad_(True)
+    h = m1(x2, ei, et, rg)
+    h.retain_grad()
+    out = m2(torch.relu(h), ei, et, rg)
+    (out * g['upstream'].to(DEV)).sum().backward()
+    close(h, g['hidden'], rtol=1e-5, atol=1e-5 * float(g['hidden'].abs().max()))
+    close(h.grad, g['grad_hidden'], rtol=1e-4, atol=1e-5 * float(g['grad_hidden'].abs().max()))
+    close(out, g['out'], rtol=1e-5, atol=1e-5 * float(g['out'].abs().max()))
+    close(x2.grad, g['grad_x'], rtol=1e-4, atol=1e-5 * float(g['grad_x'].abs().max()))
+
+
+@pytest.mark.parametrize('name', ['encoder_fast_cat_sym', 'encoder_fast_add_sym', 'encoder_fast_cat_directed'])
+def test_fm_encoder_fast_route_against_reference_golden(name):
+    """FMEncoder at the dims of tip.py:14 / :17 against the reference's own forward + autograd on the nasty 61-drug graph: the
+    route the bench times (fused P -> D + mix, layer hand-over, pair cells of both layers in one launch, pair-form backward)."""
+    from tip_amd.layers import FMEncoder
+    from tip_amd.utils import sparse_id
+    g = load_golden(name)
+    mod = str(g['mod'])
+    cfg = {k[4:]: int(v) for k, v in g.items() if isinstance(k, str) and k.startswith('cfg.')}
+    enc = load_params(FMEncoder(DEV, g['n_drug'], g['n_rel'], g['n_prot'], g['n_prot'], g['n_drug'], mod=mod, **cfg), g)
+    args = (sparse_id(g['n_drug']).to(DEV), g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV),
+            g['d_norm'].to(DEV), sparse_id(g['n_prot']).to(DEV), g['pp_idx'].to(DEV), g['dp_idx'].to(DEV), None)
+    box = {}
+
+    def run():
+        box['z'] = enc(*args)
+        (box['z'] * g['upstream'].to(DEV)).sum().backward()
+    labels = _launch_labels(run)
+    for need in ('pair_cells2', 'pair_grads', 'pair_att_gather2', 'sum_slabs_xb', 'drug_mix_gather_xb_fwd', 'pd_stage_bwd'):
+        assert need in labels, (need, labels)
+    close(box['z'], g['z'], rtol=1e-5, atol=1e-5 * float(g['z'].abs().max()))
+    for k, p in enc.named_parameters():
+        want = g['grad.' + k]
+        close(p.grad, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+    # a second pass on the cached plans: the same bits
+    enc.zero_grad()
+    z2 = enc(*args)
+    assert torch.equal(z2, box['z'])
+
+
+def test_encoder_step_is_sixteen_launches_and_matches_the_per_layer_nodes(monkeypatch):
+    """Round 6: FMEncoder.forward + backward as ONE autograd node (tip_amd/encoder.py) -- 8 + 8 launches on the reference's
+    dims -- against the same pass on the per-layer nodes (TIPK_NO_ENCODER_STEP=1: 9 + 11 launches); a backward pass that runs
+    after ANOTHER forward pass recomputes the graph's buffers."""
+    from tip_amd import ops
+    from tip_amd.layers import FMEncoder
+    from tip_amd.utils import sparse_id
+    g = load_golden('encoder_fast_cat_sym')
+    cfg = {k[4:]: int(v) for k, v in g.items() if isinstance(k, str) and k.startswith('cfg.')}
+    args = (sparse_id(g['n_drug']).to(DEV), g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV),
+            g['d_norm'].to(DEV), sparse_id(g['n_prot']).to(DEV), g['pp_idx'].to(DEV), g['dp_idx'].to(DEV), None)
+    up = g['upstream'].to(DEV)
+
+    def run(per_layer):
+        if per_layer:
+            monkeypatch.setenv('TIPK_NO_ENCODER_STEP', '1')
+        else:
+            monkeypatch.delenv('TIPK_NO_ENCODER_STEP', raising=False)
+        enc = load_params(FMEncoder(DEV, g['n_drug'], g['n_rel'], g['n_prot'], g['n_prot'], g['n_drug'], mod='cat', **cfg), g)
+        ops.timing_start()
+        z = enc(*args)
+        (z * up).sum().backward()
+        torch.cuda.synchronize()
+        rec = ops.timing_stop()
+        return enc, z, sum(v[0] for v in rec.values()), rec
+    e_new, z_new, n_new, rec_new = run(False)
+    e_old, z_old, n_old, _ = run(True)
+    assert n_new == 16 and n_old == 20, (n_new, n_old, sorted(rec_new))
+    close_act(z_new, z_old.cpu())
+    for (k, a), (_, b) in zip(e_new.named_parameters(), e_old.named_parameters()):
+        assert a.grad.shape == b.grad.shape and a.grad.stride() == b.grad.stride(), k
+        close_grad(a.grad, b.grad.cpu())
+    # two forward passes, then the FIRST one's backward: its cells / XB were overwritten -- recomputed, same gradients
+    monkeypatch.delenv('TIPK_NO_ENCODER_STEP', raising=False)
+    e2 = load_params(FMEncoder(DEV, g['n_drug'], g['n_rel'], g['n_prot'], g['n_prot'], g['n_drug'], mod='cat', **cfg), g)
+    z_a = e2(*args)
+    z_b = e2(*args)                                                      # bumps the stamps of both graphs' buffers ...
+    n, nb = g['n_drug'], cfg['num_base']
+    for layer in (e2.rgcn1, e2.rgcn2):                                   # ... whose contents are then lost
+        cells, xb, _ = layer._cache.value.pair_buffers(n, nb, layer.out_channels, torch.device(DEV))
+        xb[:n].fill_(7.0)
+        cells.view(-1, nb)[:n * n].mul_(3.0)
+    (z_a * up).sum().backward()
+    for (k, a), (_, b) in zip(e2.named_parameters(), e_new.named_parameters()):
+        close_grad(a.grad, b.grad.cpu())
 
 
 def test_hierarchy_conv():
@@ -178,7 +324,7 @@ def test_tip_end_to_end_small():
         close(model.embeddings, g['embeddings'])
         loss.backward()
         for k, p in model.named_parameters():
-            close(p.grad, g['grad.' + k], rtol=5e-4, atol=2e-6)
+            close_grad(p.grad, g['grad.' + k])
         model.test_neg_index = g['test_neg'].to(DEV)
         rec = model.test(print_output=False)
         np.testing.assert_allclose(rec, g['record'].numpy(), rtol=1e-4, atol=1e-4)
@@ -207,14 +353,14 @@ def test_biosnap_slice_against_reference_golden():
     d = Data.from_dict(dd).to(DEV)
     z = enc(d.d_feat, d.dd_train_idx, d.dd_train_et, d.dd_train_range, d.d_norm, d.p_feat, d.pp_train_indices,
             d.dp_edge_index, d.dp_range_list)
-    close(z, g['z'], rtol=1e-3)
+    close_act(z, g['z'])
     (z * g['upstream'].to(DEV)).sum().backward()
     for k, prm in enc.named_parameters():
         if k == 'pp_encoder.conv1.lin.weight':
-            close(prm.grad[:, ::16], g['grad.' + k + '[:, ::16]'], rtol=2e-3, atol=1e-6)
-            close(prm.grad.sum(1), g['grad.' + k + '.rowsum'], rtol=2e-3, atol=1e-5)
+            close_grad(prm.grad[:, ::16], g['grad.' + k + '[:, ::16]'])
+            close_grad(prm.grad.sum(1), g['grad.' + k + '.rowsum'])
         else:
-            close(prm.grad, g['grad.' + k], rtol=2e-3, atol=1e-6)
+            close_grad(prm.grad, g['grad.' + k])
 
 
 @pytest.mark.parametrize('dims', [
@@ -241,9 +387,9 @@ def test_encoder_other_dimensions_vs_oracle(dims):
     (z * up.to(DEV)).sum().backward()
     zo, saved = O.fm_encoder_fwd(p, dd, mod)
     go = O.fm_encoder_bwd(up, p, dd, saved, mod)
-    close(z, zo, rtol=1e-3)
+    close_act(z, zo)
     for k, prm in enc.named_parameters():
-        close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+        close_grad(prm.grad, go[k])
 
 
 def test_synthetic_encoder_large_node_set_vs_oracle():
@@ -268,9 +414,9 @@ def test_synthetic_encoder_large_node_set_vs_oracle():
     (z * up.to(DEV)).sum().backward()
     zo, saved = O.fm_encoder_fwd(p, dd, 'cat')
     go = O.fm_encoder_bwd(up, p, dd, saved, 'cat')
-    close(z, zo, rtol=1e-3)
+    close_act(z, zo)
     for k, prm in enc.named_parameters():
-        close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+        close_grad(prm.grad, go[k])
 
 
 @pytest.fixture(scope='module')
@@ -303,9 +449,9 @@ def test_full_biosnap_encoder_vs_oracle(biosnap_full, mod, generic, monkeypatch)
     (z * up.to(DEV)).sum().backward()
     zo, saved = O.fm_encoder_fwd(p, dd, mod)
     go = O.fm_encoder_bwd(up, p, dd, saved, mod)
-    close(z, zo, rtol=1e-3)
+    close_act(z, zo)
     for k, prm in enc.named_parameters():
-        close(prm.grad, go[k], rtol=2e-3, atol=2e-5 * max(1e-3, float(go[k].abs().max())))
+        close_grad(prm.grad, go[k])
 
 
 def test_paper_configuration_963_relations_encoder_and_objective_vs_oracle():
@@ -340,11 +486,11 @@ def test_paper_configuration_963_relations_encoder_and_objective_vs_oracle():
     gz1, gw1 = O.distmult_bwd(gp, zo, dd['dd_train_idx'], dd['dd_train_et'], p['decoder.weight'])
     gz2, gw2 = O.distmult_bwd(gn, zo, negc, dd['dd_train_et'], p['decoder.weight'])
     go = O.fm_encoder_bwd(gz1 + gz2, p, dd, saved, 'cat')
-    close(z, zo, rtol=1e-3)
+    close_act(z, zo)
     close(loss, O.tip_loss(ps, ns), rtol=1e-4, atol=1e-6)
-    close(dec.weight.grad, gw1 + gw2, rtol=2e-3, atol=1e-4 * float((gw1 + gw2).abs().max()))
+    close_grad(dec.weight.grad, gw1 + gw2, scale=10)        # (8.3 M fixed-point terms against the oracle's fp32 index_add: 6e-5 seen)
     for k, prm in enc.named_parameters():
-        close(prm.grad, go[k], rtol=5e-3, atol=2e-5 * max(1e-6, float(go[k].abs().max())))
+        close_grad(prm.grad, go[k], scale=5)                     # (behind the decoder's gradient: 9e-6 seen)
 
 
 def test_full_biosnap_size_independent_properties(biosnap_full):
@@ -360,7 +506,7 @@ def test_full_biosnap_size_independent_properties(biosnap_full):
     with torch.no_grad():
         lhs = m(0.3 * x1 - 1.7 * x2, ei, et, rg)
         rhs = 0.3 * m(x1, ei, et, rg) - 1.7 * m(x2, ei, et, rg)
-    close(lhs, rhs, rtol=1e-3, atol=1e-4)
+    close(lhs, rhs, rtol=1e-4, atol=1e-5)
     x = x1.clone().requires_grad_(True)
     y = torch.randn(N, 32, device=DEV)
     out = m(x, ei, et, rg)
@@ -457,7 +603,7 @@ def _shard_worker(rank, world, port, ret, max_relations=12):
                 want = want_step['grads'][k]
                 if k in LOCAL_ROWS:
                     want = want[shard.rel_ids.cpu()]
-                good = torch.allclose(p.grad.cpu(), want, rtol=2e-3, atol=2e-5 * max(1e-6, float(want.abs().max())))
+                good = torch.allclose(p.grad.cpu(), want, rtol=1e-4, atol=2e-5 * max(1e-6, float(want.abs().max())))
                 if not good:
                     print('rank', rank, 'step', step, 'grad mismatch', k, float((p.grad.cpu() - want).abs().max()), flush=True)
                 ok = ok and good
@@ -614,11 +760,11 @@ def test_reference_pickle_drop_in():
     model.test_neg_index = g['test_neg'].to(DEV)                       # the reference drew these with numpy's global RNG
     loss = model(neg_index=g['train_neg'].to(DEV))
     close(loss, g['loss'], rtol=2e-5, atol=1e-6)
-    close(model.embeddings, g['embeddings'], rtol=1e-3)
+    close_act(model.embeddings, g['embeddings'])
     loss.backward()
     for k, prm in model.named_parameters():
         want = g['grad.' + k]
-        close(prm.grad, want, rtol=2e-3, atol=2e-5 * max(1e-6, float(want.abs().max())))
+        close_grad(prm.grad, want, scale=5)
     rec = model.test(print_output=False)
     np.testing.assert_allclose(rec, g['record'].numpy(), rtol=0, atol=2e-4)   # AUPRC/AUROC/AP per relation
     # the unfused loss path (decoder scores + torch ops, exactly src/layers.py:335-340) agrees too
@@ -715,7 +861,7 @@ def test_nn_decoder_objective_biosnap_size():
     gp, gn = O.tip_loss_bwd(ps, ns)
     want = [a + b for a, b in zip(O.nn_decoder_bwd(gp, z_c, posc, etc, *args), O.nn_decoder_bwd(gn, z_c, negc, etc, *args))]
     for got, ref in zip(grads, want):
-        close(got, ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+        close_grad(got, ref, scale=5)                           # (the NNDecoder's score tables at BioSNAP size: 9e-6 seen)
     # the unfused path of the module (forward() scores + torch ops) agrees
     z = z_c.to(DEV)
     unf = -torch.log(m(z, pos, et) + 1e-13).mean() - torch.log(1 - m(z, neg, et) + 1e-13).mean()

@@ -88,10 +88,10 @@ def _encoder_worker(rank, world, port, ret):
         (z * up.to(DEV)).sum().backward()
         zo, saved = O.fm_encoder_fwd(p, dd, 'cat')
         go = O.fm_encoder_bwd(up, p, dd, saved, 'cat')
-        ok = torch.allclose(z.detach().cpu().double(), zo.double(), rtol=1e-3, atol=1e-5)
+        ok = torch.allclose(z.detach().cpu().double(), zo.double(), rtol=1e-5, atol=1e-5 * float(zo.abs().max()))
         for k, prm in enc.named_parameters():
             want = go[k][ids] if k.endswith('.att') else go[k]
-            good = torch.allclose(prm.grad.cpu().double(), want.double(), rtol=2e-3,
+            good = torch.allclose(prm.grad.cpu().double(), want.double(), rtol=1e-4,
                                   atol=2e-5 * max(1e-3, float(go[k].abs().max())))
             if not good:
                 print('rank', rank, 'gradient mismatch', k, float((prm.grad.cpu() - want).abs().max()), flush=True)
@@ -146,11 +146,11 @@ def _config5_worker(rank, world, port, ret, tmp):
         graph = layer._cache.value
         ok = graph.pair_fwd is None and graph.rs_bwd is None                    # large-graph route on this rank
         ok = ok and graph.fwd.n_slots > 0                                      # segment-major plan: rows in pieces
-        checks = (('out', out.detach(), ref['out'], 1e-3), ('dX', x.grad, ref['dx'], 2e-3),
-                  ('d basis', layer.basis.grad, ref['dbasis'], 2e-3), ('d root', layer.root.grad, ref['droot'], 2e-3),
-                  ('d att rows', layer.att.grad, ref['datt'][ids], 2e-3))
+        checks = (('out', out.detach(), ref['out'], 1e-4), ('dX', x.grad, ref['dx'], 2e-4),
+                  ('d basis', layer.basis.grad, ref['dbasis'], 2e-4), ('d root', layer.root.grad, ref['droot'], 2e-4),
+                  ('d att rows', layer.att.grad, ref['datt'][ids], 2e-4))
         for name, got, want, rtol in checks:
-            good = torch.allclose(got.cpu(), want, rtol=rtol, atol=rtol * 1e-2 * max(1e-6, float(want.abs().max())))
+            good = torch.allclose(got.cpu(), want, rtol=rtol, atol=2e-5 * max(1e-6, float(want.abs().max())))
             if not good:
                 print('rank', rank, name, 'differs by', float((got.cpu() - want).abs().max()), 'of', float(want.abs().max()), flush=True)
             ok = ok and good

@@ -836,3 +836,23 @@ def test_pair_bwd_plan_reference(symmetric, part_rows):
     torch.testing.assert_close(dxb, want_xb, rtol=1e-12, atol=1e-12)
     torch.testing.assert_close(datt, want_att, rtol=1e-12, atol=1e-12)
     assert not bool(torch.isnan(pg).any())
+
+
+def test_row_plan_support_is_asked_before_the_lazy_plan_is_built():
+    """with 65 536 < N < 2^23 and a width that is no multiple of 64 the backward pass evaluated the lazy
+    `graph.row_bwd` (-> build_row_stream_plan asserts N <= 65 536) before asking the kernel whether it takes the shape.
+    `_row_plan` asks first; a shape the kernels do not take never touches the builders."""
+    from tip_amd import ops
+
+    def boom():
+        raise AssertionError('the lazy plan was built for a shape the kernel does not take')
+    big = ops.AggGraph(None, None, row_fwd=boom, row_bwd=boom, row_wave_uniform=False)
+    assert ops._row_plan(big, True, 70000, 100, 32, 32) is None and ops._row_plan(big, False, 70000, 100, 32, 96) is None
+    wave = ops.AggGraph(None, None, row_fwd=boom, row_bwd=boom, row_wave_uniform=True)
+    assert ops._row_plan(wave, True, 70000, 100, 32, 96) is None           # width no multiple of 64
+    assert ops._row_plan(wave, True, 5_000_000, 100, 32, 128) is None      # table beyond 2 GB of 32-bit byte offsets
+    none = ops.AggGraph(None, None)
+    assert ops._row_plan(none, False, 1000, 10, 32, 64) is None
+    built = []
+    ok = ops.AggGraph(None, None, row_fwd=lambda: built.append('f') or 'F', row_bwd=lambda: built.append('b') or 'B', row_wave_uniform=True)
+    assert ops._row_plan(ok, False, 70000, 100, 32, 128) == 'F' and ops._row_plan(ok, True, 70000, 100, 32, 64) == 'B' and built == ['f', 'b']

@@ -35,6 +35,29 @@ def test_rgcn_layer(name, dtype):
     close(ref_shaped, g['out'])
 
 
+@pytest.mark.parametrize('name', ['rgcn_fast_sym', 'rgcn_fast_directed'])
+def test_rgcn_two_layers_at_reference_dims(name):
+    """Round 6: 64 -> 32 -> 16, num_base 32 (tip.py:14) on a 61-drug graph with self pairs, duplicate edges, one- and two-edge
+    relations and isolated drugs -- recorded from the reference's MyRGCNConv2 x 2 with the ReLU of src/layers.py:547 between."""
+    g = load_golden(name)
+    ei, rg = g['dd_idx'], g['dd_range']
+    assert bool((ei[0] == ei[1]).any()) and int((rg[:, 1] - rg[:, 0]).min()) <= 2
+    l1 = [g['l1.' + k] for k in ('basis', 'att', 'root')]
+    l2 = [g['l2.' + k] for k in ('basis', 'att', 'root')]
+    h, s1 = O.rgcn_fwd(g['x'], ei, rg, *l1)
+    close(h, g['hidden'], rtol=1e-5, atol=1e-5)
+    x1 = torch.relu(h)
+    out, s2 = O.rgcn_fwd(x1, ei, rg, *l2)
+    close(out, g['out'], rtol=1e-5, atol=1e-5)
+    gx1, gb2, ga2, gr2 = O.rgcn_bwd(g['upstream'], x1, ei, *l2, s2)
+    gh = gx1 * (h > 0).to(gx1.dtype)
+    close(gh, g['grad_hidden'], rtol=1e-4, atol=1e-5)
+    gx, gb1, ga1, gr1 = O.rgcn_bwd(gh, g['x'], ei, *l1, s1)
+    for got, key in ((gx, 'grad_x'), (gb1, 'grad.l1.basis'), (ga1, 'grad.l1.att'), (gr1, 'grad.l1.root'),
+                     (gb2, 'grad.l2.basis'), (ga2, 'grad.l2.att'), (gr2, 'grad.l2.root')):
+        close(got, g[key], rtol=1e-4, atol=1e-5 * float(g[key].abs().max()))
+
+
 def test_hier_conv():
     g = load_golden('hier_conv')
     out, saved = O.hier_conv_fwd(g['x'], g['dp_idx'], g['weight'], g['n_source'])
@@ -101,7 +124,8 @@ def _encoder_inputs(g):
     return p, data
 
 
-@pytest.mark.parametrize('name', ['encoder_cat_small', 'encoder_add_small'])
+@pytest.mark.parametrize('name', ['encoder_cat_small', 'encoder_add_small', 'encoder_fast_cat_sym', 'encoder_fast_add_sym',
+                                  'encoder_fast_cat_directed'])
 def test_fm_encoder(name):
     g = load_golden(name)
     p, data = _encoder_inputs(g)
@@ -140,14 +164,14 @@ def test_biosnap_slice_encoder():
     assert d['dd_train_idx'].shape[1] == g['n_edges'] and int(d['dd_train_idx'].sum()) == g['edge_checksum']
     p = O.init_params(d['n_drug'], d['n_prot'], 8, seed=g['param_seed'])
     z, saved = O.fm_encoder_fwd(p, d, 'cat')
-    close(z, g['z'], rtol=1e-3, atol=1e-5)
+    close(z, g['z'], rtol=1e-4, atol=1e-5)
     grads = O.fm_encoder_bwd(g['upstream'], p, d, saved, 'cat')
     for k, v in grads.items():
         if k == 'pp_encoder.conv1.lin.weight':
-            close(v[:, ::16], g['grad.' + k + '[:, ::16]'], rtol=1e-3, atol=1e-6)
-            close(v.sum(1), g['grad.' + k + '.rowsum'], rtol=1e-3, atol=1e-5)
+            close(v[:, ::16], g['grad.' + k + '[:, ::16]'], rtol=2e-4, atol=2e-5 * float(g['grad.' + k + '[:, ::16]'].abs().max()))
+            close(v.sum(1), g['grad.' + k + '.rowsum'], rtol=2e-4, atol=2e-5 * float(g['grad.' + k + '.rowsum'].abs().max()))
         else:
-            close(v, g['grad.' + k], rtol=1e-3, atol=1e-6)
+            close(v, g['grad.' + k], rtol=2e-4, atol=2e-5 * float(g['grad.' + k].abs().max()))
 
 
 def test_tip_end_to_end_loss_and_metrics():
@@ -168,7 +192,7 @@ def test_tip_end_to_end_loss_and_metrics():
     close(gw1 + gw2, g['grad.decoder.weight'])
     grads = O.fm_encoder_bwd(gz1 + gz2, p, data, saved, 'add')
     for k, v in grads.items():
-        close(v, g['grad.encoder.' + k], rtol=5e-4, atol=1e-6)
+        close(v, g['grad.encoder.' + k], rtol=2e-4, atol=2e-5 * float(g['grad.encoder.' + k].abs().max()))
     # test(): per-relation metrics on the recorded fixed test negatives
     ps = O.distmult_fwd(z, g['dd_test_idx'], g['dd_test_et'], w)
     ns = O.distmult_fwd(z, g['test_neg'], g['dd_test_et'], w)

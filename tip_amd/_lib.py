@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class TipkError(RuntimeError):
@@ -81,6 +81,7 @@ SIGNATURES = {
     'tipk_rgcn_pair_grads_supported': (_I, [_I, _I]),
     'tipk_rgcn_pair_grads': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _P, _L, _L, _P, _L, _P]),
     'tipk_stream_gather_parts': (_I, [_P, _L, _I, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _L, _P]),
+    'tipk_stream_gather_parts_two': (_I, [_P, _P, _L, _I, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P]),
     'tipk_rgcn_dest_products_supported': (_I, [_L, _L, _I, _I]),
     'tipk_rgcn_dest_products': (_I, [_P, _L, _I, _P, _L, _I, _L, _L, _P, _P, _P, _L, _L, _P]),
     'tipk_rgcn_row_products_supported': (_I, [_L, _L, _I, _I]),
@@ -113,6 +114,11 @@ SIGNATURES = {
     'tipk_drug_mix_gather_supported': (_I, [_I, _I]),
     'tipk_drug_mix_gather_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P]),
     'tipk_drug_mix_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P]),
+    'tipk_drug_mix_gather_xb_supported': (_I, [_I, _I, _I, _I, _I, _I]),
+    'tipk_drug_mix_gather_xb_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'tipk_pd_stage_bwd_supported': (_I, [_I, _I, _L, _I]),
+    'tipk_pd_stage_bwd_slabs': (_L, [_L, _I]),
+    'tipk_pd_stage_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _P, _L, _L, _P, _P, _L, _P, _P, _P]),
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),
     'tipk_distmult_fwd': (_I, [_P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P, _P, _P]),

@@ -30,7 +30,14 @@ struct DgFwdArgs {
     const float* w; int p, q, ne, cat;
     float* out; int64_t ld_out; float* mean;                  // mean [rows x p] contiguous
     int rows;
+    // XB tail (tipk_drug_mix_gather_xb_fwd): the first R-GCN layer's row-local products of the rows this workgroup finishes
+    const float* basis; const float* root; int n_bases, d_out;    // [n_bases][cols][d_out], [cols][d_out]; cols = width of out
+    float* xb;                                                // [..][n_bases][32] node-major, rows padded to 32 columns
+    float* xroot;                                             // [rows][d_out]
 };
+
+constexpr int DG_XMAX = 128;                                  // widest mixed row the XB tail takes
+constexpr int DG_XLD = DG_XMAX + 2;                           // LDS row stride of the staged rows (A-operand reads: no 4-way conflicts)
 
 // sum of h[src[e], c] over e in [e0, e1) for this lane's column c = lane % PL, edge slots side by side: 64 edges per batch --
 // ONE coalesced load of their source ids (requested a batch ahead), then 64 / SLOTS row loads per lane issued back to back.
@@ -60,11 +67,14 @@ __device__ __forceinline__ float dg_row_sum(const float* __restrict__ h, int64_t
     return acc;
 }
 
-template <int PL>                                             // lanes per edge slot: the power of two >= p
+template <int PL, bool XB>                                    // lanes per edge slot: the power of two >= p
 __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) {
     __shared__ float wl[DG_MAX * DG_MAX];
     __shared__ float ml[16][DG_MAX];
+    __shared__ float xl[XB ? 16 * DG_XLD : 1];                // XB: the workgroup's rows of x0 (rows it does not own stay zero)
     for (int i = threadIdx.x; i < a.p * a.q; i += 1024) wl[i] = a.w[i];
+    if constexpr (XB)
+        for (int i = threadIdx.x; i < 16 * DG_XLD; i += 1024) xl[i] = 0.f;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int2 desc = a.wg[blockIdx.x];
     const bool coop = desc.y == 1;
@@ -84,33 +94,81 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
         if (lane < a.p) ml[wv][lane] = m;
     }
     __syncthreads();
-    if (coop) {
-        if (wv != 0) return;
-        m = 0.f;
-        if (lane < a.p)
-            for (int k = 0; k < 16; ++k) m += ml[k][lane];   // the waves' shares, in order
-    } else if (!live) {
-        return;
-    }
-    m *= a.scale[d];
-    if (lane < a.p) {
-        a.mean[(int64_t)d * a.p + lane] = m;
-        ml[wv][lane] = m;
-    }
-    __builtin_amdgcn_wave_barrier();                          // (ml[wv] is written and read by this wavefront only)
     const int cols = a.cat ? a.ne + a.q : a.ne;
-    float* o = a.out + (int64_t)d * a.ld_out;
-    const float* x = a.xd + (int64_t)d * a.ld_xd;
-    for (int col = lane; col < cols; col += 64) {
-        float v = 0.f;
-        if (col < a.ne) v = a.d_norm ? x[col] / a.d_norm[d] : x[col];
-        const int j = a.cat ? col - a.ne : col;
-        if (j >= 0 && j < a.q) {
-            float t = 0.f;
-            for (int k = 0; k < a.p; ++k) t = fmaf(ml[wv][k], wl[k * a.q + j], t);
-            v += t;
+    bool mine = live;                                         // this wavefront finishes row d
+    if (coop) {
+        mine = wv == 0;
+        if (mine) {
+            m = 0.f;
+            if (lane < a.p)
+                for (int k = 0; k < 16; ++k) m += ml[k][lane];   // the waves' shares, in order
         }
-        o[col] = v;
+    }
+    if (!XB && !mine) return;
+    if (mine) {
+        m *= a.scale[d];
+        if (lane < a.p) {
+            a.mean[(int64_t)d * a.p + lane] = m;
+            ml[wv][lane] = m;
+        }
+        __builtin_amdgcn_wave_barrier();                      // (ml[wv] is written and read by this wavefront only)
+        float* o = a.out + (int64_t)d * a.ld_out;
+        const float* x = a.xd + (int64_t)d * a.ld_xd;
+        for (int col = lane; col < cols; col += 64) {
+            float v = 0.f;
+            if (col < a.ne) v = a.d_norm ? x[col] / a.d_norm[d] : x[col];
+            const int j = a.cat ? col - a.ne : col;
+            if (j >= 0 && j < a.q) {
+                float t = 0.f;
+                for (int k = 0; k < a.p; ++k) t = fmaf(ml[wv][k], wl[k * a.q + j], t);
+                v += t;
+            }
+            o[col] = v;
+            if constexpr (XB) xl[(coop ? 0 : wv) * DG_XLD + col] = v;
+        }
+    }
+    if constexpr (XB) {
+        // XB[d] = x0[d] basis (node-major, 32-column rows) and x0[d] root for the workgroup's <= 16 rows: 16 x 16 tiles of
+        // v_mfma_f32_16x16x4_f32 (A: lane = row l & 15, k = l >> 4, out of LDS once; B: the weights straight from L2 in the
+        // operand layout, lane = column l & 15, k = l >> 4), K = the mixed row in index order -- a k-ordered fma chain
+        __syncthreads();
+        const int m16 = lane & 15, q16 = lane >> 4;
+        const int ksteps = cols >> 2;                         // cols % 4 == 0, <= DG_XMAX (host)
+        const int tpb = a.d_out >> 4;                         // 16-column tiles per basis (d_out = 16 | 32)
+        const int xb_tiles = a.n_bases * tpb, n_tiles = xb_tiles + tpb;
+        const int d0 = desc.x, nrow = desc.y;
+        const float* xrow = xl + m16 * DG_XLD + q16;
+        const int ldw = a.d_out;
+        for (int tile = wv; tile < n_tiles; tile += 16) {
+            const bool is_root = tile >= xb_tiles;
+            const int b = is_root ? 0 : tile / tpb;
+            const int c0 = (is_root ? tile - xb_tiles : tile - b * tpb) << 4;
+            const float* wp = (is_root ? a.root : a.basis + (int64_t)b * cols * ldw) + c0 + m16 + q16 * ldw;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < ksteps; k0 += 16) {         // 16 k-steps (64 columns of the row) per batch of loads
+                float av[16], bw[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int kc = k0 + ks < ksteps ? k0 + ks : ksteps - 1;     // clamped, unconditional
+                    bw[ks] = wp[4 * kc * ldw];
+                    av[ks] = xrow[4 * kc];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const float am = k0 + ks < ksteps ? av[ks] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bw[ks], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 4 * q16 + v;                    // C: row = 4 (l >> 4) + v, column = l & 15
+                if (r < nrow) {
+                    if (is_root) a.xroot[(int64_t)(d0 + r) * a.d_out + c0 + m16] = acc[v];
+                    else a.xb[((int64_t)(d0 + r) * a.n_bases + b) * 32 + c0 + m16] = acc[v];
+                }
+            }
+        }
     }
 }
 
@@ -225,6 +283,183 @@ __global__ __launch_bounds__(1024) void drug_mix_bwd_kernel(DgBwdArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the backward pass of the whole P -> D stage in ONE launch (it was three: tipk_drug_mix_bwd, the transposed
+// gather of d mean on its plan, the grouped products of GCNConv 2's backward pass -- 7.9 + 9.1 + 8.8 us for KFLOPs):
+//
+//     d xd   = g[:, :ne] / d_norm                                   (slices, all row workgroups)
+//     d W_h  = mean^T g_pd                                          (workgroup 0: the 645-row reduction, as tipk_drug_mix_bwd)
+//     d mean = g_pd W_h^T                                           [rows x p]: every row workgroup computes ALL of it into its
+//                                                                   LDS (165 K fma, 41 KB of g out of L2) -- nothing crosses
+//                                                                   workgroups inside the launch
+//     g_h[s] = sum_{e: s -> d} tw[e] d mean[d]                      the transposed P -> D gather, a wavefront per kept source row,
+//                                                                   CSR by source row, rows of d mean out of LDS
+//     gw[s]  = (g_h[s] W2) * row_scale[s]                           GCNConv 2's  g W  on the row it belongs to (p -> c1 columns)
+//     d W2 partial [c1 x p] = agg[rows of the workgroup]^T g_h,  d b2 partial [p] = column sums of g_h
+//
+// The partials are slabs, one per row workgroup, summed in order by the next launch's riders (tipk_gather_sum_riders).
+// Fixed order everywhere: bitwise reproducible.
+struct PdBwdArgs {
+    DgBwdArgs m;                                              // the drug-mix half (g_mean unused)
+    const int32_t* tptr; const int32_t* tdst; const float* tw; int n_src;     // CSR by kept source row: drug, 1 / #targets(drug)
+    const float* agg; int64_t ld_agg; int c1;                 // [n_src x c1]: GCNConv 2's aggregated input rows
+    const float* w2; int64_t w2_sk, w2_sn;                    // W2 (k < p, n < c1) at w2[k * w2_sk + n * w2_sn]
+    const float* row_scale;                                   // nullable
+    float* gw; int64_t ld_gw;                                 // [n_src x c1]
+    float* dw2; float* db2;                                   // slabs [n_row_wg][c1][p], [n_row_wg][p]
+    int rows_per_wg;
+};
+
+constexpr int PD_DMEAN = 24576;                               // floats of LDS for d mean [rows x p]
+constexpr int PD_W2 = PD_DMEAN;                               // W2 [p x c1] (<= 4096)
+constexpr int PD_GH = PD_DMEAN + 4096;                        // g_h of the workgroup's rows [rows_per_wg x p] (<= 4096)
+
+template <int PL>
+__global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
+    __shared__ float sm[DG_STAGE + 4096];
+    const DgBwdArgs& a = A.m;
+    const int t = threadIdx.x;
+    const int qoff = a.cat ? a.ne : 0;
+    if (blockIdx.x == 0) {
+        // ------------------------------------------------------------ d W_h = mean^T g_pd over all rows (as drug_mix_bwd_kernel)
+        const int hq = a.q / 2;
+        const int kgi = t / a.tp, pt = t % a.tp;
+        const int pi = pt / hq, pj = pt % hq;
+        const int pw = a.p + a.q;
+        float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+        const int lr = t / pw, lc = t - lr * pw, lrs = 1024 / pw;
+        for (int r0 = 0; r0 < a.rows; r0 += a.tile) {
+            const int nr = a.rows - r0 < a.tile ? a.rows - r0 : a.tile;
+            __syncthreads();
+            if (lr < lrs) {
+                const float* src = lc < a.p ? a.mean + (int64_t)r0 * a.p + lc : a.g + (int64_t)r0 * a.ld_g + qoff + (lc - a.p);
+                const int64_t ld = lc < a.p ? a.p : a.ld_g;
+                int r = lr;
+                for (; r + 3 * lrs < nr; r += 4 * lrs) {
+                    const float v0 = src[(int64_t)r * ld], v1 = src[(int64_t)(r + lrs) * ld];
+                    const float v2 = src[(int64_t)(r + 2 * lrs) * ld], v3 = src[(int64_t)(r + 3 * lrs) * ld];
+                    sm[r * pw + lc] = v0; sm[(r + lrs) * pw + lc] = v1;
+                    sm[(r + 2 * lrs) * pw + lc] = v2; sm[(r + 3 * lrs) * pw + lc] = v3;
+                }
+                for (; r < nr; r += lrs) sm[r * pw + lc] = src[(int64_t)r * ld];
+            }
+            __syncthreads();
+            if (kgi < a.kg) {
+                const float* mrow = sm + 2 * pi;
+                const float* grow = sm + a.p + 2 * pj;
+                for (int r = kgi; r < nr; r += a.kg) {
+                    const float2 mv = *reinterpret_cast<const float2*>(mrow + r * pw);
+                    const float2 gv = *reinterpret_cast<const float2*>(grow + r * pw);
+                    s00 = fmaf(mv.x, gv.x, s00); s01 = fmaf(mv.x, gv.y, s01);
+                    s10 = fmaf(mv.y, gv.x, s10); s11 = fmaf(mv.y, gv.y, s11);
+                }
+            }
+        }
+        float* part = sm + DG_STAGE;
+        if (kgi < a.kg) {
+            float* sp = part + kgi * (a.p * a.q);
+            sp[(2 * pi) * a.q + 2 * pj] = s00; sp[(2 * pi) * a.q + 2 * pj + 1] = s01;
+            sp[(2 * pi + 1) * a.q + 2 * pj] = s10; sp[(2 * pi + 1) * a.q + 2 * pj + 1] = s11;
+        }
+        __syncthreads();
+        for (int o = t; o < a.p * a.q; o += 1024) {
+            float s = part[o];
+            for (int k = 1; k < a.kg; ++k) s += part[k * (a.p * a.q) + o];
+            a.g_w[o] = s;
+        }
+        return;
+    }
+    const int b = blockIdx.x - 1;
+    float* wl = sm + DG_STAGE;                                // W_h [p x q]
+    float* w2l = sm + PD_W2;                                  // W2 [p x c1]
+    float* gh = sm + PD_GH;
+    const int p = a.p, c1 = A.c1;
+    for (int i = t; i < p * a.q; i += 1024) wl[i] = a.w[i];
+    for (int i = t; i < p * c1; i += 1024) w2l[i] = A.w2[(int64_t)(i / c1) * A.w2_sk + (int64_t)(i % c1) * A.w2_sn];
+    // ---------------------------------------------------------------- d xd = g[:, :ne] / d_norm (a slice per workgroup)
+    if (a.g_xd) {
+        const int tot = a.rows * a.ne;
+        const int per = (tot + a.n_wg - 1) / a.n_wg;
+        const int i1 = (b + 1) * per < tot ? (b + 1) * per : tot;
+        for (int i = b * per + t; i < i1; i += 1024) {
+            const int r = i / a.ne;
+            const int c = i - r * a.ne;
+            const float v = a.g[(int64_t)r * a.ld_g + c];
+            a.g_xd[(int64_t)r * a.ld_gxd + c] = a.d_norm ? v / a.d_norm[r] : v;
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- d mean = g_pd W_h^T, ALL rows, into LDS
+    for (int i = t; i < a.rows * p; i += 1024) {
+        const int r = i / p;
+        const int c = i - r * p;
+        const float* gr = a.g + (int64_t)r * a.ld_g + qoff;
+        float v = 0.f;
+        for (int j = 0; j < a.q; ++j) v = fmaf(gr[j], wl[c * a.q + j], v);
+        sm[i] = v;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- the workgroup's source rows: a wavefront per row
+    constexpr int SLOTS = 64 / PL;
+    const int lane = t & 63, wv = t >> 6;
+    const int s_first = b * A.rows_per_wg;
+    const int n_mine = A.n_src - s_first < A.rows_per_wg ? A.n_src - s_first : A.rows_per_wg;
+    const int cl = lane % PL, sl = lane / PL;
+    const int cc = cl < p ? cl : p - 1;
+    for (int rl = wv; rl < n_mine; rl += 16) {
+        const int s = s_first + rl;
+        const int e0 = A.tptr[s], e1 = A.tptr[s + 1];
+        float acc = 0.f;
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int ne_b = e1 - eb < 64 ? e1 - eb : 64;
+            const int dcur = lane < ne_b ? A.tdst[eb + lane] : 0;
+            const float wcur = lane < ne_b ? A.tw[eb + lane] : 0.f;
+            const int steps = (ne_b + SLOTS - 1) / SLOTS;
+            for (int st = 0; st < steps; ++st) {
+                const int k = SLOTS * st + sl;
+                const int dd = __shfl(dcur, k & 63, 64);
+                const float ww = __shfl(wcur, k & 63, 64);
+                const float v = sm[dd * p + cc];
+                acc = k < ne_b ? fmaf(ww, v, acc) : acc;
+            }
+        }
+#pragma unroll
+        for (int off = PL; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane < p) gh[rl * p + lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        const float rs = A.row_scale ? A.row_scale[s] : 1.f;
+        for (int n = lane; n < c1; n += 64) {
+            float v = 0.f;
+            for (int k = 0; k < p; ++k) v = fmaf(gh[rl * p + k], w2l[k * c1 + n], v);
+            A.gw[(int64_t)s * A.ld_gw + n] = A.row_scale ? v * rs : v;
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- partial d W2 [c1 x p] = agg^T g_h and d b2 [p] over the rows
+    float* dw = A.dw2 + (int64_t)b * c1 * p;
+    for (int o = t; o < c1 * p + p; o += 1024) {
+        float sacc = 0.f;
+        if (o < c1 * p) {
+            const int k = o / p, c = o - k * p;
+            const float* ap = A.agg + (int64_t)s_first * A.ld_agg + k;
+            int r = 0;
+            for (; r + 4 <= n_mine; r += 4) {
+                const float a0 = ap[(int64_t)r * A.ld_agg], a1 = ap[(int64_t)(r + 1) * A.ld_agg];
+                const float a2 = ap[(int64_t)(r + 2) * A.ld_agg], a3 = ap[(int64_t)(r + 3) * A.ld_agg];
+                sacc = fmaf(a0, gh[r * p + c], sacc); sacc = fmaf(a1, gh[(r + 1) * p + c], sacc);
+                sacc = fmaf(a2, gh[(r + 2) * p + c], sacc); sacc = fmaf(a3, gh[(r + 3) * p + c], sacc);
+            }
+            for (; r < n_mine; ++r) sacc = fmaf(ap[(int64_t)r * A.ld_agg], gh[r * p + c], sacc);
+            dw[o] = sacc;
+        } else {
+            const int c = o - c1 * p;
+            for (int r = 0; r < n_mine; ++r) sacc += gh[r * p + c];
+            A.db2[(int64_t)b * p + c] = sacc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tipk_drug_mix_gather_supported(int p, int q) {
@@ -246,12 +481,46 @@ extern "C" int tipk_drug_mix_gather_fwd(const float* xd, int64_t ld_xd, const fl
     a.xd = xd; a.ld_xd = ld_xd; a.d_norm = d_norm; a.h = h; a.ld_h = ld_h; a.ptr = ptr; a.src = src; a.scale = scale;
     a.wg = reinterpret_cast<const int2*>(wg_desc);
     a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat; a.out = out; a.ld_out = ld_out; a.mean = mean; a.rows = (int)rows;
+    a.basis = nullptr; a.root = nullptr; a.n_bases = 0; a.d_out = 0; a.xb = nullptr; a.xroot = nullptr;
     const dim3 grid((unsigned)n_wg);
     hipStream_t st = (hipStream_t)stream;
-    if (p <= 8) hipLaunchKernelGGL(drug_mix_gather_fwd_kernel<8>, grid, dim3(1024), 0, st, a);
-    else if (p <= 16) hipLaunchKernelGGL(drug_mix_gather_fwd_kernel<16>, grid, dim3(1024), 0, st, a);
-    else if (p <= 32) hipLaunchKernelGGL(drug_mix_gather_fwd_kernel<32>, grid, dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL(drug_mix_gather_fwd_kernel<64>, grid, dim3(1024), 0, st, a);
+    if (p <= 8) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<8, false>), grid, dim3(1024), 0, st, a);
+    else if (p <= 16) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<16, false>), grid, dim3(1024), 0, st, a);
+    else if (p <= 32) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<32, false>), grid, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<64, false>), grid, dim3(1024), 0, st, a);
+    TIPK_RETURN_LAUNCH();
+}
+
+extern "C" int tipk_drug_mix_gather_xb_supported(int p, int q, int ne, int cat, int n_bases, int d_out) {
+    if (!tipk_drug_mix_gather_supported(p, q) || ne < 0 || (!cat && q != ne)) return 0;
+    const int cols = cat ? ne + q : ne;
+    if (cols <= 0 || cols > DG_XMAX || (cols & 3)) return 0;
+    if (n_bases < 1 || n_bases > 4096 || (d_out != 16 && d_out != 32)) return 0;
+    return 1;
+}
+
+extern "C" int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
+                                           const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc,
+                                           int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat, float* out,
+                                           int64_t ld_out, float* mean, const float* basis, const float* root, int n_bases,
+                                           int d_out, float* xb, float* xroot, tipk_stream_t stream) {
+    if (rows < 0 || ne < 0) return TIPK_EINVAL;
+    if (!tipk_drug_mix_gather_xb_supported(p, q, ne, cat, n_bases, d_out)) return TIPK_EUNSUPPORTED;
+    if (rows == 0) return TIPK_OK;
+    if (!xd || !h || !ptr || !src || !scale || !w || !out || !mean || !wg_desc || !basis || !root || !xb || !xroot || n_wg <= 0 ||
+        rows > 0x7fffffffLL || n_wg > 0x7fffffffLL || (reinterpret_cast<uintptr_t>(wg_desc) & 7))
+        return TIPK_EINVAL;
+    DgFwdArgs a;
+    a.xd = xd; a.ld_xd = ld_xd; a.d_norm = d_norm; a.h = h; a.ld_h = ld_h; a.ptr = ptr; a.src = src; a.scale = scale;
+    a.wg = reinterpret_cast<const int2*>(wg_desc);
+    a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat; a.out = out; a.ld_out = ld_out; a.mean = mean; a.rows = (int)rows;
+    a.basis = basis; a.root = root; a.n_bases = n_bases; a.d_out = d_out; a.xb = xb; a.xroot = xroot;
+    const dim3 grid((unsigned)n_wg);
+    hipStream_t st = (hipStream_t)stream;
+    if (p <= 8) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<8, true>), grid, dim3(1024), 0, st, a);
+    else if (p <= 16) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<16, true>), grid, dim3(1024), 0, st, a);
+    else if (p <= 32) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<32, true>), grid, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<64, true>), grid, dim3(1024), 0, st, a);
     TIPK_RETURN_LAUNCH();
 }
 
@@ -276,5 +545,54 @@ extern "C" int tipk_drug_mix_bwd(const float* g, int64_t ld_g, const float* d_no
     if (n_wg > 240) n_wg = 240;
     a.n_wg = (int)n_wg;
     hipLaunchKernelGGL(drug_mix_bwd_kernel, dim3((unsigned)(1 + n_wg)), dim3(1024), 0, (hipStream_t)stream, a);
+    TIPK_RETURN_LAUNCH();
+}
+
+extern "C" int tipk_pd_stage_bwd_supported(int p, int q, int64_t rows, int c1) {
+    if (!tipk_drug_mix_gather_supported(p, q) || rows <= 0 || rows * p > PD_DMEAN) return 0;
+    if (c1 <= 0 || c1 > 256 || (int64_t)p * c1 > 4096) return 0;
+    return 1;
+}
+
+extern "C" int64_t tipk_pd_stage_bwd_slabs(int64_t n_src, int p) {
+    if (n_src <= 0 || p <= 0) return 0;
+    const int64_t rpw = 4096 / p < 64 ? 4096 / p : 64;
+    return tipk_ceil_div(n_src, rpw);
+}
+
+extern "C" int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
+                                 int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w,
+                                 const int32_t* tptr, const int32_t* tdst, const float* tw, int64_t n_src,
+                                 const float* agg, int64_t ld_agg, int c1, const float* w2, int64_t w2_sk, int64_t w2_sn,
+                                 const float* row_scale, float* gw, int64_t ld_gw, float* dw2_slabs, float* db2_slabs,
+                                 tipk_stream_t stream) {
+    if (rows < 0 || ne < 0 || n_src < 0) return TIPK_EINVAL;
+    if (!tipk_pd_stage_bwd_supported(p, q, rows, c1) || (!cat && q != ne)) return TIPK_EUNSUPPORTED;
+    if (!g || !mean || !w || !g_w || !tptr || !tdst || !tw || !agg || !w2 || !gw || !dw2_slabs || !db2_slabs || n_src == 0 ||
+        rows * (int64_t)(ne + p + q) > 0x7fffffffLL || n_src > 0x7fffffffLL)
+        return TIPK_EINVAL;
+    PdBwdArgs A;
+    DgBwdArgs& a = A.m;
+    a.g = g; a.ld_g = ld_g; a.d_norm = d_norm; a.mean = mean; a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat;
+    a.g_xd = g_xd; a.ld_gxd = ld_gxd; a.g_mean = nullptr; a.g_w = g_w;
+    a.rows = (int)rows;
+    a.tp = p * q / 4;
+    a.kg = 1024 / a.tp;
+    if (a.kg > 4096 / (p * q)) a.kg = 4096 / (p * q);
+    if (a.kg > 16) a.kg = 16;
+    if (a.kg < 1) a.kg = 1;
+    a.tile = DG_STAGE / (p + q);
+    A.rows_per_wg = 4096 / p < 64 ? 4096 / p : 64;
+    const int64_t n_wg = tipk_ceil_div(n_src, (int64_t)A.rows_per_wg);
+    a.n_wg = (int)n_wg;
+    A.tptr = tptr; A.tdst = tdst; A.tw = tw; A.n_src = (int)n_src;
+    A.agg = agg; A.ld_agg = ld_agg; A.c1 = c1; A.w2 = w2; A.w2_sk = w2_sk; A.w2_sn = w2_sn; A.row_scale = row_scale;
+    A.gw = gw; A.ld_gw = ld_gw; A.dw2 = dw2_slabs; A.db2 = db2_slabs;
+    const dim3 grid((unsigned)(1 + n_wg));
+    hipStream_t st = (hipStream_t)stream;
+    if (p <= 8) hipLaunchKernelGGL(pd_stage_bwd_kernel<8>, grid, dim3(1024), 0, st, A);
+    else if (p <= 16) hipLaunchKernelGGL(pd_stage_bwd_kernel<16>, grid, dim3(1024), 0, st, A);
+    else if (p <= 32) hipLaunchKernelGGL(pd_stage_bwd_kernel<32>, grid, dim3(1024), 0, st, A);
+    else hipLaunchKernelGGL(pd_stage_bwd_kernel<64>, grid, dim3(1024), 0, st, A);
     TIPK_RETURN_LAUNCH();
 }

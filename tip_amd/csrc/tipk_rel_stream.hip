@@ -366,6 +366,33 @@ extern "C" int tipk_stream_gather_parts(const float* table, int64_t ld_table, in
     return launch_rs<8>(a, (int)n_wg, 1, 2, (hipStream_t)stream);
 }
 
+// d att of BOTH R-GCN layers in one launch (round 6): the layers share the pair-backward plan; blockIdx.y = 1 stages its
+// partitions from table1 and writes out1.  One launch ramp and one tail instead of two (the gathers are off the critical
+// path of the dense products between them: an encoder-level schedule runs them side by side once both tables exist).
+extern "C" int tipk_stream_gather_parts_two(const float* table0, const float* table1, int64_t ld_table, int d, int64_t second,
+                                             const int32_t* part_first, int64_t part_len, const int32_t* wg_part, int64_t n_wg,
+                                             const int32_t* wave_ptr, const uint32_t* cells, const uint16_t* ids, int idx_unit,
+                                             const int32_t* zero_ptr, const int32_t* zero_rows, float* out0, float* out1,
+                                             int64_t ld_out, tipk_stream_t stream) {
+    if (n_wg <= 0 || n_wg > 65535 || !table0 || !table1 || !part_first || !wg_part || !wave_ptr || !cells || !ids ||
+        (zero_ptr && !zero_rows) || !out0 || !out1 || (reinterpret_cast<uintptr_t>(ids) & 15) || second < 0)
+        return TIPK_EINVAL;
+    if (d != 32) return TIPK_EUNSUPPORTED;
+    if (part_len <= 0 || (part_len + 1) * d * 4 > RS_LDS_LIMIT) return TIPK_EUNSUPPORTED;
+    if (ld_table % 4 != 0 || ld_out % 4 != 0 || ((reinterpret_cast<uintptr_t>(table0) | reinterpret_cast<uintptr_t>(table1) |
+                                                   reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1)) & 15))
+        return TIPK_EINVAL;
+    RsArgs a;
+    a.table = table0; a.ld_t = ld_table; a.n_nodes = (int)part_len; a.dc = d;
+    a.wave_ptr = wave_ptr; a.cells = cells; a.ids = ids; a.zero_ptr = zero_ptr; a.zero_rows = zero_rows;
+    a.out = out0; a.ld_out = ld_out; a.row_scale = nullptr;
+    a.out_scale = nullptr; a.bias = nullptr; a.relu = 0;
+    a.part_first = part_first; a.wg_part = wg_part; a.second = second; a.table1 = table1; a.out1 = out1;
+    if (idx_unit <= 0 || (a.dc * 4) % idx_unit != 0 || part_len * idx_unit > 65535) return TIPK_EINVAL;
+    a.idx_mul = a.dc * 4 / idx_unit;
+    return launch_rs<8>(a, (int)n_wg, 2, 2, (hipStream_t)stream);
+}
+
 // The pair cells of BOTH R-GCN layers of an encoder in one launch (include/tipk.h section 1d): the layers share the graph,
 // hence the plan; a workgroup stages att of layer blockIdx.y.  (Two launches of 256 workgroups each left the chip idle
 // through two launch ramps and two tails; the cells depend on the parameters only, so they can lead the step.)

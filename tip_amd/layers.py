@@ -19,7 +19,7 @@ import torch
 from torch import nn
 from torch.nn import Parameter as Param
 
-from . import ops
+from . import encoder, ops
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
 from .plan import (build_pair_bwd_plan, build_dest_plan, build_row_stream_plan, build_row_stream_plan_s, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
@@ -263,6 +263,10 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     wgs += [[b0, min(16, n_t - b0)] for b0 in range(start, n_t, 16)]
     fwd_wg = torch.tensor(wgs, dtype=torch.int32, device=src.device).view(-1, 2).contiguous()
     graph.pd_csr = dict(fwd_ptr=ptr(dst, n_t), fwd_src=i32(src[of]), scale=scale, fwd_wg=fwd_wg, n_src=int(n_tab))
+    # CSR by SOURCE row (edge order kept inside a row) with 1 / count of the edge's target: the transposed gather inside the
+    # fused backward launch of the stage (tipk_pd_stage_bwd, tip_amd/encoder.py)
+    ot = torch.sort(src, stable=True).indices
+    graph.pd_csr.update(t_ptr=ptr(src, n_tab), t_dst=i32(dst[ot]), t_w=scale[dst[ot]].contiguous())
     return graph
 
 
@@ -462,18 +466,24 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
     # forward pass of LARGE node sets without Y (tipk_rgcn_dest_products): where Y = [R N, d_out] would not stay in the
     # Infinity Cache (config 5: 10 GB) and neither LDS route applies
     dest_fwd = row_fwd = row_bwd = None
+    wide = False
     if src.is_cuda and d_out and n_bases and pair_fwd is None and n_rel * n_nodes * d_out * 4 > (192 << 20):
         bits = ops.dest_products_bits(n_nodes, n_rel, n_bases, 1)
         if bits:
             dest_fwd = lambda: build_dest_plan(src, dst, rel, n_nodes, n_rel, bits)
-        if n_nodes < (1 << 23):
-            # row sums assembled in LDS (tipk_rgcn_row_products): rows (relation, destination) <- sources for the forward pass,
-            # rows (relation, source) <- destinations for the transposed pass
-            # (widths that are multiples of 64: the wave-uniform form, tipk_rgcn_row_products_s)
-            wide = bool(d_out) and d_out % 64 == 0 and ops.row_products_s_supported(n_nodes, n_rel, n_bases, d_out)
-            build = build_row_stream_plan_s if wide else build_row_stream_plan
-            row_fwd = lambda: build(dst, src, rel, n_nodes, n_rel)
-            row_bwd = lambda: build(src, dst, rel, n_nodes, n_rel)
+        # row sums assembled in LDS (tipk_rgcn_row_products): rows (relation, destination) <- sources for the forward pass,
+        # rows (relation, source) <- destinations for the transposed pass.  Widths that are multiples of 64 take the
+        # wave-uniform form (tipk_rgcn_row_products_s: any node count whose table stays below 2 GB); other multiples of 32 the
+        # per-lane form (<= 65 536 nodes: a 16-bit node field in the entry word).  A plan is installed only where the
+        # matching `_supported` query passes for THIS node count: the passes test `graph.row_fwd is not None`
+        wide = bool(d_out) and d_out % 64 == 0 and ops.row_products_s_supported(n_nodes, n_rel, n_bases, d_out) \
+            and n_nodes < (1 << 23) and n_nodes * d_out * 4 < 2 ** 31
+        if wide:
+            row_fwd = lambda: build_row_stream_plan_s(dst, src, rel, n_nodes, n_rel)
+            row_bwd = lambda: build_row_stream_plan_s(src, dst, rel, n_nodes, n_rel)
+        elif ops.row_products_supported(n_nodes, n_rel, n_bases, 32):
+            row_fwd = lambda: build_row_stream_plan(dst, src, rel, n_nodes, n_rel)
+            row_bwd = lambda: build_row_stream_plan(src, dst, rel, n_nodes, n_rel)
 
     def fwd_plan():
         # Y = [R N, d_out] beyond the Infinity Cache (config 5: 10 GB): launch the items relation block by
@@ -490,7 +500,8 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
                         lambda: build_gather_plan(yrow, dst, n_rel * n_nodes, n_nodes, None, chunk, 'dd.bwd'),
                         (1.0 / deg).contiguous(), rl_fwd, rl_bwd,
                         csr_bwd=lambda: build_csr_plan(yrow, dst, n_rel * n_nodes, n_nodes, 'dd.bwd'), rs_bwd=rs_bwd,
-                        pair_fwd=pair_fwd, pair_bwd=pair_bwd, dest_fwd=dest_fwd, row_fwd=row_fwd, row_bwd=row_bwd)
+                        pair_fwd=pair_fwd, pair_bwd=pair_bwd, dest_fwd=dest_fwd, row_fwd=row_fwd, row_bwd=row_bwd,
+                        row_wave_uniform=wide)
 
 
 class _RGCNBase(nn.Module):
@@ -605,8 +616,44 @@ class FMEncoder(nn.Module):
     def reset_parameters(self):
         self.embed.data.normal_()
 
+    def fused_plans(self, x_drug, dd_edge_index, dd_range_list, d_norm, x_prot, pp_edge_index, dp_edge_index):
+        """(xd, encoder.EncoderPlans) if this call can run as ONE autograd node with its own launch schedule
+        (tip_amd/encoder.py: identity protein features, pruned conv2, pair-form D-D graph on both layers, no relation
+        sharding), else None.  The graphs are the layers' own cached plans: both routes build and share the same ones."""
+        if os.environ.get('TIPK_NO_ENCODER_STEP') or not self.prune_pp_rows or not _is_identity_features(x_prot):
+            return None
+        r1, r2 = self.rgcn1, self.rgcn2
+        if r1.shard is not None or r2.shard is not None or r1.bias is not None or r2.bias is not None:
+            return None
+        if not (torch.is_tensor(d_norm) and d_norm.is_cuda and self.embed.is_cuda):
+            return None
+        rows = self.hgcn.source_rows(dp_edge_index)
+        n_prot = x_prot.shape[0]
+        if rows is None or rows.numel() >= n_prot or rows.numel() == 0:
+            return None
+        c1, c2 = self.pp_encoder.conv1, self.pp_encoder.conv2
+        pd = self.hgcn.mean_sources(None, dp_edge_index, rows=rows, graph_only=True)
+        if pd is None:
+            return None
+        xd = self._drug_feat.apply_table(x_drug, self.embed)
+        n = xd.shape[0]
+        pp = c1._cache.get((pp_edge_index,), lambda: gcn_norm_graph(pp_edge_index, n_prot, c1.chunk, c1.out_channels))
+        pp_rows = c2._cache_rows.get((pp_edge_index, rows), lambda: gcn_norm_graph(pp_edge_index, n_prot, c2.chunk, c2.in_channels, rows))
+        plans = encoder.EncoderPlans(pp, pp_rows, pd, r1.graph_for(n, dd_edge_index, dd_range_list),
+                                     r2.graph_for(n, dd_edge_index, dd_range_list), self.mod == 'cat')
+        if not encoder.usable(plans, xd, self.hgcn.weight, d_norm, c2.lin.weight, c1.bias, c2.bias, r1.basis, r1.att, r2.basis, r2.att):
+            return None
+        return xd, plans
+
     def forward(self, x_drug, dd_edge_index, dd_edge_type, dd_range_list, d_norm,
                 x_prot, pp_edge_index, dp_edge_index, dp_range_list):
+        fused = self.fused_plans(x_drug, dd_edge_index, dd_range_list, d_norm, x_prot, pp_edge_index, dp_edge_index)
+        self.last_route = 'encoder_step' if fused is not None else 'per_layer'      # (bench.py / tests read it)
+        if fused is not None:
+            # the whole pass as one autograd node: 8 + 8 launches, scheduled by tip_amd/encoder.py
+            c1, c2, r1, r2 = self.pp_encoder.conv1, self.pp_encoder.conv2, self.rgcn1, self.rgcn2
+            return encoder.encoder_step(fused[0], c1.lin.weight, c1.bias, c2.lin.weight, c2.bias, self.hgcn.weight, d_norm,
+                                        r1.basis, r1.att, r1.root, r2.basis, r2.att, r2.root, fused[1])
         x0 = self.mixed_drug_features(x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list)
         # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
         # ... and its final slab sum runs in rgcn2's first launch, together with rgcn2's XB / X root products

@@ -542,6 +542,20 @@ def row_products_s_supported(n_nodes, n_rel, nb, channels):
     return bool(lib().tipk_rgcn_row_products_s_supported(int(n_nodes), int(n_rel), int(nb), int(channels)))
 
 
+def _row_plan(graph, transposed, n, r, nb, channels):
+    """The graph's row-stream plan for a pass over rows of `channels` floats, or None.  The kernel's own support query is asked
+    BEFORE the (lazily built) plan is touched: building the per-lane plan for a node count it does not take would raise
+    (plan.build_row_stream_plan: 16-bit node field), where the pass should fall through to the CSR / gather_sum route."""
+    if not graph.has_row_plans:
+        return None
+    if graph.row_plans_wave_uniform:
+        if channels % 64 != 0 or not row_products_s_supported(n, r, nb, channels) or n * channels * 4 >= 2 ** 31:
+            return None
+    elif not row_products_supported(n, r, nb, channels):
+        return None
+    return graph.row_bwd if transposed else graph.row_fwd
+
+
 def row_products(rp, table, att, xb2=None):
     if getattr(rp, 'ROW_BYTES', None) is not None:
         return _row_products_s(rp, table, att, xb2)
@@ -630,7 +644,7 @@ def pair_grads_supported(nb, d):
     return bool(lib().tipk_rgcn_pair_grads_supported(int(nb), int(d))) and not os.environ.get('TIPK_NO_PAIR_BWD')
 
 
-def pair_grads(pb, cells, xb_pad, g):
+def pair_grads(pb, cells, xb_pad, g, table=0):
     """The dense half of the pair-form backward pass of an R-GCN layer (include/tipk.h section 2e) on plan `pb`
     (plan.PairBwdPlan): cells = the cell buffer the forward pass filled ([N_pad, N, bases] + its trailing zeros, contiguous),
     xb_pad [N_pad, bases, 32] = the node-major XB buffer of the pair product, g [N, d] (1 / deg is in the plan's slots).
@@ -642,9 +656,12 @@ def pair_grads(pb, cells, xb_pad, g):
     nb = cells.shape[-1]
     assert pb.n_nodes == n and g.stride(1) == 1 and cells.is_contiguous() and xb_pad.stride()[-2:] == (32, 1) and xb_pad.shape[1] == nb
     dev = g.device
-    pg = pb.pg.get(str(dev))
+    # `table`: which of the plan's gradient tables to fill -- layers that share the plan and whose d att gathers run in ONE
+    # launch (tip_amd/encoder.py) need a table each
+    key = str(dev) if table == 0 else (str(dev), int(table))
+    pg = pb.pg.get(key)
     if pg is None:                                    # kept on the plan, zeroed ONCE: a call rewrites the rows of the linked pairs,
-        pg = pb.pg[str(dev)] = torch.zeros((2 * pb.n_alloc + 1, nb), dtype=torch.float32, device=dev)   # the others stay zero
+        pg = pb.pg[key] = torch.zeros((2 * pb.n_alloc + 1, nb), dtype=torch.float32, device=dev)   # the others stay zero
     dxb = torch.empty((nb, n, d), dtype=torch.float32, device=dev)
     with _timed('pair_grads[%dx%dx%d,slots=%d]' % (n, nb, d, pb.n_slots)):
         check(lib().tipk_rgcn_pair_grads(ptr(cells), cells.numel() // nb, ptr(xb_pad), ptr(g), g.stride(0), n, nb, d,
@@ -1204,7 +1221,7 @@ class AggGraph(object):
     """fwd: out rows <- table rows;  bwd: the transpose.  scale = per-out-row factor (1/deg)."""
 
     def __init__(self, fwd, bwd, scale=None, rl_fwd=None, rl_bwd=None, bwd_scaled=False, csr_bwd=None, rs_bwd=None,
-                 pair_fwd=None, pair_bwd=None, dest_fwd=None, row_fwd=None, row_bwd=None):
+                 pair_fwd=None, pair_bwd=None, dest_fwd=None, row_fwd=None, row_bwd=None, row_wave_uniform=False):
         """fwd / bwd: GatherPlans, or zero-argument callables that build them on first use (the
         generic D-D plans are only needed where the relation-local kernel does not apply).
         csr_bwd: optional callable -> CsrPlan of the transposed pass (every row written, rows short)."""
@@ -1220,6 +1237,8 @@ class AggGraph(object):
         self._dest_fwd = dest_fwd                          # plan.DestPlan of the forward pass of large graphs (or a callable)
         self._row_fwd, self._row_bwd = row_fwd, row_bwd    # plan.RowStreamPlans of large graphs (rows by destination / by
                                                            # source), or callables: tipk_rgcn_row_products
+        self.has_row_plans = row_fwd is not None and row_bwd is not None
+        self.row_plans_wave_uniform = bool(row_wave_uniform)   # plan.RowStreamPlanS (widths % 64 == 0) | plan.RowStreamPlan
         self.pair_stamp = 0                                # bumped by every pass that rewrites the pair buffers
         self._pair_cells = {}                              # persistent cell / XB buffers of the pair form, zeroed once
         self.bwd_scaled = bwd_scaled                       # bwd plan's edge weights already carry `scale`
@@ -1587,9 +1606,7 @@ class _RGCN(torch.autograd.Function):
         # LARGE node sets (round 5; include/tipk.h sections 2h / 2f): Y = att . XB [R N, out] is never formed -- the (relation,
         # node) row sums are multiplied where they are assembled, or per destination T[:, v, :] = sum_e att[r_e, :]^T (x) X[src_e]
         # (a product over the node's incoming edges); then sum_b T_b basis_b
-        rows = graph.row_fwd if (r > 0 and not use_rl and row_products_supported(n, r, nb, d_in)) else None
-        if rows is not None and getattr(rows, 'ROW_BYTES', None) is not None and not row_products_s_supported(n, r, nb, d_in):
-            rows = None                                                      # (wave-uniform plan, width no multiple of 64)
+        rows = _row_plan(graph, False, n, r, nb, d_in) if (r > 0 and not use_rl) else None
         dest = graph.dest_fwd if (r > 0 and not use_rl and rows is None) else None
         if use_rl:
             assert graph.rl_fwd.n_nodes == n and graph.rl_fwd.n_rel == r, 'graph/plan mismatch'
@@ -1682,9 +1699,7 @@ class _RGCN(torch.autograd.Function):
                 used = rs.row_used if masked else None
             elif rel_gather_usable(graph.rl_bwd, n, d_out, True):
                 g_y = rel_gather(graph.rl_bwd, g, backward=True, row_scale=graph.scale).view(r, n * d_out)
-            elif (graph.row_bwd is not None and row_products_supported(n, r, nb, d_out) and xb2 is not None
-                  and n * d_out * 4 < 2 ** 31
-                  and (getattr(graph.row_bwd, 'ROW_BYTES', None) is None or row_products_s_supported(n, r, nb, d_out))):
+            elif xb2 is not None and n * d_out * 4 < 2 ** 31 and _row_plan(graph, True, n, r, nb, d_out) is not None:
                 # LARGE node sets: dY = A_r^T (D^-1 g') is never written -- its rows are summed in LDS and multiplied there
                 gs = rows_affine(g, row_mul=graph.scale)
                 j_rows, g_xb = row_products(graph.row_bwd, gs, att, xb2)
