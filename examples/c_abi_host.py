@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""A host that is NOT the tip_amd package: one R-GCN layer forward + backward through the op-level C ABI alone.
+
+    python examples/c_abi_host.py [fixture.npz ...]        (default: tests/golden/rgcn_sym.npz rgcn_directed.npz)
+
+What a maintainer of the reference would write to route `MyRGCNConv2.forward` (src/layers.py:157-188) and its autograd to
+libtipk.so from any language with a C FFI: `tipk_graph_build` once per graph, `tipk_rgcn_fwd` / `tipk_rgcn_bwd` per pass,
+`tipk_graph_destroy` at the end (include/tipk.h section 10).  Only ctypes + torch-for-device-memory are used here: neither
+`tip_amd.ops` nor `tip_amd.plan` (nor any other module of the package) is imported -- asserted at the end.  The fixtures are
+outputs and autograd gradients of the reference's own layers (oracle/make_golden.py); both the range-list form (MyRGCNConv2)
+and the edge-type form (MyRGCNConv) of the graph are built.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, I, L = C.c_void_p, C.c_int, C.c_int64
+
+
+def load_library():
+    lib = C.CDLL(os.path.join(ROOT, 'tip_amd', 'libtipk.so'))
+    lib.tipk_strerror.restype = C.c_char_p
+    lib.tipk_strerror.argtypes = [I]
+    lib.tipk_graph_build.restype = I
+    lib.tipk_graph_build.argtypes = [P, P, P, I, L, L, L, P, C.POINTER(P)]
+    lib.tipk_graph_destroy.restype = I
+    lib.tipk_graph_destroy.argtypes = [P]
+    lib.tipk_rgcn_workspace_bytes.restype = L
+    lib.tipk_rgcn_workspace_bytes.argtypes = [P, I, I, I]
+    lib.tipk_rgcn_fwd.restype = I
+    lib.tipk_rgcn_fwd.argtypes = [P, P, L, I, P, P, P, I, I, I, P, L, P, L, P]
+    lib.tipk_rgcn_bwd.restype = I
+    lib.tipk_rgcn_bwd.argtypes = [P, P, L, I, P, P, P, I, I, P, L, P, L, P, L, P, P, P, P, L, P]
+    return lib
+
+
+def ok(lib, status, what):
+    if status != 0:
+        raise RuntimeError('%s: %s (%d)' % (what, lib.tipk_strerror(status).decode(), status))
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Layer(object):
+    """One R-GCN layer on a graph handle: forward(x, relu) / backward(grad_out)."""
+
+    def __init__(self, lib, graph, basis, att, root, dev):
+        self.lib, self.graph = lib, graph
+        self.basis, self.att, self.root = (t.to(dev).contiguous() for t in (basis, att, root))
+        self.nb, self.d_in, self.d_out = basis.shape
+        n = lib.tipk_rgcn_workspace_bytes(graph, self.d_in, self.d_out, self.nb)
+        assert n > 0
+        self.ws = torch.empty(n, dtype=torch.uint8, device=dev)           # caller-owned, reused by both passes
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def forward(self, x, relu=False):
+        self.x, self.relu = x, relu
+        self.out = torch.empty((x.shape[0], self.d_out), dtype=torch.float32, device=x.device)
+        ok(self.lib, self.lib.tipk_rgcn_fwd(self.graph, ptr(x), x.stride(0), self.d_in, ptr(self.basis), ptr(self.att), ptr(self.root),
+                                            self.nb, self.d_out, int(relu), ptr(self.out), self.out.stride(0), ptr(self.ws),
+                                            self.ws.numel(), self.stream), 'tipk_rgcn_fwd')
+        return self.out
+
+    def backward(self, g):
+        x = self.x
+        gx = torch.empty_like(x)
+        gb, ga, gr = torch.empty_like(self.basis), torch.empty_like(self.att), torch.empty_like(self.root)
+        gate = self.out if self.relu else None
+        ok(self.lib, self.lib.tipk_rgcn_bwd(self.graph, ptr(x), x.stride(0), self.d_in, ptr(self.basis), ptr(self.att), ptr(self.root),
+                                            self.nb, self.d_out, ptr(g), g.stride(0), ptr(gate), self.d_out if self.relu else 0,
+                                            ptr(gx), gx.stride(0), ptr(gb), ptr(ga), ptr(gr), ptr(self.ws), self.ws.numel(),
+                                            self.stream), 'tipk_rgcn_bwd')
+        return gx, gb, ga, gr
+
+
+def build_graph(lib, ei, et, rg, n, r):
+    h = C.c_void_p()
+    ok(lib, lib.tipk_graph_build(ptr(ei), ptr(et), ptr(rg), 8, ei.shape[1], n, r, None, C.byref(h)), 'tipk_graph_build')
+    return h
+
+
+def check(name, got, want, rtol, scale):
+    got, want = got.detach().cpu().double(), torch.as_tensor(want).double()
+    err = float((got - want).abs().max())
+    lim = rtol * float(want.abs().max()) * scale + 1e-12
+    if not (err <= lim and bool(torch.isfinite(got).all())):
+        raise SystemExit('%s: max |diff| %.3e > %.3e' % (name, err, lim))
+    return err / max(1e-30, float(want.abs().max()))
+
+
+def run_single(lib, path, dev):
+    g = {k: torch.from_numpy(v) if v.dtype.kind in 'fi' and v.ndim else v for k, v in np.load(path).items()}
+    x = g['x'].to(dev).contiguous()
+    n, r = x.shape[0], g['att'].shape[0]
+    ei, et, rg = g['dd_idx'].to(dev).contiguous(), g['dd_et'].to(dev).contiguous(), g['dd_range'].to(dev).contiguous()
+    worst = 0.0
+    for form in ('range_list', 'edge_type'):                                # MyRGCNConv2 | MyRGCNConv
+        graph = build_graph(lib, ei, None if form == 'range_list' else et, rg if form == 'range_list' else None, n, r)
+        layer = Layer(lib, graph, g['basis'], g['att'], g['root'], dev)
+        out = layer.forward(x)
+        gx, gb, ga, gr = layer.backward(g['upstream'].to(dev).contiguous())
+        torch.cuda.synchronize()
+        for name, got, want in (('out', out, g['out']), ('grad_x', gx, g['grad_x']), ('grad.basis', gb, g['grad.basis']),
+                                ('grad.att', ga, g['grad.att']), ('grad.root', gr, g['grad.root'])):
+            worst = max(worst, check('%s[%s] %s' % (os.path.basename(path), form, name), got, want, 2e-5, 1.0))
+        out2 = layer.forward(x)
+        assert torch.equal(out2, out), 'not bitwise reproducible'
+        ok(lib, lib.tipk_graph_destroy(graph), 'tipk_graph_destroy')
+    return worst
+
+
+def run_two_layers(lib, path, dev):
+    """64 -> 32 (ReLU inside the layer's last kernel) -> 16 on the nasty 61-drug graph, gradients through both layers."""
+    g = {k: torch.from_numpy(v) if v.dtype.kind in 'fi' and v.ndim else v for k, v in np.load(path).items()}
+    x = g['x'].to(dev).contiguous()
+    n, r = x.shape[0], g['l1.att'].shape[0]
+    graph = build_graph(lib, g['dd_idx'].to(dev).contiguous(), None, g['dd_range'].to(dev).contiguous(), n, r)
+    l1 = Layer(lib, graph, g['l1.basis'], g['l1.att'], g['l1.root'], dev)
+    l2 = Layer(lib, graph, g['l2.basis'], g['l2.att'], g['l2.root'], dev)
+    out = l2.forward(l1.forward(x, relu=True))
+    gx1, gb2, ga2, gr2 = l2.backward(g['upstream'].to(dev).contiguous())
+    gx, gb1, ga1, gr1 = l1.backward(gx1)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for name, got, want in (('out', out, g['out']), ('grad_x', gx, g['grad_x']), ('l1.basis', gb1, g['grad.l1.basis']),
+                            ('l1.att', ga1, g['grad.l1.att']), ('l1.root', gr1, g['grad.l1.root']), ('l2.basis', gb2, g['grad.l2.basis']),
+                            ('l2.att', ga2, g['grad.l2.att']), ('l2.root', gr2, g['grad.l2.root'])):
+        worst = max(worst, check('%s %s' % (os.path.basename(path), name), got, want, 2e-5, 1.0))
+    ok(lib, lib.tipk_graph_destroy(graph), 'tipk_graph_destroy')
+    return worst
+
+
+def main():
+    dev = torch.device('cuda:0')
+    lib = load_library()
+    golden = os.path.join(ROOT, 'tests', 'golden')
+    paths = sys.argv[1:] or [os.path.join(golden, f) for f in ('rgcn_sym.npz', 'rgcn_directed.npz', 'rgcn_fast_sym.npz', 'rgcn_fast_directed.npz')]
+    for path in paths:
+        fn = run_two_layers if 'fast' in os.path.basename(path) else run_single
+        print('%-26s max error %.2e of max|want|' % (os.path.basename(path), fn(lib, path, dev)))
+    # malformed input: an id out of range is refused, as the reference raises IndexError
+    bad = torch.tensor([[0, 1], [1, 99]], device=dev)
+    h = C.c_void_p()
+    st = lib.tipk_graph_build(ptr(bad), ptr(torch.zeros(2, dtype=torch.int64, device=dev)), None, 8, 2, 5, 1, None, C.byref(h))
+    assert st != 0 and not h.value, 'out-of-range node id accepted'
+    assert not any(m == 'tip_amd' or m.startswith('tip_amd.') for m in sys.modules), 'the host imported the package'
+    print('C-ABI host ok')
+
+
+if __name__ == '__main__':
+    main()

@@ -602,18 +602,20 @@ int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const float* d_n
 
 /* Round 6 -- the backward pass of the whole P -> D stage in ONE launch: tipk_drug_mix_bwd + the transposed gather of
  * d mean + the products of GCNConv 2's backward pass (autograd of src/layers.py:526-539 and of PPEncoder.conv2, :394):
- *     g_xd = g[:, :ne] / d_norm,   g_w = mean^T g_pd                        as tipk_drug_mix_bwd
+ *     g_xd = g[:, :ne] / d_norm                                             as tipk_drug_mix_bwd
+ *     g_w_slabs[j] = mean^T g_pd over the j-th share of the rows  [p x q], tipk_pd_stage_bwd_wh_slabs() slabs
  *     g_h[s] = sum_{e in [tptr[s], tptr[s + 1])} tw[e] * (g_pd W^T)[tdst[e]]     per kept source row s (CSR by source row:
  *                                                                                drug ids, 1 / #targets(drug)); never stored
  *     gw[s, :] = (g_h[s] W2) * row_scale[s]        [n_src x c1]; W2 (k < p, n < c1) at w2[k * w2_sk + n * w2_sn]
  *     dw2_slabs[j] = agg[rows of workgroup j]^T g_h    [c1 x p] per row workgroup,  db2_slabs[j] = column sums of g_h  [p]
  *   agg [n_src x c1]: GCNConv 2's aggregated input rows (tipk_gather_sum_lin's first output).  The slabs --
  *   tipk_pd_stage_bwd_slabs(n_src, p) of each -- are summed in order by the caller (riders of the next launch).
- *   Supported: tipk_drug_mix_gather_supported(p, q), rows * p <= 24 576, p * c1 <= 4 096. */
+ *   Supported: tipk_drug_mix_gather_supported(p, q), c1 <= 64, p * c1 <= 4 096. */
 int tipk_pd_stage_bwd_supported(int p, int q, int64_t rows, int c1);
 int64_t tipk_pd_stage_bwd_slabs(int64_t n_src, int p);
+int tipk_pd_stage_bwd_wh_slabs(void);
 int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
-                      int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w,
+                      int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w_slabs,
                       const int32_t* tptr, const int32_t* tdst, const float* tw, int64_t n_src,
                       const float* agg, int64_t ld_agg, int c1, const float* w2, int64_t w2_sk, int64_t w2_sn,
                       const float* row_scale, float* gw, int64_t ld_gw, float* dw2_slabs, float* db2_slabs,
@@ -838,6 +840,46 @@ int tipk_peer_status(void* mailbox, int world, int64_t max_floats, uint64_t* err
 int tipk_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, uint64_t* const* steps, uint64_t* ticket /* device */,
                    double lr, double beta1, double beta2, double eps, double weight_decay, tipk_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * 10. Op-level entries (round 6): a graph handle that OWNS the preprocessed buffers of a D-D graph
+ *     and ONE call per pass of an R-GCN layer -- reference MyRGCNConv2.forward(x, edge_index, edge_type, range_list)
+ *     (src/layers.py:157-188; with edge_type instead of range_list: MyRGCNConv.forward, :76-99) and its autograd -- for a host
+ *     that is not this package's Python: raw device pointers + handle + caller-supplied workspace + stream.
+ *
+ *     tipk_graph_build (the only entry of the library that allocates, and that synchronises: preprocessing, once per graph):
+ *         edge_index [2][n_edges] (row 0 sources, row 1 destinations), and either range_list [n_rel][2] (start, end) of
+ *         consecutive blocks, as MyRGCNConv2 takes it, or edge_type [n_edges]; idx_bytes 4 | 8 for all three; the arrays may
+ *         live on the device or on the host.  in_degree (nullable, float [n_nodes]): the in-degree of the WHOLE graph when the
+ *         edge list is one rank's shard of the relations.  Ids out of range -> TIPK_EINVAL (the reference raises IndexError).
+ *         The handle holds two CSRs (rows of the output by destination; rows (relation, source) by destination list) and
+ *         1 / max(1, in-degree): edge order inside a row = order of the edge list, so every pass is bitwise reproducible.
+ *     tipk_rgcn_fwd:   out = relu?( D^-1 sum_r A_r X W_r + X root ),  W_r = sum_b att[r, b] basis[b]
+ *         x [N x d_in] (row stride ld_x), basis [n_bases x d_in x d_out], att [R x n_bases], root [d_in x d_out] contiguous.
+ *     tipk_rgcn_bwd:   from grad_out [N x d_out]; out_relu (nullable) = the forward output when relu was set (its mask is
+ *         applied first) -> g_x [N x d_in], g_basis, g_att, g_root (shapes of the parameters, contiguous, overwritten).
+ *     workspace: tipk_rgcn_workspace_bytes(graph, d_in, d_out, n_bases) bytes, 16-byte aligned, caller-owned, reusable
+ *         between calls on one stream (the backward pass recomputes XB: nothing is kept across the two calls but the
+ *         caller's own X, parameters and -- with relu -- the output).
+ *     Route: basis-first, transform-then-gather (Y = att . XB [R N x d_out] is the largest temporary), any shapes.  The
+ *     LDS-resident pair form of the PyTorch modules (tip_amd/encoder.py) is the faster route at BioSNAP size; its plans
+ *     are built by tip_amd/plan.py and are not behind this handle.
+ */
+typedef struct tipk_graph tipk_graph;
+int tipk_graph_build(const void* edge_index, const void* edge_type /* nullable */, const void* range_list /* nullable */,
+                     int idx_bytes, int64_t n_edges, int64_t n_nodes, int64_t n_rel, const float* in_degree /* nullable */,
+                     tipk_graph** graph_out);
+int tipk_graph_destroy(tipk_graph* graph);
+int tipk_graph_info(const tipk_graph* graph, int64_t* n_nodes, int64_t* n_rel, int64_t* n_edges,
+                    const float** inv_degree /* device, owned by the handle */);
+int64_t tipk_rgcn_workspace_bytes(const tipk_graph* graph, int d_in, int d_out, int n_bases);
+int tipk_rgcn_fwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_in, const float* basis, const float* att,
+                  const float* root, int n_bases, int d_out, int relu, float* out, int64_t ld_out,
+                  void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
+int tipk_rgcn_bwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_in, const float* basis, const float* att,
+                  const float* root, int n_bases, int d_out, const float* grad_out, int64_t ld_g,
+                  const float* out_relu /* nullable */, int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att,
+                  float* g_root, void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
 
 #ifdef __cplusplus
 }

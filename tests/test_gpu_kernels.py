@@ -1610,8 +1610,9 @@ def test_pd_stage_bwd(ops, n, n_src, p, q, ne, cat, c1):
     def run(scale):
         return encoder.pd_stage_bwd(gup.to(DEV), dn.to(DEV), mean.to(DEV), w.to(DEV), ne, cat, graph, agg.to(DEV), w2_store.to(DEV).t(),
                                     scale)
-    g_xd, g_w, gw, j_w2, j_b2 = run(rs.to(DEV))
-    ops.gemm_group([], [j_w2, j_b2])
+    g_xd, j_wh, gw, j_w2, j_b2 = run(rs.to(DEV))
+    ops.gemm_group([], [j_w2, j_b2, j_wh])
+    g_w = j_wh.out
     close(g_xd, gd[:, :ne] / dn.double().unsqueeze(1), rtol=2e-5, atol=2e-6)
     close(g_w, mean.double().t() @ g_pd, rtol=2e-5, atol=2e-5 * float((mean.double().t() @ g_pd).abs().max()))
     close(gw, want_gw, rtol=2e-5, atol=2e-5 * float(want_gw.abs().max()))
@@ -1620,8 +1621,8 @@ def test_pd_stage_bwd(ops, n, n_src, p, q, ne, cat, c1):
     close(j_b2.out, g_h.sum(0), rtol=2e-5, atol=2e-5 * float(g_h.abs().sum(0).max()))
     assert float(gw[n_src - 3:].abs().max()) == 0.0                    # rows without edges: exact zeros
     again = run(rs.to(DEV))
-    ops.gemm_group([], [again[3], again[4]])
-    assert torch.equal(again[0], g_xd) and torch.equal(again[1], g_w) and torch.equal(again[2], gw)
+    ops.gemm_group([], [again[3], again[4], again[1]])
+    assert torch.equal(again[0], g_xd) and torch.equal(again[1].out, g_w) and torch.equal(again[2], gw)
     assert torch.equal(again[3].out, j_w2.out) and torch.equal(again[4].out, j_b2.out)
     plain = run(None)
     close(plain[2], g_h @ w2.double(), rtol=2e-5, atol=2e-5 * float((g_h @ w2.double()).abs().max()))

@@ -118,6 +118,7 @@ SIGNATURES = {
     'tipk_drug_mix_gather_xb_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_pd_stage_bwd_supported': (_I, [_I, _I, _L, _I]),
     'tipk_pd_stage_bwd_slabs': (_L, [_L, _I]),
+    'tipk_pd_stage_bwd_wh_slabs': (_I, []),
     'tipk_pd_stage_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _P, _L, _L, _P, _P, _L, _P, _P, _P]),
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),
     'tipk_distmult_fwd': (_I, [_P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
@@ -142,6 +143,12 @@ SIGNATURES = {
     'tipk_peer_status': (_I, [_P, _I, _L, C.POINTER(C.c_uint64)]),
     'tipk_adam_step': (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_L), C.POINTER(_P), _P,
                        C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+    'tipk_graph_build': (_I, [_P, _P, _P, _I, _L, _L, _L, _P, C.POINTER(C.c_void_p)]),
+    'tipk_graph_destroy': (_I, [_P]),
+    'tipk_graph_info': (_I, [_P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_void_p)]),
+    'tipk_rgcn_workspace_bytes': (_L, [_P, _I, _I, _I]),
+    'tipk_rgcn_fwd': (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _I, _P, _L, _P, _L, _P]),
+    'tipk_rgcn_bwd': (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P]),
     'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),
     'tipk_split_scatter': (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -38,6 +38,7 @@ struct DgFwdArgs {
 
 constexpr int DG_XMAX = 128;                                  // widest mixed row the XB tail takes
 constexpr int DG_XLD = DG_XMAX + 2;                           // LDS row stride of the staged rows (A-operand reads: no 4-way conflicts)
+constexpr int DG_CP = 4;                                      // workgroups per block of rows in the XB launch (column parts)
 
 // sum of h[src[e], c] over e in [e0, e1) for this lane's column c = lane % PL, edge slots side by side: 64 edges per batch --
 // ONE coalesced load of their source ids (requested a batch ahead), then 64 / SLOTS row loads per lane issued back to back.
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
     if constexpr (XB)
         for (int i = threadIdx.x; i < 16 * DG_XLD; i += 1024) xl[i] = 0.f;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int2 desc = a.wg[blockIdx.x];
+    // XB: DG_CP workgroups share a block of rows -- each repeats the (cheap) gather and takes every DG_CP-th tile of the products,
+    // part 0 writes x0 / mean.  The products of 16 rows are 3.5 us of fp32 MFMA on ONE CU; 41 row blocks alone left 215 CUs idle
+    const int cpart = XB ? (int)(blockIdx.x % DG_CP) : 0;
+    const int2 desc = a.wg[XB ? blockIdx.x / DG_CP : blockIdx.x];
     const bool coop = desc.y == 1;
     const int c = lane % PL;
     const int cc = c < a.p ? c : a.p - 1;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
     if (mine) {
         m *= a.scale[d];
         if (lane < a.p) {
-            a.mean[(int64_t)d * a.p + lane] = m;
+            if (cpart == 0) a.mean[(int64_t)d * a.p + lane] = m;
             ml[wv][lane] = m;
         }
         __builtin_amdgcn_wave_barrier();                      // (ml[wv] is written and read by this wavefront only)
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
                 for (int k = 0; k < a.p; ++k) t = fmaf(ml[wv][k], wl[k * a.q + j], t);
                 v += t;
             }
-            o[col] = v;
+            if (cpart == 0) o[col] = v;
             if constexpr (XB) xl[(coop ? 0 : wv) * DG_XLD + col] = v;
         }
     }
@@ -139,33 +143,59 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
         const int d0 = desc.x, nrow = desc.y;
         const float* xrow = xl + m16 * DG_XLD + q16;
         const int ldw = a.d_out;
-        for (int tile = wv; tile < n_tiles; tile += 16) {
-            const bool is_root = tile >= xb_tiles;
-            const int b = is_root ? 0 : tile / tpb;
-            const int c0 = (is_root ? tile - xb_tiles : tile - b * tpb) << 4;
-            const float* wp = (is_root ? a.root : a.basis + (int64_t)b * cols * ldw) + c0 + m16 + q16 * ldw;
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // ALL the weight loads of a wavefront's tiles are requested before the first product
+        constexpr int TPW = 2;                                // tiles of one batch per wavefront (66 tiles / 4 parts / 16 waves at BioSNAP)
+        constexpr int TS = 16 * DG_CP;                        // tile stride of a wavefront
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        for (int t0 = cpart + DG_CP * wv; t0 < n_tiles; t0 += TS * TPW) {
+            f32x4 acc[TPW];
+            const float* wp[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int tile = t0 + TS * i;
+                tile = tile < n_tiles ? tile : n_tiles - 1;    // clamped, unconditional loads
+                const bool is_root = tile >= xb_tiles;
+                const int b = is_root ? 0 : tile / tpb;
+                const int c0 = (is_root ? tile - xb_tiles : tile - b * tpb) << 4;
+                wp[i] = (is_root ? a.root : a.basis + (int64_t)b * cols * ldw) + c0 + m16 + q16 * ldw;
+            }
             for (int k0 = 0; k0 < ksteps; k0 += 16) {         // 16 k-steps (64 columns of the row) per batch of loads
-                float av[16], bw[16];
+                float av[16], bw[TPW][16];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const int kc = k0 + ks < ksteps ? k0 + ks : ksteps - 1;
+                        bw[i][ks] = wp[i][4 * kc * ldw];
+                    }
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
-                    const int kc = k0 + ks < ksteps ? k0 + ks : ksteps - 1;     // clamped, unconditional
-                    bw[ks] = wp[4 * kc * ldw];
-                    av[ks] = xrow[4 * kc];
+                    const int kc = k0 + ks < ksteps ? k0 + ks : ksteps - 1;
+                    const float v = xrow[4 * kc];
+                    av[ks] = k0 + ks < ksteps ? v : 0.f;
                 }
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const float am = k0 + ks < ksteps ? av[ks] : 0.f;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am, bw[ks], acc, 0, 0, 0);
-                }
+                for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i)             // five independent accumulators: the 40-cycle latency is covered
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bw[i][ks], acc[i], 0, 0, 0);
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = 4 * q16 + v;                    // C: row = 4 (l >> 4) + v, column = l & 15
-                if (r < nrow) {
-                    if (is_root) a.xroot[(int64_t)(d0 + r) * a.d_out + c0 + m16] = acc[v];
-                    else a.xb[((int64_t)(d0 + r) * a.n_bases + b) * 32 + c0 + m16] = acc[v];
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = t0 + TS * i;
+                if (tile < n_tiles) {                          // (wave-uniform)
+                    const bool is_root = tile >= xb_tiles;
+                    const int b = is_root ? 0 : tile / tpb;
+                    const int c0 = (is_root ? tile - xb_tiles : tile - b * tpb) << 4;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = 4 * q16 + v;            // C: row = 4 (l >> 4) + v, column = l & 15
+                        if (r < nrow) {
+                            if (is_root) a.xroot[(int64_t)(d0 + r) * a.d_out + c0 + m16] = acc[i][v];
+                            else a.xb[((int64_t)(d0 + r) * a.n_bases + b) * 32 + c0 + m16] = acc[i][v];
+                        }
+                    }
                 }
             }
         }
@@ -311,26 +341,39 @@ struct PdBwdArgs {
     int rows_per_wg;
 };
 
-constexpr int PD_DMEAN = 24576;                               // floats of LDS for d mean [rows x p]
-constexpr int PD_W2 = PD_DMEAN;                               // W2 [p x c1] (<= 4096)
-constexpr int PD_GH = PD_DMEAN + 4096;                        // g_h of the workgroup's rows [rows_per_wg x p] (<= 4096)
+// LDS of a row workgroup (floats): W_h^T [q x p] | W2 [p x c1] | g_h [64 x p] | the workgroup's rows of agg [64 x c1] | per-wave
+// gathered rows of g_pd [16][4][q]; workgroup 0 uses the first DG_STAGE + 4096 floats as drug_mix_bwd_kernel does
+constexpr int PD_OFF_WH = 0;                                  // <= 4096
+constexpr int PD_OFF_W2 = 4096;                               // <= 4096
+constexpr int PD_OFF_GH = 8192;                               // <= 4096
+constexpr int PD_OFF_AGG = 12288;                             // <= 4096
+constexpr int PD_OFF_TQ = 16384;                              // 16 waves x PD_ROWS x 64
+constexpr int PD_ROWS = 4;                                    // source rows per wavefront (rows_per_wg = 64)
+constexpr int PD_WH_WGS = 8;                                  // workgroups (= slabs) of d W_h
+constexpr int PD_LDS = DG_STAGE + 4096;
+static_assert(PD_OFF_TQ + 16 * PD_ROWS * DG_MAX <= PD_LDS, "LDS layout");
 
 template <int PL>
 __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
-    __shared__ float sm[DG_STAGE + 4096];
+    __shared__ float sm[PD_LDS];
     const DgBwdArgs& a = A.m;
     const int t = threadIdx.x;
     const int qoff = a.cat ? a.ne : 0;
-    if (blockIdx.x == 0) {
-        // ------------------------------------------------------------ d W_h = mean^T g_pd over all rows (as drug_mix_bwd_kernel)
+    if (blockIdx.x < PD_WH_WGS) {
+        // ------------------------------------------------------------ d W_h = mean^T g_pd: PD_WH_WGS workgroups take a share of the
+        // rows each and leave a slab [p x q] (summed in order by the caller's riders).  One workgroup for all 645 rows was the
+        // long pole of the launch (five dependent tile-load round trips + a 40-step chain per thread).
+        const int share = (a.rows + PD_WH_WGS - 1) / PD_WH_WGS;
+        const int ra0 = (int)blockIdx.x * share;
+        const int ra1 = ra0 + share < a.rows ? ra0 + share : a.rows;
         const int hq = a.q / 2;
         const int kgi = t / a.tp, pt = t % a.tp;
         const int pi = pt / hq, pj = pt % hq;
         const int pw = a.p + a.q;
         float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
         const int lr = t / pw, lc = t - lr * pw, lrs = 1024 / pw;
-        for (int r0 = 0; r0 < a.rows; r0 += a.tile) {
-            const int nr = a.rows - r0 < a.tile ? a.rows - r0 : a.tile;
+        for (int r0 = ra0; r0 < ra1; r0 += a.tile) {
+            const int nr = ra1 - r0 < a.tile ? ra1 - r0 : a.tile;
             __syncthreads();
             if (lr < lrs) {
                 const float* src = lc < a.p ? a.mean + (int64_t)r0 * a.p + lc : a.g + (int64_t)r0 * a.ld_g + qoff + (lc - a.p);
@@ -348,7 +391,14 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
             if (kgi < a.kg) {
                 const float* mrow = sm + 2 * pi;
                 const float* grow = sm + a.p + 2 * pj;
-                for (int r = kgi; r < nr; r += a.kg) {
+                int r = kgi;
+                for (; r + a.kg < nr; r += 2 * a.kg) {
+                    const float2 m0 = *reinterpret_cast<const float2*>(mrow + r * pw), g0 = *reinterpret_cast<const float2*>(grow + r * pw);
+                    const float2 m1 = *reinterpret_cast<const float2*>(mrow + (r + a.kg) * pw), g1 = *reinterpret_cast<const float2*>(grow + (r + a.kg) * pw);
+                    s00 = fmaf(m0.x, g0.x, s00); s01 = fmaf(m0.x, g0.y, s01); s10 = fmaf(m0.y, g0.x, s10); s11 = fmaf(m0.y, g0.y, s11);
+                    s00 = fmaf(m1.x, g1.x, s00); s01 = fmaf(m1.x, g1.y, s01); s10 = fmaf(m1.y, g1.x, s10); s11 = fmaf(m1.y, g1.y, s11);
+                }
+                for (; r < nr; r += a.kg) {
                     const float2 mv = *reinterpret_cast<const float2*>(mrow + r * pw);
                     const float2 gv = *reinterpret_cast<const float2*>(grow + r * pw);
                     s00 = fmaf(mv.x, gv.x, s00); s01 = fmaf(mv.x, gv.y, s01);
@@ -363,20 +413,35 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
             sp[(2 * pi + 1) * a.q + 2 * pj] = s10; sp[(2 * pi + 1) * a.q + 2 * pj + 1] = s11;
         }
         __syncthreads();
+        float* slab = a.g_w + (int64_t)blockIdx.x * (a.p * a.q);
         for (int o = t; o < a.p * a.q; o += 1024) {
             float s = part[o];
             for (int k = 1; k < a.kg; ++k) s += part[k * (a.p * a.q) + o];
-            a.g_w[o] = s;
+            slab[o] = s;
         }
         return;
     }
-    const int b = blockIdx.x - 1;
-    float* wl = sm + DG_STAGE;                                // W_h [p x q]
-    float* w2l = sm + PD_W2;                                  // W2 [p x c1]
-    float* gh = sm + PD_GH;
-    const int p = a.p, c1 = A.c1;
-    for (int i = t; i < p * a.q; i += 1024) wl[i] = a.w[i];
+    const int b = blockIdx.x - PD_WH_WGS;
+    float* wlt = sm + PD_OFF_WH;                              // W_h^T [q x p]
+    float* w2l = sm + PD_OFF_W2;                              // W2 [p x c1]
+    float* gh = sm + PD_OFF_GH;
+    float* aggl = sm + PD_OFF_AGG;                            // the workgroup's rows of agg
+    const int p = a.p, q = a.q, c1 = A.c1;
+    const int lane = t & 63, wv = t >> 6;
+    float* tq = sm + PD_OFF_TQ + wv * (PD_ROWS * DG_MAX);     // this wavefront's gathered rows [PD_ROWS][q]
+    const int s_first = b * A.rows_per_wg;
+    const int n_mine = A.n_src - s_first < A.rows_per_wg ? A.n_src - s_first : A.rows_per_wg;
+    // Everything that depends on nothing inside the launch is requested FIRST, in one batch: the weights, the workgroup's rows of
+    // agg, the row pointers of the wavefront's source rows.
+    for (int i = t; i < p * q; i += 1024) wlt[(i % q) * p + i / q] = a.w[i];
     for (int i = t; i < p * c1; i += 1024) w2l[i] = A.w2[(int64_t)(i / c1) * A.w2_sk + (int64_t)(i % c1) * A.w2_sn];
+    for (int i = t; i < n_mine * c1; i += 1024) aggl[i] = A.agg[(int64_t)(s_first + i / c1) * A.ld_agg + (i % c1)];
+    // rows of this wavefront: rl = wv + 16 i, i < PD_ROWS; lanes 0 .. 2 PD_ROWS - 1 fetch their (begin, end)
+    int pv = 0;
+    {
+        const int i = lane >> 1, rl = wv + 16 * i;
+        if (lane < 2 * PD_ROWS && rl < n_mine) pv = A.tptr[s_first + rl + (lane & 1)];
+    }
     // ---------------------------------------------------------------- d xd = g[:, :ne] / d_norm (a slice per workgroup)
     if (a.g_xd) {
         const int tot = a.rows * a.ne;
@@ -389,50 +454,84 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
             a.g_xd[(int64_t)r * a.ld_gxd + c] = a.d_norm ? v / a.d_norm[r] : v;
         }
     }
-    __syncthreads();
-    // ---------------------------------------------------------------- d mean = g_pd W_h^T, ALL rows, into LDS
-    for (int i = t; i < a.rows * p; i += 1024) {
-        const int r = i / p;
-        const int c = i - r * p;
-        const float* gr = a.g + (int64_t)r * a.ld_g + qoff;
-        float v = 0.f;
-        for (int j = 0; j < a.q; ++j) v = fmaf(gr[j], wl[c * a.q + j], v);
-        sm[i] = v;
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- the workgroup's source rows: a wavefront per row
-    constexpr int SLOTS = 64 / PL;
-    const int lane = t & 63, wv = t >> 6;
-    const int s_first = b * A.rows_per_wg;
-    const int n_mine = A.n_src - s_first < A.rows_per_wg ? A.n_src - s_first : A.rows_per_wg;
+    // ---------------------------------------------------------------- the transposed gather on g_pd ITSELF (q columns), the dense map
+    // after it:  g_h[s] = (sum_e tw[e] g_pd[dst[e]]) W_h^T  -- 256 fma per source row instead of d mean for all 645 drugs in every
+    // workgroup (the first version: 17 us of bank-conflicted LDS reads).  Rows of g_pd come straight from L2 (41 KB), the four
+    // rows of a wavefront side by side: edge ids in one load per row, then one row load per edge slot and step.
+    constexpr int SLOTS = 64 / PL;                            // PL = lanes per edge slot: the power of two >= q
     const int cl = lane % PL, sl = lane / PL;
-    const int cc = cl < p ? cl : p - 1;
-    for (int rl = wv; rl < n_mine; rl += 16) {
-        const int s = s_first + rl;
-        const int e0 = A.tptr[s], e1 = A.tptr[s + 1];
-        float acc = 0.f;
-        for (int eb = e0; eb < e1; eb += 64) {
-            const int ne_b = e1 - eb < 64 ? e1 - eb : 64;
-            const int dcur = lane < ne_b ? A.tdst[eb + lane] : 0;
-            const float wcur = lane < ne_b ? A.tw[eb + lane] : 0.f;
-            const int steps = (ne_b + SLOTS - 1) / SLOTS;
-            for (int st = 0; st < steps; ++st) {
-                const int k = SLOTS * st + sl;
-                const int dd = __shfl(dcur, k & 63, 64);
-                const float ww = __shfl(wcur, k & 63, 64);
-                const float v = sm[dd * p + cc];
-                acc = k < ne_b ? fmaf(ww, v, acc) : acc;
+    const int cq = cl < q ? cl : q - 1;
+    const float* gp = a.g + qoff + cq;
+    int e0r[PD_ROWS], e1r[PD_ROWS], dcur[PD_ROWS];
+    float wcur[PD_ROWS], acc[PD_ROWS];
+    int max_steps = 0;
+#pragma unroll
+    for (int i = 0; i < PD_ROWS; ++i) {
+        e0r[i] = __shfl(pv, 2 * i, 64);
+        e1r[i] = __shfl(pv, 2 * i + 1, 64);
+        const bool in = e0r[i] + lane < e1r[i];
+        dcur[i] = in ? A.tdst[e0r[i] + lane] : 0;
+        wcur[i] = in ? A.tw[e0r[i] + lane] : 0.f;
+        acc[i] = 0.f;
+        const int ne_b = e1r[i] - e0r[i] < 64 ? e1r[i] - e0r[i] : 64;
+        const int st = (ne_b + SLOTS - 1) / SLOTS;
+        max_steps = st > max_steps ? st : max_steps;
+    }
+    for (int st0 = 0; st0 < max_steps; st0 += 4) {            // (wave-uniform bound; 4 steps x PD_ROWS row loads in flight per trip:
+        float v[4][PD_ROWS], ww[4][PD_ROWS];                  //  a source row with 60 edges took 16 dependent round trips one by one)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = SLOTS * (st0 + u) + sl;
+#pragma unroll
+            for (int i = 0; i < PD_ROWS; ++i) {
+                const int dd = __shfl(dcur[i], k & 63, 64);
+                ww[u][i] = __shfl(wcur[i], k & 63, 64);       // 0 beyond the row's edges
+                v[u][i] = gp[(int64_t)dd * a.ld_g];
             }
         }
 #pragma unroll
-        for (int off = PL; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane < p) gh[rl * p + lane] = acc;
-        __builtin_amdgcn_wave_barrier();
-        const float rs = A.row_scale ? A.row_scale[s] : 1.f;
-        for (int n = lane; n < c1; n += 64) {
-            float v = 0.f;
-            for (int k = 0; k < p; ++k) v = fmaf(gh[rl * p + k], w2l[k * c1 + n], v);
-            A.gw[(int64_t)s * A.ld_gw + n] = A.row_scale ? v * rs : v;
+        for (int u = 0; u < 4; ++u) {
+            const int k = SLOTS * (st0 + u) + sl;
+#pragma unroll
+            for (int i = 0; i < PD_ROWS; ++i) acc[i] = (k < 64 && e0r[i] + k < e1r[i]) ? fmaf(ww[u][i], v[u][i], acc[i]) : acc[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PD_ROWS; ++i) {                       // rows with more than 64 edges: further batches, row by row
+        for (int eb = e0r[i] + 64; eb < e1r[i]; eb += 64) {
+            const int ne_b = e1r[i] - eb < 64 ? e1r[i] - eb : 64;
+            const int dc = lane < ne_b ? A.tdst[eb + lane] : 0;
+            const float wc = lane < ne_b ? A.tw[eb + lane] : 0.f;
+            for (int st = 0; st < (ne_b + SLOTS - 1) / SLOTS; ++st) {
+                const int k = SLOTS * st + sl;
+                const int dd = __shfl(dc, k & 63, 64);
+                const float w1 = __shfl(wc, k & 63, 64);
+                const float v1 = gp[(int64_t)dd * a.ld_g];
+                acc[i] = k < ne_b ? fmaf(w1, v1, acc[i]) : acc[i];
+            }
+        }
+#pragma unroll
+        for (int off = PL; off < 64; off <<= 1) acc[i] += __shfl_xor(acc[i], off, 64);      // the slots, in a fixed tree
+        if (lane < q) tq[i * DG_MAX + lane] = acc[i];
+    }
+    __syncthreads();                                          // (W_h^T, W2 and the agg rows are in LDS; tq is per wave)
+#pragma unroll
+    for (int i = 0; i < PD_ROWS; ++i) {
+        const int rl = wv + 16 * i;
+        if (rl < n_mine) {                                    // (wave-uniform)
+            const int s = s_first + rl;
+            if (lane < p) {
+                float v = 0.f;
+                for (int j = 0; j < q; ++j) v = fmaf(tq[i * DG_MAX + j], wlt[j * p + lane], v);
+                gh[rl * p + lane] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float rs = A.row_scale ? A.row_scale[s] : 1.f;
+            for (int n = lane; n < c1; n += 64) {
+                float v = 0.f;
+                for (int k = 0; k < p; ++k) v = fmaf(gh[rl * p + k], w2l[k * c1 + n], v);
+                A.gw[(int64_t)s * A.ld_gw + n] = A.row_scale ? v * rs : v;
+            }
         }
     }
     __syncthreads();
@@ -442,15 +541,7 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
         float sacc = 0.f;
         if (o < c1 * p) {
             const int k = o / p, c = o - k * p;
-            const float* ap = A.agg + (int64_t)s_first * A.ld_agg + k;
-            int r = 0;
-            for (; r + 4 <= n_mine; r += 4) {
-                const float a0 = ap[(int64_t)r * A.ld_agg], a1 = ap[(int64_t)(r + 1) * A.ld_agg];
-                const float a2 = ap[(int64_t)(r + 2) * A.ld_agg], a3 = ap[(int64_t)(r + 3) * A.ld_agg];
-                sacc = fmaf(a0, gh[r * p + c], sacc); sacc = fmaf(a1, gh[(r + 1) * p + c], sacc);
-                sacc = fmaf(a2, gh[(r + 2) * p + c], sacc); sacc = fmaf(a3, gh[(r + 3) * p + c], sacc);
-            }
-            for (; r < n_mine; ++r) sacc = fmaf(ap[(int64_t)r * A.ld_agg], gh[r * p + c], sacc);
+            for (int r = 0; r < n_mine; ++r) sacc = fmaf(aggl[r * c1 + k], gh[r * p + c], sacc);
             dw[o] = sacc;
         } else {
             const int c = o - c1 * p;
@@ -515,7 +606,8 @@ extern "C" int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const
     a.wg = reinterpret_cast<const int2*>(wg_desc);
     a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat; a.out = out; a.ld_out = ld_out; a.mean = mean; a.rows = (int)rows;
     a.basis = basis; a.root = root; a.n_bases = n_bases; a.d_out = d_out; a.xb = xb; a.xroot = xroot;
-    const dim3 grid((unsigned)n_wg);
+    if (n_wg * DG_CP > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    const dim3 grid((unsigned)(n_wg * DG_CP));
     hipStream_t st = (hipStream_t)stream;
     if (p <= 8) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<8, true>), grid, dim3(1024), 0, st, a);
     else if (p <= 16) hipLaunchKernelGGL((drug_mix_gather_fwd_kernel<16, true>), grid, dim3(1024), 0, st, a);
@@ -549,32 +641,33 @@ extern "C" int tipk_drug_mix_bwd(const float* g, int64_t ld_g, const float* d_no
 }
 
 extern "C" int tipk_pd_stage_bwd_supported(int p, int q, int64_t rows, int c1) {
-    if (!tipk_drug_mix_gather_supported(p, q) || rows <= 0 || rows * p > PD_DMEAN) return 0;
-    if (c1 <= 0 || c1 > 256 || (int64_t)p * c1 > 4096) return 0;
+    if (!tipk_drug_mix_gather_supported(p, q) || rows <= 0) return 0;
+    if (c1 <= 0 || c1 > 64 || (int64_t)p * c1 > 4096) return 0;                 // (a workgroup's 64 rows of agg and of g_h in LDS)
     return 1;
 }
 
+extern "C" int tipk_pd_stage_bwd_wh_slabs(void) { return PD_WH_WGS; }
+
 extern "C" int64_t tipk_pd_stage_bwd_slabs(int64_t n_src, int p) {
     if (n_src <= 0 || p <= 0) return 0;
-    const int64_t rpw = 4096 / p < 64 ? 4096 / p : 64;
-    return tipk_ceil_div(n_src, rpw);
+    return tipk_ceil_div(n_src, (int64_t)(16 * PD_ROWS));
 }
 
 extern "C" int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
-                                 int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w,
+                                 int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w_slabs,
                                  const int32_t* tptr, const int32_t* tdst, const float* tw, int64_t n_src,
                                  const float* agg, int64_t ld_agg, int c1, const float* w2, int64_t w2_sk, int64_t w2_sn,
                                  const float* row_scale, float* gw, int64_t ld_gw, float* dw2_slabs, float* db2_slabs,
                                  tipk_stream_t stream) {
     if (rows < 0 || ne < 0 || n_src < 0) return TIPK_EINVAL;
     if (!tipk_pd_stage_bwd_supported(p, q, rows, c1) || (!cat && q != ne)) return TIPK_EUNSUPPORTED;
-    if (!g || !mean || !w || !g_w || !tptr || !tdst || !tw || !agg || !w2 || !gw || !dw2_slabs || !db2_slabs || n_src == 0 ||
+    if (!g || !mean || !w || !g_w_slabs || !tptr || !tdst || !tw || !agg || !w2 || !gw || !dw2_slabs || !db2_slabs || n_src == 0 ||
         rows * (int64_t)(ne + p + q) > 0x7fffffffLL || n_src > 0x7fffffffLL)
         return TIPK_EINVAL;
     PdBwdArgs A;
     DgBwdArgs& a = A.m;
     a.g = g; a.ld_g = ld_g; a.d_norm = d_norm; a.mean = mean; a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat;
-    a.g_xd = g_xd; a.ld_gxd = ld_gxd; a.g_mean = nullptr; a.g_w = g_w;
+    a.g_xd = g_xd; a.ld_gxd = ld_gxd; a.g_mean = nullptr; a.g_w = g_w_slabs;
     a.rows = (int)rows;
     a.tp = p * q / 4;
     a.kg = 1024 / a.tp;
@@ -582,17 +675,17 @@ extern "C" int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_no
     if (a.kg > 16) a.kg = 16;
     if (a.kg < 1) a.kg = 1;
     a.tile = DG_STAGE / (p + q);
-    A.rows_per_wg = 4096 / p < 64 ? 4096 / p : 64;
+    A.rows_per_wg = 16 * PD_ROWS;                                               // 64 rows: 64 p <= 4096 floats of g_h
     const int64_t n_wg = tipk_ceil_div(n_src, (int64_t)A.rows_per_wg);
     a.n_wg = (int)n_wg;
     A.tptr = tptr; A.tdst = tdst; A.tw = tw; A.n_src = (int)n_src;
     A.agg = agg; A.ld_agg = ld_agg; A.c1 = c1; A.w2 = w2; A.w2_sk = w2_sk; A.w2_sn = w2_sn; A.row_scale = row_scale;
     A.gw = gw; A.ld_gw = ld_gw; A.dw2 = dw2_slabs; A.db2 = db2_slabs;
-    const dim3 grid((unsigned)(1 + n_wg));
+    const dim3 grid((unsigned)(PD_WH_WGS + n_wg));
     hipStream_t st = (hipStream_t)stream;
-    if (p <= 8) hipLaunchKernelGGL(pd_stage_bwd_kernel<8>, grid, dim3(1024), 0, st, A);
-    else if (p <= 16) hipLaunchKernelGGL(pd_stage_bwd_kernel<16>, grid, dim3(1024), 0, st, A);
-    else if (p <= 32) hipLaunchKernelGGL(pd_stage_bwd_kernel<32>, grid, dim3(1024), 0, st, A);
+    if (q <= 8) hipLaunchKernelGGL(pd_stage_bwd_kernel<8>, grid, dim3(1024), 0, st, A);
+    else if (q <= 16) hipLaunchKernelGGL(pd_stage_bwd_kernel<16>, grid, dim3(1024), 0, st, A);
+    else if (q <= 32) hipLaunchKernelGGL(pd_stage_bwd_kernel<32>, grid, dim3(1024), 0, st, A);
     else hipLaunchKernelGGL(pd_stage_bwd_kernel<64>, grid, dim3(1024), 0, st, A);
     TIPK_RETURN_LAUNCH();
 }

@@ -117,7 +117,7 @@ def drug_mix_gather_xb(xd, h, w_h, d_norm, cat, pd_graph, basis, root, xb_nb):
 
 
 def pd_stage_bwd(g_x0, d_norm, mean, w_h, ne, cat, pd_graph, agg, w2, row_scale, want_xd=True):
-    """(d xd, d W_h, gw = (g_h W2) * row_scale, slab job of d W2 ([in, out] storage), slab job of d b2): the backward pass of the
+    """(d xd, slab job of d W_h, gw = (g_h W2) * row_scale, slab job of d W2 ([in, out] storage), slab job of d b2): the backward pass of the
     P -> D stage down to the input of conv2's transposed gather, one launch (`tipk_pd_stage_bwd`)."""
     csr = pd_graph.pd_csr
     n, p = mean.shape
@@ -127,7 +127,7 @@ def pd_stage_bwd(g_x0, d_norm, mean, w_h, ne, cat, pd_graph, agg, w2, row_scale,
     dev = g_x0.device
     n_slabs = int(lib().tipk_pd_stage_bwd_slabs(n_src, p))
     g_xd = torch.empty((n, ne), dtype=torch.float32, device=dev) if want_xd else None
-    g_w = torch.empty((p, q), dtype=torch.float32, device=dev)
+    g_w = torch.empty((int(lib().tipk_pd_stage_bwd_wh_slabs()), p, q), dtype=torch.float32, device=dev)
     gw = torch.empty((n_src, c1), dtype=torch.float32, device=dev)
     dw2 = torch.empty((n_slabs, c1, p), dtype=torch.float32, device=dev)
     db2 = torch.empty((n_slabs, p), dtype=torch.float32, device=dev)
@@ -137,7 +137,7 @@ def pd_stage_bwd(g_x0, d_norm, mean, w_h, ne, cat, pd_graph, agg, w2, row_scale,
                                       ptr(csr['t_ptr']), ptr(csr['t_dst']), ptr(csr['t_w']), n_src,
                                       ptr(agg), agg.stride(0), c1, ptr(w2), w2.stride(0), w2.stride(1), ptr(row_scale),
                                       ptr(gw), gw.stride(0), ptr(dw2), ptr(db2), stream_ptr(dev)), 'tipk_pd_stage_bwd')
-    return g_xd, g_w, gw, ops.slab_job(dw2), ops.slab_job(db2)
+    return g_xd, ops.slab_job(g_w), gw, ops.slab_job(dw2), ops.slab_job(db2)
 
 
 def pair_att_gather_two(pb, pg_a, pg_b):
@@ -257,17 +257,17 @@ class _EncoderStep(torch.autograd.Function):
         # 13. layer 1's dense gradients + both d att slab sums
         g_x0, g_basis1, g_root1 = rgcn_dense_backward(x0, basis1, root1, g_x1, dxb1, None, [j_att1, j_att2])
         # 14. the P -> D stage down to conv2's g W, d W2 / d b2 as slabs
-        g_xd, g_wh, gw, j_w2, j_b2 = pd_stage_bwd(g_x0, d_norm, mean, w_h, ctx.ne, plans.cat, plans.pd, agg2, w2, plans.pp_rows.scale,
+        g_xd, j_wh, gw, j_w2, j_b2 = pd_stage_bwd(g_x0, d_norm, mean, w_h, ctx.ne, plans.cat, plans.pd, agg2, w2, plans.pp_rows.scale,
                                                  want_xd=ctx.needs_input_grad[0])
         # 15. conv2's transposed gather; conv1's ReLU gate and the partial rows of its bias gradient in the epilogue
-        g_h1, parts = ops.gather_sum(plans.pp_rows.bwd, gw, riders=[j_w2, j_b2], gate=h1, colsum=True)
+        g_h1, parts = ops.gather_sum(plans.pp_rows.bwd, gw, riders=[j_w2, j_b2, j_wh], gate=h1, colsum=True)
         # 16. conv1's transposed gather IS d W1 (identity features)
         g_agg = ops.rows_affine(g_h1, row_mul=plans.pp.scale) if plans.pp.scale is not None else g_h1
         j_b1 = ops.slab_job(parts)
         g_table = ops.gather_sum(plans.pp.bwd, g_agg, riders=[j_b1])
         g_w1 = g_table.t() if w1.t().is_contiguous() else ops.transpose(g_table)
         g_w2 = j_w2.out.t()                                                   # [in, out] storage behind the [out, in] shape
-        return (g_xd, g_w1, j_b1.out.view(-1), g_w2, j_b2.out.view(-1), g_wh, None,
+        return (g_xd, g_w1, j_b1.out.view(-1), g_w2, j_b2.out.view(-1), j_wh.out, None,
                 g_basis1, j_att1.out, g_root1, g_basis2, j_att2.out, g_root2, None)
 
 

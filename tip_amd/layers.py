@@ -420,6 +420,10 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
         on_dev = bool(d_out and src.is_cuda)
+        # workgroups of the pair-form gathers PER LAYER: the encoder gathers both layers' cells, and both layers' d att, in one
+        # launch each -- 2 x (CUs / 2) workgroups are one round of the chip (140 KB of LDS: one workgroup per CU); with CUs
+        # per layer every CU staged its table twice (25.2 -> 21.1 us and 28.0 -> 24.4 us at BioSNAP).  TIPK_PAIR_WGS: experiments
+        pair_wgs = int(os.environ.get('TIPK_PAIR_WGS', 0)) or max(1, n_cu // 2)
         # launch = (workgroups x column blocks), sized for 1 or 2 workgroups per CU (tipk_rel_gather_occupancy)
         wg_f = (ops.rel_gather_wgs(n_nodes, d_out, False, n_cu) if on_dev else 0) or n_cu
         wg_b = (ops.rel_gather_wgs(n_nodes, d_out, True, n_cu) if on_dev else 0) or n_cu
@@ -440,7 +444,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             k_bw = torch.sort((rel * n_nodes + dst) * n_nodes + src).values
             symmetric = bool(torch.equal(k_fw, k_bw)) and bool(ops.lib().tipk_pair_product_supported(n_bases, d_out))
             keep = src <= dst if symmetric else torch.ones_like(src, dtype=torch.bool)
-            pair_fwd = build_stream_plan_rows(src[keep] * n_nodes + dst[keep], rel[keep], n_nodes * n_nodes, n_rel, n_cu,
+            pair_fwd = build_stream_plan_rows(src[keep] * n_nodes + dst[keep], rel[keep], n_nodes * n_nodes, n_rel, pair_wgs,
                                               (n_bases // split_p) // 4, ops.rel_stream_piece())
             pair_fwd.symmetric = symmetric
             # which pairs are linked at all, one bit per (source, destination): the product fetches only their cells
@@ -453,7 +457,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             # linked pair; d att walks half the edges of a symmetric graph.  The plan does not depend on the layer's width:
             # the layers of a model share it
             sym, lanes_p = pair_fwd.symmetric, (n_bases // split_p) // 4
-            pair_bwd = lambda: _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, 1.0 / deg, sym, n_cu, lanes_p)
+            pair_bwd = lambda: _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, 1.0 / deg, sym, pair_wgs, lanes_p)
         if split_s:
             # compact node-major rows when the products of dY can run on them (tipk_rgcn_node_products); with the pair-form
             # backward pass the plan is only built if some pass asks for it (a forward pass on the Y route of a sharded run)
