@@ -1138,7 +1138,7 @@ def main():
                        else 'eager (one ctypes call per kernel)',
                        'collective': shard.collective if shard is not None else None,
                        'collective_timing': shard.collective_report if shard is not None else None,
-                       'rccl_ranks': world if (shard is not None and dist.is_initialized() and dist.get_backend() == 'nccl') else 0,
+                       'rccl_ranks': dist.get_world_size() if (shard is not None and dist.is_initialized() and dist.get_backend() == 'nccl') else 0,
                        'forward_routes': [list(l._cache.value.fwd_route.values()) if l._cache.value is not None else None
                                           for l in (enc.rgcn1, enc.rgcn2)] if shard is not None else None},
             'preprocess_s': preprocess_s, 'init_s': init_s,

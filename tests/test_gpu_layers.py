@@ -579,7 +579,7 @@ def _shard_worker(rank, world, port, ret, max_relations=12):
         full_sd, neg = rp['full_sd'], rp['neg'].to(DEV)
         ref_test_neg = rp['test_neg'].to(DEV)
         shard = make_shard(dd['dd_train_range'], rank, world)
-        assert 0 < shard.rel_ids.numel() < R
+        assert shard.rel_ids.numel() < R and (world > R or shard.rel_ids.numel() > 0)
         NS.manual_seed(77)
         model = TIP(st, torch.device(DEV), data=dd, shard=shard)           # this rank's relations only
         stamp('sharded model built')
@@ -626,7 +626,23 @@ def _shard_worker(rank, world, port, ret, max_relations=12):
         dist.destroy_process_group()
 
 
-def _run_shard_workers(world, max_relations):
+def _run_shard_workers(world, max_relations, env=None):
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})                                     # (spawned ranks inherit it: ops reads TIPK_FWD_ROUTE at import)
+    try:
+        _run_shard_workers_(world, max_relations)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _run_shard_workers_(world, max_relations):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -647,6 +663,14 @@ def _run_shard_workers(world, max_relations):
 @pytest.mark.timeout(600)
 def test_sharded_training_step_two_ranks():
     _run_shard_workers(2, 12)
+
+
+@pytest.mark.timeout(600)
+def test_sharded_step_with_a_rank_that_holds_no_relation():
+    """More ranks than relations (2 relations over 3 ranks: rank 2 holds none) with the TIMED forward-route decision: the rank
+    without relations still takes part in every collective of the step -- the route-timing all-reduce included -- and the
+    job's loss, embeddings, gradients, parameters after two Adam steps and test() record equal the unsharded model's."""
+    _run_shard_workers(3, 2, env={'TIPK_FWD_ROUTE': 'timed'})
 
 
 @pytest.mark.timeout(900)

@@ -401,7 +401,7 @@ def pair_link_words(src, dst, n_nodes):
     return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
 
 
-def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None):
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None, paired=False):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
     scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `in_degree`: [N]
     in-degree of the WHOLE graph when `edge_index` is only one rank's shard (tip_amd/dist.py)."""
@@ -420,10 +420,11 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
         # relation-local plans for the LDS-resident kernels (used when a relation's table fits in LDS)
         n_cu = torch.cuda.get_device_properties(src.device).multi_processor_count if src.is_cuda else 256
         on_dev = bool(d_out and src.is_cuda)
-        # workgroups of the pair-form gathers PER LAYER: the encoder gathers both layers' cells, and both layers' d att, in one
-        # launch each -- 2 x (CUs / 2) workgroups are one round of the chip (140 KB of LDS: one workgroup per CU); with CUs
-        # per layer every CU staged its table twice (25.2 -> 21.1 us and 28.0 -> 24.4 us at BioSNAP).  TIPK_PAIR_WGS: experiments
-        pair_wgs = int(os.environ.get('TIPK_PAIR_WGS', 0)) or max(1, n_cu // 2)
+        # workgroups of the pair-form gathers PER LAYER.  paired: the layer is one of the two of an FMEncoder, which gathers both
+        # layers' cells, and both layers' d att, in one launch each (tip_amd/encoder.py) -- 2 x (CUs / 2) workgroups are one round
+        # of the chip (140 KB of LDS: one workgroup per CU); with CUs per layer every CU staged its table twice (25.2 -> 21.1 us
+        # and 28.0 -> 24.4 us at BioSNAP).  A layer on its own fills the chip by itself.  TIPK_PAIR_WGS: experiments
+        pair_wgs = int(os.environ.get('TIPK_PAIR_WGS', 0)) or (max(1, n_cu // 2) if paired else n_cu)
         # launch = (workgroups x column blocks), sized for 1 or 2 workgroups per CU (tipk_rel_gather_occupancy)
         wg_f = (ops.rel_gather_wgs(n_nodes, d_out, False, n_cu) if on_dev else 0) or n_cu
         wg_b = (ops.rel_gather_wgs(n_nodes, d_out, True, n_cu) if on_dev else 0) or n_cu
@@ -523,6 +524,7 @@ class _RGCNBase(nn.Module):
             self.register_parameter('bias', None)
         self._cache = _PlanCache()
         self.shard = None                       # tip_amd.dist.RelationShard for multi-GPU runs
+        self.paired = False                     # one of the two layers of an FMEncoder (sizes the pair plans: rgcn_graph)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -560,7 +562,7 @@ class MyRGCNConv2(_RGCNBase):
         def build():
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
             return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
-                              d_out=self.out_channels, n_bases=self.num_bases)
+                              d_out=self.out_channels, n_bases=self.num_bases, paired=self.paired and self.shard is None)
         return self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
 
     def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False, next_layer=None):
@@ -613,6 +615,7 @@ class FMEncoder(nn.Module):
         d_in = n_embed + self.hgcn.out_dim if mod == 'cat' else n_embed
         self.rgcn1 = MyRGCNConv2(d_in, n_hid1, num_dd_et, num_base, after_relu=False)
         self.rgcn2 = MyRGCNConv2(n_hid1, n_hid2, num_dd_et, num_base, after_relu=True)
+        self.rgcn1.paired = self.rgcn2.paired = True
         self._drug_feat = _FeatureInput()
         self.prune_pp_rows = True               # conv2 of the P-P encoder only for the rows the P -> D stage reads (forward())
         self.reset_parameters()
