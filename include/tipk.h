@@ -743,6 +743,9 @@ int tipk_pair_table_loss(const float* s1t, const float* s2t, int64_t ld, int64_t
  * of a relation-sharded run passes (start of r's block in the WHOLE triple list) - rel_ptr[r], so that its negatives
  * are exactly the negatives the unsharded run draws for those relations, whatever the number of ranks.
  */
+/* workgroups per CU the bitmap sampler is launched with for this node count (plan the units for CUs x this many workgroups):
+ * 2 when two bitmaps of n_nodes^2 bits fit the LDS of a CU (512-thread workgroups), 1 (1024 threads), 0 = no bitmap route */
+int tipk_negsample_wgs_per_cu(int64_t n_nodes);
 int tipk_typed_negative_sampling(const int64_t* pos_key_sorted, const int64_t* rel_ptr /* [n_rel+1] */,
                                  int64_t n_rel, int64_t n_nodes, uint64_t seed,
                                  uint64_t* call_counter /* nullable device uint64[2 or 3], see above */, int advance,

@@ -129,6 +129,7 @@ SIGNATURES = {
     'tipk_pair_table_fwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_pair_table_bwd': (_I, [_P, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P, _P]),
     'tipk_pair_table_loss': (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _L, _F, _P, _P, _P, _P]),
+    'tipk_negsample_wgs_per_cu': (_I, [_L]),
     'tipk_typed_negative_sampling': (_I, [_P, _P, _L, _L, C.c_uint64, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _L, _P]),
     'tipk_counter_advance': (_I, [_P, _P]),
     'tipk_rank_metrics': (_I, [_P, _P, _P, _L, _L, _P, _P]),

@@ -129,6 +129,7 @@ def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
         keys = sorted_positive_keys(pos_edge_index, num_nodes, rel_ptr)
         dev = pos_edge_index.device
         n_wg = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
+        n_wg *= max(1, int(ops.lib().tipk_negsample_wgs_per_cu(int(num_nodes))))       # (two 512-thread workgroups per CU where two bitmaps fit)
         wg_ptr, wg_units = sampler_units(rel_ptr, n_wg)
         # the same keys as 32-bit words (n^2 < 2^31): what the bitmap route sets its bits from -- half the bytes per step
         keys32 = keys.to(torch.int32).contiguous() if int(num_nodes) ** 2 < 2 ** 31 and dev.type == 'cuda' else None
