@@ -608,15 +608,18 @@ int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const float* d_n
  *                                                                                drug ids, 1 / #targets(drug)); never stored
  *     gw[s, :] = (g_h[s] W2) * row_scale[s]        [n_src x c1]; W2 (k < p, n < c1) at w2[k * w2_sk + n * w2_sn]
  *     dw2_slabs[j] = agg[rows of workgroup j]^T g_h    [c1 x p] per row workgroup,  db2_slabs[j] = column sums of g_h  [p]
- *   agg [n_src x c1]: GCNConv 2's aggregated input rows (tipk_gather_sum_lin's first output).  The slabs --
- *   tipk_pd_stage_bwd_slabs(n_src, p) of each -- are summed in order by the caller (riders of the next launch).
+ *   agg [n_src x c1]: GCNConv 2's aggregated input rows (tipk_gather_sum_lin's first output).  wg_rows int32 [n_row_wg + 1]:
+ *   the deal of the source rows to workgroups -- consecutive rows, at most max_rows of them and (unless one row alone has more)
+ *   at most max_edges edges per workgroup (tipk_pd_stage_bwd_limits), wg_rows[0] = 0, wg_rows[n_row_wg] = n_src.  The slabs --
+ *   n_row_wg of each -- are summed in order by the caller (riders of the next launch).
  *   Supported: tipk_drug_mix_gather_supported(p, q), c1 <= 64, p * c1 <= 4 096. */
 int tipk_pd_stage_bwd_supported(int p, int q, int64_t rows, int c1);
-int64_t tipk_pd_stage_bwd_slabs(int64_t n_src, int p);
+int tipk_pd_stage_bwd_limits(int* max_rows, int* max_edges);
 int tipk_pd_stage_bwd_wh_slabs(void);
 int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
                       int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w_slabs,
                       const int32_t* tptr, const int32_t* tdst, const float* tw, int64_t n_src,
+                      const int32_t* wg_rows, int64_t n_row_wg,
                       const float* agg, int64_t ld_agg, int c1, const float* w2, int64_t w2_sk, int64_t w2_sn,
                       const float* row_scale, float* gw, int64_t ld_gw, float* dw2_slabs, float* db2_slabs,
                       tipk_stream_t stream);

@@ -117,9 +117,9 @@ SIGNATURES = {
     'tipk_drug_mix_gather_xb_supported': (_I, [_I, _I, _I, _I, _I, _I]),
     'tipk_drug_mix_gather_xb_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_pd_stage_bwd_supported': (_I, [_I, _I, _L, _I]),
-    'tipk_pd_stage_bwd_slabs': (_L, [_L, _I]),
+    'tipk_pd_stage_bwd_limits': (_I, [C.POINTER(_I), C.POINTER(_I)]),
     'tipk_pd_stage_bwd_wh_slabs': (_I, []),
-    'tipk_pd_stage_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _P, _L, _L, _P, _P, _L, _P, _P, _P]),
+    'tipk_pd_stage_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _L, _I, _P, _L, _L, _P, _P, _L, _P, _P, _P]),
     'tipk_col_sum': (_I, [_P, _L, _L, _L, _P, _P, _P]),
     'tipk_distmult_fwd': (_I, [_P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _P]),
     'tipk_distmult_bwd': (_I, [_P, _P, _P, _L, _I, _P, _L, _P, _P, _I, _P, _I, _L, _I, _P, _L, _P, _P, _P]),

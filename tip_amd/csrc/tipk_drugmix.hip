@@ -338,20 +338,27 @@ struct PdBwdArgs {
     const float* row_scale;                                   // nullable
     float* gw; int64_t ld_gw;                                 // [n_src x c1]
     float* dw2; float* db2;                                   // slabs [n_row_wg][c1][p], [n_row_wg][p]
+    const int32_t* wg_rows;                                   // [n_row_wg + 1] first source row of every row workgroup
     int rows_per_wg;
+    int dbg;                                                  // debug builds: 1 = no d W_h, 2 = no gather, 4 = no d W2 partials, 8 = no prelude
 };
 
-// LDS of a row workgroup (floats): W_h^T [q x p] | W2 [p x c1] | g_h [64 x p] | the workgroup's rows of agg [64 x c1] | per-wave
-// gathered rows of g_pd [16][4][q]; workgroup 0 uses the first DG_STAGE + 4096 floats as drug_mix_bwd_kernel does
+// LDS of a row workgroup (floats): W_h^T [q x p] | W2 [p x c1] | g_h [64 x p] | the workgroup's rows of agg [64 x c1] | the gathered
+// rows [64 x q] | a chunk of weighted rows of g_pd [PD_CHUNK_E x q'] | the chunk's edge ids, weights + the row pointers;
+// workgroups 0 .. PD_WH_WGS - 1 use the first DG_STAGE + 4096 floats as drug_mix_bwd_kernel does
 constexpr int PD_OFF_WH = 0;                                  // <= 4096
 constexpr int PD_OFF_W2 = 4096;                               // <= 4096
 constexpr int PD_OFF_GH = 8192;                               // <= 4096
 constexpr int PD_OFF_AGG = 12288;                             // <= 4096
-constexpr int PD_OFF_TQ = 16384;                              // 16 waves x PD_ROWS x 64
-constexpr int PD_ROWS = 4;                                    // source rows per wavefront (rows_per_wg = 64)
+constexpr int PD_OFF_TQ = 16384;                              // 64 x q <= 4096
+constexpr int PD_CHUNK_E = 512;                               // edges per chunk at most (fewer when 512 q > PD_PROD floats)
+constexpr int PD_PROD = 16384;
+constexpr int PD_OFF_PROD = 20480;                            // chunk x q <= PD_PROD floats
+constexpr int PD_OFF_EID = PD_OFF_PROD + PD_PROD;             // ids [512] | weights [512] | row pointers [65]
+constexpr int PD_ROWS = 4;                                    // (rows_per_wg = 64)
 constexpr int PD_WH_WGS = 8;                                  // workgroups (= slabs) of d W_h
-constexpr int PD_LDS = DG_STAGE + 4096;
-static_assert(PD_OFF_TQ + 16 * PD_ROWS * DG_MAX <= PD_LDS, "LDS layout");
+constexpr int PD_LDS = PD_OFF_EID + 2 * PD_CHUNK_E + 128;
+static_assert(PD_LDS >= DG_STAGE + 4096 && PD_LDS * 4 <= 160 * 1024, "LDS layout");
 
 template <int PL>
 __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
     const int t = threadIdx.x;
     const int qoff = a.cat ? a.ne : 0;
     if (blockIdx.x < PD_WH_WGS) {
+        if (TIPK_DBG(A.dbg & 1)) return;
         // ------------------------------------------------------------ d W_h = mean^T g_pd: PD_WH_WGS workgroups take a share of the
         // rows each and leave a slab [p x q] (summed in order by the caller's riders).  One workgroup for all 645 rows was the
         // long pole of the launch (five dependent tile-load round trips + a 40-step chain per thread).
@@ -426,22 +434,23 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
     float* w2l = sm + PD_OFF_W2;                              // W2 [p x c1]
     float* gh = sm + PD_OFF_GH;
     float* aggl = sm + PD_OFF_AGG;                            // the workgroup's rows of agg
+    float* tq = sm + PD_OFF_TQ;                               // the workgroup's gathered rows [rows_per_wg][q]
+    float* prod = sm + PD_OFF_PROD;                           // weighted rows of g_pd of a chunk of edges [PD_CHUNK_E][q]
+    int* eid = reinterpret_cast<int*>(sm + PD_OFF_EID);       // ids | weights of the chunk's edges
+    float* ewt = sm + PD_OFF_EID + PD_CHUNK_E;
+    int* rptr = reinterpret_cast<int*>(sm + PD_OFF_EID + 2 * PD_CHUNK_E);   // row pointers of the workgroup's rows [rows_per_wg + 1]
     const int p = a.p, q = a.q, c1 = A.c1;
-    const int lane = t & 63, wv = t >> 6;
-    float* tq = sm + PD_OFF_TQ + wv * (PD_ROWS * DG_MAX);     // this wavefront's gathered rows [PD_ROWS][q]
-    const int s_first = b * A.rows_per_wg;
-    const int n_mine = A.n_src - s_first < A.rows_per_wg ? A.n_src - s_first : A.rows_per_wg;
+    // a workgroup's rows: consecutive, at most 64 of them and -- unless a single row has more -- at most PD_CHUNK_E edges
+    // (the plan's deal: BioSNAP has a block of proteins that 65 ... 94 drugs target each -- 64 ROWS per workgroup gave three
+    // workgroups 2 200 ... 3 300 edges, seven chunks each, against a mean of 326)
+    const int s_first = A.wg_rows[b];
+    const int n_mine = A.wg_rows[b + 1] - s_first;
     // Everything that depends on nothing inside the launch is requested FIRST, in one batch: the weights, the workgroup's rows of
-    // agg, the row pointers of the wavefront's source rows.
+    // agg, the row pointers of its source rows.
     for (int i = t; i < p * q; i += 1024) wlt[(i % q) * p + i / q] = a.w[i];
     for (int i = t; i < p * c1; i += 1024) w2l[i] = A.w2[(int64_t)(i / c1) * A.w2_sk + (int64_t)(i % c1) * A.w2_sn];
     for (int i = t; i < n_mine * c1; i += 1024) aggl[i] = A.agg[(int64_t)(s_first + i / c1) * A.ld_agg + (i % c1)];
-    // rows of this wavefront: rl = wv + 16 i, i < PD_ROWS; lanes 0 .. 2 PD_ROWS - 1 fetch their (begin, end)
-    int pv = 0;
-    {
-        const int i = lane >> 1, rl = wv + 16 * i;
-        if (lane < 2 * PD_ROWS && rl < n_mine) pv = A.tptr[s_first + rl + (lane & 1)];
-    }
+    if (t <= n_mine) rptr[t] = A.tptr[s_first + t];
     // ---------------------------------------------------------------- d xd = g[:, :ne] / d_norm (a slice per workgroup)
     if (a.g_xd) {
         const int tot = a.rows * a.ne;
@@ -454,88 +463,99 @@ __global__ __launch_bounds__(1024) void pd_stage_bwd_kernel(PdBwdArgs A) {
             a.g_xd[(int64_t)r * a.ld_gxd + c] = a.d_norm ? v / a.d_norm[r] : v;
         }
     }
+    if (TIPK_DBG(A.dbg & 2)) return;
+    __syncthreads();
     // ---------------------------------------------------------------- the transposed gather on g_pd ITSELF (q columns), the dense map
     // after it:  g_h[s] = (sum_e tw[e] g_pd[dst[e]]) W_h^T  -- 256 fma per source row instead of d mean for all 645 drugs in every
-    // workgroup (the first version: 17 us of bank-conflicted LDS reads).  Rows of g_pd come straight from L2 (41 KB), the four
-    // rows of a wavefront side by side: edge ids in one load per row, then one row load per edge slot and step.
-    constexpr int SLOTS = 64 / PL;                            // PL = lanes per edge slot: the power of two >= q
-    const int cl = lane % PL, sl = lane / PL;
+    // workgroup.  EDGE-parallel: the workgroup's rows are consecutive, so are their edges; (edge, column) pairs are dealt to the
+    // threads -- every row load of up to 512 edges in flight at once, whatever the rows' lengths (a hub protein has 94 edges, the
+    // mean row 5: a wavefront per row walked a hub as a chain of dependent loads, 12 of the launch's 18 us) -- the weighted rows
+    // go to LDS, and thread (row, column) adds its row's entries there in edge order: fixed order, reproducible.
+    const int E0 = rptr[0], E1 = rptr[n_mine];
+    constexpr int EPP = 1024 / PL;                            // edges per pass (PL threads per edge: the power of two >= q)
+    int chunk_e = PD_PROD / q;                                // edges per chunk: whole passes, <= PD_CHUNK_E, chunk_e q <= PD_PROD
+    chunk_e = chunk_e < PD_CHUNK_E ? chunk_e : PD_CHUNK_E;
+    chunk_e = chunk_e / EPP * EPP;                            // (EPP <= 128, PD_PROD / q >= 256)
+    const int passes = chunk_e / EPP;
+    const int cl = t % PL, el = t / PL;
     const int cq = cl < q ? cl : q - 1;
-    const float* gp = a.g + qoff + cq;
-    int e0r[PD_ROWS], e1r[PD_ROWS], dcur[PD_ROWS];
-    float wcur[PD_ROWS], acc[PD_ROWS];
-    int max_steps = 0;
+    // thread -> the (row, column) sums it owns: item = t + 1024 k  (rows_per_wg x q <= 4096 items)
+    float racc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = E0; c0 < E1; c0 += chunk_e) {
+        const int ne_c = E1 - c0 < chunk_e ? E1 - c0 : chunk_e;
+        if (t < chunk_e) {
+            const bool in = t < ne_c;
+            eid[t] = in ? A.tdst[c0 + t] : 0;
+            ewt[t] = in ? A.tw[c0 + t] : 0.f;
+        }
+        __syncthreads();
+        if (TIPK_DBG(A.dbg & 16)) return;
+        for (int p0 = 0; p0 < passes; p0 += 8) {              // 8 row loads per thread in flight
+            float v[8], w8[8];
 #pragma unroll
-    for (int i = 0; i < PD_ROWS; ++i) {
-        e0r[i] = __shfl(pv, 2 * i, 64);
-        e1r[i] = __shfl(pv, 2 * i + 1, 64);
-        const bool in = e0r[i] + lane < e1r[i];
-        dcur[i] = in ? A.tdst[e0r[i] + lane] : 0;
-        wcur[i] = in ? A.tw[e0r[i] + lane] : 0.f;
-        acc[i] = 0.f;
-        const int ne_b = e1r[i] - e0r[i] < 64 ? e1r[i] - e0r[i] : 64;
-        const int st = (ne_b + SLOTS - 1) / SLOTS;
-        max_steps = st > max_steps ? st : max_steps;
+            for (int u = 0; u < 8; ++u) {
+                int e = (p0 + u) * EPP + el;
+                e = e < chunk_e ? e : chunk_e - 1;            // clamped, unconditional
+                w8[u] = ewt[e];
+                v[u] = a.g[(int64_t)eid[e] * a.ld_g + qoff + cq];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (p0 + u) * EPP + el;
+                if (cl < q && e < chunk_e) prod[e * q + cl] = w8[u] * v[u];
+            }
+            if ((p0 + 8) * EPP >= ne_c) break;                // (uniform: the rest of the chunk is padding)
+        }
+        __syncthreads();
+        if (TIPK_DBG(A.dbg & 32)) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = t + 1024 * k;
+            if (item < n_mine * q) {
+                const int r = item / q, c = item - r * q;
+                int lo = rptr[r] - c0, hi = rptr[r + 1] - c0;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > ne_c ? ne_c : hi;
+                float sacc = racc[k];
+                int e = lo;
+                for (; e + 8 <= hi; e += 8) {                 // eight reads in flight, added in edge order
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = prod[(e + u) * q + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc += v[u];
+                }
+                for (; e < hi; ++e) sacc += prod[e * q + c];
+                racc[k] = sacc;
+            }
+        }
+        __syncthreads();                                      // (the chunk has been read)
+        if (TIPK_DBG(A.dbg & 64)) return;
     }
-    for (int st0 = 0; st0 < max_steps; st0 += 4) {            // (wave-uniform bound; 4 steps x PD_ROWS row loads in flight per trip:
-        float v[4][PD_ROWS], ww[4][PD_ROWS];                  //  a source row with 60 edges took 16 dependent round trips one by one)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = SLOTS * (st0 + u) + sl;
-#pragma unroll
-            for (int i = 0; i < PD_ROWS; ++i) {
-                const int dd = __shfl(dcur[i], k & 63, 64);
-                ww[u][i] = __shfl(wcur[i], k & 63, 64);       // 0 beyond the row's edges
-                v[u][i] = gp[(int64_t)dd * a.ld_g];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = SLOTS * (st0 + u) + sl;
-#pragma unroll
-            for (int i = 0; i < PD_ROWS; ++i) acc[i] = (k < 64 && e0r[i] + k < e1r[i]) ? fmaf(ww[u][i], v[u][i], acc[i]) : acc[i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PD_ROWS; ++i) {                       // rows with more than 64 edges: further batches, row by row
-        for (int eb = e0r[i] + 64; eb < e1r[i]; eb += 64) {
-            const int ne_b = e1r[i] - eb < 64 ? e1r[i] - eb : 64;
-            const int dc = lane < ne_b ? A.tdst[eb + lane] : 0;
-            const float wc = lane < ne_b ? A.tw[eb + lane] : 0.f;
-            for (int st = 0; st < (ne_b + SLOTS - 1) / SLOTS; ++st) {
-                const int k = SLOTS * st + sl;
-                const int dd = __shfl(dc, k & 63, 64);
-                const float w1 = __shfl(wc, k & 63, 64);
-                const float v1 = gp[(int64_t)dd * a.ld_g];
-                acc[i] = k < ne_b ? fmaf(w1, v1, acc[i]) : acc[i];
-            }
-        }
-#pragma unroll
-        for (int off = PL; off < 64; off <<= 1) acc[i] += __shfl_xor(acc[i], off, 64);      // the slots, in a fixed tree
-        if (lane < q) tq[i * DG_MAX + lane] = acc[i];
-    }
-    __syncthreads();                                          // (W_h^T, W2 and the agg rows are in LDS; tq is per wave)
-#pragma unroll
-    for (int i = 0; i < PD_ROWS; ++i) {
-        const int rl = wv + 16 * i;
-        if (rl < n_mine) {                                    // (wave-uniform)
-            const int s = s_first + rl;
-            if (lane < p) {
-                float v = 0.f;
-                for (int j = 0; j < q; ++j) v = fmaf(tq[i * DG_MAX + j], wlt[j * p + lane], v);
-                gh[rl * p + lane] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const float rs = A.row_scale ? A.row_scale[s] : 1.f;
-            for (int n = lane; n < c1; n += 64) {
-                float v = 0.f;
-                for (int k = 0; k < p; ++k) v = fmaf(gh[rl * p + k], w2l[k * c1 + n], v);
-                A.gw[(int64_t)s * A.ld_gw + n] = A.row_scale ? v * rs : v;
-            }
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int item = t + 1024 * k;
+        if (item < n_mine * q) tq[item] = racc[k];
     }
     __syncthreads();
+    // g_h = tq W_h^T: thread (row, column < p)
+    for (int item = t; item < n_mine * p; item += 1024) {
+        const int r = item / p, c = item - r * p;
+        float v = 0.f;
+        for (int j = 0; j < q; ++j) v = fmaf(tq[r * q + j], wlt[j * p + c], v);
+        gh[item] = v;
+    }
+    __syncthreads();
+    // gw = (g_h W2) * row_scale: thread (row, column < c1)
+    for (int item = t; item < n_mine * c1; item += 1024) {
+        const int r = item / c1, n = item - r * c1;
+        const int sr = s_first + r;
+        float v = 0.f;
+        for (int k = 0; k < p; ++k) v = fmaf(gh[r * p + k], w2l[k * c1 + n], v);
+        A.gw[(int64_t)sr * A.ld_gw + n] = A.row_scale ? v * A.row_scale[sr] : v;
+    }
     // ---------------------------------------------------------------- partial d W2 [c1 x p] = agg^T g_h and d b2 [p] over the rows
+    if (TIPK_DBG(A.dbg & 4)) return;
     float* dw = A.dw2 + (int64_t)b * c1 * p;
     for (int o = t; o < c1 * p + p; o += 1024) {
         float sacc = 0.f;
@@ -648,20 +668,23 @@ extern "C" int tipk_pd_stage_bwd_supported(int p, int q, int64_t rows, int c1) {
 
 extern "C" int tipk_pd_stage_bwd_wh_slabs(void) { return PD_WH_WGS; }
 
-extern "C" int64_t tipk_pd_stage_bwd_slabs(int64_t n_src, int p) {
-    if (n_src <= 0 || p <= 0) return 0;
-    return tipk_ceil_div(n_src, (int64_t)(16 * PD_ROWS));
+extern "C" int tipk_pd_stage_bwd_limits(int* max_rows, int* max_edges) {
+    if (max_rows) *max_rows = 16 * PD_ROWS;
+    if (max_edges) *max_edges = PD_CHUNK_E;
+    return TIPK_OK;
 }
 
 extern "C" int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
                                  int64_t rows, int ne, int cat, float* g_xd, int64_t ld_gxd, float* g_w_slabs,
                                  const int32_t* tptr, const int32_t* tdst, const float* tw, int64_t n_src,
+                                 const int32_t* wg_rows, int64_t n_row_wg,
                                  const float* agg, int64_t ld_agg, int c1, const float* w2, int64_t w2_sk, int64_t w2_sn,
                                  const float* row_scale, float* gw, int64_t ld_gw, float* dw2_slabs, float* db2_slabs,
                                  tipk_stream_t stream) {
     if (rows < 0 || ne < 0 || n_src < 0) return TIPK_EINVAL;
     if (!tipk_pd_stage_bwd_supported(p, q, rows, c1) || (!cat && q != ne)) return TIPK_EUNSUPPORTED;
     if (!g || !mean || !w || !g_w_slabs || !tptr || !tdst || !tw || !agg || !w2 || !gw || !dw2_slabs || !db2_slabs || n_src == 0 ||
+        !wg_rows || n_row_wg <= 0 || n_row_wg > 0x7fffffLL ||
         rows * (int64_t)(ne + p + q) > 0x7fffffffLL || n_src > 0x7fffffffLL)
         return TIPK_EINVAL;
     PdBwdArgs A;
@@ -675,12 +698,14 @@ extern "C" int tipk_pd_stage_bwd(const float* g, int64_t ld_g, const float* d_no
     if (a.kg > 16) a.kg = 16;
     if (a.kg < 1) a.kg = 1;
     a.tile = DG_STAGE / (p + q);
-    A.rows_per_wg = 16 * PD_ROWS;                                               // 64 rows: 64 p <= 4096 floats of g_h
-    const int64_t n_wg = tipk_ceil_div(n_src, (int64_t)A.rows_per_wg);
+    A.rows_per_wg = 16 * PD_ROWS;                                               // 64 rows at most: 64 p <= 4096 floats of g_h
+    A.wg_rows = wg_rows;
+    const int64_t n_wg = n_row_wg;
     a.n_wg = (int)n_wg;
     A.tptr = tptr; A.tdst = tdst; A.tw = tw; A.n_src = (int)n_src;
     A.agg = agg; A.ld_agg = ld_agg; A.c1 = c1; A.w2 = w2; A.w2_sk = w2_sk; A.w2_sn = w2_sn; A.row_scale = row_scale;
     A.gw = gw; A.ld_gw = ld_gw; A.dw2 = dw2_slabs; A.db2 = db2_slabs;
+    A.dbg = TIPK_DBG(tipk_option(TIPK_OPT_DM_DEBUG));
     const dim3 grid((unsigned)(PD_WH_WGS + n_wg));
     hipStream_t st = (hipStream_t)stream;
     if (q <= 8) hipLaunchKernelGGL(pd_stage_bwd_kernel<8>, grid, dim3(1024), 0, st, A);

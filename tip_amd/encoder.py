@@ -81,7 +81,7 @@ def usable(plans, xd, w_h, d_norm, c2_weight, c1_bias, c2_bias, basis1, att1, ba
     c1 = c2_weight.shape[1]
     if not (c2_weight.t().is_contiguous() and not c2_weight.is_contiguous()):      # d W2 leaves as [in, out] slabs: the stored layout
         return False
-    if not L.tipk_pd_stage_bwd_supported(int(p), int(q), int(n), int(c1)) or 't_ptr' not in plans.pd.pd_csr:
+    if not L.tipk_pd_stage_bwd_supported(int(p), int(q), int(n), int(c1)) or 't_wg' not in plans.pd.pd_csr:
         return False
     if not (ops.gather_sum_lin_supported(c1, p, plans.pp_rows.fwd.group_slots) and ops.gather_sum_epilogue_supported(plans.pp_rows.bwd, c1)
             and ops.gather_sum_epilogue_supported(plans.pp.bwd, c1)):
@@ -125,7 +125,7 @@ def pd_stage_bwd(g_x0, d_norm, mean, w_h, ne, cat, pd_graph, agg, w2, row_scale,
     n_src, c1 = agg.shape
     assert w2.shape == (p, c1) and g_x0.stride(1) == 1 and agg.stride(1) == 1 and csr['t_ptr'].numel() == n_src + 1
     dev = g_x0.device
-    n_slabs = int(lib().tipk_pd_stage_bwd_slabs(n_src, p))
+    n_slabs = int(csr['t_wg'].numel()) - 1
     g_xd = torch.empty((n, ne), dtype=torch.float32, device=dev) if want_xd else None
     g_w = torch.empty((int(lib().tipk_pd_stage_bwd_wh_slabs()), p, q), dtype=torch.float32, device=dev)
     gw = torch.empty((n_src, c1), dtype=torch.float32, device=dev)
@@ -134,7 +134,7 @@ def pd_stage_bwd(g_x0, d_norm, mean, w_h, ne, cat, pd_graph, agg, w2, row_scale,
     with ops._timed('pd_stage_bwd[%dx%dx%d,rows=%d]' % (n, p, q, n_src)):
         check(lib().tipk_pd_stage_bwd(ptr(g_x0), g_x0.stride(0), ptr(d_norm), ptr(mean), ptr(w_h), p, q, n, ne, int(cat),
                                       ptr(g_xd), g_xd.stride(0) if g_xd is not None else 0, ptr(g_w),
-                                      ptr(csr['t_ptr']), ptr(csr['t_dst']), ptr(csr['t_w']), n_src,
+                                      ptr(csr['t_ptr']), ptr(csr['t_dst']), ptr(csr['t_w']), n_src, ptr(csr['t_wg']), n_slabs,
                                       ptr(agg), agg.stride(0), c1, ptr(w2), w2.stride(0), w2.stride(1), ptr(row_scale),
                                       ptr(gw), gw.stride(0), ptr(dw2), ptr(db2), stream_ptr(dev)), 'tipk_pd_stage_bwd')
     return g_xd, ops.slab_job(g_w), gw, ops.slab_job(dw2), ops.slab_job(db2)

@@ -267,6 +267,22 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     # fused backward launch of the stage (tipk_pd_stage_bwd, tip_amd/encoder.py)
     ot = torch.sort(src, stable=True).indices
     graph.pd_csr.update(t_ptr=ptr(src, n_tab), t_dst=i32(dst[ot]), t_w=scale[dst[ot]].contiguous())
+    # ... and the deal of the source rows to that launch's workgroups: consecutive rows, at most max_rows of them and at most
+    # max_edges edges (a row with more edges than that has a workgroup to itself)
+    if src.is_cuda:
+        import ctypes
+        mr, me = ctypes.c_int(0), ctypes.c_int(0)
+        ops.lib().tipk_pd_stage_bwd_limits(ctypes.byref(mr), ctypes.byref(me))
+        cnt_s = torch.bincount(src, minlength=n_tab).tolist()
+        bounds, rows_in, edges_in = [0], 0, 0
+        for r_, c_ in enumerate(cnt_s):
+            if rows_in and (rows_in == mr.value or edges_in + c_ > me.value):
+                bounds.append(r_)
+                rows_in, edges_in = 0, 0
+            rows_in += 1
+            edges_in += c_
+        bounds.append(int(n_tab))
+        graph.pd_csr['t_wg'] = torch.tensor(bounds, dtype=torch.int32, device=src.device)
     return graph
 
 
