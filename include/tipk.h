@@ -567,8 +567,10 @@ int tipk_drug_mix_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const
  *     out[d, :]  = cat(xd[d] / d_norm[d], mean[d] W)   (cat != 0)   or   xd[d] / d_norm[d] + mean[d] W   (q == ne)
  *   h [n_src x p] (row stride ld_h), W [p x q] contiguous, p and q even and <= 64 (tipk_drug_mix_gather_supported),
  *   CSR by drug: ptr int32 [rows + 1], src int32 [edges]; `mean` [rows x p] contiguous is an OUTPUT (kept for the backward).
- *   wg_desc int32 [n_wg][2] = { first drug, drugs } of a 16-wave workgroup: up to 16 consecutive drugs, a wavefront each, or
- *   ONE drug whose edges the 16 wavefronts share (hub rows: one BioSNAP drug has 2 834 targets) -- every drug exactly once.
+ *   wg_desc int32 [n_wg][2] = { first, n | W << 8 } of a 16-wave workgroup: rows order[first .. first + n) (order = NULL: the
+ *   drugs first .. first + n - 1 themselves), W wavefronts per row sharing its edges, n <= 16 / W, W in {1, 4, 16} (W = 0: the
+ *   round-5 form -- n consecutive drugs a wavefront each, or ONE drug on all 16) -- every drug exactly once.  Round 6 deals the
+ *   drugs by edge count (tip_amd.layers.hier_graph): > 512 edges alone, 65 ... 512 four to a workgroup, the rest sixteen.
  * Backward, from g = d out [rows x (cat ? ne + q : ne)], one launch (tipk_drug_mix_bwd):
  *     g_xd   = g[:, :ne] / d_norm                          (nullable: not wanted)
  *     g_mean = g_pd W^T                                    [rows x p] contiguous (nullable), g_pd = the last q (cat) / all
@@ -578,7 +580,8 @@ int tipk_drug_mix_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const
  * All sums in fixed order. */
 int tipk_drug_mix_gather_supported(int p, int q);
 int tipk_drug_mix_gather_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
-                             const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc, int64_t n_wg,
+                             const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc,
+                             const int32_t* order /* nullable */, int64_t n_wg,
                              const float* w, int p, int q, int64_t rows, int ne, int cat, float* out, int64_t ld_out,
                              float* mean, tipk_stream_t stream);
 int tipk_drug_mix_bwd(const float* g, int64_t ld_g, const float* d_norm, const float* mean, const float* w, int p, int q,
@@ -596,7 +599,7 @@ int tipk_drug_mix_bwd(const float* g, int64_t ld_g, const float* d_norm, const f
 int tipk_drug_mix_gather_xb_supported(int p, int q, int ne, int cat, int n_bases, int d_out);
 int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
                                 const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc,
-                                int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat, float* out,
+                                const int32_t* order /* nullable */, int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat, float* out,
                                 int64_t ld_out, float* mean, const float* basis, const float* root, int n_bases, int d_out,
                                 float* xb, float* xroot, tipk_stream_t stream);
 

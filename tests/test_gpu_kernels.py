@@ -1535,6 +1535,7 @@ def test_drug_mix_gather_xb_fwd(ops, n, n_src, p, q, ne, cat, nb, d_out):
     dst = torch.randint(0, max(1, n - 2), (E,), generator=g)
     if n >= 100:
         dst[:700] = 3                                                  # a hub: more than 512 targets -> all 16 wavefronts on it
+        dst[700:900], dst[900:1000], dst[1000:1070] = 5, 9, 11         # 65 ... 512 targets: four wavefronts each
     ei = torch.stack([src, dst + n_src]).to(DEV)
     graph = hier_graph(ei, n_src + n, n_src, table_rows=n_src, d=p)
     cols = ne + q if cat else ne

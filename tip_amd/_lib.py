@@ -112,10 +112,10 @@ SIGNATURES = {
     'tipk_gate_colsum': (_I, [_P, _L, _P, _L, _P, _L, _L, _L, _P, _P]),
     'tipk_drug_mix_fwd': (_I, [_P, _L, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P]),
     'tipk_drug_mix_gather_supported': (_I, [_I, _I]),
-    'tipk_drug_mix_gather_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P]),
+    'tipk_drug_mix_gather_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P]),
     'tipk_drug_mix_bwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P]),
     'tipk_drug_mix_gather_xb_supported': (_I, [_I, _I, _I, _I, _I, _I]),
-    'tipk_drug_mix_gather_xb_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'tipk_drug_mix_gather_xb_fwd': (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _I, _I, _L, _I, _I, _P, _L, _P, _P, _P, _I, _I, _P, _P, _P]),
     'tipk_pd_stage_bwd_supported': (_I, [_I, _I, _L, _I]),
     'tipk_pd_stage_bwd_limits': (_I, [C.POINTER(_I), C.POINTER(_I)]),
     'tipk_pd_stage_bwd_wh_slabs': (_I, []),

@@ -26,7 +26,8 @@ struct DgFwdArgs {
     const float* xd; int64_t ld_xd; const float* d_norm;
     const float* h; int64_t ld_h;                             // source rows [n_src x p]
     const int32_t* ptr; const int32_t* src; const float* scale;   // CSR by drug
-    const int2* wg;                                           // per workgroup: {first drug, drugs (<= 16)}; 1 drug = all 16 waves on it
+    const int2* wg;                                           // per workgroup: {first, n | W << 8}: n <= 16 / W rows, W waves each
+    const int32_t* order;                                     // rows in the order the workgroups take them (nullable: identity)
     const float* w; int p, q, ne, cat;
     float* out; int64_t ld_out; float* mean;                  // mean [rows x p] contiguous
     int rows;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
     __shared__ float wl[DG_MAX * DG_MAX];
     __shared__ float ml[16][DG_MAX];
     __shared__ float xl[XB ? 16 * DG_XLD : 1];                // XB: the workgroup's rows of x0 (rows it does not own stay zero)
+    __shared__ int rowid[16];                                 // XB: the rows' ids
     for (int i = threadIdx.x; i < a.p * a.q; i += 1024) wl[i] = a.w[i];
     if constexpr (XB)
         for (int i = threadIdx.x; i < 16 * DG_XLD; i += 1024) xl[i] = 0.f;
@@ -81,17 +83,24 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
     // part 0 writes x0 / mean.  The products of 16 rows are 3.5 us of fp32 MFMA on ONE CU; 41 row blocks alone left 215 CUs idle
     const int cpart = XB ? (int)(blockIdx.x % DG_CP) : 0;
     const int2 desc = a.wg[XB ? blockIdx.x / DG_CP : blockIdx.x];
-    const bool coop = desc.y == 1;
+    // W wavefronts share a row's edges (partial sums through LDS, added in wave order): rows are dealt by edge count -- one
+    // with more than 512 edges has the workgroup to itself (W = 16: one BioSNAP drug has 2 834 protein targets), rows with
+    // 65 ... 512 edges go four to a workgroup (W = 4; 84 drugs have 130 ... 250 targets: a wavefront alone walked them as four
+    // dependent batches, the long pole of the launch), the others sixteen (W = 1)
+    const int nrow = desc.y & 255;
+    const int W = (desc.y >> 8) ? (desc.y >> 8) : (nrow == 1 ? 16 : 1);
+    const int li = wv / W, sub = wv - li * W;
     const int c = lane % PL;
     const int cc = c < a.p ? c : a.p - 1;
-    int d = desc.x + (coop ? 0 : wv);
-    const bool live = coop || wv < desc.y;
+    const bool live = li < nrow;
+    int d = 0;
+    if (live) d = a.order ? a.order[desc.x + li] : desc.x + li;
     float m = 0.f;
     if (live) {
         int e0 = a.ptr[d], e1 = a.ptr[d + 1];
-        if (coop) {                                          // the 16 waves share the drug's edges, partial sums through LDS
-            const int per = ((e1 - e0 + 15) / 16 + 63) & ~63;
-            e0 = e0 + wv * per;
+        if (W > 1) {
+            const int per = ((e1 - e0 + W - 1) / W + 63) & ~63;
+            e0 = e0 + sub * per;
             e1 = e0 + per < e1 ? e0 + per : e1;
         }
         m = e0 < e1 ? dg_row_sum<PL>(a.h, a.ld_h, a.src, e0, e1, cc, lane) : 0.f;
@@ -99,14 +108,11 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
     }
     __syncthreads();
     const int cols = a.cat ? a.ne + a.q : a.ne;
-    bool mine = live;                                         // this wavefront finishes row d
-    if (coop) {
-        mine = wv == 0;
-        if (mine) {
-            m = 0.f;
-            if (lane < a.p)
-                for (int k = 0; k < 16; ++k) m += ml[k][lane];   // the waves' shares, in order
-        }
+    const bool mine = live && sub == 0;                       // this wavefront finishes row d
+    if (mine && W > 1) {
+        m = 0.f;
+        if (lane < a.p)
+            for (int k = 0; k < W; ++k) m += ml[wv + k][lane];   // the waves' shares, in order
     }
     if (!XB && !mine) return;
     if (mine) {
@@ -128,8 +134,10 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
                 v += t;
             }
             if (cpart == 0) o[col] = v;
-            if constexpr (XB) xl[(coop ? 0 : wv) * DG_XLD + col] = v;
+            if constexpr (XB) xl[li * DG_XLD + col] = v;
         }
+        if constexpr (XB)
+            if (lane == 0) rowid[li] = d;
     }
     if constexpr (XB) {
         // XB[d] = x0[d] basis (node-major, 32-column rows) and x0[d] root for the workgroup's <= 16 rows: 16 x 16 tiles of
@@ -140,7 +148,6 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
         const int ksteps = cols >> 2;                         // cols % 4 == 0, <= DG_XMAX (host)
         const int tpb = a.d_out >> 4;                         // 16-column tiles per basis (d_out = 16 | 32)
         const int xb_tiles = a.n_bases * tpb, n_tiles = xb_tiles + tpb;
-        const int d0 = desc.x, nrow = desc.y;
         const float* xrow = xl + m16 * DG_XLD + q16;
         const int ldw = a.d_out;
         // ALL the weight loads of a wavefront's tiles are requested before the first product
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(1024) void drug_mix_gather_fwd_kernel(DgFwdArgs a) 
                     for (int v = 0; v < 4; ++v) {
                         const int r = 4 * q16 + v;            // C: row = 4 (l >> 4) + v, column = l & 15
                         if (r < nrow) {
-                            if (is_root) a.xroot[(int64_t)(d0 + r) * a.d_out + c0 + m16] = acc[i][v];
-                            else a.xb[((int64_t)(d0 + r) * a.n_bases + b) * 32 + c0 + m16] = acc[i][v];
+                            if (is_root) a.xroot[(int64_t)rowid[r] * a.d_out + c0 + m16] = acc[i][v];
+                            else a.xb[((int64_t)rowid[r] * a.n_bases + b) * 32 + c0 + m16] = acc[i][v];
                         }
                     }
                 }
@@ -581,8 +588,8 @@ extern "C" int tipk_drug_mix_gather_supported(int p, int q) {
 
 extern "C" int tipk_drug_mix_gather_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
                                         const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc,
-                                        int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat, float* out,
-                                        int64_t ld_out, float* mean, tipk_stream_t stream) {
+                                        const int32_t* order, int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat,
+                                        float* out, int64_t ld_out, float* mean, tipk_stream_t stream) {
     if (rows < 0 || ne < 0 || !tipk_drug_mix_gather_supported(p, q) || (!cat && q != ne)) return TIPK_EINVAL;
     if (rows == 0) return TIPK_OK;
     if (!xd || !h || !ptr || !src || !scale || !w || !out || !mean || !wg_desc || n_wg <= 0 || rows > 0x7fffffffLL ||
@@ -590,7 +597,7 @@ extern "C" int tipk_drug_mix_gather_fwd(const float* xd, int64_t ld_xd, const fl
         return TIPK_EINVAL;
     DgFwdArgs a;
     a.xd = xd; a.ld_xd = ld_xd; a.d_norm = d_norm; a.h = h; a.ld_h = ld_h; a.ptr = ptr; a.src = src; a.scale = scale;
-    a.wg = reinterpret_cast<const int2*>(wg_desc);
+    a.wg = reinterpret_cast<const int2*>(wg_desc); a.order = order;
     a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat; a.out = out; a.ld_out = ld_out; a.mean = mean; a.rows = (int)rows;
     a.basis = nullptr; a.root = nullptr; a.n_bases = 0; a.d_out = 0; a.xb = nullptr; a.xroot = nullptr;
     const dim3 grid((unsigned)n_wg);
@@ -612,9 +619,9 @@ extern "C" int tipk_drug_mix_gather_xb_supported(int p, int q, int ne, int cat, 
 
 extern "C" int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const float* d_norm, const float* h, int64_t ld_h,
                                            const int32_t* ptr, const int32_t* src, const float* scale, const int32_t* wg_desc,
-                                           int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne, int cat, float* out,
-                                           int64_t ld_out, float* mean, const float* basis, const float* root, int n_bases,
-                                           int d_out, float* xb, float* xroot, tipk_stream_t stream) {
+                                           const int32_t* order, int64_t n_wg, const float* w, int p, int q, int64_t rows, int ne,
+                                           int cat, float* out, int64_t ld_out, float* mean, const float* basis, const float* root,
+                                           int n_bases, int d_out, float* xb, float* xroot, tipk_stream_t stream) {
     if (rows < 0 || ne < 0) return TIPK_EINVAL;
     if (!tipk_drug_mix_gather_xb_supported(p, q, ne, cat, n_bases, d_out)) return TIPK_EUNSUPPORTED;
     if (rows == 0) return TIPK_OK;
@@ -623,7 +630,7 @@ extern "C" int tipk_drug_mix_gather_xb_fwd(const float* xd, int64_t ld_xd, const
         return TIPK_EINVAL;
     DgFwdArgs a;
     a.xd = xd; a.ld_xd = ld_xd; a.d_norm = d_norm; a.h = h; a.ld_h = ld_h; a.ptr = ptr; a.src = src; a.scale = scale;
-    a.wg = reinterpret_cast<const int2*>(wg_desc);
+    a.wg = reinterpret_cast<const int2*>(wg_desc); a.order = order;
     a.w = w; a.p = p; a.q = q; a.ne = ne; a.cat = cat; a.out = out; a.ld_out = ld_out; a.mean = mean; a.rows = (int)rows;
     a.basis = basis; a.root = root; a.n_bases = n_bases; a.d_out = d_out; a.xb = xb; a.xroot = xroot;
     if (n_wg * DG_CP > 0x7fffffffLL) return TIPK_EUNSUPPORTED;

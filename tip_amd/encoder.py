@@ -109,8 +109,8 @@ def drug_mix_gather_xb(xd, h, w_h, d_norm, cat, pd_graph, basis, root, xb_nb):
     xroot = torch.empty((n, d_out), dtype=torch.float32, device=xd.device)
     with ops._timed('drug_mix_gather_xb_fwd[%dx%dx%d -> %dx%d]' % (n, p, q, nb, d_out)):
         check(lib().tipk_drug_mix_gather_xb_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(h), h.stride(0), ptr(csr['fwd_ptr']),
-                                                ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), csr['fwd_wg'].shape[0],
-                                                ptr(w_h), p, q, n, ne, int(cat), ptr(out), out.stride(0), ptr(mean),
+                                                ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), ptr(csr['fwd_order']),
+                                                csr['fwd_wg'].shape[0], ptr(w_h), p, q, n, ne, int(cat), ptr(out), out.stride(0), ptr(mean),
                                                 ptr(basis), ptr(root), nb, d_out, ptr(xb_nb), ptr(xroot), stream_ptr(xd.device)),
               'tipk_drug_mix_gather_xb_fwd')
     return out, mean, xroot

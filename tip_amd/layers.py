@@ -250,19 +250,19 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     i32 = lambda t: t.to(torch.int32).contiguous()
     of = torch.sort(dst, stable=True).indices
     ptr = lambda idx, n: i32(torch.cat([idx.new_zeros(1), torch.cumsum(torch.bincount(idx, minlength=n), 0)]))
-    # workgroups of the forward launch: 16 consecutive targets, a wavefront each -- a target with more than 512 edges
-    # (BioSNAP: one drug has 2 834 protein targets) gets the 16 wavefronts of a workgroup to itself
-    cnt_t = torch.bincount(dst, minlength=n_t).tolist()
-    wgs, start = [], 0
-    for tgt, c_ in enumerate(cnt_t):
-        if c_ > 512:
-            if tgt > start:
-                wgs += [[b0, min(16, tgt - b0)] for b0 in range(start, tgt, 16)]
-            wgs.append([tgt, 1])
-            start = tgt + 1
-    wgs += [[b0, min(16, n_t - b0)] for b0 in range(start, n_t, 16)]
+    # workgroups of the forward launch (16 wavefronts): targets dealt by edge count -- one with more than 512 edges has a
+    # workgroup to itself (W = 16 wavefronts on it: one BioSNAP drug has 2 834 protein targets), those with 65 ... 512 edges go
+    # four to a workgroup (W = 4), the others sixteen (a wavefront each); desc = {first index into `order`, n | W << 8}
+    cnt_t = torch.bincount(dst, minlength=n_t)
+    order = torch.sort(cnt_t, descending=True, stable=True).indices
+    cs = cnt_t[order].tolist()
+    n_big = sum(1 for c_ in cs if c_ > 512)
+    n_mid = sum(1 for c_ in cs if 64 < c_ <= 512)
+    wgs = [[i, 1 | (16 << 8)] for i in range(n_big)]
+    wgs += [[b0, min(4, n_big + n_mid - b0) | (4 << 8)] for b0 in range(n_big, n_big + n_mid, 4)]
+    wgs += [[b0, min(16, n_t - b0) | (1 << 8)] for b0 in range(n_big + n_mid, n_t, 16)]
     fwd_wg = torch.tensor(wgs, dtype=torch.int32, device=src.device).view(-1, 2).contiguous()
-    graph.pd_csr = dict(fwd_ptr=ptr(dst, n_t), fwd_src=i32(src[of]), scale=scale, fwd_wg=fwd_wg, n_src=int(n_tab))
+    graph.pd_csr = dict(fwd_ptr=ptr(dst, n_t), fwd_src=i32(src[of]), scale=scale, fwd_wg=fwd_wg, fwd_order=i32(order), n_src=int(n_tab))
     # CSR by SOURCE row (edge order kept inside a row) with 1 / count of the edge's target: the transposed gather inside the
     # fused backward launch of the stage (tipk_pd_stage_bwd, tip_amd/encoder.py)
     ot = torch.sort(src, stable=True).indices

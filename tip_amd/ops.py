@@ -1886,7 +1886,7 @@ class _DrugMixGather(torch.autograd.Function):
         mean = torch.empty((n, p), dtype=torch.float32, device=xd.device)
         with _timed('drug_mix_gather_fwd[%dx%dx%d]' % (n, p, q)):
             check(lib().tipk_drug_mix_gather_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(h), h.stride(0), ptr(csr['fwd_ptr']),
-                                                 ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), csr['fwd_wg'].shape[0],
+                                                 ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), ptr(csr['fwd_order']), csr['fwd_wg'].shape[0],
                                                  ptr(weight), p, q, n, ne, int(cat),
                                                  ptr(out), out.stride(0), ptr(mean), stream_ptr(xd.device)),
                   'tipk_drug_mix_gather_fwd')

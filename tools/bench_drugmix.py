@@ -24,7 +24,7 @@ for (p, q, ne, cat) in ((16, 16, 48, 1), (16, 64, 64, 0)):
     g_xd, g_h, g_w = torch.empty(n, ne, device=dev), torch.empty(ns, p, device=dev), torch.empty(p, q, device=dev)
     def fwd():
         check(lib().tipk_drug_mix_gather_fwd(ptr(xd), ne, ptr(dn), ptr(h), p, ptr(csr['fwd_ptr']), ptr(csr['fwd_src']), ptr(csr['scale']),
-                                             ptr(csr['fwd_wg']), csr['fwd_wg'].shape[0], ptr(w), p, q, n, ne, cat, ptr(out), out.stride(0),
+                                             ptr(csr['fwd_wg']), ptr(csr['fwd_order']), csr['fwd_wg'].shape[0], ptr(w), p, q, n, ne, cat, ptr(out), out.stride(0),
                                              ptr(mean), stream_ptr(dev)), 'fwd')
     g_mean = torch.empty(n, p, device=dev)
     def bwd(want_xd=True, want_m=True):
