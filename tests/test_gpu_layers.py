@@ -88,13 +88,15 @@ def test_rgcn_pair_route_against_reference_golden(name):
 
     def run():
         # exactly as FMEncoder.forward drives the two layers (ReLU fused, slab sum handed over, cells of both layers together)
-        h = m1(x, ei, et, rg, fuse_relu='gated_downstream', defer_output=True, next_layer=m2)
-        box['out'] = m2(h, ei, et, rg, gate_input=True)
+        tok = object()
+        h = m1(x, ei, et, rg, fuse_relu='gated_downstream', defer_output=True, next_layer=m2, cells_token=tok)
+        box['out'] = m2(h, ei, et, rg, gate_input=True, cells_token=tok)
         (box['out'] * g['upstream'].to(DEV)).sum().backward()
     labels = _launch_labels(run)
     for need in ('pair_cells', 'pair_grads', 'pair_att_gather', 'sum_slabs_xb'):
         assert need in labels, (need, labels)
     assert 'gather_sum[dd' not in labels and 'rel_gather' not in labels and 'rel_stream' not in labels, labels
+    assert 'pair_cells2' in labels and 'pair_cells[' not in labels, labels      # ONE cell launch for both layers (token handed over)
     graph = m1.graph_for(x.shape[0], ei, rg)
     assert graph.pair_fwd is not None and graph.pair_fwd.symmetric == ('sym' in name)
     close(box['out'], g['out'], rtol=1e-5, atol=1e-5 * float(g['out'].abs().max()))

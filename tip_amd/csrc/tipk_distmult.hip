@@ -480,7 +480,14 @@ __device__ __forceinline__ int pr_round_i32(float x) {
 template <int I>
 __device__ __forceinline__ void pr_fmac_row_bcast(float& acc, float x, float y) {   // acc += (lane I of the row's x) * y
     // (the combiner folds a broadcast into v_add / v_mul but not into the tied-accumulator v_fmac)
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(I & 15));
+    // DPP reads `x` from OTHER lanes: a VALU write of x needs 2 wait states before it, and the hazard recognizer does not look
+    // inside inline assembly.  The FIRST instruction of every chain (I % 16 == 0: the chains below run I = 0 .. K - 1 over one
+    // unchanged x) carries the s_nop itself, so a register copy the compiler may place in front of the chain is covered too;
+    // inside a chain x is read-only.  The row-of-16 lane mapping (I & 15) is why the kernel asserts K <= 16.
+    if constexpr ((I & 15) == 0)
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(I & 15));
+    else
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(I & 15));
 }
 typedef float pr_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float pr_lds_f32_t;
@@ -499,6 +506,7 @@ __global__ __launch_bounds__(1024) void distmult_objective_kernel(
     const int32_t* __restrict__ tasks, int n_tasks, const IT* __restrict__ pu, const IT* __restrict__ pv,
     const IT* __restrict__ nu, const IT* __restrict__ nv, int64_t n_total, int want_grad,
     unsigned long long* __restrict__ ws, int dbg) {
+    static_assert(K <= 16 && (K & (K - 1)) == 0, "the w row travels as the DPP broadcast of a 16-lane row");
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
     const int t = threadIdx.x;
     constexpr int ld = K + 4, lg = K + 1;

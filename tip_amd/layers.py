@@ -555,14 +555,14 @@ class _RGCNBase(nn.Module):
         """in-degree over the relations of ALL ranks when this layer holds one shard of them."""
         return None if self.shard is None else self.shard.in_degree
 
-    def _run(self, x, graph, fuse_relu=False, gate_input=False, defer_output=False, partner=None):
+    def _run(self, x, graph, fuse_relu=False, gate_input=False, defer_output=False, partner=None, cells_token=None):
         if self.bias is not None:
             out = ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard) + self.bias
             if gate_input or fuse_relu == 'gated_downstream':
                 raise NotImplementedError('ReLU-mask hand-over between layers is only wired for bias=False')
             return torch.relu(out) if fuse_relu else out
         return ops.rgcn(x, self.basis, self.att, self.root, graph, self.shard, relu=fuse_relu, gate_input=gate_input,
-                        defer_output=defer_output, partner=partner)
+                        defer_output=defer_output, partner=partner, cells_token=cells_token)
 
     def __repr__(self):
         return '%s(%d, %d, num_relations=%d)' % (self.__class__.__name__, self.in_channels, self.out_channels,
@@ -581,7 +581,8 @@ class MyRGCNConv2(_RGCNBase):
                               d_out=self.out_channels, n_bases=self.num_bases, paired=self.paired and self.shard is None)
         return self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
 
-    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False, next_layer=None):
+    def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False, next_layer=None,
+                cells_token=None):
         """`fuse_relu` (extension): apply the ReLU that follows the layer in FMEncoder
         (src/layers.py:547) inside the layer's last kernel; 'gated_downstream' additionally leaves
         the ReLU's backward mask to the one consumer, which is called with `gate_input=True`.
@@ -595,8 +596,8 @@ class MyRGCNConv2(_RGCNBase):
         partner = None
         if next_layer is not None and self.shard is None and next_layer.shard is None and next_layer.bias is None and \
                 next_layer.num_relations == self.num_relations and next_layer.num_bases == self.num_bases:
-            partner = (next_layer.att, next_layer.graph_for(n, edge_index, range_list), next_layer.out_channels)
-        return self._run(x, graph, fuse_relu, gate_input, defer_output, partner)
+            partner = (next_layer.att, next_layer.graph_for(n, edge_index, range_list), next_layer.out_channels, cells_token)
+        return self._run(x, graph, fuse_relu, gate_input, defer_output, partner, cells_token if next_layer is None else None)
 
 
 class MyRGCNConv(_RGCNBase):
@@ -681,9 +682,10 @@ class FMEncoder(nn.Module):
         # ReLU (:547) is applied by rgcn1's last kernel and its backward mask by rgcn2's (x1 has no other consumer)
         # ... and its final slab sum runs in rgcn2's first launch, together with rgcn2's XB / X root products
         # rgcn2's pair cells ride in rgcn1's cell launch
+        tok = object()                                         # "rgcn1 gathered rgcn2's cells in THIS pass"
         x1 = self.rgcn1(x0, dd_edge_index, dd_edge_type, dd_range_list, fuse_relu='gated_downstream', defer_output=True,
-                        next_layer=self.rgcn2)
-        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True)
+                        next_layer=self.rgcn2, cells_token=tok)
+        return self.rgcn2(x1, dd_edge_index, dd_edge_type, dd_range_list, gate_input=True, cells_token=tok)
 
     def mixed_drug_features(self, x_drug, d_norm, x_prot, pp_edge_index, dp_edge_index, dp_range_list):
         """The input of the D-D layers (src/layers.py:522-539): P-P GCN x2 -> P -> D mean -> dense map, drug embedding /
@@ -798,6 +800,13 @@ class NNDecoder(nn.Module):
         (`tipk_pair_table_loss`); the four weight gradients and d z follow through the four small products."""
         p = torch.relu(ops.matmul(z, self.w1_l1))
         q = torch.relu(ops.matmul(z, self.w2_l1))
+        if not ops.pair_table_loss_supported(z.shape[0]):
+            # node sets whose two table rows (24 B per node) exceed the kernel's LDS: scores by the table kernels, the loss as the
+            # reference spells it -- still every FLOP on the device, through tipk_pair_table_fwd / _bwd (ADVICE r5)
+            neg = ops.unpack_pairs(neg_index) if getattr(neg_index, '_tipk_packed_pairs', False) else neg_index
+            pos_s = self(z, pos_index, edge_type)
+            neg_s = self(z, neg, edge_type)
+            return (-torch.log(pos_s + EPS).mean() - torch.log(1 - neg_s + EPS).mean()).view(1)
         s1t = ops.matmul(self.w1_l2, p.t())                      # [R, N]
         s2t = ops.matmul(self.w2_l2, q.t())
         return ops.pair_table_objective(s1t, s2t, pos_index, neg_index, edge_type)

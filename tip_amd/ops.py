@@ -1502,7 +1502,7 @@ class _RGCN(torch.autograd.Function):
     into directly; d att rows are shard-local and never travel."""
 
     @staticmethod
-    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False, defer_output=False, partner=None):
+    def forward(ctx, x, basis, att, root, graph, shard, relu, gate_input=False, defer_output=False, partner=None, cells_token=None):
         """relu: False | True | 'gated_downstream' (ReLU applied here, its backward mask applied by the
         consumer, which must be the ONLY consumer and run with gate_input=True).
         gate_input: x is the ReLU output of the producing layer; dX is masked with (x > 0) while it is
@@ -1571,9 +1571,12 @@ class _RGCN(torch.autograd.Function):
             else:
                 xb, _, xroot = gemm_group([gemm_job(x, basis), gemm_job(x, basis, out=xb_nb[:n].permute(1, 0, 2)), gemm_job(x, root)])
                 ctx.xb_stamp, xbt = None, None
+            # the token is an OBJECT the caller made for this forward pass and handed to both layers (FMEncoder.forward): it says
+            # "the previous layer gathered your cells in THIS pass" -- not a (pointer, version) pair, which a raw-pointer parameter
+            # update (tipk_adam_step does not bump `_version`) would leave looking current
             tok = getattr(graph, 'cells_token', None)
             graph.cells_token = None
-            if tok == (att.data_ptr(), att._version, graph.pair_stamp - 1):
+            if cells_token is not None and tok is not None and tok[0] is cells_token and tok[1] == graph.pair_stamp - 1:
                 pass                                         # this layer's cells were gathered with the previous layer's (below)
             elif partner is not None and shard is None and pair_cells_partner_ok(graph, att, partner[1], partner[0], n):
                 # the cells depend on the parameters only: the NEXT layer's (same graph, its own att) are gathered in this
@@ -1583,7 +1586,7 @@ class _RGCN(torch.autograd.Function):
                 cells2 = g2.pair_buffers(n, nb, d_out2, x.device)[0]
                 stream_gather_two(pair, att, att2, cells.view(-1, nb)[:n * n], cells2.view(-1, nb)[:n * n])
                 g2.pair_stamp += 1
-                g2.cells_token = (att2.data_ptr(), att2._version, g2.pair_stamp)
+                g2.cells_token = (partner[3] if len(partner) > 3 else None, g2.pair_stamp)
             else:
                 stream_gather(pair, att, write_zeros=False, out=cells.view(-1, nb)[:n * n], label='pair_cells[dd.fwd]', kind=1)
             slabs = pair_product(cells, xb_nb, symmetric=pair.symmetric, links=getattr(pair, 'links', None), zeros=zeros, xbt=xbt)
@@ -1744,7 +1747,7 @@ class _RGCN(torch.autograd.Function):
                     g_x = gemm(g, root.t(), out=g_x, c_in=g_x)           # replicated term, added once
                     if ctx.gate_input:
                         g_x = rows_affine(g_x, gate=x)
-                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None, None, None
+                return g_x, w_basis.out, g_att, w_root.out, None, None, None, None, None, None, None
         j_root = gemm_job(x.t(), g)
         if shard is None:
             j_basis = gemm_job(x.t(), g_xb)                              # [B, in, out]
@@ -1776,13 +1779,13 @@ class _RGCN(torch.autograd.Function):
             g_x = gemm(g, root.t(), out=g_x, c_in=g_x)                   # replicated term, added once
             if ctx.gate_input:
                 g_x = rows_affine(g_x, gate=x)
-        return g_x, g_basis, g_att, g_root, None, None, None, None, None, None
+        return g_x, g_basis, g_att, g_root, None, None, None, None, None, None, None
 
 
-def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False, defer_output=False, partner=None):
-    """partner (optional): (att, graph, d_out) of the NEXT R-GCN layer on the same D-D graph -- its pair cells are gathered in
-    this layer's cell launch (`stream_gather_two`)."""
-    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input, defer_output, partner)
+def rgcn(x, basis, att, root, graph, shard=None, relu=False, gate_input=False, defer_output=False, partner=None, cells_token=None):
+    """partner (optional): (att, graph, d_out, token) of the NEXT R-GCN layer on the same D-D graph -- its pair cells are gathered
+    in this layer's cell launch (`stream_gather_two`); the next layer is then called with cells_token = the same token object."""
+    return _RGCN.apply(x, basis, att, root, graph, shard, relu, gate_input, defer_output, partner, cells_token)
 
 
 class _DrugMix(torch.autograd.Function):
@@ -2234,6 +2237,11 @@ class _PairTableLoss(torch.autograd.Function):
     def backward(ctx, g):
         g1, g2 = ctx.saved_tensors
         return g1 * g, g2 * g, None, None, None
+
+
+def pair_table_loss_supported(n_nodes):
+    """True if `tipk_pair_table_loss` takes a node set of this size (two table rows of a relation in LDS: 24 B per node)."""
+    return 0 < int(n_nodes) * 24 <= 150 * 1024 and int(n_nodes) <= 65535
 
 
 def pair_table_objective(s1t, s2t, pos_index, neg_index, edge_type):
