@@ -64,11 +64,18 @@ struct RsArgs {
     int64_t second;                    // rows between the two halves
 };
 
+template <typename T> using rs_lds_t = const __attribute__((address_space(3))) T;
+
 // a lane's piece of a row: float4 (16-byte rows and wider) or float2 (8-byte rows: tables of up to 19 000 nodes)
 template <int VW> struct RsVec;
 template <> struct RsVec<4> {
     typedef float4 T;
     static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ T lds_load(unsigned addr) {             // ds_read_b128 at a 32-bit LDS byte address
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 x = *reinterpret_cast<const __attribute__((address_space(3))) f4*>((uintptr_t)addr);
+        return make_float4(x.x, x.y, x.z, x.w);
+    }
     static __device__ __forceinline__ void add(T& a, const T& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     static __device__ __forceinline__ void scale(T& a, float s) { a.x *= s; a.y *= s; a.z *= s; a.w *= s; }
     static __device__ __forceinline__ T shfl_down(const T& a, int d) {
@@ -79,6 +86,11 @@ template <> struct RsVec<4> {
 template <> struct RsVec<2> {
     typedef float2 T;
     static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); }
+    static __device__ __forceinline__ T lds_load(unsigned addr) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 x = *reinterpret_cast<const __attribute__((address_space(3))) f2*>((uintptr_t)addr);
+        return make_float2(x.x, x.y);
+    }
     static __device__ __forceinline__ void add(T& a, const T& b) { a.x += b.x; a.y += b.y; }
     static __device__ __forceinline__ void scale(T& a, float s) { a.x *= s; a.y *= s; }
     static __device__ __forceinline__ T shfl_down(const T& a, int d) {
@@ -112,8 +124,8 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
     const int b_first = b;
 #endif
     const int b1 = __builtin_amdgcn_readfirstlane(a.wave_ptr[gw + 1]);
-    const char* tabb = reinterpret_cast<const char*>(tab + c0);
-    const unsigned ldt4 = (unsigned)a.idx_mul;
+    const unsigned tab32 = (unsigned)(uintptr_t)(rs_lds_t<float>*)(tab + c0);     // LDS byte address of this lane's piece of row 0
+    const unsigned ldt4 = (unsigned)__builtin_amdgcn_readfirstlane(a.idx_mul);      // (<= 64: a 16-bit factor)
 
     // A band is walked in about a microsecond; its record (cell word + ids) comes from HBM and takes two under
     // load, so records are requested RS_DEPTH bands ahead (loads are unconditional: the band index is clamped
@@ -213,16 +225,19 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
             if (k < len) {
                 // one step: 8 pre-scaled ids -> 8 row addresses (SDWA adds) -> 8 ds_read_b128 -> one wait, rows
                 // added last to first (the last row's arrival implies the others: LDS returns in order)
+                // (round 6) a row address = base + id16 * idx_mul in ONE instruction: v_mad_u32_u16 takes the 16-bit half of the
+                // id word it is told to (op_sel) -- unpack (v_and / v_lshrrev) + v_mad_u32_u24 were 16 of a step's ~51 VALU
+                // instructions, and the VALU time of these launches ADDS to their LDS time (profiles/r06_lds.json)
                 const unsigned w4[4] = {iw[k].x, iw[k].y, iw[k].z, iw[k].w};
-                const char* ad[8];
+                unsigned ad[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    const unsigned idj = (jj & 1) ? (w4[jj >> 1] >> 16) : (w4[jj >> 1] & 0xffffu);
-                    ad[jj] = UNIT ? tabb + idj : tabb + __umul24(idj, ldt4);
+                    if (jj & 1) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad[jj]) : "v"(w4[jj >> 1]), "s"(ldt4), "v"(tab32));
+                    else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(ad[jj]) : "v"(w4[jj >> 1]), "s"(ldt4), "v"(tab32));
                 }
                 vec_t v[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = *reinterpret_cast<const vec_t*>(ad[jj]);
+                for (int jj = 0; jj < 8; ++jj) v[jj] = V::lds_load(ad[jj]);
 #pragma unroll
                 for (int jj = 7; jj >= 0; --jj) V::add(acc, v[jj]);
             }
