@@ -5,7 +5,8 @@
 
 What a maintainer of the reference would write to route `MyRGCNConv2.forward` (src/layers.py:157-188) and its autograd to
 libtipk.so from any language with a C FFI: `tipk_graph_build` once per graph, `tipk_rgcn_fwd` / `tipk_rgcn_bwd` per pass,
-`tipk_graph_destroy` at the end (include/tipk.h section 10).  Only ctypes + torch-for-device-memory are used here: neither
+`tipk_graph_destroy` at the end (include/tipk.h section 10) -- and the same for the other two layer kinds of the path, `GCNConv`
+as `PPEncoder` uses it (`tipk_gcn_*`, identity and dense features) and `MyHierarchyConv` (`tipk_hier_*`).  Only ctypes + torch-for-device-memory are used here: neither
 `tip_amd.ops` nor `tip_amd.plan` (nor any other module of the package) is imported -- asserted at the end.  The fixtures are
 outputs and autograd gradients of the reference's own layers (oracle/make_golden.py); both the range-list form (MyRGCNConv2)
 and the edge-type form (MyRGCNConv) of the graph are built.
@@ -35,6 +36,22 @@ def load_library():
     lib.tipk_rgcn_fwd.argtypes = [P, P, L, I, P, P, P, I, I, I, P, L, P, L, P]
     lib.tipk_rgcn_bwd.restype = I
     lib.tipk_rgcn_bwd.argtypes = [P, P, L, I, P, P, P, I, I, P, L, P, L, P, L, P, P, P, P, L, P]
+    lib.tipk_gcn_graph_build.restype = I
+    lib.tipk_gcn_graph_build.argtypes = [P, I, L, L, C.POINTER(P)]
+    lib.tipk_gcn_workspace_bytes.restype = L
+    lib.tipk_gcn_workspace_bytes.argtypes = [P, I, I]
+    lib.tipk_gcn_fwd.restype = I
+    lib.tipk_gcn_fwd.argtypes = [P, P, L, I, P, L, L, P, I, I, P, L, P, L, P]
+    lib.tipk_gcn_bwd.restype = I
+    lib.tipk_gcn_bwd.argtypes = [P, P, L, I, P, L, L, I, P, L, P, L, P, L, P, L, L, P, P, L, P]
+    lib.tipk_hier_graph_build.restype = I
+    lib.tipk_hier_graph_build.argtypes = [P, I, L, L, L, C.POINTER(P)]
+    lib.tipk_hier_workspace_bytes.restype = L
+    lib.tipk_hier_workspace_bytes.argtypes = [P, I, I]
+    lib.tipk_hier_fwd.restype = I
+    lib.tipk_hier_fwd.argtypes = [P, P, L, I, P, I, P, L, P, L, P]
+    lib.tipk_hier_bwd.restype = I
+    lib.tipk_hier_bwd.argtypes = [P, P, L, I, P, I, P, L, P, L, P, P, L, P]
     return lib
 
 
@@ -136,14 +153,100 @@ def run_two_layers(lib, path, dev):
     return worst
 
 
+def load(path):
+    return {k: torch.from_numpy(v) if v.dtype.kind in 'fi' and v.ndim else v for k, v in np.load(path).items()}
+
+
+def run_pp_encoder(lib, path, dev):
+    """PPEncoder = GCNConv(n_prot, 32) + ReLU + GCNConv(32, 16) on identity features (src/layers.py:380-395) through
+    tipk_gcn_graph_build / tipk_gcn_fwd / tipk_gcn_bwd; the dense-feature fixture runs the same two layers on x [n, 24]."""
+    g = load(path)
+    dense = 'x' in g
+    n = int(g['x'].shape[0]) if dense else int(g['n_prot'])
+    ei = g['pp_idx'].to(dev).contiguous()
+    h = C.c_void_p()
+    ok(lib, lib.tipk_gcn_graph_build(ptr(ei), 8, ei.shape[1], n, C.byref(h)), 'tipk_gcn_graph_build')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w1, b1, w2, b2 = (g[k].to(dev) for k in ('conv1.lin.weight', 'conv1.bias', 'conv2.lin.weight', 'conv2.bias'))
+    d1, d2 = w1.shape[0], w2.shape[0]
+    ws = torch.empty(max(lib.tipk_gcn_workspace_bytes(h, n, d1), lib.tipk_gcn_workspace_bytes(h, d1, d2)), dtype=torch.uint8, device=dev)
+    h1 = torch.empty(n, d1, device=dev)
+    out = torch.empty(n, d2, device=dev)
+    up = g['upstream'].to(dev).contiguous()
+    g_h1, g_w2, g_b2, g_b1 = torch.empty(n, d1, device=dev), torch.empty(d2, d1, device=dev), torch.empty(d2, device=dev), torch.empty(d1, device=dev)
+    if dense:
+        x = g['x'].to(dev).contiguous()
+        w1c = w1.contiguous()                                                 # [out, in] memory: w_so = in, w_si = 1
+        g_w1 = torch.empty_like(w1c)
+        g_x = torch.empty_like(x)
+        ok(lib, lib.tipk_gcn_fwd(h, ptr(x), x.stride(0), x.shape[1], ptr(w1c), w1c.stride(0), 1, ptr(b1), d1, 1, ptr(h1), d1, ptr(ws), ws.numel(), st), 'gcn_fwd 1')
+    else:
+        w1t = w1.t().contiguous()                                             # [in, out] memory: lin(I) = W^T is read in place
+        g_w1t = torch.empty_like(w1t)
+        ok(lib, lib.tipk_gcn_fwd(h, None, 0, n, ptr(w1t), 1, d1, ptr(b1), d1, 1, ptr(h1), d1, ptr(ws), ws.numel(), st), 'gcn_fwd 1')
+    w2c = w2.contiguous()
+    ok(lib, lib.tipk_gcn_fwd(h, ptr(h1), d1, d1, ptr(w2c), d1, 1, ptr(b2), d2, 0, ptr(out), d2, ptr(ws), ws.numel(), st), 'gcn_fwd 2')
+    ok(lib, lib.tipk_gcn_bwd(h, ptr(h1), d1, d1, ptr(w2c), d1, 1, d2, ptr(up), d2, None, 0, ptr(g_h1), d1, ptr(g_w2), d1, 1, ptr(g_b2),
+                             ptr(ws), ws.numel(), st), 'gcn_bwd 2')
+    if dense:
+        ok(lib, lib.tipk_gcn_bwd(h, ptr(x), x.stride(0), x.shape[1], ptr(w1c), w1c.stride(0), 1, d1, ptr(g_h1), d1, ptr(h1), d1, ptr(g_x),
+                                 g_x.stride(0), ptr(g_w1), g_w1.stride(0), 1, ptr(g_b1), ptr(ws), ws.numel(), st), 'gcn_bwd 1')
+    else:
+        ok(lib, lib.tipk_gcn_bwd(h, None, 0, n, ptr(w1t), 1, d1, d1, ptr(g_h1), d1, ptr(h1), d1, None, 0, ptr(g_w1t), 1, d1, ptr(g_b1),
+                                 ptr(ws), ws.numel(), st), 'gcn_bwd 1')
+        g_w1 = g_w1t.t()
+    torch.cuda.synchronize()
+    worst = 0.0
+    checks = [('out', out, g['out']), ('conv1.lin.weight', g_w1, g['grad.conv1.lin.weight'])]
+    if not dense:
+        checks += [('conv2.lin.weight', g_w2, g['grad.conv2.lin.weight']), ('conv2.bias', g_b2, g['grad.conv2.bias']),
+                   ('conv1.bias', g_b1, g['grad.conv1.bias'])]
+    else:
+        checks += [('grad_x', g_x, g['grad_x'])]
+    for name, got, want in checks:
+        worst = max(worst, check('%s %s' % (os.path.basename(path), name), got, want, 2e-5, 1.0))
+    ok(lib, lib.tipk_graph_destroy(h), 'tipk_graph_destroy')
+    return worst
+
+
+def run_hier(lib, path, dev):
+    """MyHierarchyConv (src/layers.py:196-247) through tipk_hier_graph_build / tipk_hier_fwd / tipk_hier_bwd."""
+    g = load(path)
+    x = g['x'].to(dev).contiguous()
+    n_all, d_in = x.shape
+    n_src = int(g['n_source'])
+    w = g['weight'].to(dev).contiguous()
+    d_out = w.shape[1]
+    ei = g['dp_idx'].to(dev).contiguous()
+    h = C.c_void_p()
+    ok(lib, lib.tipk_hier_graph_build(ptr(ei), 8, ei.shape[1], n_all, n_src, C.byref(h)), 'tipk_hier_graph_build')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws = torch.empty(lib.tipk_hier_workspace_bytes(h, d_in, d_out), dtype=torch.uint8, device=dev)
+    out = torch.empty(n_all - n_src, d_out, device=dev)
+    up = g['upstream'].to(dev).contiguous()
+    g_x, g_w = torch.empty_like(x), torch.empty_like(w)
+    ok(lib, lib.tipk_hier_fwd(h, ptr(x), d_in, d_in, ptr(w), d_out, ptr(out), d_out, ptr(ws), ws.numel(), st), 'tipk_hier_fwd')
+    ok(lib, lib.tipk_hier_bwd(h, ptr(x), d_in, d_in, ptr(w), d_out, ptr(up), d_out, ptr(g_x), d_in, ptr(g_w), ptr(ws), ws.numel(), st),
+       'tipk_hier_bwd')
+    torch.cuda.synchronize()
+    worst = 0.0
+    for name, got, want in (('out', out, g['out']), ('grad_x', g_x, g['grad_x']), ('grad.weight', g_w, g['grad.weight'])):
+        worst = max(worst, check('%s %s' % (os.path.basename(path), name), got, want, 2e-5, 1.0))
+    ok(lib, lib.tipk_graph_destroy(h), 'tipk_graph_destroy')
+    return worst
+
+
 def main():
     dev = torch.device('cuda:0')
     lib = load_library()
     golden = os.path.join(ROOT, 'tests', 'golden')
-    paths = sys.argv[1:] or [os.path.join(golden, f) for f in ('rgcn_sym.npz', 'rgcn_directed.npz', 'rgcn_fast_sym.npz', 'rgcn_fast_directed.npz')]
+    paths = sys.argv[1:] or [os.path.join(golden, f) for f in ('rgcn_sym.npz', 'rgcn_directed.npz', 'rgcn_fast_sym.npz', 'rgcn_fast_directed.npz',
+                                                                 'pp_encoder.npz', 'pp_encoder_dense.npz', 'hier_conv.npz')]
     for path in paths:
-        fn = run_two_layers if 'fast' in os.path.basename(path) else run_single
-        print('%-26s max error %.2e of max|want|' % (os.path.basename(path), fn(lib, path, dev)))
+        base = os.path.basename(path)
+        fn = run_pp_encoder if base.startswith('pp_encoder') else run_hier if base.startswith('hier') else \
+            run_two_layers if 'fast' in base else run_single
+        print('%-26s max error %.2e of max|want|' % (base, fn(lib, path, dev)))
     # malformed input: an id out of range is refused, as the reference raises IndexError
     bad = torch.tensor([[0, 1], [1, 99]], device=dev)
     h = C.c_void_p()

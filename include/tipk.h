@@ -890,6 +890,38 @@ int tipk_rgcn_bwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_i
                   const float* out_relu /* nullable */, int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att,
                   float* g_root, void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
 
+/* 10b. The other two layer kinds of the path behind the same kind of handle (tipk_graph_destroy frees them all):
+ *   GCNConv as PPEncoder uses it (PyG 2.0.1 semantics, src/layers.py:386-394): tipk_gcn_graph_build forms
+ *   A_hat = D^-1/2 (A + I) D^-1/2 -- existing self loops replaced by exactly one unit loop per node, D = in-degree incl. the
+ *   loop, flow source -> target -- as two weighted CSRs.
+ *     tipk_gcn_fwd:  out = relu?( A_hat (x W^T) + bias );  x = NULL: identity features (lin(I) = W^T, read in place: w_so must be 1);
+ *                    weight element (o, i) at weight[o * w_so + i * w_si] (any layout of the [out, in] parameter).
+ *     tipk_gcn_bwd:  grad_out (masked with out_relu > 0 when given) -> g_x (nullable; needs x), g_weight (element (o, i) at
+ *                    g_weight[o * gw_so + i * gw_si]; dense x: gw_si must be 1; identity: gw_so must be 1 -- d W is the transposed
+ *                    aggregate written in place), g_bias (nullable).
+ *   MyHierarchyConv (src/layers.py:196-247): tipk_hier_graph_build keeps the edges that end in rows [n_source, n_all) of the
+ *   concatenated node space; tipk_hier_fwd: out [n_all - n_source x d_out] = mean over incoming edges of x [n_all x d_in] . weight
+ *   [d_in x d_out]; tipk_hier_bwd -> g_x [n_all x d_in] (nullable), g_weight.
+ *   Workspaces: tipk_gcn_workspace_bytes / tipk_hier_workspace_bytes, 16-byte aligned, caller-owned.  (The fused objective of the
+ *   DistMult decoder is one C call already: tipk_distmult_loss_store, section 4.) */
+int tipk_gcn_graph_build(const void* edge_index, int idx_bytes, int64_t n_edges, int64_t n_nodes, tipk_graph** graph_out);
+int64_t tipk_gcn_workspace_bytes(const tipk_graph* graph, int d_in, int d_out);
+int tipk_gcn_fwd(const tipk_graph* graph, const float* x /* nullable */, int64_t ld_x, int d_in, const float* weight, int64_t w_so,
+                 int64_t w_si, const float* bias /* nullable */, int d_out, int relu, float* out, int64_t ld_out,
+                 void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
+int tipk_gcn_bwd(const tipk_graph* graph, const float* x /* nullable */, int64_t ld_x, int d_in, const float* weight, int64_t w_so,
+                 int64_t w_si, int d_out, const float* grad_out, int64_t ld_g, const float* out_relu /* nullable */, int64_t ld_relu,
+                 float* g_x /* nullable */, int64_t ld_gx, float* g_weight, int64_t gw_so, int64_t gw_si, float* g_bias /* nullable */,
+                 void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
+int tipk_hier_graph_build(const void* edge_index, int idx_bytes, int64_t n_edges, int64_t n_all, int64_t n_source,
+                          tipk_graph** graph_out);
+int64_t tipk_hier_workspace_bytes(const tipk_graph* graph, int d_in, int d_out);
+int tipk_hier_fwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_in, const float* weight, int d_out, float* out,
+                  int64_t ld_out, void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
+int tipk_hier_bwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_in, const float* weight, int d_out,
+                  const float* grad_out, int64_t ld_g, float* g_x /* nullable */, int64_t ld_gx, float* g_weight,
+                  void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,7 +2,8 @@
 
 `examples/c_abi_host.py` is a stand-alone program: ctypes on libtipk.so + torch for device memory, importing neither
 `tip_amd.ops` nor `tip_amd.plan` (it asserts that no module of the package was loaded).  It builds graph handles
-(`tipk_graph_build`, range-list and edge-type form), runs `tipk_rgcn_fwd` / `tipk_rgcn_bwd` and compares with the outputs and
+(`tipk_graph_build`, range-list and edge-type form; `tipk_gcn_graph_build`, `tipk_hier_graph_build`), runs `tipk_rgcn_fwd` /
+`tipk_rgcn_bwd`, `tipk_gcn_fwd/_bwd` (PPEncoder on identity and on dense features), `tipk_hier_fwd/_bwd` and compares with the outputs and
 autograd gradients of the reference's own MyRGCNConv2 / MyRGCNConv recorded in tests/golden (rgcn_sym, rgcn_directed, and
 the two-layer 64 -> 32 -> 16 fixtures with the ReLU between the layers).  It runs in a child process: this pytest process
 has the package imported (tests/conftest.py builds the library through it)."""
@@ -19,4 +20,4 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_rgcn_layer_through_the_graph_handle_from_a_foreign_host():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'c_abi_host.py')], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'C-ABI host ok' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
-    assert out.stdout.count('max error') == 4
+    assert out.stdout.count('max error') == 7

@@ -150,6 +150,14 @@ SIGNATURES = {
     'tipk_rgcn_workspace_bytes': (_L, [_P, _I, _I, _I]),
     'tipk_rgcn_fwd': (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _I, _P, _L, _P, _L, _P]),
     'tipk_rgcn_bwd': (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P]),
+    'tipk_gcn_graph_build': (_I, [_P, _I, _L, _L, C.POINTER(C.c_void_p)]),
+    'tipk_gcn_workspace_bytes': (_L, [_P, _I, _I]),
+    'tipk_gcn_fwd': (_I, [_P, _P, _L, _I, _P, _L, _L, _P, _I, _I, _P, _L, _P, _L, _P]),
+    'tipk_gcn_bwd': (_I, [_P, _P, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _P, _L, _P, _L, _L, _P, _P, _L, _P]),
+    'tipk_hier_graph_build': (_I, [_P, _I, _L, _L, _L, C.POINTER(C.c_void_p)]),
+    'tipk_hier_workspace_bytes': (_L, [_P, _I, _I]),
+    'tipk_hier_fwd': (_I, [_P, _P, _L, _I, _P, _I, _P, _L, _P, _L, _P]),
+    'tipk_hier_bwd': (_I, [_P, _P, _L, _I, _P, _I, _P, _L, _P, _L, _P, _P, _L, _P]),
     'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),
     'tipk_split_scatter': (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

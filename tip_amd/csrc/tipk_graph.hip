@@ -23,12 +23,16 @@
 #include "tipk_common.h"
 
 struct tipk_graph {
+    int kind;              // 0: D-D relation graph (R-GCN), 1: normalised adjacency (GCNConv), 2: bipartite mean (MyHierarchyConv)
     int64_t n_nodes, n_rel, n_edges;
-    int32_t* fwd_ptr;      // [n_nodes + 1]            edges by destination
-    int32_t* fwd_row;      // [n_edges]                row (relation * n_nodes + source) of Y
-    int32_t* bwd_ptr;      // [n_rel * n_nodes + 1]    edges by (relation, source)
-    int32_t* bwd_row;      // [n_edges]                destination
-    float* inv_deg;        // [n_nodes]                1 / max(1, in-degree over all relations)
+    int32_t* fwd_ptr;      // [n_out + 1]              edges by output row (R-GCN: destination)
+    int32_t* fwd_row;      // [n_edges]                table row (R-GCN: relation * n_nodes + source, a row of Y)
+    int32_t* bwd_ptr;      // [n_table + 1]            the transpose (R-GCN: by (relation, source))
+    int32_t* bwd_row;      // [n_edges]
+    float* inv_deg;        // R-GCN: [n_nodes] 1 / max(1, in-degree over all relations)
+    float* fwd_w;          // kinds 1, 2: weight of every edge in fwd order / in bwd order (GCN norm; 1 / #edges of the target)
+    float* bwd_w;
+    int64_t n_out, n_table, n_source;      // kinds 1, 2: rows of the output / of the table; kind 2: first target row
 };
 
 namespace {
@@ -40,6 +44,8 @@ struct GrArgs {
     const float* out_scale;                    // nullable: per output row
     const float* addend; int64_t ld_add;       // nullable
     const float* gate; int64_t ld_gate;        // nullable: the TABLE row is masked with gate[i] > 0 (ReLU backward)
+    const float* edge_w;                       // nullable: per edge (in list order)
+    const float* bias;                         // nullable: per column, added before the ReLU
     int relu, d;
     float* out; int64_t ld_out;
 };
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(256) void graph_rows_kernel(GrArgs a) {
                 v2 = a.gate[(int64_t)i2 * a.ld_gate + c] > 0.f ? v2 : 0.f; v3 = a.gate[(int64_t)i3 * a.ld_gate + c] > 0.f ? v3 : 0.f;
             }
             if (a.table_scale) { v0 *= a.table_scale[i0]; v1 *= a.table_scale[i1]; v2 *= a.table_scale[i2]; v3 *= a.table_scale[i3]; }
+            if (a.edge_w) { v0 *= a.edge_w[e]; v1 *= a.edge_w[e + 1]; v2 *= a.edge_w[e + 2]; v3 *= a.edge_w[e + 3]; }
             s += v0; s += v1; s += v2; s += v3;
         }
         for (; e < e1; ++e) {
@@ -69,10 +76,12 @@ __global__ __launch_bounds__(256) void graph_rows_kernel(GrArgs a) {
             float v0 = a.table[(int64_t)i0 * a.ld_t + c];
             if (a.gate) v0 = a.gate[(int64_t)i0 * a.ld_gate + c] > 0.f ? v0 : 0.f;
             if (a.table_scale) v0 *= a.table_scale[i0];
+            if (a.edge_w) v0 *= a.edge_w[e];
             s += v0;
         }
         if (a.out_scale) s *= a.out_scale[r];
         if (a.addend) s += a.addend[r * a.ld_add + c];
+        if (a.bias) s += a.bias[c];
         if (a.relu) s = fmaxf(s, 0.f);
         a.out[r * a.ld_out + c] = s;
     }
@@ -193,7 +202,7 @@ extern "C" int tipk_graph_build(const void* edge_index, const void* edge_type, c
     tipk_graph* g = new (std::nothrow) tipk_graph;
     if (!g) return TIPK_EINVAL;
     memset(g, 0, sizeof(*g));
-    g->n_nodes = n_nodes; g->n_rel = n_rel; g->n_edges = n_edges;
+    g->kind = 0; g->n_nodes = n_nodes; g->n_rel = n_rel; g->n_edges = n_edges; g->n_out = n_nodes; g->n_table = n_rel * n_nodes;
     auto up = [&](void** d, const void* h, size_t bytes) -> int {
         hipError_t e = hipMalloc(d, bytes ? bytes : 4);
         if (e != hipSuccess) return tipk_hip_status(e);
@@ -212,7 +221,7 @@ extern "C" int tipk_graph_build(const void* edge_index, const void* edge_type, c
 extern "C" int tipk_graph_destroy(tipk_graph* g) {
     if (!g) return TIPK_OK;
     int st = TIPK_OK;
-    void* bufs[5] = {g->fwd_ptr, g->fwd_row, g->bwd_ptr, g->bwd_row, g->inv_deg};
+    void* bufs[7] = {g->fwd_ptr, g->fwd_row, g->bwd_ptr, g->bwd_row, g->inv_deg, g->fwd_w, g->bwd_w};
     for (void* b : bufs)
         if (b) { const int s = tipk_hip_status(hipFree(b)); if (s != TIPK_OK) st = s; }
     delete g;
@@ -229,14 +238,14 @@ extern "C" int tipk_graph_info(const tipk_graph* g, int64_t* n_nodes, int64_t* n
 }
 
 extern "C" int64_t tipk_rgcn_workspace_bytes(const tipk_graph* g, int d_in, int d_out, int n_bases) {
-    if (!g || d_in <= 0 || d_out <= 0 || n_bases <= 0) return -1;
+    if (!g || g->kind != 0 || d_in <= 0 || d_out <= 0 || n_bases <= 0) return -1;
     return carve(nullptr, g->n_nodes, g->n_rel, n_bases, d_out).bytes;
 }
 
 extern "C" int tipk_rgcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* basis, const float* att,
                              const float* root, int n_bases, int d_out, int relu, float* out, int64_t ld_out, void* workspace,
                              int64_t workspace_bytes, tipk_stream_t stream) {
-    if (!g || !x || !basis || !root || !out || !workspace || d_in <= 0 || d_out <= 0 || n_bases <= 0 || ld_x < d_in || ld_out < d_out ||
+    if (!g || g->kind != 0 || !x || !basis || !root || !out || !workspace || d_in <= 0 || d_out <= 0 || n_bases <= 0 || ld_x < d_in || ld_out < d_out ||
         (g->n_rel > 0 && !att))
         return TIPK_EINVAL;
     const int64_t n = g->n_nodes, r = g->n_rel;
@@ -265,7 +274,7 @@ extern "C" int tipk_rgcn_bwd(const tipk_graph* g, const float* x, int64_t ld_x, 
                              const float* root, int n_bases, int d_out, const float* grad_out, int64_t ld_g, const float* out_relu,
                              int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att, float* g_root, void* workspace,
                              int64_t workspace_bytes, tipk_stream_t stream) {
-    if (!g || !x || !basis || !root || !grad_out || !g_x || !g_basis || !g_root || !workspace || d_in <= 0 || d_out <= 0 || n_bases <= 0 ||
+    if (!g || g->kind != 0 || !x || !basis || !root || !grad_out || !g_x || !g_basis || !g_root || !workspace || d_in <= 0 || d_out <= 0 || n_bases <= 0 ||
         ld_x < d_in || ld_g < d_out || ld_gx < d_in || (g->n_rel > 0 && (!att || !g_att)) || (out_relu && ld_relu < d_out))
         return TIPK_EINVAL;
     const int64_t n = g->n_nodes, r = g->n_rel;
@@ -314,4 +323,248 @@ extern "C" int tipk_rgcn_bwd(const tipk_graph* g, const float* x, int64_t ld_x, 
     d = gemm_desc(n, d_in, d_out, w.dxb, d_out, 1, basis, 1, d_out, g_x, ld_gx);
     d.kbatch = n_bases; d.a_sq = n * d_out; d.b_sq = (int64_t)d_in * d_out; d.c_in = g_x; d.cin_sm = ld_gx;
     return tipk_gemm_f32(&d, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GCNConv and MyHierarchyConv behind the same kind of handle (include/tipk.h section 10b).
+
+namespace {
+
+// weighted pair of CSRs from (out row, table row, weight) triples, stable in list order; everything uploaded into `g`
+int build_weighted(tipk_graph* g, const std::vector<int64_t>& orow, const std::vector<int64_t>& trow, const std::vector<float>& w,
+                   int64_t n_out, int64_t n_table) {
+    const size_t e = orow.size();
+    std::vector<int32_t> fptr((size_t)n_out + 1, 0), frow(e), bptr((size_t)n_table + 1, 0), brow(e);
+    std::vector<float> fw(e), bw(e);
+    for (size_t i = 0; i < e; ++i) { ++fptr[(size_t)orow[i] + 1]; ++bptr[(size_t)trow[i] + 1]; }
+    for (size_t i = 1; i < fptr.size(); ++i) fptr[i] += fptr[i - 1];
+    for (size_t i = 1; i < bptr.size(); ++i) bptr[i] += bptr[i - 1];
+    std::vector<int32_t> fpos(fptr.begin(), fptr.end() - 1), bpos(bptr.begin(), bptr.end() - 1);
+    for (size_t i = 0; i < e; ++i) {
+        const int32_t f = fpos[(size_t)orow[i]]++, b = bpos[(size_t)trow[i]]++;
+        frow[(size_t)f] = (int32_t)trow[i]; fw[(size_t)f] = w[i];
+        brow[(size_t)b] = (int32_t)orow[i]; bw[(size_t)b] = w[i];
+    }
+    auto up = [&](void** d, const void* h, size_t bytes) -> int {
+        hipError_t er = hipMalloc(d, bytes ? bytes : 4);
+        if (er != hipSuccess) return tipk_hip_status(er);
+        return bytes ? tipk_hip_status(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice)) : TIPK_OK;
+    };
+    int st = up((void**)&g->fwd_ptr, fptr.data(), fptr.size() * 4);
+    if (st == TIPK_OK) st = up((void**)&g->fwd_row, frow.data(), e * 4);
+    if (st == TIPK_OK) st = up((void**)&g->bwd_ptr, bptr.data(), bptr.size() * 4);
+    if (st == TIPK_OK) st = up((void**)&g->bwd_row, brow.data(), e * 4);
+    if (st == TIPK_OK) st = up((void**)&g->fwd_w, fw.data(), e * 4);
+    if (st == TIPK_OK) st = up((void**)&g->bwd_w, bw.data(), e * 4);
+    g->n_out = n_out; g->n_table = n_table; g->n_edges = (int64_t)e;
+    return st;
+}
+
+int fetch_index(const void* p, int idx_bytes, int64_t count, std::vector<int64_t>& dst) {
+    dst.resize((size_t)count);
+    if (count == 0) return TIPK_OK;
+    if (idx_bytes == 8) return tipk_hip_status(hipMemcpy(dst.data(), p, (size_t)count * 8, hipMemcpyDefault));
+    std::vector<int32_t> tmp((size_t)count);
+    const int st = tipk_hip_status(hipMemcpy(tmp.data(), p, (size_t)count * 4, hipMemcpyDefault));
+    for (int64_t i = 0; i < count; ++i) dst[(size_t)i] = tmp[(size_t)i];
+    return st;
+}
+
+int gate_rows(const float* in, int64_t ld_in, const float* gate, int64_t ld_gate, float* out, int64_t rows, int d, hipStream_t hs) {
+    const int64_t tot = rows * d;
+    if (tot <= 0) return TIPK_OK;
+    hipLaunchKernelGGL(graph_gate_kernel, dim3((unsigned)tipk_ceil_div(tot, (int64_t)256)), dim3(256), 0, hs, in, ld_in, gate, ld_gate, out,
+                       rows, d);
+    return tipk_hip_status(hipGetLastError());
+}
+
+}  // namespace
+
+// GCNConv (PyG 2.0.1 semantics, as PPEncoder uses it: src/layers.py:386-394): A_hat = D^-1/2 (A + I) D^-1/2 with existing self
+// loops replaced by exactly one unit loop per node, D = in-degree including the loop, flow source -> target.
+extern "C" int tipk_gcn_graph_build(const void* edge_index, int idx_bytes, int64_t n_edges, int64_t n_nodes, tipk_graph** out) {
+    if (!out) return TIPK_EINVAL;
+    *out = nullptr;
+    if ((idx_bytes != 4 && idx_bytes != 8) || n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return TIPK_EINVAL;
+    if (n_edges + n_nodes >= 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    std::vector<int64_t> ei;
+    int st = fetch_index(edge_index, idx_bytes, 2 * n_edges, ei);
+    if (st != TIPK_OK) return st;
+    std::vector<int64_t> src, dst;
+    src.reserve((size_t)(n_edges + n_nodes)); dst.reserve((size_t)(n_edges + n_nodes));
+    for (int64_t i = 0; i < n_edges; ++i) {
+        const int64_t s = ei[(size_t)i], d = ei[(size_t)(n_edges + i)];
+        if (s < 0 || s >= n_nodes || d < 0 || d >= n_nodes) return TIPK_EINVAL;
+        if (s != d) { src.push_back(s); dst.push_back(d); }                   // add_remaining_self_loops: one loop per node below
+    }
+    for (int64_t v = 0; v < n_nodes; ++v) { src.push_back(v); dst.push_back(v); }
+    std::vector<double> deg((size_t)n_nodes, 0.0);
+    for (size_t i = 0; i < dst.size(); ++i) deg[(size_t)dst[i]] += 1.0;
+    std::vector<float> dis((size_t)n_nodes), w(src.size());
+    for (int64_t v = 0; v < n_nodes; ++v) dis[(size_t)v] = deg[(size_t)v] > 0 ? 1.0f / sqrtf((float)deg[(size_t)v]) : 0.f;
+    for (size_t i = 0; i < src.size(); ++i) w[i] = dis[(size_t)src[i]] * dis[(size_t)dst[i]];
+    tipk_graph* g = new (std::nothrow) tipk_graph;
+    if (!g) return TIPK_EINVAL;
+    memset(g, 0, sizeof(*g));
+    g->kind = 1; g->n_nodes = n_nodes;
+    st = build_weighted(g, dst, src, w, n_nodes, n_nodes);                    // out[target] += w * table[source]
+    if (st != TIPK_OK) { tipk_graph_destroy(g); return st; }
+    *out = g;
+    return TIPK_OK;
+}
+
+extern "C" int64_t tipk_gcn_workspace_bytes(const tipk_graph* g, int d_in, int d_out) {
+    if (!g || g->kind != 1 || d_out <= 0) return -1;
+    return 2 * align256(g->n_nodes * (int64_t)d_out * 4) + align256(256 * (int64_t)d_out * 4);
+}
+
+// out = relu?( A_hat (x W^T) + bias );  x = NULL: identity features (lin(I) = W^T: d_in = n_nodes); weight element (o, i) at
+// weight[o * w_so + i * w_si]
+extern "C" int tipk_gcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* weight, int64_t w_so, int64_t w_si,
+                            const float* bias, int d_out, int relu, float* out, int64_t ld_out, void* workspace,
+                            int64_t workspace_bytes, tipk_stream_t stream) {
+    if (!g || g->kind != 1 || !weight || !out || !workspace || d_out <= 0 || ld_out < d_out || (x && (d_in <= 0 || ld_x < d_in)))
+        return TIPK_EINVAL;
+    const int64_t n = g->n_nodes;
+    if (workspace_bytes < tipk_gcn_workspace_bytes(g, d_in, d_out) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
+    float* xl = (float*)workspace;
+    GrArgs a;
+    memset(&a, 0, sizeof(a));
+    if (x) {
+        tipk_gemm_desc d = gemm_desc(n, d_out, d_in, x, ld_x, 1, weight, w_si, w_so, xl, d_out);          // x W^T
+        const int st = tipk_gemm_f32(&d, stream);
+        if (st != TIPK_OK) return st;
+        a.table = xl; a.ld_t = d_out;
+    } else {
+        // identity features: lin(I) = W^T read in place -- table row i, column o = weight[o * w_so + i * w_si]; the gather wants
+        // unit-stride columns (this package stores lin.weight as [in, out] memory behind its [out, in] shape: w_so = 1)
+        if (w_so != 1) return TIPK_EUNSUPPORTED;
+        a.table = weight; a.ld_t = w_si;
+    }
+    a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = n; a.edge_w = g->fwd_w; a.bias = bias; a.relu = relu; a.d = d_out;
+    a.out = out; a.ld_out = ld_out;
+    return gr_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int tipk_gcn_bwd(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* weight, int64_t w_so, int64_t w_si,
+                            int d_out, const float* grad_out, int64_t ld_g, const float* out_relu, int64_t ld_relu, float* g_x,
+                            int64_t ld_gx, float* g_weight, int64_t gw_so, int64_t gw_si, float* g_bias, void* workspace,
+                            int64_t workspace_bytes, tipk_stream_t stream) {
+    if (!g || g->kind != 1 || !weight || !grad_out || !g_weight || !workspace || d_out <= 0 || ld_g < d_out ||
+        (x && (d_in <= 0 || ld_x < d_in)) || (g_x && (!x || ld_gx < d_in)) || (out_relu && ld_relu < d_out))
+        return TIPK_EINVAL;
+    const int64_t n = g->n_nodes;
+    if (workspace_bytes < tipk_gcn_workspace_bytes(g, d_in, d_out) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
+    hipStream_t hs = (hipStream_t)stream;
+    char* wp = (char*)workspace;
+    float* gp_buf = (float*)wp;
+    float* gxl = (float*)(wp + align256(n * (int64_t)d_out * 4));
+    float* scratch = (float*)(wp + 2 * align256(n * (int64_t)d_out * 4));
+    int st;
+    const float* gp = grad_out;
+    int64_t ld_gp = ld_g;
+    if (out_relu) {
+        if ((st = gate_rows(grad_out, ld_g, out_relu, ld_relu, gp_buf, n, d_out, hs)) != TIPK_OK) return st;
+        gp = gp_buf; ld_gp = d_out;
+    }
+    if (g_bias && (st = tipk_col_sum(gp, ld_gp, n, d_out, scratch, g_bias, stream)) != TIPK_OK) return st;
+    // d (x W^T) = A_hat^T g'
+    float* gxl_out = gxl;
+    int64_t ld_gxl = d_out;
+    if (!x && gw_so == 1) { gxl_out = g_weight; ld_gxl = gw_si; }              // identity features: d W = (d lin)^T, written in place
+    GrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.table = gp; a.ld_t = ld_gp; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = n; a.edge_w = g->bwd_w; a.d = d_out;
+    a.out = gxl_out; a.ld_out = ld_gxl;
+    if ((st = gr_launch(a, hs)) != TIPK_OK) return st;
+    if (!x) return gw_so == 1 ? TIPK_OK : TIPK_EUNSUPPORTED;
+    // d W (o, i) = sum_v gxl[v, o] x[v, i];  d x = gxl W
+    tipk_gemm_desc d = gemm_desc(d_out, d_in, n, gxl, 1, d_out, x, ld_x, 1, g_weight, gw_so);
+    if (gw_si != 1) return TIPK_EUNSUPPORTED;
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    if (g_x) {
+        d = gemm_desc(n, d_in, d_out, gxl, d_out, 1, weight, w_so, w_si, g_x, ld_gx);
+        if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    }
+    return TIPK_OK;
+}
+
+// MyHierarchyConv (src/layers.py:196-247): mean over the incoming edges of the rows [n_source, n_all) of the concatenated
+// node space (edges that end below n_source are ignored, as `aggr_out[self.unique_source_num:]` drops them), then . weight
+extern "C" int tipk_hier_graph_build(const void* edge_index, int idx_bytes, int64_t n_edges, int64_t n_all, int64_t n_source,
+                                     tipk_graph** out) {
+    if (!out) return TIPK_EINVAL;
+    *out = nullptr;
+    if ((idx_bytes != 4 && idx_bytes != 8) || n_edges < 0 || n_all <= 0 || n_source < 0 || n_source >= n_all || (n_edges > 0 && !edge_index))
+        return TIPK_EINVAL;
+    if (n_edges >= 0x7fffffffLL) return TIPK_EUNSUPPORTED;
+    std::vector<int64_t> ei;
+    int st = fetch_index(edge_index, idx_bytes, 2 * n_edges, ei);
+    if (st != TIPK_OK) return st;
+    const int64_t n_t = n_all - n_source;
+    std::vector<int64_t> orow, trow;
+    std::vector<double> cnt((size_t)n_t, 0.0);
+    for (int64_t i = 0; i < n_edges; ++i) {
+        const int64_t s = ei[(size_t)i], d = ei[(size_t)(n_edges + i)];
+        if (s < 0 || s >= n_all || d < 0 || d >= n_all) return TIPK_EINVAL;
+        if (d >= n_source) { orow.push_back(d - n_source); trow.push_back(s); cnt[(size_t)(d - n_source)] += 1.0; }
+    }
+    std::vector<float> w(orow.size());
+    for (size_t i = 0; i < orow.size(); ++i) w[i] = 1.0f / (float)cnt[(size_t)orow[i]];      // 'mean': sum / count
+    tipk_graph* g = new (std::nothrow) tipk_graph;
+    if (!g) return TIPK_EINVAL;
+    memset(g, 0, sizeof(*g));
+    g->kind = 2; g->n_nodes = n_all; g->n_source = n_source;
+    st = build_weighted(g, orow, trow, w, n_t, n_all);
+    if (st != TIPK_OK) { tipk_graph_destroy(g); return st; }
+    *out = g;
+    return TIPK_OK;
+}
+
+extern "C" int64_t tipk_hier_workspace_bytes(const tipk_graph* g, int d_in, int d_out) {
+    if (!g || g->kind != 2 || d_in <= 0 || d_out <= 0) return -1;
+    return 2 * align256(g->n_out * (int64_t)d_in * 4);
+}
+
+// out [n_target x d_out] = mean(x over incoming edges) . weight;  x [n_all x d_in], weight [d_in x d_out] contiguous
+extern "C" int tipk_hier_fwd(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* weight, int d_out, float* out,
+                             int64_t ld_out, void* workspace, int64_t workspace_bytes, tipk_stream_t stream) {
+    if (!g || g->kind != 2 || !x || !weight || !out || !workspace || d_in <= 0 || d_out <= 0 || ld_x < d_in || ld_out < d_out) return TIPK_EINVAL;
+    if (workspace_bytes < tipk_hier_workspace_bytes(g, d_in, d_out) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
+    float* mean = (float*)workspace;
+    GrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.table = x; a.ld_t = ld_x; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = g->n_out; a.edge_w = g->fwd_w; a.d = d_in;
+    a.out = mean; a.ld_out = d_in;
+    int st = gr_launch(a, (hipStream_t)stream);
+    if (st != TIPK_OK) return st;
+    tipk_gemm_desc d = gemm_desc(g->n_out, d_out, d_in, mean, d_in, 1, weight, d_out, 1, out, ld_out);
+    return tipk_gemm_f32(&d, stream);
+}
+
+extern "C" int tipk_hier_bwd(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* weight, int d_out,
+                             const float* grad_out, int64_t ld_g, float* g_x, int64_t ld_gx, float* g_weight, void* workspace,
+                             int64_t workspace_bytes, tipk_stream_t stream) {
+    if (!g || g->kind != 2 || !x || !weight || !grad_out || !g_weight || !workspace || d_in <= 0 || d_out <= 0 || ld_x < d_in ||
+        ld_g < d_out || (g_x && ld_gx < d_in))
+        return TIPK_EINVAL;
+    if (workspace_bytes < tipk_hier_workspace_bytes(g, d_in, d_out) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
+    hipStream_t hs = (hipStream_t)stream;
+    float* mean = (float*)workspace;
+    float* g_mean = (float*)((char*)workspace + align256(g->n_out * (int64_t)d_in * 4));
+    GrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.table = x; a.ld_t = ld_x; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = g->n_out; a.edge_w = g->fwd_w; a.d = d_in;
+    a.out = mean; a.ld_out = d_in;
+    int st = gr_launch(a, hs);                                                 // the mean again (nothing is kept between the calls)
+    if (st != TIPK_OK) return st;
+    tipk_gemm_desc d = gemm_desc(d_in, d_out, g->n_out, mean, 1, d_in, grad_out, ld_g, 1, g_weight, d_out);     // mean^T g
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    if (!g_x) return TIPK_OK;
+    d = gemm_desc(g->n_out, d_in, d_out, grad_out, ld_g, 1, weight, 1, d_out, g_mean, d_in);                     // g W^T
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    memset(&a, 0, sizeof(a));
+    a.table = g_mean; a.ld_t = d_in; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = g->n_table; a.edge_w = g->bwd_w; a.d = d_in;
+    a.out = g_x; a.ld_out = ld_gx;
+    return gr_launch(a, hs);                                                   // rows nobody reads from: zeros
 }
