@@ -52,6 +52,10 @@ def load_library():
     lib.tipk_hier_fwd.argtypes = [P, P, L, I, P, I, P, L, P, L, P]
     lib.tipk_hier_bwd.restype = I
     lib.tipk_hier_bwd.argtypes = [P, P, L, I, P, I, P, L, P, L, P, P, L, P]
+    lib.tipk_rows_affine.restype = I
+    lib.tipk_rows_affine.argtypes = [P, L, P, P, P, L, P, L, L, L, I, P]
+    lib.tipk_distmult_loss.restype = I
+    lib.tipk_distmult_loss.argtypes = [P, L, I, P, L, P, P, P, P, I, P, I, L, P, L, P, P, P, P, P]
     return lib
 
 
@@ -236,16 +240,85 @@ def run_hier(lib, path, dev):
     return worst
 
 
+def run_tip_step(lib, path, dev):
+    """The WHOLE training step of TIP (mod = 'add'; src/layers.py:328-342 on top of :520-550) through the op-level C ABI alone:
+    P-P GCN x 2 -> P -> D mean . W -> embed / d_norm + . -> R-GCN (ReLU) -> R-GCN -> DistMult objective, and every gradient
+    back, against the reference's own loss and autograd gradients on the negatives its sampler drew (`tip_add_small`)."""
+    g = load(path)
+    f = lambda k: g[k].to(dev).contiguous()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n_d, n_p, R = int(g['n_drug']), int(g['n_prot']), int(g['n_dd_et'])
+    E = g['dd_train_idx'].shape[1]
+    zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    empty = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    handle = lambda: C.c_void_p()
+    # graphs: once
+    gp, gh, gd = handle(), handle(), handle()
+    pp, dp, dd, rg = f('pp_train_indices'), f('dp_edge_index'), f('dd_train_idx'), f('dd_train_range')
+    ok(lib, lib.tipk_gcn_graph_build(ptr(pp), 8, pp.shape[1], n_p, C.byref(gp)), 'gcn graph')
+    ok(lib, lib.tipk_hier_graph_build(ptr(dp), 8, dp.shape[1], n_p + n_d, n_p, C.byref(gh)), 'hier graph')
+    ok(lib, lib.tipk_graph_build(ptr(dd), None, ptr(rg), 8, E, n_d, R, None, C.byref(gd)), 'dd graph')
+    w1t = g['encoder.pp_encoder.conv1.lin.weight'].t().contiguous().to(dev)       # [in, out] memory: lin(I) = W^T in place
+    b1, w2, b2 = f('encoder.pp_encoder.conv1.bias'), f('encoder.pp_encoder.conv2.lin.weight'), f('encoder.pp_encoder.conv2.bias')
+    wh, embed, d_norm = f('encoder.hgcn.weight'), f('encoder.embed'), f('d_norm')
+    l1 = Layer(lib, gd, g['encoder.rgcn1.basis'], g['encoder.rgcn1.att'], g['encoder.rgcn1.root'], dev)
+    l2 = Layer(lib, gd, g['encoder.rgcn2.basis'], g['encoder.rgcn2.att'], g['encoder.rgcn2.root'], dev)
+    wdec = f('decoder.weight')
+    d1, d2, dh = w1t.shape[1], w2.shape[0], wh.shape[1]
+    ws = torch.empty(max(lib.tipk_gcn_workspace_bytes(gp, n_p, d1), lib.tipk_gcn_workspace_bytes(gp, d1, d2),
+                         lib.tipk_hier_workspace_bytes(gh, d2, dh)), dtype=torch.uint8, device=dev)
+    # ---- forward
+    h1, h2all = empty(n_p, d1), zeros(n_p + n_d, d2)                          # (the drug rows of the concatenation stay zero: :526)
+    ok(lib, lib.tipk_gcn_fwd(gp, None, 0, n_p, ptr(w1t), 1, d1, ptr(b1), d1, 1, ptr(h1), d1, ptr(ws), ws.numel(), st), 'conv1')
+    ok(lib, lib.tipk_gcn_fwd(gp, ptr(h1), d1, d1, ptr(w2), d1, 1, ptr(b2), d2, 0, ptr(h2all), d2, ptr(ws), ws.numel(), st), 'conv2')
+    pd = empty(n_d, dh)
+    ok(lib, lib.tipk_hier_fwd(gh, ptr(h2all), d2, d2, ptr(wh), dh, ptr(pd), dh, ptr(ws), ws.numel(), st), 'hier')
+    x0 = empty(n_d, dh)
+    ok(lib, lib.tipk_rows_affine(ptr(embed), dh, None, ptr(d_norm), None, 0, ptr(x0), dh, n_d, dh, 0, st), 'embed / d_norm')
+    ok(lib, lib.tipk_rows_affine(ptr(pd), dh, None, None, None, 0, ptr(x0), dh, n_d, dh, 1, st), '+ pd')
+    x1 = l1.forward(x0, relu=True)
+    z = l2.forward(x1)
+    loss, g_z, g_wdec = zeros(1), zeros(*z.shape), zeros(*wdec.shape)
+    neg, et = f('train_neg'), f('dd_train_et')
+    ok(lib, lib.tipk_distmult_loss(ptr(z), n_d, z.shape[1], ptr(wdec), R, ptr(dd[0]), ptr(dd[1]), ptr(neg[0]), ptr(neg[1]), 8, ptr(et), 8, E,
+                                   None, 0, ptr(loss), ptr(g_z), ptr(g_wdec), None, st), 'objective')
+    # ---- backward
+    g_x1, gb2_, ga2_, gr2_ = l2.backward(g_z)
+    g_x0, gb1_, ga1_, gr1_ = l1.backward(g_x1)
+    g_embed = empty(n_d, dh)
+    ok(lib, lib.tipk_rows_affine(ptr(g_x0), dh, None, ptr(d_norm), None, 0, ptr(g_embed), dh, n_d, dh, 0, st), 'd embed')
+    g_h2all, g_wh = empty(n_p + n_d, d2), empty(*wh.shape)
+    ok(lib, lib.tipk_hier_bwd(gh, ptr(h2all), d2, d2, ptr(wh), dh, ptr(g_x0), dh, ptr(g_h2all), d2, ptr(g_wh), ptr(ws), ws.numel(), st), 'hier bwd')
+    g_h1, g_w2, g_b2 = empty(n_p, d1), empty(d2, d1), empty(d2)
+    ok(lib, lib.tipk_gcn_bwd(gp, ptr(h1), d1, d1, ptr(w2), d1, 1, d2, ptr(g_h2all), d2, None, 0, ptr(g_h1), d1, ptr(g_w2), d1, 1, ptr(g_b2),
+                             ptr(ws), ws.numel(), st), 'conv2 bwd')
+    g_w1t, g_b1 = torch.empty_like(w1t), empty(d1)
+    ok(lib, lib.tipk_gcn_bwd(gp, None, 0, n_p, ptr(w1t), 1, d1, d1, ptr(g_h1), d1, ptr(h1), d1, None, 0, ptr(g_w1t), 1, d1, ptr(g_b1),
+                             ptr(ws), ws.numel(), st), 'conv1 bwd')
+    torch.cuda.synchronize()
+    worst = check('tip step loss', loss, g['loss'].reshape(1), 2e-5, 1.0)
+    worst = max(worst, check('tip step embeddings', z, g['embeddings'], 2e-5, 1.0))
+    got = {'encoder.embed': g_embed, 'encoder.pp_encoder.conv1.lin.weight': g_w1t.t(), 'encoder.pp_encoder.conv1.bias': g_b1,
+           'encoder.pp_encoder.conv2.lin.weight': g_w2, 'encoder.pp_encoder.conv2.bias': g_b2, 'encoder.hgcn.weight': g_wh,
+           'encoder.rgcn1.basis': gb1_, 'encoder.rgcn1.att': ga1_, 'encoder.rgcn1.root': gr1_, 'encoder.rgcn2.basis': gb2_,
+           'encoder.rgcn2.att': ga2_, 'encoder.rgcn2.root': gr2_, 'decoder.weight': g_wdec}
+    for k, v in got.items():
+        worst = max(worst, check('tip step grad.' + k, v, g['grad.' + k], 1e-4, 1.0))
+    for h in (gp, gh, gd):
+        ok(lib, lib.tipk_graph_destroy(h), 'tipk_graph_destroy')
+    return worst
+
+
 def main():
     dev = torch.device('cuda:0')
     lib = load_library()
     golden = os.path.join(ROOT, 'tests', 'golden')
     paths = sys.argv[1:] or [os.path.join(golden, f) for f in ('rgcn_sym.npz', 'rgcn_directed.npz', 'rgcn_fast_sym.npz', 'rgcn_fast_directed.npz',
-                                                                 'pp_encoder.npz', 'pp_encoder_dense.npz', 'hier_conv.npz')]
+                                                                 'pp_encoder.npz', 'pp_encoder_dense.npz', 'hier_conv.npz', 'tip_add_small.npz')]
     for path in paths:
         base = os.path.basename(path)
         fn = run_pp_encoder if base.startswith('pp_encoder') else run_hier if base.startswith('hier') else \
-            run_two_layers if 'fast' in base else run_single
+            run_tip_step if base.startswith('tip_') else run_two_layers if 'fast' in base else run_single
         print('%-26s max error %.2e of max|want|' % (base, fn(lib, path, dev)))
     # malformed input: an id out of range is refused, as the reference raises IndexError
     bad = torch.tensor([[0, 1], [1, 99]], device=dev)
