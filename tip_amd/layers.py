@@ -19,7 +19,7 @@ import torch
 from torch import nn
 from torch.nn import Parameter as Param
 
-from . import encoder, ops
+from . import encoder, ops, switches
 from .data import Data, build_data_dict
 from .neg_sampling import typed_negative_sampling
 from .plan import (build_pair_bwd_plan, build_dest_plan, build_row_stream_plan, build_row_stream_plan_s, build_gather_plan, build_gather_plan_segmented, build_rel_plan, build_stream_plan, build_stream_plan_rows, build_csr_plan, group_slots_for,
@@ -644,7 +644,7 @@ class FMEncoder(nn.Module):
         """(xd, encoder.EncoderPlans) if this call can run as ONE autograd node with its own launch schedule
         (tip_amd/encoder.py: identity protein features, pruned conv2, pair-form D-D graph on both layers, no relation
         sharding), else None.  The graphs are the layers' own cached plans: both routes build and share the same ones."""
-        if os.environ.get('TIPK_NO_ENCODER_STEP') or not self.prune_pp_rows or not _is_identity_features(x_prot):
+        if switches.on('TIPK_NO_ENCODER_STEP') or not self.prune_pp_rows or not _is_identity_features(x_prot):
             return None
         r1, r2 = self.rgcn1, self.rgcn2
         if r1.shard is not None or r2.shard is not None or r1.bias is not None or r2.bias is not None:

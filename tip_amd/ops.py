@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, switches
 from ._lib import SlabSumDesc, GemmDesc, WgGemmDesc, check, lib, ptr, stream_ptr, require_device
 
 def _f32c(t):
@@ -168,7 +168,7 @@ def sum_slabs(slabs, out=None, alpha=1.0, accumulate=False, row_scale=None, adde
 
 def rel_gather_split(n_nodes, d, backward):
     """column blocks `tipk_rel_gather` would use for this shape; 0 = use the generic gather_sum."""
-    if os.environ.get('TIPK_NO_RELLOCAL'):
+    if switches.on('TIPK_NO_RELLOCAL'):
         return 0
     return int(lib().tipk_rel_gather_supported(n_nodes, d, int(backward)))
 
@@ -216,7 +216,7 @@ def rel_gather(rp, table, backward, row_scale=None, reduce=True):
 def stream_gather_split(n_table, d, max_split=4):
     """column blocks `tipk_stream_gather` would use for a table [n_table, d]; 0 = it does not fit in LDS.
     max_split: 4 on the D-D passes, 16 for the P-P graph (2-column blocks of 8-byte rows)."""
-    if os.environ.get('TIPK_NO_RELLOCAL'):                 # (test hook: the generic fabric-gather route on a small graph)
+    if switches.on('TIPK_NO_RELLOCAL'):                 # (test hook: the generic fabric-gather route on a small graph)
         return 0
     return int(lib().tipk_stream_gather_supported(n_table, d, max_split))
 
@@ -232,7 +232,7 @@ def dy_products_fused(r, nc, nb):
     """True when `dy_products` takes the fused one-pass kernel for this shape (it alone honours `row_used`)."""
     import ctypes as C
     s_c, s_r = C.c_int(0), C.c_int(0)
-    if os.environ.get('TIPK_NO_DY_FUSED'):
+    if switches.on('TIPK_NO_DY_FUSED'):
         return False
     check(lib().tipk_rgcn_dy_products_plan(r, nc, nb, C.byref(s_c), C.byref(s_r)), 'tipk_rgcn_dy_products_plan')
     return s_c.value != 0
@@ -280,7 +280,7 @@ def stream_gather_two(sp, table0, table1, out0, out1, label='pair_cells2[dd.fwd]
 def pair_cells_partner_ok(graph, att, graph2, att2, n):
     """True when the pair cells of a second layer (graph2, att2) can be gathered in the launch that gathers (graph, att)'s:
     the same plan shape (the layers share the D-D graph), att tables of one shape, one column block."""
-    if os.environ.get('TIPK_NO_CELLS_TWO'):
+    if switches.on('TIPK_NO_CELLS_TWO'):
         return False
     p1, p2 = graph.pair_fwd, graph2.pair_fwd
     if p1 is None or p2 is None or att.shape != att2.shape or att.stride() != att2.stride():
@@ -453,7 +453,7 @@ def dy_products(g_y, att, xb2, row_used=None, n_nodes=0):
     r, nc = g_y.shape
     nb = att.shape[1]
     s_c, s_r = C.c_int(0), C.c_int(0)
-    if not os.environ.get('TIPK_NO_DY_FUSED') and g_y.stride(1) == 1 and att.stride(1) == 1 and xb2.stride(1) == 1:
+    if not switches.on('TIPK_NO_DY_FUSED') and g_y.stride(1) == 1 and att.stride(1) == 1 and xb2.stride(1) == 1:
         check(lib().tipk_rgcn_dy_products_plan(r, nc, nb, C.byref(s_c), C.byref(s_r)), 'tipk_rgcn_dy_products_plan')
     if s_c.value == 0:
         assert row_used is None, 'the two-GEMM path reads every row of dY'
@@ -509,7 +509,7 @@ def node_products(dyc, cr, att, xb, xbt=None):
 
 def dest_products_bits(n_nodes, n_rel, nb, d_in):
     """bits of the relation field of a destination-major edge word (`tipk_rgcn_dest_products`); 0 = shape not supported."""
-    if os.environ.get('TIPK_NO_DEST_FWD'):
+    if switches.on('TIPK_NO_DEST_FWD'):
         return 0
     return int(lib().tipk_rgcn_dest_products_supported(int(n_nodes), int(n_rel), int(nb), int(d_in)))
 
@@ -531,13 +531,13 @@ def dest_products(dp, x, att):
 
 
 def row_products_supported(n_nodes, n_rel, nb, channels):
-    if os.environ.get('TIPK_NO_ROW_PRODUCTS'):
+    if switches.on('TIPK_NO_ROW_PRODUCTS'):
         return False
     return bool(lib().tipk_rgcn_row_products_supported(int(n_nodes), int(n_rel), int(nb), int(channels)))
 
 
 def row_products_s_supported(n_nodes, n_rel, nb, channels):
-    if os.environ.get('TIPK_NO_ROW_PRODUCTS_S'):
+    if switches.on('TIPK_NO_ROW_PRODUCTS_S'):
         return False
     return bool(lib().tipk_rgcn_row_products_s_supported(int(n_nodes), int(n_rel), int(nb), int(channels)))
 
@@ -631,7 +631,7 @@ def sum_slabs_xb(slabs, row_scale, addend, relu, x_out, basis, root, xb_pad):
 
 
 def sum_slabs_xb_supported(d_in, d_out):
-    return d_in == 32 and 1 <= d_out <= 32 and not os.environ.get('TIPK_NO_LAYER_HANDOVER')
+    return d_in == 32 and 1 <= d_out <= 32 and not switches.on('TIPK_NO_LAYER_HANDOVER')
 
 
 def _finish_pending(x, pend):
@@ -641,7 +641,7 @@ def _finish_pending(x, pend):
 
 
 def pair_grads_supported(nb, d):
-    return bool(lib().tipk_rgcn_pair_grads_supported(int(nb), int(d))) and not os.environ.get('TIPK_NO_PAIR_BWD')
+    return bool(lib().tipk_rgcn_pair_grads_supported(int(nb), int(d))) and not switches.on('TIPK_NO_PAIR_BWD')
 
 
 def pair_grads(pb, cells, xb_pad, g, table=0):
@@ -991,7 +991,7 @@ def relation_tasks(edge_type, pos_index=None):
             start = torch.cumsum(counts, 0) - counts
             dev = rels.device
             mirrored = False
-            if pos_index is not None and not os.environ.get('TIPK_NO_SYMMETRIC_POS') and bool((counts % 2 == 0).all()):
+            if pos_index is not None and not switches.on('TIPK_NO_SYMMETRIC_POS') and bool((counts % 2 == 0).all()):
                 half = counts // 2
                 pos = torch.arange(edge_type.numel(), device=dev)
                 run_of = torch.repeat_interleave(torch.arange(rels.numel(), device=dev), counts)
@@ -1101,7 +1101,7 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     et = edge_type.contiguous()
     if packed:
         tasks = relation_tasks(et, pos_index)
-        if (tasks is None or z.shape[1] not in (4, 8, 16) or os.environ.get('TIPK_FLOAT_ATOMICS') or z.shape[0] > 65535
+        if (tasks is None or z.shape[1] not in (4, 8, 16) or switches.on('TIPK_FLOAT_ATOMICS') or z.shape[0] > 65535
                 or neg_index.numel() != pos_index.shape[1]):
             neg_index, packed = unpack_pairs(neg_index).type_as(pos_index), False      # the general kernels take plain ids
     if packed and not getattr(neg_index, '_tipk_sampled', False):      # a packed tensor that is not the sampler's own output
@@ -1126,7 +1126,7 @@ def distmult_loss(z, weight, pos_index, neg_index, edge_type, need_grad=True):
     nu, nv = _uv(neg_index)
     assert pu.dtype == nu.dtype and pu.numel() == nu.numel()
     tasks = relation_tasks(et, pos_index)
-    ws = None if (tasks is None or os.environ.get('TIPK_FLOAT_ATOMICS')) else \
+    ws = None if (tasks is None or switches.on('TIPK_FLOAT_ATOMICS')) else \
         _det_workspace(z.device, z.shape[0], z.shape[1], weight.shape[0])
     if ws is not None:                                     # deterministic path: its finalize launch overwrites the outputs
         loss = torch.empty((1,), dtype=torch.float32, device=z.device)
@@ -1159,7 +1159,7 @@ def typed_negative_sampling_device(pos_key_sorted, rel_ptr, n_rel, n_nodes, seed
     require_device(pos_key_sorted, rel_ptr, call_counter)
     dev = pos_key_sorted.device
     st = stream_ptr(dev)
-    wg_ptr, wg_units = wg if (wg is not None and not os.environ.get('TIPK_NO_BITMAP')) else (None, None)
+    wg_ptr, wg_units = wg if (wg is not None and not switches.on('TIPK_NO_BITMAP')) else (None, None)
     # a stream state with a ticket word {position, seed, ticket}: the sampling launch moves the position on itself
     adv = 1 if (call_counter is not None and call_counter.numel() >= 3 and n_positions > 0 and n_rel > 0) else 0
     if packed:                                     # one 32-bit word u | v << 16 per position (same draws, same pairs)
@@ -1202,7 +1202,7 @@ def pair_product(cells, xb_nb, symmetric=False, links=None, zeros=None, xbt=None
     assert xbt is None or (tuple(xbt.shape) == (n, d, nb) and xbt.is_contiguous() and xbt.dtype == torch.float32)
     assert cells.is_contiguous() and xb_nb.shape[:2] == (n_pad, nb) and n_pad % PAIR_KGROUP == 0
     padded = xb_nb.stride() == (nb * 32, 32, 1) and d <= 32
-    if (not lib().tipk_pair_product_supported(nb, d) or os.environ.get('TIPK_NO_PAIR_PRODUCT') or not padded) and not symmetric:
+    if (not lib().tipk_pair_product_supported(nb, d) or switches.on('TIPK_NO_PAIR_PRODUCT') or not padded) and not symmetric:
         job = gemm_job(cells, xb_nb, reduce_batch=True, kgroup=PAIR_KGROUP)      # same sums on the tiled GEMM
         with _timed('gemm[%s]' % job.label):
             check(lib().tipk_gemm_f32(job.desc, stream_ptr(cells.device)), 'tipk_gemm_f32')
