@@ -130,9 +130,7 @@ def _cached_keys(pos_edge_index, num_nodes, range_list, range_ident=None):
         dev = pos_edge_index.device
         n_wg = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
         n_wg *= max(1, int(ops.lib().tipk_negsample_wgs_per_cu(int(num_nodes))))       # (two 512-thread workgroups per CU where two bitmaps fit)
-        import os
-        wg_ptr, wg_units = sampler_units(rel_ptr, n_wg, build_cost=float(os.environ.get('TIPK_SAMPLER_BUILD_COST', 0.15)),
-                                         fixed_cost=int(os.environ.get('TIPK_SAMPLER_FIXED_COST', 2048)))
+        wg_ptr, wg_units = sampler_units(rel_ptr, n_wg)     # (cost-model constants swept in round 6: 0.15 ... 2.0 -> 52.4 ... 53.6 us)
         # the same keys as 32-bit words (n^2 < 2^31): what the bitmap route sets its bits from -- half the bytes per step
         keys32 = keys.to(torch.int32).contiguous() if int(num_nodes) ** 2 < 2 ** 31 and dev.type == 'cuda' else None
         hit = (keys, rel_ptr.to(dev), rel_ptr.numel() - 1, (wg_ptr.to(dev), wg_units.to(dev)), (pos_edge_index, keys32))
