@@ -856,3 +856,32 @@ def test_row_plan_support_is_asked_before_the_lazy_plan_is_built():
     built = []
     ok = ops.AggGraph(None, None, row_fwd=lambda: built.append('f') or 'F', row_bwd=lambda: built.append('b') or 'B', row_wave_uniform=True)
     assert ops._row_plan(ok, False, 70000, 100, 32, 128) == 'F' and ops._row_plan(ok, True, 70000, 100, 32, 64) == 'B' and built == ['f', 'b']
+
+
+def test_pd_stage_row_deal_and_forward_workgroup_descs():
+    """Round 6 plans of the fused P -> D launches (tip_amd/layers.py): source rows dealt to workgroups by EDGES (a cluster of hub
+    rows must not land in one workgroup), and the forward launch's rows dealt by edge count with W wavefronts per row."""
+    from tip_amd.layers import deal_rows_by_edges, drug_workgroups
+    g = torch.Generator().manual_seed(3)
+    counts = torch.randint(0, 9, (500,), generator=g).tolist()
+    counts[200:240] = [90] * 40                                        # a cluster of hubs, as in BioSNAP's P -> D graph
+    counts[300] = 2000                                                  # one row beyond the edge limit: alone
+    b = deal_rows_by_edges(counts, 64, 512)
+    assert b[0] == 0 and b[-1] == 500 and all(x < y for x, y in zip(b, b[1:]))
+    for lo, hi in zip(b, b[1:]):
+        e = sum(counts[lo:hi])
+        assert hi - lo <= 64 and (e <= 512 or hi - lo == 1), (lo, hi, e)
+    assert max(sum(counts[lo:hi]) for lo, hi in zip(b, b[1:]) if hi - lo > 1) <= 512
+    assert deal_rows_by_edges([], 64, 512) == [0, 0] and deal_rows_by_edges([5], 64, 512) == [0, 1]
+    cnt = torch.tensor([3, 700, 0, 65, 512, 64, 1, 100, 99, 98, 97] + [2] * 40)
+    order, descs = drug_workgroups(cnt)
+    seen = []
+    for first, packed in descs:
+        n, w = packed & 255, packed >> 8
+        rows = order[first:first + n].tolist()
+        seen += rows
+        assert n >= 1 and n * w <= 16 and w in (1, 4, 16)
+        for r in rows:
+            c = int(cnt[r])
+            assert (w == 16) == (c > 512) and (w == 4) == (64 < c <= 512)
+    assert sorted(seen) == list(range(cnt.numel()))

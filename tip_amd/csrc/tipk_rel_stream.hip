@@ -266,12 +266,13 @@ __global__ __launch_bounds__(1024) void stream_gather_kernel(RsArgs a) {
         walk(b + 3, c3q, i3q, c1q, i1q);
     }
 #ifdef TIPK_DEBUG
-    if (lane == 0 && blockIdx.y == 0 && gw < 4096) {
+    const int gws = gw + (int)blockIdx.y * (int)gridDim.x * 16;         // (column blocks / the second table behind the first)
+    if (lane == 0 && gws < 4096) {
         const unsigned long long now = __builtin_readcyclecounter();
-        tipk_rs_stamps[gw * 4 + 0] = now - st0;
-        tipk_rs_stamps[gw * 4 + 1] = st1 - st0;
-        tipk_rs_stamps[gw * 4 + 2] = now - st1;
-        tipk_rs_stamps[gw * 4 + 3] = (unsigned long long)(b1 - b_first);
+        tipk_rs_stamps[gws * 4 + 0] = now - st0;
+        tipk_rs_stamps[gws * 4 + 1] = st1 - st0;
+        tipk_rs_stamps[gws * 4 + 2] = now - st1;
+        tipk_rs_stamps[gws * 4 + 3] = (unsigned long long)(b1 - b_first) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4 /* HW_ID: cu/se */) << 32);
     }
 #endif
     // rows (relation, node) without edges

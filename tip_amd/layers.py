@@ -253,14 +253,7 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
     # workgroups of the forward launch (16 wavefronts): targets dealt by edge count -- one with more than 512 edges has a
     # workgroup to itself (W = 16 wavefronts on it: one BioSNAP drug has 2 834 protein targets), those with 65 ... 512 edges go
     # four to a workgroup (W = 4), the others sixteen (a wavefront each); desc = {first index into `order`, n | W << 8}
-    cnt_t = torch.bincount(dst, minlength=n_t)
-    order = torch.sort(cnt_t, descending=True, stable=True).indices
-    cs = cnt_t[order].tolist()
-    n_big = sum(1 for c_ in cs if c_ > 512)
-    n_mid = sum(1 for c_ in cs if 64 < c_ <= 512)
-    wgs = [[i, 1 | (16 << 8)] for i in range(n_big)]
-    wgs += [[b0, min(4, n_big + n_mid - b0) | (4 << 8)] for b0 in range(n_big, n_big + n_mid, 4)]
-    wgs += [[b0, min(16, n_t - b0) | (1 << 8)] for b0 in range(n_big + n_mid, n_t, 16)]
+    order, wgs = drug_workgroups(torch.bincount(dst, minlength=n_t))
     fwd_wg = torch.tensor(wgs, dtype=torch.int32, device=src.device).view(-1, 2).contiguous()
     graph.pd_csr = dict(fwd_ptr=ptr(dst, n_t), fwd_src=i32(src[of]), scale=scale, fwd_wg=fwd_wg, fwd_order=i32(order), n_src=int(n_tab))
     # CSR by SOURCE row (edge order kept inside a row) with 1 / count of the edge's target: the transposed gather inside the
@@ -273,17 +266,40 @@ def hier_graph(edge_index, n_all, n_source, chunk=DEFAULT_CHUNK, table_rows=None
         import ctypes
         mr, me = ctypes.c_int(0), ctypes.c_int(0)
         ops.lib().tipk_pd_stage_bwd_limits(ctypes.byref(mr), ctypes.byref(me))
-        cnt_s = torch.bincount(src, minlength=n_tab).tolist()
-        bounds, rows_in, edges_in = [0], 0, 0
-        for r_, c_ in enumerate(cnt_s):
-            if rows_in and (rows_in == mr.value or edges_in + c_ > me.value):
-                bounds.append(r_)
-                rows_in, edges_in = 0, 0
-            rows_in += 1
-            edges_in += c_
-        bounds.append(int(n_tab))
+        bounds = deal_rows_by_edges(torch.bincount(src, minlength=n_tab).tolist(), mr.value, me.value)
         graph.pd_csr['t_wg'] = torch.tensor(bounds, dtype=torch.int32, device=src.device)
     return graph
+
+
+def deal_rows_by_edges(counts, max_rows, max_edges):
+    """Boundaries [0, ..., len(counts)] of consecutive row blocks with at most max_rows rows and -- unless a single row alone has
+    more -- at most max_edges edges each (the row workgroups of tipk_pd_stage_bwd).  BioSNAP's P -> D graph has ~100 consecutive
+    proteins that 65 ... 94 drugs target: blocks of 64 ROWS gave three workgroups 2 200 ... 3 300 edges against a mean of 326."""
+    bounds, rows_in, edges_in = [0], 0, 0
+    for r_, c_ in enumerate(counts):
+        if rows_in and (rows_in == max_rows or edges_in + c_ > max_edges):
+            bounds.append(r_)
+            rows_in, edges_in = 0, 0
+        rows_in += 1
+        edges_in += c_
+    bounds.append(len(counts))
+    return bounds
+
+
+def drug_workgroups(counts):
+    """(order, descs) of the forward P -> D launch: rows by decreasing edge count; desc = [first index into order, n | W << 8] --
+    a row with more than 512 edges alone on the 16 wavefronts of a workgroup (W = 16), rows with 65 ... 512 edges four to a
+    workgroup (W = 4), the others sixteen (W = 1).  Every row exactly once."""
+    cnt_t = torch.as_tensor(counts)
+    n_t = int(cnt_t.numel())
+    order = torch.sort(cnt_t, descending=True, stable=True).indices
+    cs = cnt_t[order].tolist()
+    n_big = sum(1 for c_ in cs if c_ > 512)
+    n_mid = sum(1 for c_ in cs if 64 < c_ <= 512)
+    wgs = [[i, 1 | (16 << 8)] for i in range(n_big)]
+    wgs += [[b0, min(4, n_big + n_mid - b0) | (4 << 8)] for b0 in range(n_big, n_big + n_mid, 4)]
+    wgs += [[b0, min(16, n_t - b0) | (1 << 8)] for b0 in range(n_big + n_mid, n_t, 16)]
+    return order, wgs
 
 
 class MyHierarchyConv(nn.Module):
