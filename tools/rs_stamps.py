@@ -41,3 +41,6 @@ for rec in bench.dd_launches(enc, dev):
           % (wb.sum(1).mean(), wb.sum(1).min(), wb.sum(1).max(), np.corrcoef(wb.sum(1), wl.mean(1))[0, 1]))
     q = np.quantile(loop, [0.1, 0.5, 0.9, 0.99])
     print('   band loop quantiles 10/50/90/99 %%: %s' % ' '.join('%.0f' % v for v in q))
+    by_wave = wl.mean(0)
+    print('   band loop by wave index in the workgroup: ' + ' '.join('%.0f' % v for v in by_wave))
+    print('   bands by wave index:                      ' + ' '.join('%.1f' % v for v in wb.mean(0)))
