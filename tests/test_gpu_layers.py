@@ -605,9 +605,12 @@ def _shard_worker(rank, world, port, ret, max_relations=12):
                 want = want_step['grads'][k]
                 if k in LOCAL_ROWS:
                     want = want[shard.rel_ids.cpu()]
-                good = torch.allclose(p.grad.cpu(), want, rtol=1e-4, atol=2e-5 * max(1e-6, float(want.abs().max())))
+                if want.numel() == 0:                                  # (a rank without relations: its att / decoder rows are empty)
+                    good = p.grad is None or p.grad.numel() == 0
+                else:
+                    good = torch.allclose(p.grad.cpu(), want, rtol=1e-4, atol=2e-5 * max(1e-6, float(want.abs().max())))
                 if not good:
-                    print('rank', rank, 'step', step, 'grad mismatch', k, float((p.grad.cpu() - want).abs().max()), flush=True)
+                    print('rank', rank, 'step', step, 'grad mismatch', k, flush=True)
                 ok = ok and good
             opt_s.step()
             stamp('sharded step %d' % step)
