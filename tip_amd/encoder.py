@@ -271,5 +271,55 @@ class _EncoderStep(torch.autograd.Function):
                 g_basis1, j_att1.out, g_root1, g_basis2, j_att2.out, g_root2, None)
 
 
+class _PDStage(torch.autograd.Function):
+    """x0 = mix(xd / d_norm, mean_targets(conv2(h1)) W_h) as ONE autograd node (conv2 aggregate-first on the kept rows + the P -> D
+    stage): the part of the encoder step that a relation-SHARDED run repeats on every rank -- there the R-GCN layers stay on
+    their own nodes (`ops._RGCN` with the shard's collectives), but this stage can use the fused launches of `_EncoderStep`:
+    forward `tipk_gather_sum_lin` + `tipk_drug_mix_gather_fwd`, backward `tipk_pd_stage_bwd` + conv2's transposed gather with
+    conv1's ReLU gate and bias partials in its epilogue (3 + 2 launches where the per-layer nodes take 3 + 4).  The returned
+    gradient of h1 is already masked with (h1 > 0); the partial rows of conv1's bias gradient go to `link.parts`."""
+
+    @staticmethod
+    def forward(ctx, h1, w2, b2, xd, w_h, d_norm, pp_rows, pd, cat, link):
+        h1, xd, w_h = ops._f32c(h1), ops._f32c(xd), ops._f32c(w_h).contiguous()
+        agg2, h_prot = ops.gather_sum_lin(pp_rows.fwd, h1, w2, b2, False, row_scale=pp_rows.scale)
+        x0, mean, w_h = ops.drug_mix_gather_launch(xd, h_prot, w_h, d_norm, cat, pd)
+        ctx.pp_rows, ctx.pd, ctx.cat, ctx.link, ctx.ne = pp_rows, pd, cat, link, xd.shape[1]
+        ctx.save_for_backward(h1, w2, w_h, d_norm, agg2, mean)
+        return x0
+
+    @staticmethod
+    def backward(ctx, g):
+        h1, w2, w_h, d_norm, agg2, mean = ctx.saved_tensors
+        pd = ctx.pd
+        g = ops._f32c(g)
+        g_xd, j_wh, gw, j_w2, j_b2 = pd_stage_bwd(g, d_norm, mean, w_h, ctx.ne, ctx.cat, pd, agg2, w2, ctx.pp_rows.scale,
+                                                 want_xd=ctx.needs_input_grad[3])
+        want = ctx.link is not None
+        res = ops.gather_sum(ctx.pp_rows.bwd, gw, riders=[j_w2, j_b2, j_wh], gate=h1, colsum=want)
+        g_h1 = res[0] if want else res
+        if want:
+            ctx.link.parts = res[1]
+        return g_h1, j_w2.out.t(), j_b2.out.view(-1), g_xd, j_wh.out, None, None, None, None, None
+
+
+def pd_stage_usable(pp_rows, pd, xd, w_h, d_norm, w2, b2):
+    """True if `pd_stage` takes this call (the same support queries as `usable`, without the D-D layers)."""
+    if pp_rows is None or pd is None or b2 is None or not xd.is_cuda or 't_wg' not in pd.pd_csr:
+        return False
+    p, q = w_h.shape
+    c1 = w2.shape[1]
+    if not (w2.t().is_contiguous() and not w2.is_contiguous() and w_h.is_contiguous() and d_norm is not None and d_norm.is_contiguous()):
+        return False
+    if not lib().tipk_pd_stage_bwd_supported(int(p), int(q), int(xd.shape[0]), int(c1)):
+        return False
+    return bool(ops.drug_mix_gather_supported(torch.empty((1, p), device=xd.device), w_h, d_norm)
+                and ops.gather_sum_lin_supported(c1, p, pp_rows.fwd.group_slots) and ops.gather_sum_epilogue_supported(pp_rows.bwd, c1))
+
+
+def pd_stage(h1, w2, b2, xd, w_h, d_norm, pp_rows, pd, cat, link=None):
+    return _PDStage.apply(h1, w2, b2, xd, w_h, d_norm, pp_rows, pd, cat, link)
+
+
 def encoder_step(xd, w1, b1, w2, b2, w_h, d_norm, basis1, att1, root1, basis2, att2, root2, plans):
     return _EncoderStep.apply(xd, w1, b1, w2, b2, w_h, d_norm, basis1, att1, root1, basis2, att2, root2, plans)

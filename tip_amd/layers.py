@@ -721,6 +721,14 @@ class FMEncoder(nn.Module):
                 # and the partial rows of conv1's bias gradient are produced in THAT launch's epilogue (h1 has no other consumer)
                 link = ops.GateLink() if c1.bias is not None else None
                 h1 = c1(x_prot, pp_edge_index, fuse_relu='gated_downstream', link=link)
+                # conv2 + the P -> D stage as ONE node with the fused launches of tip_amd/encoder.py where they apply (round 6:
+                # what a relation-sharded run repeats on every rank takes 3 + 2 launches instead of 3 + 4)
+                pd_g = self.hgcn.mean_sources(None, dp_edge_index, rows=rows, graph_only=True)
+                n_p = x_prot.shape[0]
+                g_rows = c2._cache_rows.get((pp_edge_index, rows), lambda: gcn_norm_graph(pp_edge_index, n_p, c2.chunk, c2.in_channels, rows))
+                if not switches.on('TIPK_NO_ENCODER_STEP') and torch.is_tensor(d_norm) and \
+                        encoder.pd_stage_usable(g_rows, pd_g, xd, self.hgcn.weight, d_norm, c2.lin.weight, c2.bias):
+                    return encoder.pd_stage(h1, c2.lin.weight, c2.bias, xd, self.hgcn.weight, d_norm, g_rows, pd_g, self.mod == 'cat', link)
                 h_prot = c2(h1, pp_edge_index, rows=rows, gate_input=True, link=link)     # [len(rows), hid2]
             else:
                 h1 = c1(x_prot, pp_edge_index, fuse_relu=True)

@@ -1872,6 +1872,25 @@ def drug_mix_gather_supported(h, weight, d_norm):
                 (d_norm is None or d_norm.is_contiguous()) and lib().tipk_drug_mix_gather_supported(int(p), int(q)))
 
 
+def drug_mix_gather_launch(xd, h, weight, d_norm, cat, graph):
+    """(x0, mean, weight as passed to the kernel): the forward launch of the fused P -> D + drug-mix stage (`tipk_drug_mix_gather_fwd`)."""
+    xd, h, weight = _f32c(xd), _f32c(h), _f32c(weight).contiguous()
+    csr = graph.pd_csr
+    require_device(xd, h, weight, d_norm, csr['fwd_ptr'])
+    n, ne = xd.shape
+    p, q = weight.shape
+    assert h.shape == (csr['n_src'], p) and csr['fwd_ptr'].numel() == n + 1
+    out = torch.empty((n, ne + q if cat else ne), dtype=torch.float32, device=xd.device)
+    mean = torch.empty((n, p), dtype=torch.float32, device=xd.device)
+    with _timed('drug_mix_gather_fwd[%dx%dx%d]' % (n, p, q)):
+        check(lib().tipk_drug_mix_gather_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(h), h.stride(0), ptr(csr['fwd_ptr']),
+                                             ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), ptr(csr['fwd_order']), csr['fwd_wg'].shape[0],
+                                             ptr(weight), p, q, n, ne, int(cat),
+                                             ptr(out), out.stride(0), ptr(mean), stream_ptr(xd.device)),
+              'tipk_drug_mix_gather_fwd')
+    return out, mean, weight
+
+
 class _DrugMixGather(torch.autograd.Function):
     """x0 = cat(xd / d_norm, mean(H) W) or xd / d_norm + mean(H) W with mean(H)[d] = the mean of the source rows that point
     at d (MyHierarchyConv, src/layers.py:229-242, + the mix of :532-539): one launch forward; backward one launch for
@@ -1879,21 +1898,8 @@ class _DrugMixGather(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xd, h, weight, d_norm, cat, graph):
-        xd, h, weight = _f32c(xd), _f32c(h), _f32c(weight).contiguous()
-        csr = graph.pd_csr
-        require_device(xd, h, weight, d_norm, csr['fwd_ptr'])
-        n, ne = xd.shape
-        p, q = weight.shape
-        assert h.shape == (csr['n_src'], p) and csr['fwd_ptr'].numel() == n + 1
-        out = torch.empty((n, ne + q if cat else ne), dtype=torch.float32, device=xd.device)
-        mean = torch.empty((n, p), dtype=torch.float32, device=xd.device)
-        with _timed('drug_mix_gather_fwd[%dx%dx%d]' % (n, p, q)):
-            check(lib().tipk_drug_mix_gather_fwd(ptr(xd), xd.stride(0), ptr(d_norm), ptr(h), h.stride(0), ptr(csr['fwd_ptr']),
-                                                 ptr(csr['fwd_src']), ptr(csr['scale']), ptr(csr['fwd_wg']), ptr(csr['fwd_order']), csr['fwd_wg'].shape[0],
-                                                 ptr(weight), p, q, n, ne, int(cat),
-                                                 ptr(out), out.stride(0), ptr(mean), stream_ptr(xd.device)),
-                  'tipk_drug_mix_gather_fwd')
-        ctx.cat, ctx.ne, ctx.graph = cat, ne, graph
+        out, mean, weight = drug_mix_gather_launch(xd, h, weight, d_norm, cat, graph)
+        ctx.cat, ctx.ne, ctx.graph = cat, xd.shape[1], graph
         ctx.save_for_backward(mean, weight, d_norm)
         return out
 
