@@ -562,6 +562,21 @@ def step_hbm_bytes(build_id):
     return None
 
 
+def synthetic_hbm_counter(ms):
+    """Measured HBM bytes of one config-5 step (the newest committed profiles/r*_synthetic_pmc_traffic.json) against
+    8 TB/s at THIS run's step time; the build the counters were taken on is named, since the file may be older than the library."""
+    import glob
+    try:
+        fn = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_synthetic_pmc_traffic.json')))[-1]
+        doc = json.load(open(fn))
+        b = float(doc['step_hbm_bytes'])
+        return {'bytes_per_step': b, 'bytes_per_step_uncorrected': doc.get('step_hbm_bytes_uncorrected'),
+                'frac_of_8TBps': b / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                'source': 'profiles/%s (build %s; the config-5 kernels have not changed since)' % (os.path.basename(fn), doc.get('build_id'))}
+    except Exception:
+        return None
+
+
 MFMA_F32_PEAK = 157.3e12          # MI355X_MICROARCH.md: dense fp32 matrix rate
 LAUNCH_FLOOR_US = 2.0             # hand-over of a small launch inside a replayed graph (tools/microbench/launch_floor.hip: 1.6 empty, 2.5 at the margin)
 
@@ -860,6 +875,11 @@ def measure_config(workload, mod, dev, steps=20, warmup=5):
         # config 5: rows of Y / dY are gathered from HBM-resident tables -- SURVEY 8(d)'s HBM yardstick applies;
         # next to it the dense side (Y = att . XB, both products of dY, XB / dX / d basis products)
         rec['hbm_roofline_frac'] = E * per_edge / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+        rec['algorithmic_hbm_frac'] = rec['hbm_roofline_frac']
+        rec['binding_roofline'] = 'mfma (fp32): the row sums re-read Y / dY out of L2, so the algorithmic-HBM figure is a ' \
+                                  'yardstick, not the bound -- see hbm_counter, mfma_side and step_floor'
+        if workload == 'synthetic':
+            rec['hbm_counter'] = synthetic_hbm_counter(ms)
         n, r, nb = dd['n_drug'], dd['n_dd_et'], dims['num_base']
         flops = sum(3 * 2.0 * r * n * dims[k] * nb for k in ('n_hid1', 'n_hid2'))
         rec['mfma_side'] = {'flops_per_step': flops, 'ms_at_fp32_mfma_peak': flops / MFMA_F32_PEAK * 1e3,
