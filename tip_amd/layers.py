@@ -408,20 +408,22 @@ def relation_of_edges(range_list, n_edges, device):
     return torch.repeat_interleave(torch.arange(rg.shape[0]), sizes).to(device)
 
 
-_PAIR_BWD_PLANS = []          # [(key, plan)], most recent first: the R-GCN layers of a model run on the same graph
-
-
-def _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg, lanes):
-    """`build_pair_bwd_plan`, cached on what the plan depends on (edge list, relation of every edge, 1 / deg, launch shape)."""
-    key = (src.data_ptr(), dst.data_ptr(), int(src.numel()), int(n_nodes), int(n_rel), bool(symmetric), int(n_wg), int(lanes),
-           str(src.device), int(src.sum()), int((dst * (rel + 1)).sum()), float(scale.double().sum()))
-    for k, plan in _PAIR_BWD_PLANS:
-        if k == key:
-            return plan
-    plan = build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg, lanes, ops.rel_stream_piece())
-    _PAIR_BWD_PLANS.insert(0, (key, plan))
-    del _PAIR_BWD_PLANS[4:]
-    return plan
+def _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg, lanes, share=None):
+    """`build_pair_bwd_plan`; the R-GCN layers of one model run on the same graph and share the plan (it does not depend on the
+    layer's width).  share = (dict owned by the model, (edge_index, range_list) as the caller passed them): the entry keeps
+    those tensors alive, so their identity + version IS the edge list -- no checksums, no device sync, nothing global."""
+    build = lambda: build_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, scale, symmetric, n_wg, lanes, ops.rel_stream_piece())
+    if share is None:
+        return build()
+    cache, owners = share
+    key = tuple((id(t), t._version) if torch.is_tensor(t) else None for t in owners) + \
+        (int(n_nodes), int(n_rel), bool(symmetric), int(n_wg), int(lanes))
+    hit = cache.get(key)
+    if hit is None:
+        while len(cache) >= 2:                                # (a training and an evaluation graph)
+            cache.pop(next(iter(cache)))
+        hit = cache[key] = (build(), owners)
+    return hit[0]
 
 
 def pair_link_words(src, dst, n_nodes):
@@ -433,7 +435,8 @@ def pair_link_words(src, dst, n_nodes):
     return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
 
 
-def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None, paired=False):
+def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=None, d_out=None, n_bases=None, paired=False,
+               plan_share=None):
     """fwd: destination <- row (rel*N + src) of Y;  bwd: (rel*N + src) <- destination row of g;
     scale = 1 / max(1, in-degree over ALL relations) (torch-scatter 'mean').  `in_degree`: [N]
     in-degree of the WHOLE graph when `edge_index` is only one rank's shard (tip_amd/dist.py)."""
@@ -490,7 +493,7 @@ def rgcn_graph(edge_index, rel, n_nodes, n_rel, chunk=DEFAULT_CHUNK, in_degree=N
             # linked pair; d att walks half the edges of a symmetric graph.  The plan does not depend on the layer's width:
             # the layers of a model share it
             sym, lanes_p = pair_fwd.symmetric, (n_bases // split_p) // 4
-            pair_bwd = lambda: _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, 1.0 / deg, sym, pair_wgs, lanes_p)
+            pair_bwd = lambda: _shared_pair_bwd_plan(src, dst, rel, n_nodes, n_rel, 1.0 / deg, sym, pair_wgs, lanes_p, plan_share)
         if split_s:
             # compact node-major rows when the products of dY can run on them (tipk_rgcn_node_products); with the pair-form
             # backward pass the plan is only built if some pass asks for it (a forward pass on the Y route of a sharded run)
@@ -557,6 +560,7 @@ class _RGCNBase(nn.Module):
         self._cache = _PlanCache()
         self.shard = None                       # tip_amd.dist.RelationShard for multi-GPU runs
         self.paired = False                     # one of the two layers of an FMEncoder (sizes the pair plans: rgcn_graph)
+        self.plan_share = None                  # dict shared with the other layers on the same graph (pair backward plan)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -594,7 +598,8 @@ class MyRGCNConv2(_RGCNBase):
         def build():
             rel = relation_of_edges(range_list, edge_index.shape[1], edge_index.device)
             return rgcn_graph(edge_index, rel, n, self.num_relations, self.chunk, in_degree=self._global_degree(),
-                              d_out=self.out_channels, n_bases=self.num_bases, paired=self.paired and self.shard is None)
+                              d_out=self.out_channels, n_bases=self.num_bases, paired=self.paired and self.shard is None,
+                              plan_share=None if self.plan_share is None else (self.plan_share, (edge_index, range_list)))
         return self._cache.get((edge_index, range_list if torch.is_tensor(range_list) else None), build)
 
     def forward(self, x, edge_index, edge_type, range_list, fuse_relu=False, gate_input=False, defer_output=False, next_layer=None,
@@ -649,6 +654,7 @@ class FMEncoder(nn.Module):
         self.rgcn1 = MyRGCNConv2(d_in, n_hid1, num_dd_et, num_base, after_relu=False)
         self.rgcn2 = MyRGCNConv2(n_hid1, n_hid2, num_dd_et, num_base, after_relu=True)
         self.rgcn1.paired = self.rgcn2.paired = True
+        self.rgcn1.plan_share = self.rgcn2.plan_share = {}
         self._drug_feat = _FeatureInput()
         self.prune_pp_rows = True               # conv2 of the P-P encoder only for the rows the P -> D stage reads (forward())
         self.reset_parameters()
