@@ -922,6 +922,27 @@ int tipk_hier_bwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_i
                   const float* grad_out, int64_t ld_g, float* g_x /* nullable */, int64_t ld_gx, float* g_weight,
                   void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
 
+/* 10c. Plan construction in C++ (tip_amd/csrc/tipk_pairplan.hip), exposed as HOST arrays: the work lists of the wave-stream
+ *     gathers (section 1d) and of the pair-form backward pass (section 2e) from index arrays in host memory -- the same arrays,
+ *     bit for bit, as tip_amd/plan.py `build_stream_plan_rows` / `build_pair_bwd_plan` and tip_amd/layers.py `pair_link_words`
+ *     (tests/test_host_plans.py).  The graph handle of section 10 builds its pair-form plans with these (tipk_graph_prepare_rgcn);
+ *     a host that manages its own device buffers can upload them and call the kernel-level entries itself.
+ *     Arrays by name -- stream plan: "wave_ptr", "cells", "ids" (uint16), "zero_ptr", "zero_rows"; pair backward plan: "slots",
+ *     "node_desc", "tile_node", "part_first", "wg_part" and the gather's under "gather.<name>"; link words: "links".
+ *     Scalars by name: "n_rows", "n_table", "n_bands", "n_edges", "n_wg", "lanes", "piece", "idx_unit", "row_bytes" (prefixed with
+ *     "gather." on a pair plan) and "n_slots", "n_parts", "part_len", "n_alloc", "symmetric"; -1 = unknown name.
+ *     wide_steps / row_bytes 0 = the defaults (16; lanes * 16). */
+typedef struct tipk_host_plan tipk_host_plan;
+int tipk_plan_stream_rows(const int64_t* out_row, const int64_t* tab_row, int64_t n_edges, int64_t n_rows, int64_t n_table,
+                          int n_wg, int lanes, int piece, int wide_steps, int row_bytes, tipk_host_plan** plan_out);
+int tipk_plan_pair_bwd(const int64_t* src, const int64_t* dst, const int64_t* rel, int64_t n_edges, int64_t n_nodes, int64_t n_rel,
+                       const float* scale /* [n_nodes] 1 / in-degree */, int symmetric, int n_wg, int lanes, int piece,
+                       tipk_host_plan** plan_out);
+int tipk_plan_link_words(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, tipk_host_plan** plan_out);
+int tipk_host_plan_array(const tipk_host_plan* plan, const char* name, const void** data, int64_t* count, int* elem_bytes);
+int64_t tipk_host_plan_scalar(const tipk_host_plan* plan, const char* name);
+void tipk_host_plan_free(tipk_host_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,12 @@ SIGNATURES = {
     'tipk_hier_workspace_bytes': (_L, [_P, _I, _I]),
     'tipk_hier_fwd': (_I, [_P, _P, _L, _I, _P, _I, _P, _L, _P, _L, _P]),
     'tipk_hier_bwd': (_I, [_P, _P, _L, _I, _P, _I, _P, _L, _P, _L, _P, _P, _L, _P]),
+    'tipk_plan_stream_rows': (_I, [_P, _P, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
+    'tipk_plan_pair_bwd': (_I, [_P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _I, _P]),
+    'tipk_plan_link_words': (_I, [_P, _P, _L, _L, _P]),
+    'tipk_host_plan_array': (_I, [_P, C.c_char_p, _P, _P, _P]),
+    'tipk_host_plan_scalar': (_L, [_P, C.c_char_p]),
+    'tipk_host_plan_free': (None, [_P]),
     'tipk_split_flags': (_I, [_P, _L, _L, C.c_double, C.c_uint64, _P, _P, _P]),
     'tipk_split_scatter': (_I, [_P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
