@@ -20,6 +20,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P, I, L = C.c_void_p, C.c_int, C.c_int64
+ROUTES = set()                # routes the R-GCN layers of the current fixture took (0 generic | 1 | 2 pair form)
 
 
 def load_library():
@@ -36,6 +37,12 @@ def load_library():
     lib.tipk_rgcn_fwd.argtypes = [P, P, L, I, P, P, P, I, I, I, P, L, P, L, P]
     lib.tipk_rgcn_bwd.restype = I
     lib.tipk_rgcn_bwd.argtypes = [P, P, L, I, P, P, P, I, I, P, L, P, L, P, L, P, P, P, P, L, P]
+    lib.tipk_rgcn_bwd_ex.restype = I
+    lib.tipk_rgcn_bwd_ex.argtypes = [P, P, L, I, P, P, P, I, I, P, L, P, L, P, L, P, P, P, P, L, I, P]
+    lib.tipk_graph_prepare_rgcn.restype = I
+    lib.tipk_graph_prepare_rgcn.argtypes = [P, I, I]
+    lib.tipk_graph_rgcn_route.restype = I
+    lib.tipk_graph_rgcn_route.argtypes = [P, I, I]
     lib.tipk_gcn_graph_build.restype = I
     lib.tipk_gcn_graph_build.argtypes = [P, I, L, L, C.POINTER(P)]
     lib.tipk_gcn_workspace_bytes.restype = L
@@ -69,16 +76,24 @@ def ptr(t):
 
 
 class Layer(object):
-    """One R-GCN layer on a graph handle: forward(x, relu) / backward(grad_out)."""
+    """One R-GCN layer on a graph handle: forward(x, relu) / backward(grad_out).
+    fast: ask the handle for the LDS-resident pair form of this layer shape (`tipk_graph_prepare_rgcn`; the generic route stays
+    where the graph or the shape does not qualify); `route` = 0 generic | 1 pair-form forward | 2 pair form both ways."""
 
-    def __init__(self, lib, graph, basis, att, root, dev):
+    def __init__(self, lib, graph, basis, att, root, dev, fast=False):
         self.lib, self.graph = lib, graph
         self.basis, self.att, self.root = (t.to(dev).contiguous() for t in (basis, att, root))
         self.nb, self.d_in, self.d_out = basis.shape
-        n = lib.tipk_rgcn_workspace_bytes(graph, self.d_in, self.d_out, self.nb)
+        if fast:
+            st = lib.tipk_graph_prepare_rgcn(graph, self.nb, self.d_out)
+            if st != -2:                                                  # TIPK_EUNSUPPORTED: not a pair-form shape
+                ok(lib, st, 'tipk_graph_prepare_rgcn')
+        self.route = lib.tipk_graph_rgcn_route(graph, self.nb, self.d_out)
+        n = lib.tipk_rgcn_workspace_bytes(graph, self.d_in, self.d_out, self.nb)      # (after prepare: the route sizes it)
         assert n > 0
         self.ws = torch.empty(n, dtype=torch.uint8, device=dev)           # caller-owned, reused by both passes
         self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.ws_from_fwd = False
 
     def forward(self, x, relu=False):
         self.x, self.relu = x, relu
@@ -86,6 +101,7 @@ class Layer(object):
         ok(self.lib, self.lib.tipk_rgcn_fwd(self.graph, ptr(x), x.stride(0), self.d_in, ptr(self.basis), ptr(self.att), ptr(self.root),
                                             self.nb, self.d_out, int(relu), ptr(self.out), self.out.stride(0), ptr(self.ws),
                                             self.ws.numel(), self.stream), 'tipk_rgcn_fwd')
+        self.ws_from_fwd = True                                           # nothing else runs on this layer's workspace
         return self.out
 
     def backward(self, g):
@@ -93,10 +109,12 @@ class Layer(object):
         gx = torch.empty_like(x)
         gb, ga, gr = torch.empty_like(self.basis), torch.empty_like(self.att), torch.empty_like(self.root)
         gate = self.out if self.relu else None
-        ok(self.lib, self.lib.tipk_rgcn_bwd(self.graph, ptr(x), x.stride(0), self.d_in, ptr(self.basis), ptr(self.att), ptr(self.root),
-                                            self.nb, self.d_out, ptr(g), g.stride(0), ptr(gate), self.d_out if self.relu else 0,
-                                            ptr(gx), gx.stride(0), ptr(gb), ptr(ga), ptr(gr), ptr(self.ws), self.ws.numel(),
-                                            self.stream), 'tipk_rgcn_bwd')
+        flags = 1 if self.ws_from_fwd else 0                              # TIPK_RGCN_WORKSPACE_FROM_FWD
+        ok(self.lib, self.lib.tipk_rgcn_bwd_ex(self.graph, ptr(x), x.stride(0), self.d_in, ptr(self.basis), ptr(self.att), ptr(self.root),
+                                               self.nb, self.d_out, ptr(g), g.stride(0), ptr(gate), self.d_out if self.relu else 0,
+                                               ptr(gx), gx.stride(0), ptr(gb), ptr(ga), ptr(gr), ptr(self.ws), self.ws.numel(), flags,
+                                               self.stream), 'tipk_rgcn_bwd_ex')
+        self.ws_from_fwd = False
         return gx, gb, ga, gr
 
 
@@ -115,7 +133,7 @@ def check(name, got, want, rtol, scale):
     return err / max(1e-30, float(want.abs().max()))
 
 
-def run_single(lib, path, dev):
+def run_single(lib, path, dev, fast=False):
     g = {k: torch.from_numpy(v) if v.dtype.kind in 'fi' and v.ndim else v for k, v in np.load(path).items()}
     x = g['x'].to(dev).contiguous()
     n, r = x.shape[0], g['att'].shape[0]
@@ -123,7 +141,8 @@ def run_single(lib, path, dev):
     worst = 0.0
     for form in ('range_list', 'edge_type'):                                # MyRGCNConv2 | MyRGCNConv
         graph = build_graph(lib, ei, None if form == 'range_list' else et, rg if form == 'range_list' else None, n, r)
-        layer = Layer(lib, graph, g['basis'], g['att'], g['root'], dev)
+        layer = Layer(lib, graph, g['basis'], g['att'], g['root'], dev, fast)
+        ROUTES.add(layer.route)
         out = layer.forward(x)
         gx, gb, ga, gr = layer.backward(g['upstream'].to(dev).contiguous())
         torch.cuda.synchronize()
@@ -132,18 +151,26 @@ def run_single(lib, path, dev):
             worst = max(worst, check('%s[%s] %s' % (os.path.basename(path), form, name), got, want, 2e-5, 1.0))
         out2 = layer.forward(x)
         assert torch.equal(out2, out), 'not bitwise reproducible'
+        again = layer.backward(g['upstream'].to(dev).contiguous())          # workspace from THIS forward pass
+        layer.ws.fill_(255)                                                   # ... and from nothing: recomputed (NaN bit patterns)
+        cold = layer.backward(g['upstream'].to(dev).contiguous())
+        for a, b, c in zip((gx, gb, ga, gr), again, cold):
+            assert torch.equal(a, b) and torch.equal(a, c), 'backward pass depends on the workspace'
         ok(lib, lib.tipk_graph_destroy(graph), 'tipk_graph_destroy')
     return worst
 
 
-def run_two_layers(lib, path, dev):
+def run_two_layers(lib, path, dev, fast=False):
     """64 -> 32 (ReLU inside the layer's last kernel) -> 16 on the nasty 61-drug graph, gradients through both layers."""
     g = {k: torch.from_numpy(v) if v.dtype.kind in 'fi' and v.ndim else v for k, v in np.load(path).items()}
     x = g['x'].to(dev).contiguous()
     n, r = x.shape[0], g['l1.att'].shape[0]
     graph = build_graph(lib, g['dd_idx'].to(dev).contiguous(), None, g['dd_range'].to(dev).contiguous(), n, r)
-    l1 = Layer(lib, graph, g['l1.basis'], g['l1.att'], g['l1.root'], dev)
-    l2 = Layer(lib, graph, g['l2.basis'], g['l2.att'], g['l2.root'], dev)
+    l1 = Layer(lib, graph, g['l1.basis'], g['l1.att'], g['l1.root'], dev, fast)
+    l2 = Layer(lib, graph, g['l2.basis'], g['l2.att'], g['l2.root'], dev, fast)
+    ROUTES.update((l1.route, l2.route))
+    if fast:                                                                  # reference dims (32 bases, 64 -> 32 -> 16): pair form both ways
+        assert (l1.route, l2.route) == (2, 2), (l1.route, l2.route)
     out = l2.forward(l1.forward(x, relu=True))
     gx1, gb2, ga2, gr2 = l2.backward(g['upstream'].to(dev).contiguous())
     gx, gb1, ga1, gr1 = l1.backward(gx1)
@@ -240,7 +267,7 @@ def run_hier(lib, path, dev):
     return worst
 
 
-def run_tip_step(lib, path, dev):
+def run_tip_step(lib, path, dev, fast=False):
     """The WHOLE training step of TIP (mod = 'add'; src/layers.py:328-342 on top of :520-550) through the op-level C ABI alone:
     P-P GCN x 2 -> P -> D mean . W -> embed / d_norm + . -> R-GCN (ReLU) -> R-GCN -> DistMult objective, and every gradient
     back, against the reference's own loss and autograd gradients on the negatives its sampler drew (`tip_add_small`)."""
@@ -261,8 +288,9 @@ def run_tip_step(lib, path, dev):
     w1t = g['encoder.pp_encoder.conv1.lin.weight'].t().contiguous().to(dev)       # [in, out] memory: lin(I) = W^T in place
     b1, w2, b2 = f('encoder.pp_encoder.conv1.bias'), f('encoder.pp_encoder.conv2.lin.weight'), f('encoder.pp_encoder.conv2.bias')
     wh, embed, d_norm = f('encoder.hgcn.weight'), f('encoder.embed'), f('d_norm')
-    l1 = Layer(lib, gd, g['encoder.rgcn1.basis'], g['encoder.rgcn1.att'], g['encoder.rgcn1.root'], dev)
-    l2 = Layer(lib, gd, g['encoder.rgcn2.basis'], g['encoder.rgcn2.att'], g['encoder.rgcn2.root'], dev)
+    l1 = Layer(lib, gd, g['encoder.rgcn1.basis'], g['encoder.rgcn1.att'], g['encoder.rgcn1.root'], dev, fast)
+    l2 = Layer(lib, gd, g['encoder.rgcn2.basis'], g['encoder.rgcn2.att'], g['encoder.rgcn2.root'], dev, fast)
+    ROUTES.update((l1.route, l2.route))
     wdec = f('decoder.weight')
     d1, d2, dh = w1t.shape[1], w2.shape[0], wh.shape[1]
     ws = torch.empty(max(lib.tipk_gcn_workspace_bytes(gp, n_p, d1), lib.tipk_gcn_workspace_bytes(gp, d1, d2),
@@ -319,7 +347,12 @@ def main():
         base = os.path.basename(path)
         fn = run_pp_encoder if base.startswith('pp_encoder') else run_hier if base.startswith('hier') else \
             run_tip_step if base.startswith('tip_') else run_two_layers if 'fast' in base else run_single
-        print('%-26s max error %.2e of max|want|' % (base, fn(lib, path, dev)))
+        if fn in (run_single, run_two_layers, run_tip_step):                  # R-GCN layers: the generic route, then the pair form
+            ROUTES.clear()
+            worst = max(fn(lib, path, dev, fast=False), fn(lib, path, dev, fast=True))
+            print('%-26s max error %.2e of max|want|   (R-GCN routes taken: %s)' % (base, worst, sorted(ROUTES)))
+        else:
+            print('%-26s max error %.2e of max|want|' % (base, fn(lib, path, dev)))
     # malformed input: an id out of range is refused, as the reference raises IndexError
     bad = torch.tensor([[0, 1], [1, 99]], device=dev)
     h = C.c_void_p()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TIPK_ABI_VERSION 22
+#define TIPK_ABI_VERSION 23
 
 #define TIPK_OK            0
 #define TIPK_EINVAL      (-1)
@@ -870,10 +870,21 @@ int tipk_adam_step(int n_tensors, float* const* params, const float* const* grad
  *     workspace: tipk_rgcn_workspace_bytes(graph, d_in, d_out, n_bases) bytes, 16-byte aligned, caller-owned, reusable
  *         between calls on one stream (the backward pass recomputes XB: nothing is kept across the two calls but the
  *         caller's own X, parameters and -- with relu -- the output).
- *     Route: basis-first, transform-then-gather (Y = att . XB [R N x d_out] is the largest temporary), any shapes.  The
- *     LDS-resident pair form of the PyTorch modules (tip_amd/encoder.py) is the faster route at BioSNAP size; its plans
- *     are built by tip_amd/plan.py and are not behind this handle.
+ *     Routes.  Generic (any shapes): basis-first, transform-then-gather, Y = att . XB [R N x d_out] the largest temporary.
+ *     PAIR FORM (what the PyTorch modules take at BioSNAP size; 17.7 ms -> see DESIGN.md section 1b for the step at BioSNAP size):
+ *     tipk_graph_prepare_rgcn(graph, n_bases, d_out) builds the plans of the LDS-resident pair form for that layer shape --
+ *     on the host, with the C++ builders of section 10c; allocates and synchronises like tipk_graph_build -- when the graph
+ *     qualifies (<= 1 024 nodes, an att table [R x n_bases] that fits in LDS, n_bases and d_out the pair kernels support);
+ *     TIPK_EUNSUPPORTED otherwise, and the generic route stays.  Call it once per layer shape BEFORE asking for the
+ *     workspace size; tipk_rgcn_fwd / _bwd then run sections 1d + 2c (+ 2e) on the handle's plans.  tipk_graph_rgcn_route:
+ *     0 generic, 1 pair-form forward (backward generic), 2 pair form both ways.  The handle keeps the edge list on the host
+ *     (12 bytes per edge) for later prepare calls until tipk_graph_release_host.
+ *     tipk_rgcn_bwd_ex(..., flags, stream): TIPK_RGCN_WORKSPACE_FROM_FWD = the workspace still holds what tipk_rgcn_fwd of THIS
+ *     layer left in it (pair cells and XB: the caller ran nothing else on that workspace in between) -- the backward pass then
+ *     skips recomputing them; tipk_rgcn_bwd = flags 0 (always safe).  On a prepared route the handle's gradient table is
+ *     scratch of the backward call: one backward pass per handle at a time (calls on one stream are ordered anyway).
  */
+#define TIPK_RGCN_WORKSPACE_FROM_FWD 1
 typedef struct tipk_graph tipk_graph;
 int tipk_graph_build(const void* edge_index, const void* edge_type /* nullable */, const void* range_list /* nullable */,
                      int idx_bytes, int64_t n_edges, int64_t n_nodes, int64_t n_rel, const float* in_degree /* nullable */,
@@ -889,6 +900,13 @@ int tipk_rgcn_bwd(const tipk_graph* graph, const float* x, int64_t ld_x, int d_i
                   const float* root, int n_bases, int d_out, const float* grad_out, int64_t ld_g,
                   const float* out_relu /* nullable */, int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att,
                   float* g_root, void* workspace, int64_t workspace_bytes, tipk_stream_t stream);
+int tipk_rgcn_bwd_ex(const tipk_graph* graph, const float* x, int64_t ld_x, int d_in, const float* basis, const float* att,
+                     const float* root, int n_bases, int d_out, const float* grad_out, int64_t ld_g,
+                     const float* out_relu /* nullable */, int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att,
+                     float* g_root, void* workspace, int64_t workspace_bytes, int flags, tipk_stream_t stream);
+int tipk_graph_prepare_rgcn(tipk_graph* graph, int n_bases, int d_out);
+int tipk_graph_rgcn_route(const tipk_graph* graph, int n_bases, int d_out);
+int tipk_graph_release_host(tipk_graph* graph);
 
 /* 10b. The other two layer kinds of the path behind the same kind of handle (tipk_graph_destroy frees them all):
  *   GCNConv as PPEncoder uses it (PyG 2.0.1 semantics, src/layers.py:386-394): tipk_gcn_graph_build forms

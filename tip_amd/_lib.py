@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtipk.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class TipkError(RuntimeError):
@@ -158,6 +158,10 @@ SIGNATURES = {
     'tipk_hier_workspace_bytes': (_L, [_P, _I, _I]),
     'tipk_hier_fwd': (_I, [_P, _P, _L, _I, _P, _I, _P, _L, _P, _L, _P]),
     'tipk_hier_bwd': (_I, [_P, _P, _L, _I, _P, _I, _P, _L, _P, _L, _P, _P, _L, _P]),
+    'tipk_rgcn_bwd_ex': (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _P]),
+    'tipk_graph_prepare_rgcn': (_I, [_P, _I, _I]),
+    'tipk_graph_rgcn_route': (_I, [_P, _I, _I]),
+    'tipk_graph_release_host': (_I, [_P]),
     'tipk_plan_stream_rows': (_I, [_P, _P, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
     'tipk_plan_pair_bwd': (_I, [_P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _I, _P]),
     'tipk_plan_link_words': (_I, [_P, _P, _L, _L, _P]),

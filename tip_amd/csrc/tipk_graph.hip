@@ -14,13 +14,49 @@
 // tipk_graph_build sorts the edge list ON THE HOST, once (stable counting sorts: the order of additions inside a row is the
 // order of the edge list -- every pass is bitwise reproducible), and keeps two CSRs on the device: rows of the output by
 // destination -> rows (relation, source) of Y, and rows (relation, source) of dY -> destinations.  The gathers are a
-// wavefront per output row; the dense products are the library's own MFMA GEMM (tipk_gemm_f32).  The LDS-resident pair form
-// that the PyTorch modules take at BioSNAP size (tip_amd/encoder.py) is faster there; its plans are built by tip_amd/plan.py.
+// wavefront per output row; the dense products are the library's own MFMA GEMM (tipk_gemm_f32).
+//
+// The PAIR-FORM route (the one the PyTorch modules take at BioSNAP size: <= 1 024 nodes, an att table that fits in LDS) is behind
+// the handle as well: tipk_graph_prepare_rgcn builds its plans on the host with tipk_pairplan.hip -- the arrays tip_amd/plan.py
+// builds, bit for bit -- and tipk_rgcn_fwd / _bwd then run the wave-stream cell gather, the pair product, the pair gradients and
+// the partitioned d att gather (include/tipk.h sections 1d, 2c, 2e) instead of the generic passes.
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 #include "tipk_common.h"
+#include "tipk_pairplan.h"
+
+namespace {
+
+constexpr int PAIR_KGROUP = 8;             // source nodes per slab of tipk_pair_product
+
+// device arrays of a wave-stream plan
+struct StreamDev {
+    int32_t* wave_ptr = nullptr; uint32_t* cells = nullptr; uint16_t* ids = nullptr; int32_t* zero_ptr = nullptr; int32_t* zero_rows = nullptr;
+    int64_t n_wg = 0, n_bands = 0;
+    int idx_unit = 1;
+};
+
+// the pair-form plans of one (n_bases, symmetric) shape: forward cells plan, link words, and -- once a width with pair
+// gradients was prepared -- the backward plan with its gradient table (transient inside a backward call: owned here)
+struct PairRoute {
+    int n_bases = 0, lanes = 0;
+    bool symmetric = false, has_bwd = false;
+    StreamDev fwd;
+    uint32_t* links = nullptr;
+    float* zeros = nullptr;                // 64 floats of zeros (tipk_pair_product reads them in place of unlinked cells)
+    int32_t* slots = nullptr; int32_t* node_desc = nullptr; int32_t* tile_node = nullptr; int32_t* part_first = nullptr; int32_t* wg_part = nullptr;
+    StreamDev gather;
+    int64_t n_slots = 0, n_parts = 0, part_len = 0, n_alloc = 0;
+    float* pg = nullptr;                   // [2 n_alloc + 1][n_bases], zeroed once: a call rewrites the rows of the linked pairs
+    std::vector<void*> owned;
+};
+
+struct HostEdges { std::vector<int32_t> src, dst, rel; };
+
+}  // namespace
 
 struct tipk_graph {
     int kind;              // 0: D-D relation graph (R-GCN), 1: normalised adjacency (GCNConv), 2: bipartite mean (MyHierarchyConv)
@@ -33,6 +69,9 @@ struct tipk_graph {
     float* fwd_w;          // kinds 1, 2: weight of every edge in fwd order / in bwd order (GCN norm; 1 / #edges of the target)
     float* bwd_w;
     int64_t n_out, n_table, n_source;      // kinds 1, 2: rows of the output / of the table; kind 2: first target row
+    HostEdges* host;                       // kind 0: the edge list on the host until tipk_graph_release_host (plans are built from it)
+    std::vector<PairRoute*>* routes;       // kind 0: prepared pair-form routes
+    int symmetric_known, symmetric;        // kind 0: every relation links u -> v as often as v -> u (computed on first use)
 };
 
 namespace {
@@ -214,6 +253,14 @@ extern "C" int tipk_graph_build(const void* edge_index, const void* edge_type, c
     if (st == TIPK_OK) st = up((void**)&g->bwd_row, brow.data(), brow.size() * 4);
     if (st == TIPK_OK) st = up((void**)&g->inv_deg, inv.data(), inv.size() * 4);
     if (st != TIPK_OK) { tipk_graph_destroy(g); return st; }
+    // the edge list stays on the host (12 bytes per edge) for tipk_graph_prepare_rgcn, until tipk_graph_release_host
+    g->host = new (std::nothrow) HostEdges;
+    g->routes = new (std::nothrow) std::vector<PairRoute*>;
+    if (!g->host || !g->routes) { tipk_graph_destroy(g); return TIPK_EINVAL; }
+    g->host->src.resize((size_t)n_edges); g->host->dst.resize((size_t)n_edges); g->host->rel.resize((size_t)n_edges);
+    for (int64_t i = 0; i < n_edges; ++i) {
+        g->host->src[(size_t)i] = (int32_t)src[i]; g->host->dst[(size_t)i] = (int32_t)dst[i]; g->host->rel[(size_t)i] = (int32_t)rel[(size_t)i];
+    }
     *out = g;
     return TIPK_OK;
 }
@@ -224,8 +271,24 @@ extern "C" int tipk_graph_destroy(tipk_graph* g) {
     void* bufs[7] = {g->fwd_ptr, g->fwd_row, g->bwd_ptr, g->bwd_row, g->inv_deg, g->fwd_w, g->bwd_w};
     for (void* b : bufs)
         if (b) { const int s = tipk_hip_status(hipFree(b)); if (s != TIPK_OK) st = s; }
+    if (g->routes) {
+        for (PairRoute* pr : *g->routes) {
+            for (void* b : pr->owned)
+                if (b) { const int s = tipk_hip_status(hipFree(b)); if (s != TIPK_OK) st = s; }
+            delete pr;
+        }
+        delete g->routes;
+    }
+    delete g->host;
     delete g;
     return st;
+}
+
+extern "C" int tipk_graph_release_host(tipk_graph* g) {
+    if (!g) return TIPK_EINVAL;
+    delete g->host;
+    g->host = nullptr;
+    return TIPK_OK;
 }
 
 extern "C" int tipk_graph_info(const tipk_graph* g, int64_t* n_nodes, int64_t* n_rel, int64_t* n_edges, const float** inv_degree) {
@@ -237,9 +300,179 @@ extern "C" int tipk_graph_info(const tipk_graph* g, int64_t* n_nodes, int64_t* n
     return TIPK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The pair-form route behind the handle.
+
+namespace {
+
+template <class T> int upload(PairRoute* pr, T** dev, const void* host, size_t count) {
+    void* d = nullptr;
+    const size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&d, bytes ? bytes : 4);
+    if (e != hipSuccess) return tipk_hip_status(e);
+    pr->owned.push_back(d);
+    *dev = (T*)d;
+    return bytes && host ? tipk_hip_status(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice)) : TIPK_OK;
+}
+
+int upload_stream(PairRoute* pr, StreamDev& sd, const tipk_plan::StreamPlanH& sp) {
+    int st = upload(pr, &sd.wave_ptr, sp.wave_ptr.data(), sp.wave_ptr.size());
+    if (st == TIPK_OK) st = upload(pr, &sd.cells, sp.cells.data(), sp.cells.size());
+    if (st == TIPK_OK) st = upload(pr, &sd.ids, sp.ids.data(), sp.ids.size());
+    if (st == TIPK_OK) st = upload(pr, &sd.zero_ptr, sp.zero_ptr.data(), sp.zero_ptr.size());
+    if (st == TIPK_OK) st = upload(pr, &sd.zero_rows, sp.zero_rows.data(), sp.zero_rows.size());
+    sd.n_wg = sp.n_wg; sd.n_bands = sp.n_bands; sd.idx_unit = sp.idx_unit;
+    return st;
+}
+
+// the route prepared for this layer shape (nullptr: the generic route)
+const PairRoute* route_for(const tipk_graph* g, int n_bases, int d_out) {
+    if (!g->routes || !tipk_pair_product_supported(n_bases, d_out)) return nullptr;
+    for (const PairRoute* pr : *g->routes)
+        if (pr->n_bases == n_bases) return pr;
+    return nullptr;
+}
+
+inline int64_t pad_group(int64_t n) { return (n + PAIR_KGROUP - 1) / PAIR_KGROUP * PAIR_KGROUP; }
+
+// workspace of the pair route (floats): cells [N_pad][N][nb] | XB [N_pad][nb][32] | X root / g' [N][d_out] |
+// product slabs [N_pad / 8][N][d_out] | d XB [nb][N][d_out] | d att slabs [parts][R][nb]
+struct PairWs { float* cells; float* xb; float* t; float* slabs; float* dxb; float* att_slabs; int64_t bytes; };
+
+PairWs carve_pair(void* base, int64_t n, int64_t r, int nb, int d_out, int64_t n_parts) {
+    PairWs w;
+    char* p = (char*)base;
+    int64_t off = 0;
+    const int64_t n_pad = pad_group(n);
+    w.cells = (float*)(p + off); off += align256(n_pad * n * nb * 4);
+    w.xb = (float*)(p + off); off += align256(n_pad * nb * 32 * 4);
+    w.t = (float*)(p + off); off += align256(n * d_out * 4);
+    w.slabs = (float*)(p + off); off += align256(n_pad / PAIR_KGROUP * n * d_out * 4);
+    w.dxb = (float*)(p + off); off += align256((int64_t)nb * n * d_out * 4);
+    w.att_slabs = (float*)(p + off); off += align256(std::max<int64_t>(n_parts, 1) * r * nb * 4);
+    w.bytes = off;
+    return w;
+}
+
+// XB into the node-major buffer of the pair product (rows padded to 32 columns, everything the product does not write zero)
+// and the pair cells C[u][v][:] = sum of att[r, :] over the relations linking u -> v
+int pair_operands(const tipk_graph* g, const PairRoute* pr, const PairWs& w, const float* x, int64_t ld_x, int d_in, const float* basis,
+                  const float* att, int d_out, tipk_stream_t stream) {
+    const int64_t n = g->n_nodes, r = g->n_rel;
+    const int nb = pr->n_bases;
+    int st = tipk_hip_status(hipMemsetAsync(w.xb, 0, (size_t)(pad_group(n) * nb * 32 * 4), (hipStream_t)stream));
+    if (st != TIPK_OK) return st;
+    tipk_gemm_desc d = gemm_desc(n, d_out, d_in, x, ld_x, 1, basis, d_out, 1, w.xb, (int64_t)nb * 32);
+    d.batch = nb; d.a_sz = 0; d.b_sz = (int64_t)d_in * d_out; d.c_sz = 32;
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    return tipk_stream_gather(att, nb, r, nb, pr->fwd.n_wg, pr->fwd.wave_ptr, pr->fwd.cells, pr->fwd.ids, pr->fwd.idx_unit, nullptr,
+                              pr->fwd.zero_rows, nullptr, w.cells, nb, 1, 4, nullptr, nullptr, 0, stream);
+}
+
+// the dense products of d XB [nb][N][d_out] and g' that every route ends with
+int dense_grads(const float* x, int64_t ld_x, int d_in, const float* basis, const float* root, int n_bases, int d_out, int64_t n,
+                const float* gp, int64_t ld_gp, const float* dxb, float* g_x, int64_t ld_gx, float* g_basis, float* g_root, tipk_stream_t stream) {
+    int st;
+    // d basis_b = X^T d XB_b (batched, A shared),  d root = X^T g'
+    tipk_gemm_desc d = gemm_desc(d_in, d_out, n, x, 1, ld_x, dxb, d_out, 1, g_basis, d_out);
+    d.batch = n_bases; d.a_sz = 0; d.b_sz = n * d_out; d.c_sz = (int64_t)d_in * d_out;
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    d = gemm_desc(d_in, d_out, n, x, 1, ld_x, gp, ld_gp, 1, g_root, d_out);
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    // dX = g' root^T, then += sum_b d XB_b basis_b^T (the batch reduced inside the product, on top of the first term)
+    d = gemm_desc(n, d_in, d_out, gp, ld_gp, 1, root, 1, d_out, g_x, ld_gx);
+    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    d = gemm_desc(n, d_in, d_out, dxb, d_out, 1, basis, 1, d_out, g_x, ld_gx);
+    d.kbatch = n_bases; d.a_sq = n * d_out; d.b_sq = (int64_t)d_in * d_out; d.c_in = g_x; d.cin_sm = ld_gx;
+    return tipk_gemm_f32(&d, stream);
+}
+
+int gate_rows(const float* in, int64_t ld_in, const float* gate, int64_t ld_gate, float* out, int64_t rows, int d, hipStream_t hs);
+
+}  // namespace
+
+extern "C" int tipk_graph_prepare_rgcn(tipk_graph* g, int n_bases, int d_out) {
+    if (!g || g->kind != 0 || n_bases <= 0 || d_out <= 0) return TIPK_EINVAL;
+    const int64_t n = g->n_nodes, r = g->n_rel, e = g->n_edges;
+    if (!g->routes || n > 1024 || r <= 0 || e <= 0 || n * n >= (1 << 24) || !tipk_pair_product_supported(n_bases, d_out) || d_out > 32)
+        return TIPK_EUNSUPPORTED;
+    const int split = tipk_stream_gather_supported(r, n_bases, 4);
+    if (!split || (n_bases / split) % 4) return TIPK_EUNSUPPORTED;
+    const int lanes = (n_bases / split) / 4, piece = tipk_stream_gather_piece();
+    PairRoute* pr = nullptr;
+    for (PairRoute* q : *g->routes)
+        if (q->n_bases == n_bases) pr = q;
+    const bool want_bwd = tipk_rgcn_pair_grads_supported(n_bases, d_out) != 0;
+    if (pr && (pr->has_bwd || !want_bwd)) return TIPK_OK;
+    if (!g->host) return TIPK_EINVAL;                                          // tipk_graph_release_host was called
+    int dev = 0, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    std::vector<int64_t> src((size_t)e), dst((size_t)e), rel((size_t)e);
+    for (int64_t i = 0; i < e; ++i) { src[(size_t)i] = g->host->src[(size_t)i]; dst[(size_t)i] = g->host->dst[(size_t)i]; rel[(size_t)i] = g->host->rel[(size_t)i]; }
+    if (!g->symmetric_known) {
+        g->symmetric = tipk_plan::relations_symmetric(src.data(), dst.data(), rel.data(), e, n);
+        g->symmetric_known = 1;
+    }
+    int st = TIPK_OK;
+    if (!pr) {
+        pr = new (std::nothrow) PairRoute;
+        if (!pr) return TIPK_EINVAL;
+        g->routes->push_back(pr);                                              // (owned by the handle from here on, whatever happens)
+        pr->n_bases = n_bases; pr->lanes = lanes; pr->symmetric = g->symmetric != 0;
+        // every relation symmetric => cell (u, v) == cell (v, u): the cells with u <= v only, from half the edges
+        std::vector<int64_t> out_row, tab_row;
+        out_row.reserve((size_t)e); tab_row.reserve((size_t)e);
+        for (int64_t i = 0; i < e; ++i)
+            if (!pr->symmetric || src[(size_t)i] <= dst[(size_t)i]) { out_row.push_back(src[(size_t)i] * n + dst[(size_t)i]); tab_row.push_back(rel[(size_t)i]); }
+        tipk_plan::StreamPlanH sp;
+        tipk_plan::build_stream_plan_rows(out_row.data(), tab_row.data(), (int64_t)out_row.size(), n * n, r, n_cu, lanes, piece, 0, 0, sp);
+        std::vector<uint32_t> links;
+        tipk_plan::pair_link_words(src.data(), dst.data(), e, n, links);
+        st = upload_stream(pr, pr->fwd, sp);
+        if (st == TIPK_OK) st = upload(pr, &pr->links, links.data(), links.size());
+        if (st == TIPK_OK) st = upload(pr, &pr->zeros, (const void*)nullptr, (size_t)64);
+        if (st == TIPK_OK) st = tipk_hip_status(hipMemset(pr->zeros, 0, 64 * 4));
+        if (st != TIPK_OK) { pr->n_bases = -1; return st; }                    // (a route no shape matches; freed with the handle)
+    }
+    if (want_bwd && !pr->has_bwd) {
+        std::vector<float> scale((size_t)n);
+        st = tipk_hip_status(hipMemcpy(scale.data(), g->inv_deg, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (st != TIPK_OK) return st;
+        tipk_plan::PairBwdH pb;
+        if (!tipk_plan::build_pair_bwd_plan(src.data(), dst.data(), rel.data(), e, n, r, scale.data(), pr->symmetric, n_cu, lanes, piece, pb))
+            return TIPK_OK;                                                    // forward in pair form, backward on the generic route
+        st = upload(pr, &pr->slots, pb.slots.data(), pb.slots.size());
+        if (st == TIPK_OK) st = upload(pr, &pr->node_desc, pb.node_desc.data(), pb.node_desc.size());
+        if (st == TIPK_OK) st = upload(pr, &pr->tile_node, pb.tile_node.data(), pb.tile_node.size());
+        if (st == TIPK_OK) st = upload(pr, &pr->part_first, pb.part_first.data(), pb.part_first.size());
+        if (st == TIPK_OK) st = upload(pr, &pr->wg_part, pb.wg_part.data(), pb.wg_part.size());
+        if (st == TIPK_OK) st = upload_stream(pr, pr->gather, pb.gather);
+        const size_t pg_count = (size_t)(2 * pb.n_alloc + 1) * (size_t)n_bases;
+        if (st == TIPK_OK) st = upload(pr, &pr->pg, (const void*)nullptr, pg_count);
+        if (st == TIPK_OK) st = tipk_hip_status(hipMemset(pr->pg, 0, pg_count * 4));
+        if (st != TIPK_OK) return st;
+        pr->n_slots = pb.n_slots; pr->n_parts = pb.n_parts; pr->part_len = pb.part_len; pr->n_alloc = pb.n_alloc;
+        pr->has_bwd = true;
+    }
+    return TIPK_OK;
+}
+
+extern "C" int tipk_graph_rgcn_route(const tipk_graph* g, int n_bases, int d_out) {
+    if (!g || g->kind != 0) return TIPK_EINVAL;
+    const PairRoute* pr = route_for(g, n_bases, d_out);
+    if (!pr) return 0;
+    return 1 + (pr->has_bwd && tipk_rgcn_pair_grads_supported(n_bases, d_out) ? 1 : 0);
+}
+
 extern "C" int64_t tipk_rgcn_workspace_bytes(const tipk_graph* g, int d_in, int d_out, int n_bases) {
     if (!g || g->kind != 0 || d_in <= 0 || d_out <= 0 || n_bases <= 0) return -1;
-    return carve(nullptr, g->n_nodes, g->n_rel, n_bases, d_out).bytes;
+    const int64_t generic = carve(nullptr, g->n_nodes, g->n_rel, n_bases, d_out).bytes;
+    const PairRoute* pr = route_for(g, n_bases, d_out);
+    if (!pr) return generic;
+    // (a route whose backward pass runs on the generic passes needs their workspace as well)
+    return std::max(generic, carve_pair(nullptr, g->n_nodes, g->n_rel, n_bases, d_out, pr->n_parts).bytes);
 }
 
 extern "C" int tipk_rgcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* basis, const float* att,
@@ -249,9 +482,23 @@ extern "C" int tipk_rgcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, 
         (g->n_rel > 0 && !att))
         return TIPK_EINVAL;
     const int64_t n = g->n_nodes, r = g->n_rel;
-    const Ws w = carve(workspace, n, r, n_bases, d_out);
-    if (workspace_bytes < w.bytes || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
+    if (workspace_bytes < tipk_rgcn_workspace_bytes(g, d_in, d_out, n_bases) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
     int st;
+    const PairRoute* pr = route_for(g, n_bases, d_out);
+    if (pr && ld_out == d_out) {
+        // PAIR FORM (tip_amd/ops.py `_RGCN.forward`, same launches): sum_r A_r X W_r = sum over the linked pairs (u -> v) of
+        // C[u, v, :] . XB[u],  C[u, v, :] = sum of att[r, :] over the relations linking u -> v
+        const PairWs pw = carve_pair(workspace, n, r, n_bases, d_out, pr->n_parts);
+        if ((st = pair_operands(g, pr, pw, x, ld_x, d_in, basis, att, d_out, stream)) != TIPK_OK) return st;
+        tipk_gemm_desc dr = gemm_desc(n, d_out, d_in, x, ld_x, 1, root, d_out, 1, pw.t, d_out);
+        if ((st = tipk_gemm_f32(&dr, stream)) != TIPK_OK) return st;
+        const int64_t n_pad = pad_group(n);
+        if ((st = tipk_pair_product(pw.cells, pw.xb, n_pad, n, n_bases, d_out, PAIR_KGROUP, pr->symmetric, pr->links, pr->zeros, nullptr,
+                                    pw.slabs, stream)) != TIPK_OK)
+            return st;
+        return tipk_sum_slabs_ex(pw.slabs, n_pad / PAIR_KGROUP, n * d_out, n * d_out, 1.f, 0, g->inv_deg, d_out, pw.t, relu, out, stream);
+    }
+    const Ws w = carve(workspace, n, r, n_bases, d_out);
     // XB_b = X basis_b (one batched product, A shared), X root
     tipk_gemm_desc d = gemm_desc(n, d_out, d_in, x, ld_x, 1, basis, d_out, 1, w.xb, d_out);
     d.batch = n_bases; d.a_sz = 0; d.b_sz = (int64_t)d_in * d_out; d.c_sz = n * d_out;
@@ -274,14 +521,48 @@ extern "C" int tipk_rgcn_bwd(const tipk_graph* g, const float* x, int64_t ld_x, 
                              const float* root, int n_bases, int d_out, const float* grad_out, int64_t ld_g, const float* out_relu,
                              int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att, float* g_root, void* workspace,
                              int64_t workspace_bytes, tipk_stream_t stream) {
+    return tipk_rgcn_bwd_ex(g, x, ld_x, d_in, basis, att, root, n_bases, d_out, grad_out, ld_g, out_relu, ld_relu, g_x, ld_gx, g_basis, g_att,
+                            g_root, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int tipk_rgcn_bwd_ex(const tipk_graph* g, const float* x, int64_t ld_x, int d_in, const float* basis, const float* att,
+                                const float* root, int n_bases, int d_out, const float* grad_out, int64_t ld_g, const float* out_relu,
+                                int64_t ld_relu, float* g_x, int64_t ld_gx, float* g_basis, float* g_att, float* g_root, void* workspace,
+                                int64_t workspace_bytes, int flags, tipk_stream_t stream) {
     if (!g || g->kind != 0 || !x || !basis || !root || !grad_out || !g_x || !g_basis || !g_root || !workspace || d_in <= 0 || d_out <= 0 || n_bases <= 0 ||
-        ld_x < d_in || ld_g < d_out || ld_gx < d_in || (g->n_rel > 0 && (!att || !g_att)) || (out_relu && ld_relu < d_out))
+        ld_x < d_in || ld_g < d_out || ld_gx < d_in || (g->n_rel > 0 && (!att || !g_att)) || (out_relu && ld_relu < d_out) ||
+        (flags & ~TIPK_RGCN_WORKSPACE_FROM_FWD))
         return TIPK_EINVAL;
     const int64_t n = g->n_nodes, r = g->n_rel;
-    const Ws w = carve(workspace, n, r, n_bases, d_out);
-    if (workspace_bytes < w.bytes || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
+    if (workspace_bytes < tipk_rgcn_workspace_bytes(g, d_in, d_out, n_bases) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return TIPK_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
     int st;
+    const PairRoute* pr = route_for(g, n_bases, d_out);
+    if (pr && pr->has_bwd && tipk_rgcn_pair_grads_supported(n_bases, d_out)) {
+        // PAIR-FORM BACKWARD (tip_amd/ops.py `pair_backward`): per linked pair one gradient row pg[(u, v), :] = XB[u] . g'[v] / deg(v)
+        // and d XB[u] += C[u, v, :] (x) g'[v] / deg(v) in one launch; d att[r, :] = sum of the pair rows r links (partitioned
+        // wave-stream gather -> slabs -> ordered sum); then the dense products of d XB as on the generic route
+        const PairWs pw = carve_pair(workspace, n, r, n_bases, d_out, pr->n_parts);
+        const float* gp = grad_out;
+        int64_t ld_gp = ld_g;
+        if (out_relu) {
+            if ((st = gate_rows(grad_out, ld_g, out_relu, ld_relu, pw.t, n, d_out, hs)) != TIPK_OK) return st;
+            gp = pw.t; ld_gp = d_out;
+        }
+        if (!(flags & TIPK_RGCN_WORKSPACE_FROM_FWD) && (st = pair_operands(g, pr, pw, x, ld_x, d_in, basis, att, d_out, stream)) != TIPK_OK)
+            return st;
+        if ((st = tipk_rgcn_pair_grads(pw.cells, pad_group(n) * n, pw.xb, gp, ld_gp, n, n_bases, d_out, pr->node_desc, pr->slots, pr->tile_node,
+                                       pr->n_slots, pw.dxb, n * d_out, d_out, pr->pg, 2 * pr->n_alloc + 1, stream)) != TIPK_OK)
+            return st;
+        if ((st = tipk_stream_gather_parts(pr->pg, n_bases, n_bases, pr->n_alloc, pr->part_first, pr->part_len, pr->wg_part, pr->gather.n_wg,
+                                           pr->gather.wave_ptr, pr->gather.cells, pr->gather.ids, pr->gather.idx_unit, pr->gather.zero_ptr,
+                                           pr->gather.zero_rows, pw.att_slabs, n_bases, stream)) != TIPK_OK)
+            return st;
+        if ((st = tipk_sum_slabs_ex(pw.att_slabs, pr->n_parts, r * n_bases, r * n_bases, 1.f, 0, nullptr, n_bases, nullptr, 0, g_att, stream)) != TIPK_OK)
+            return st;
+        return dense_grads(x, ld_x, d_in, basis, root, n_bases, d_out, n, gp, ld_gp, pw.dxb, g_x, ld_gx, g_basis, g_root, stream);
+    }
+    const Ws w = carve(workspace, n, r, n_bases, d_out);
     // g' = g (.) [out > 0] (only when the layer applied the ReLU itself)
     const float* gp = grad_out;
     int64_t ld_gp = ld_g;
@@ -311,18 +592,7 @@ extern "C" int tipk_rgcn_bwd(const tipk_graph* g, const float* x, int64_t ld_x, 
     } else {
         if ((st = tipk_hip_status(hipMemsetAsync(w.dxb, 0, (size_t)n_bases * n * d_out * 4, hs))) != TIPK_OK) return st;
     }
-    // d basis_b = X^T d XB_b (batched, A shared),  d root = X^T g'
-    d = gemm_desc(d_in, d_out, n, x, 1, ld_x, w.dxb, d_out, 1, g_basis, d_out);
-    d.batch = n_bases; d.a_sz = 0; d.b_sz = n * d_out; d.c_sz = (int64_t)d_in * d_out;
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
-    d = gemm_desc(d_in, d_out, n, x, 1, ld_x, gp, ld_gp, 1, g_root, d_out);
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
-    // dX = g' root^T, then += sum_b d XB_b basis_b^T (the batch reduced inside the product, on top of the first term)
-    d = gemm_desc(n, d_in, d_out, gp, ld_gp, 1, root, 1, d_out, g_x, ld_gx);
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
-    d = gemm_desc(n, d_in, d_out, w.dxb, d_out, 1, basis, 1, d_out, g_x, ld_gx);
-    d.kbatch = n_bases; d.a_sq = n * d_out; d.b_sq = (int64_t)d_in * d_out; d.c_in = g_x; d.cin_sm = ld_gx;
-    return tipk_gemm_f32(&d, stream);
+    return dense_grads(x, ld_x, d_in, basis, root, n_bases, d_out, n, gp, ld_gp, w.dxb, g_x, ld_gx, g_basis, g_root, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

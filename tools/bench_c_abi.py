@@ -31,37 +31,43 @@ def main():
     t0 = time.perf_counter()
     g = host.build_graph(lib, ei, None, rg, n, r)
     build_s = time.perf_counter() - t0
-    torch.manual_seed(0)
-    mk = lambda *s: torch.randn(*s, device=dev) * 0.1
-    l1 = host.Layer(lib, g, mk(32, 64, 32), mk(r, 32), mk(64, 32), dev)
-    l2 = host.Layer(lib, g, mk(32, 32, 16), mk(r, 32), mk(32, 16), dev)
-    x, gz = mk(n, 64), mk(n, 16)
+    for fast in (False, True):
+        torch.manual_seed(0)
+        mk = lambda *s: torch.randn(*s, device=dev) * 0.1
+        t0 = time.perf_counter()
+        l1 = host.Layer(lib, g, mk(32, 64, 32), mk(r, 32), mk(64, 32), dev, fast)
+        l2 = host.Layer(lib, g, mk(32, 32, 16), mk(r, 32), mk(32, 16), dev, fast)
+        torch.cuda.synchronize()
+        prep_s = time.perf_counter() - t0
+        x, gz = mk(n, 64), mk(n, 16)
 
-    def step():
-        h = l1.forward(x, relu=True)
-        l2.forward(h)
-        gh = l2.backward(gz)[0]
-        l1.backward(gh)
+        def step():
+            h = l1.forward(x, relu=True)
+            l2.forward(h)
+            gh = l2.backward(gz)[0]
+            l1.backward(gh)
 
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        l1.stream = l2.stream = C.c_void_p(s.cuda_stream)
-        for _ in range(3):
-            step()
-        s.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr, stream=s):
-            step()
-    for _ in range(5):
-        gr.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gr.replay()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print('op-level C ABI, both D-D layers fwd + bwd at BioSNAP size (N = %d, R = %d, E = %d): %.3f ms per step = %.2f G edges/s; '
-          'tipk_graph_build %.2f s' % (n, r, e, ms, e / ms / 1e6, build_s))
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            l1.stream = l2.stream = C.c_void_p(s.cuda_stream)
+            for _ in range(3):
+                step()
+            s.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                step()
+        for _ in range(5):
+            gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gr.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        print('op-level C ABI, both D-D layers fwd + bwd at BioSNAP size (N = %d, R = %d, E = %d), routes %d / %d: %.3f ms per step = '
+              '%.2f G edges/s; tipk_graph_build %.2f s, layers + tipk_graph_prepare_rgcn %.2f s'
+              % (n, r, e, l1.route, l2.route, ms, e / ms / 1e6, build_s, prep_s))
+        del gr, l1, l2
     host.ok(lib, lib.tipk_graph_destroy(g), 'tipk_graph_destroy')
 
 
