@@ -902,6 +902,22 @@ def measure_config(workload, mod, dev, steps=20, warmup=5):
     return rec
 
 
+def op_level_record():
+    """What a host that is not this package gets (include/tipk.h section 10): the two D-D layers through tipk_graph_build /
+    tipk_graph_prepare_rgcn / tipk_rgcn_fwd / tipk_rgcn_bwd_ex alone, timed by tools/bench_c_abi.py in a CHILD process (ctypes +
+    torch for device memory; neither tip_amd.ops nor tip_amd.plan) -- generic route and pair form."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_c_abi.py'), '--json', '--steps', '50'], capture_output=True,
+                           text=True, timeout=600)
+        line = [l for l in p.stdout.splitlines() if l.startswith('{')]
+        if p.returncode != 0 or not line:
+            return {'error': (p.stderr or p.stdout)[-400:]}
+        return json.loads(line[-1])
+    except Exception as exc:                                       # noqa: BLE001
+        return {'error': repr(exc)}
+
+
 def train_step_record(dev, epochs=20, decoder='distmult'):
     """The whole graphed training epoch of tip.py:24-30 (sampler + encoder + fused objective + backward + fused Adam)
     on BASELINE config 2: ms per epoch.  decoder = 'nn': the same epoch with the NNDecoder (model/ddm-nn.py:65-102)."""
@@ -1268,6 +1284,7 @@ def main():
                 except Exception as exc:                           # noqa: BLE001
                     out[key] = {'error': repr(exc)}
                     release()
+            out['op_level_c_abi'] = op_level_record()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -871,7 +871,8 @@ int tipk_adam_step(int n_tensors, float* const* params, const float* const* grad
  *         between calls on one stream (the backward pass recomputes XB: nothing is kept across the two calls but the
  *         caller's own X, parameters and -- with relu -- the output).
  *     Routes.  Generic (any shapes): basis-first, transform-then-gather, Y = att . XB [R N x d_out] the largest temporary.
- *     PAIR FORM (what the PyTorch modules take at BioSNAP size; 17.7 ms -> see DESIGN.md section 1b for the step at BioSNAP size):
+ *     PAIR FORM (what the PyTorch modules take at BioSNAP size; both D-D layers forward + backward through these entries:
+ *     17.5 ms on the generic route, 0.18 ms in pair form -- tools/bench_c_abi.py, `op_level_c_abi` on the bench line):
  *     tipk_graph_prepare_rgcn(graph, n_bases, d_out) builds the plans of the LDS-resident pair form for that layer shape --
  *     on the host, with the C++ builders of section 10c; allocates and synchronises like tipk_graph_build -- when the graph
  *     qualifies (<= 1 024 nodes, an att table [R x n_bases] that fits in LDS, n_bases and d_out the pair kernels support);

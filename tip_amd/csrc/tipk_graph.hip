@@ -356,34 +356,48 @@ PairWs carve_pair(void* base, int64_t n, int64_t r, int nb, int d_out, int64_t n
 
 // XB into the node-major buffer of the pair product (rows padded to 32 columns, everything the product does not write zero)
 // and the pair cells C[u][v][:] = sum of att[r, :] over the relations linking u -> v
+// (root != nullptr: X root into w.t in the same grouped launch)
 int pair_operands(const tipk_graph* g, const PairRoute* pr, const PairWs& w, const float* x, int64_t ld_x, int d_in, const float* basis,
-                  const float* att, int d_out, tipk_stream_t stream) {
+                  const float* att, const float* root, int d_out, tipk_stream_t stream) {
     const int64_t n = g->n_nodes, r = g->n_rel;
     const int nb = pr->n_bases;
     int st = tipk_hip_status(hipMemsetAsync(w.xb, 0, (size_t)(pad_group(n) * nb * 32 * 4), (hipStream_t)stream));
     if (st != TIPK_OK) return st;
-    tipk_gemm_desc d = gemm_desc(n, d_out, d_in, x, ld_x, 1, basis, d_out, 1, w.xb, (int64_t)nb * 32);
-    d.batch = nb; d.a_sz = 0; d.b_sz = (int64_t)d_in * d_out; d.c_sz = 32;
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    tipk_gemm_desc d[2];
+    d[0] = gemm_desc(n, d_out, d_in, x, ld_x, 1, basis, d_out, 1, w.xb, (int64_t)nb * 32);
+    d[0].batch = nb; d[0].a_sz = 0; d[0].b_sz = (int64_t)d_in * d_out; d[0].c_sz = 32;
+    d[1] = gemm_desc(n, d_out, d_in, x, ld_x, 1, root, d_out, 1, w.t, d_out);
+    if ((st = tipk_gemm_f32_group(d, root ? 2 : 1, stream)) != TIPK_OK) return st;
     return tipk_stream_gather(att, nb, r, nb, pr->fwd.n_wg, pr->fwd.wave_ptr, pr->fwd.cells, pr->fwd.ids, pr->fwd.idx_unit, nullptr,
                               pr->fwd.zero_rows, nullptr, w.cells, nb, 1, 4, nullptr, nullptr, 0, stream);
 }
 
-// the dense products of d XB [nb][N][d_out] and g' that every route ends with
+// the dense products of d XB [nb][N][d_out] and g' that every route ends with, plus (pair form) the ordered sum of the d att
+// slabs: ONE launch when the reductions fit the waves of a workgroup per output tile (tipk_gemm_wg_group: BioSNAP does),
+// else product by product
 int dense_grads(const float* x, int64_t ld_x, int d_in, const float* basis, const float* root, int n_bases, int d_out, int64_t n,
-                const float* gp, int64_t ld_gp, const float* dxb, float* g_x, int64_t ld_gx, float* g_basis, float* g_root, tipk_stream_t stream) {
+                const float* gp, int64_t ld_gp, const float* dxb, float* g_x, int64_t ld_gx, float* g_basis, float* g_root,
+                const tipk_slab_sum_desc* att_sum, tipk_stream_t stream) {
     int st;
-    // d basis_b = X^T d XB_b (batched, A shared),  d root = X^T g'
-    tipk_gemm_desc d = gemm_desc(d_in, d_out, n, x, 1, ld_x, dxb, d_out, 1, g_basis, d_out);
-    d.batch = n_bases; d.a_sz = 0; d.b_sz = n * d_out; d.c_sz = (int64_t)d_in * d_out;
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
-    d = gemm_desc(d_in, d_out, n, x, 1, ld_x, gp, ld_gp, 1, g_root, d_out);
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    // d basis_b = X^T d XB_b (batched, A shared),  d root = X^T g',  dX = sum_b d XB_b basis_b^T + g' root^T
+    tipk_wg_gemm_desc w[3];
+    memset(w, 0, sizeof(w));
+    w[0].p = gemm_desc(d_in, d_out, n, x, 1, ld_x, dxb, d_out, 1, g_basis, d_out);
+    w[0].p.batch = n_bases; w[0].p.a_sz = 0; w[0].p.b_sz = n * d_out; w[0].p.c_sz = (int64_t)d_in * d_out;
+    w[1].p = gemm_desc(d_in, d_out, n, x, 1, ld_x, gp, ld_gp, 1, g_root, d_out);
+    w[2].p = gemm_desc(n, d_in, d_out, dxb, d_out, 1, basis, 1, d_out, g_x, ld_gx);
+    w[2].p.kbatch = n_bases; w[2].p.a_sq = n * d_out; w[2].p.b_sq = (int64_t)d_in * d_out;
+    w[2].a2 = gp; w[2].a2_sm = ld_gp; w[2].a2_sk = 1; w[2].b2 = root; w[2].b2_sk = 1; w[2].b2_sn = d_out; w[2].k2 = d_out;
+    if (tipk_gemm_wg_group_supported(&w[0]) && tipk_gemm_wg_group_supported(&w[1]) && tipk_gemm_wg_group_supported(&w[2]))
+        return tipk_gemm_wg_group(w, 3, att_sum, att_sum ? 1 : 0, stream);
+    if (att_sum && (st = tipk_sum_slabs_group(att_sum, 1, stream)) != TIPK_OK) return st;
+    if ((st = tipk_gemm_f32(&w[0].p, stream)) != TIPK_OK) return st;
+    if ((st = tipk_gemm_f32(&w[1].p, stream)) != TIPK_OK) return st;
     // dX = g' root^T, then += sum_b d XB_b basis_b^T (the batch reduced inside the product, on top of the first term)
-    d = gemm_desc(n, d_in, d_out, gp, ld_gp, 1, root, 1, d_out, g_x, ld_gx);
+    tipk_gemm_desc d = gemm_desc(n, d_in, d_out, gp, ld_gp, 1, root, 1, d_out, g_x, ld_gx);
     if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
-    d = gemm_desc(n, d_in, d_out, dxb, d_out, 1, basis, 1, d_out, g_x, ld_gx);
-    d.kbatch = n_bases; d.a_sq = n * d_out; d.b_sq = (int64_t)d_in * d_out; d.c_in = g_x; d.cin_sm = ld_gx;
+    d = w[2].p;
+    d.c_in = g_x; d.cin_sm = ld_gx;
     return tipk_gemm_f32(&d, stream);
 }
 
@@ -489,9 +503,7 @@ extern "C" int tipk_rgcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, 
         // PAIR FORM (tip_amd/ops.py `_RGCN.forward`, same launches): sum_r A_r X W_r = sum over the linked pairs (u -> v) of
         // C[u, v, :] . XB[u],  C[u, v, :] = sum of att[r, :] over the relations linking u -> v
         const PairWs pw = carve_pair(workspace, n, r, n_bases, d_out, pr->n_parts);
-        if ((st = pair_operands(g, pr, pw, x, ld_x, d_in, basis, att, d_out, stream)) != TIPK_OK) return st;
-        tipk_gemm_desc dr = gemm_desc(n, d_out, d_in, x, ld_x, 1, root, d_out, 1, pw.t, d_out);
-        if ((st = tipk_gemm_f32(&dr, stream)) != TIPK_OK) return st;
+        if ((st = pair_operands(g, pr, pw, x, ld_x, d_in, basis, att, root, d_out, stream)) != TIPK_OK) return st;
         const int64_t n_pad = pad_group(n);
         if ((st = tipk_pair_product(pw.cells, pw.xb, n_pad, n, n_bases, d_out, PAIR_KGROUP, pr->symmetric, pr->links, pr->zeros, nullptr,
                                     pw.slabs, stream)) != TIPK_OK)
@@ -549,7 +561,7 @@ extern "C" int tipk_rgcn_bwd_ex(const tipk_graph* g, const float* x, int64_t ld_
             if ((st = gate_rows(grad_out, ld_g, out_relu, ld_relu, pw.t, n, d_out, hs)) != TIPK_OK) return st;
             gp = pw.t; ld_gp = d_out;
         }
-        if (!(flags & TIPK_RGCN_WORKSPACE_FROM_FWD) && (st = pair_operands(g, pr, pw, x, ld_x, d_in, basis, att, d_out, stream)) != TIPK_OK)
+        if (!(flags & TIPK_RGCN_WORKSPACE_FROM_FWD) && (st = pair_operands(g, pr, pw, x, ld_x, d_in, basis, att, nullptr, d_out, stream)) != TIPK_OK)
             return st;
         if ((st = tipk_rgcn_pair_grads(pw.cells, pad_group(n) * n, pw.xb, gp, ld_gp, n, n_bases, d_out, pr->node_desc, pr->slots, pr->tile_node,
                                        pr->n_slots, pw.dxb, n * d_out, d_out, pr->pg, 2 * pr->n_alloc + 1, stream)) != TIPK_OK)
@@ -558,9 +570,11 @@ extern "C" int tipk_rgcn_bwd_ex(const tipk_graph* g, const float* x, int64_t ld_
                                            pr->gather.wave_ptr, pr->gather.cells, pr->gather.ids, pr->gather.idx_unit, pr->gather.zero_ptr,
                                            pr->gather.zero_rows, pw.att_slabs, n_bases, stream)) != TIPK_OK)
             return st;
-        if ((st = tipk_sum_slabs_ex(pw.att_slabs, pr->n_parts, r * n_bases, r * n_bases, 1.f, 0, nullptr, n_bases, nullptr, 0, g_att, stream)) != TIPK_OK)
-            return st;
-        return dense_grads(x, ld_x, d_in, basis, root, n_bases, d_out, n, gp, ld_gp, pw.dxb, g_x, ld_gx, g_basis, g_root, stream);
+        tipk_slab_sum_desc sum;
+        memset(&sum, 0, sizeof(sum));
+        sum.in = pw.att_slabs; sum.n_slabs = pr->n_parts; sum.slab_stride = r * n_bases; sum.count = r * n_bases; sum.alpha = 1.f;
+        sum.cols = n_bases; sum.out = g_att;
+        return dense_grads(x, ld_x, d_in, basis, root, n_bases, d_out, n, gp, ld_gp, pw.dxb, g_x, ld_gx, g_basis, g_root, &sum, stream);
     }
     const Ws w = carve(workspace, n, r, n_bases, d_out);
     // g' = g (.) [out > 0] (only when the layer applied the ReLU itself)
@@ -592,7 +606,7 @@ extern "C" int tipk_rgcn_bwd_ex(const tipk_graph* g, const float* x, int64_t ld_
     } else {
         if ((st = tipk_hip_status(hipMemsetAsync(w.dxb, 0, (size_t)n_bases * n * d_out * 4, hs))) != TIPK_OK) return st;
     }
-    return dense_grads(x, ld_x, d_in, basis, root, n_bases, d_out, n, gp, ld_gp, w.dxb, g_x, ld_gx, g_basis, g_root, stream);
+    return dense_grads(x, ld_x, d_in, basis, root, n_bases, d_out, n, gp, ld_gp, w.dxb, g_x, ld_gx, g_basis, g_root, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

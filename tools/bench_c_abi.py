@@ -22,6 +22,7 @@ from tip_amd.data import build_data_dict                        # noqa: E402  (t
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--json', action='store_true', help='one JSON object on the last line (bench.py reads it)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = host.load_library()
@@ -31,6 +32,7 @@ def main():
     t0 = time.perf_counter()
     g = host.build_graph(lib, ei, None, rg, n, r)
     build_s = time.perf_counter() - t0
+    rec = {'workload': 'both D-D R-GCN layers (64 -> 32 -> 16, 32 bases) fwd + bwd, N = %d, R = %d, E = %d' % (n, r, e), 'graph_build_s': build_s}
     for fast in (False, True):
         torch.manual_seed(0)
         mk = lambda *s: torch.randn(*s, device=dev) * 0.1
@@ -67,8 +69,13 @@ def main():
         print('op-level C ABI, both D-D layers fwd + bwd at BioSNAP size (N = %d, R = %d, E = %d), routes %d / %d: %.3f ms per step = '
               '%.2f G edges/s; tipk_graph_build %.2f s, layers + tipk_graph_prepare_rgcn %.2f s'
               % (n, r, e, l1.route, l2.route, ms, e / ms / 1e6, build_s, prep_s))
+        rec['pair_form' if fast else 'generic'] = {'routes': [l1.route, l2.route], 'ms_per_step': ms, 'edges_per_s': e / ms * 1e3,
+                                                   'layers_and_prepare_s': prep_s}
         del gr, l1, l2
     host.ok(lib, lib.tipk_graph_destroy(g), 'tipk_graph_destroy')
+    if args.json:
+        import json
+        print(json.dumps(rec))
 
 
 if __name__ == '__main__':
