@@ -118,6 +118,49 @@ def test_rgcn_pair_route_against_reference_golden(name):
     close(x2.grad, g['grad_x'], rtol=1e-4, atol=1e-5 * float(g['grad_x'].abs().max()))
 
 
+@pytest.mark.parametrize('name', ['rgcn_fast_sym', 'rgcn_fast_directed'])
+def test_graph_handle_pair_form_is_the_modules_pair_form_bit_for_bit(name):
+    """The op-level handle after `tipk_graph_prepare_rgcn` (plans built in C++, include/tipk.h section 10c) against the PyTorch
+    module on the same layer: the same plans, the same launches -- the same bits, forward and all four gradients."""
+    import ctypes as C
+    from tip_amd import _lib
+    from tip_amd.layers import MyRGCNConv2
+    L = _lib.lib()
+    g = load_golden(name)
+    r = g['l1.att'].shape[0]
+    m1 = load_params(MyRGCNConv2(64, 32, r, 32, after_relu=False), g, 'l1.')
+    ei, et, rg = g['dd_idx'].to(DEV), g['dd_et'].to(DEV), g['dd_range'].to(DEV)
+    x = g['x'].to(DEV).requires_grad_(True)
+    up = torch.randn(x.shape[0], 32, generator=torch.Generator().manual_seed(1)).to(DEV)
+    want = m1(x, ei, et, rg)
+    assert m1.graph_for(x.shape[0], ei, rg).pair_fwd is not None
+    want.backward(up)
+    h = C.c_void_p()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    assert L.tipk_graph_build(ptr(ei), None, ptr(rg), 8, ei.shape[1], x.shape[0], r, None, C.byref(h)) == 0
+    try:
+        assert L.tipk_graph_rgcn_route(h, 32, 32) == 0
+        assert L.tipk_graph_prepare_rgcn(h, 32, 32) == 0
+        assert L.tipk_graph_rgcn_route(h, 32, 32) == 2
+        assert L.tipk_graph_prepare_rgcn(h, 5, 32) == -2 and L.tipk_graph_rgcn_route(h, 5, 32) == 0       # not a pair-form shape
+        ws = torch.empty(L.tipk_rgcn_workspace_bytes(h, 64, 32, 32), dtype=torch.uint8, device=DEV)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        xd, basis, att, root = x.detach(), m1.basis.detach().contiguous(), m1.att.detach().contiguous(), m1.root.detach().contiguous()
+        out = torch.empty(x.shape[0], 32, device=DEV)
+        assert L.tipk_rgcn_fwd(h, ptr(xd), 64, 64, ptr(basis), ptr(att), ptr(root), 32, 32, 0, ptr(out), 32, ptr(ws), ws.numel(), st) == 0
+        assert torch.equal(out, want.detach())
+        gx, gb, ga, gr = torch.empty_like(xd), torch.empty_like(basis), torch.empty_like(att), torch.empty_like(root)
+        assert L.tipk_rgcn_bwd_ex(h, ptr(xd), 64, 64, ptr(basis), ptr(att), ptr(root), 32, 32, ptr(up), 32, None, 0, ptr(gx), 64, ptr(gb),
+                                  ptr(ga), ptr(gr), ptr(ws), ws.numel(), 1, st) == 0
+        for got, ref in ((gx, x.grad), (gb, m1.basis.grad), (ga, m1.att.grad), (gr, m1.root.grad)):
+            assert torch.equal(got, ref)
+        assert L.tipk_graph_release_host(h) == 0
+        assert L.tipk_graph_prepare_rgcn(h, 32, 32) == 0                   # prepared already: nothing to build
+        assert L.tipk_graph_prepare_rgcn(h, 16, 32) == -1                  # a new shape needs the edge list back
+    finally:
+        assert L.tipk_graph_destroy(h) == 0
+
+
 @pytest.mark.parametrize('name', ['encoder_fast_cat_sym', 'encoder_fast_add_sym', 'encoder_fast_cat_directed'])
 def test_fm_encoder_fast_route_against_reference_golden(name):
     """FMEncoder at the dims of tip.py:14 / :17 against the reference's own forward + autograd on the nasty 61-drug graph: the
