@@ -907,6 +907,8 @@ def op_level_record():
     tipk_graph_prepare_rgcn / tipk_rgcn_fwd / tipk_rgcn_bwd_ex alone, timed by tools/bench_c_abi.py in a CHILD process (ctypes +
     torch for device memory; neither tip_amd.ops nor tip_amd.plan) -- generic route and pair form."""
     import subprocess
+    if any(k.startswith('ROCPROF') for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return {'skipped': 'under rocprofv3 (a traced child would add its kernels to the profile of the step)'}
     try:
         p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_c_abi.py'), '--json', '--steps', '50'], capture_output=True,
                            text=True, timeout=600)
