@@ -154,6 +154,24 @@ def test_graph_handle_pair_form_is_the_modules_pair_form_bit_for_bit(name):
                                   ptr(ga), ptr(gr), ptr(ws), ws.numel(), 1, st) == 0
         for got, ref in ((gx, x.grad), (gb, m1.basis.grad), (ga, m1.att.grad), (gr, m1.root.grad)):
             assert torch.equal(got, ref)
+        # ... and without TIPK_RGCN_WORKSPACE_FROM_FWD, on a workspace that holds nothing (NaN bit patterns): cells and XB recomputed
+        ws.fill_(255)
+        cold = [torch.empty_like(t) for t in (gx, gb, ga, gr)]
+        assert L.tipk_rgcn_bwd(h, ptr(xd), 64, 64, ptr(basis), ptr(att), ptr(root), 32, 32, ptr(up), 32, None, 0, ptr(cold[0]), 64,
+                               ptr(cold[1]), ptr(cold[2]), ptr(cold[3]), ptr(ws), ws.numel(), st) == 0
+        for got, ref in zip(cold, (gx, gb, ga, gr)):
+            assert torch.equal(got, ref)
+        # the ReLU inside the layer: forward with relu = 1, the mask applied by the backward pass from the output
+        out_r = torch.empty_like(out)
+        assert L.tipk_rgcn_fwd(h, ptr(xd), 64, 64, ptr(basis), ptr(att), ptr(root), 32, 32, 1, ptr(out_r), 32, ptr(ws), ws.numel(), st) == 0
+        assert torch.equal(out_r, torch.relu(out))
+        assert L.tipk_rgcn_bwd_ex(h, ptr(xd), 64, 64, ptr(basis), ptr(att), ptr(root), 32, 32, ptr(up), 32, ptr(out_r), 32, ptr(cold[0]), 64,
+                                  ptr(cold[1]), ptr(cold[2]), ptr(cold[3]), ptr(ws), ws.numel(), 1, st) == 0
+        x3 = g['x'].to(DEV).requires_grad_(True)
+        m1.zero_grad()
+        torch.relu(m1(x3, ei, et, rg)).backward(up)
+        for got, ref in zip(cold, (x3.grad, m1.basis.grad, m1.att.grad, m1.root.grad)):
+            close(got, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
         assert L.tipk_graph_release_host(h) == 0
         assert L.tipk_graph_prepare_rgcn(h, 32, 32) == 0                   # prepared already: nothing to build
         assert L.tipk_graph_prepare_rgcn(h, 16, 32) == -1                  # a new shape needs the edge list back
