@@ -872,7 +872,7 @@ int tipk_adam_step(int n_tensors, float* const* params, const float* const* grad
  *         caller's own X, parameters and -- with relu -- the output).
  *     Routes.  Generic (any shapes): basis-first, transform-then-gather, Y = att . XB [R N x d_out] the largest temporary.
  *     PAIR FORM (what the PyTorch modules take at BioSNAP size; both D-D layers forward + backward through these entries:
- *     17.5 ms on the generic route, 0.18 ms in pair form -- tools/bench_c_abi.py, `op_level_c_abi` on the bench line):
+ *     1.9 ms on the generic route, 0.18 ms in pair form -- tools/bench_c_abi.py, `op_level_c_abi` on the bench line):
  *     tipk_graph_prepare_rgcn(graph, n_bases, d_out) builds the plans of the LDS-resident pair form for that layer shape --
  *     on the host, with the C++ builders of section 10c; allocates and synchronises like tipk_graph_build -- when the graph
  *     qualifies (<= 1 024 nodes, an att table [R x n_bases] that fits in LDS, n_bases and d_out the pair kernels support);
@@ -957,6 +957,10 @@ int tipk_plan_stream_rows(const int64_t* out_row, const int64_t* tab_row, int64_
 int tipk_plan_pair_bwd(const int64_t* src, const int64_t* dst, const int64_t* rel, int64_t n_edges, int64_t n_nodes, int64_t n_rel,
                        const float* scale /* [n_nodes] 1 / in-degree */, int symmetric, int n_wg, int lanes, int piece,
                        tipk_host_plan** plan_out);
+/* grouped gather plan of section 1 (plan.py `build_gather_plan` with group_slots = G > 0; chunk 0 = from the edge count):
+ * arrays "row_id", "edge_w" (float; empty without weights), "items", "perm" (int64); scalars "n_items", "chunk", "group_slots". */
+int tipk_plan_gather(const int64_t* out_row, const int64_t* table_row, const float* edge_w /* nullable */, int64_t n_edges,
+                     int64_t n_out, int64_t n_table, int chunk, int group_slots, tipk_host_plan** plan_out);
 int tipk_plan_link_words(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, tipk_host_plan** plan_out);
 int tipk_host_plan_array(const tipk_host_plan* plan, const char* name, const void** data, int64_t* count, int* elem_bytes);
 int64_t tipk_host_plan_scalar(const tipk_host_plan* plan, const char* name);

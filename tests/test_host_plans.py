@@ -9,7 +9,7 @@ import torch
 
 from tip_amd import _lib
 from tip_amd.layers import pair_link_words
-from tip_amd.plan import build_pair_bwd_plan, build_stream_plan_rows
+from tip_amd.plan import build_gather_plan, build_pair_bwd_plan, build_stream_plan_rows, group_slots_for
 
 
 def _i64(t):
@@ -24,10 +24,10 @@ class HostPlan(object):
     def array(self, name):
         data, count, eb = C.c_void_p(), C.c_int64(), C.c_int()
         assert self.lib.tipk_host_plan_array(self.h, name.encode(), C.byref(data), C.byref(count), C.byref(eb)) == 0, name
-        dt = {2: np.uint16, 4: np.int32}[eb.value]
+        dt, ct = {2: (np.uint16, C.c_uint16), 4: (np.int32, C.c_int32), 8: (np.int64, C.c_int64)}[eb.value]
         if count.value == 0:
             return np.zeros(0, dtype=dt)
-        return np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint16 if eb.value == 2 else C.c_int32)), shape=(count.value,)).astype(dt).copy()
+        return np.ctypeslib.as_array(C.cast(data, C.POINTER(ct)), shape=(count.value,)).astype(dt).copy()
 
     def scalar(self, name):
         return int(self.lib.tipk_host_plan_scalar(self.h, name.encode()))
@@ -174,3 +174,38 @@ def test_link_words_match_layers_py():
             assert np.array_equal(hp.array('links'), want)
         finally:
             hp.free()
+
+
+@pytest.mark.parametrize('n_out,n_table,n_edges,d,weights,hubs', [
+    (500, 700, 20000, 32, True, 3),           # a GCN-like graph: weighted edges, a few hub rows cut into pieces
+    (645, 19081 + 645, 18596, 16, True, 2),   # the P -> D stage's shape
+    (64, 64 * 7, 60000, 32, False, 4),        # few destination rows with thousands of edges each (the D-D forward pass)
+    (300, 300, 0, 16, False, 0),              # no edges: every row still gets its (empty) item
+    (100, 50, 3000, 64, True, 1),             # d = 64: blocks of 64 slots
+])
+def test_grouped_gather_plan_matches_plan_py(n_out, n_table, n_edges, d, weights, hubs):
+    gen = torch.Generator().manual_seed(n_out + d)
+    if n_edges:
+        out_row, tab_row = _random_runs(gen, n_out, n_table, n_edges, hubs)
+    else:
+        out_row = tab_row = torch.zeros(0, dtype=torch.int64)
+    w = torch.rand(n_edges, generator=gen) if weights else None
+    G = group_slots_for(d)
+    gp = build_gather_plan(out_row, tab_row, n_out, n_table, edge_w=w, group_slots=G)
+    (a, pa), (b, pb) = _i64(out_row), _i64(tab_row)
+    wn = None if w is None else np.ascontiguousarray(w.numpy())
+    h = C.c_void_p()
+    assert _lib.lib().tipk_plan_gather(pa, pb, None if wn is None else wn.ctypes.data_as(C.c_void_p), n_edges, n_out, n_table, 0, G,
+                                       C.byref(h)) == 0
+    hp = HostPlan(h)
+    try:
+        assert hp.scalar('chunk') == gp.chunk and hp.scalar('group_slots') == G and hp.scalar('n_items') == gp.items.shape[0]
+        assert np.array_equal(hp.array('items'), gp.items.numpy().reshape(-1))
+        assert np.array_equal(hp.array('row_id'), gp.row_id.numpy())
+        assert np.array_equal(hp.array('perm'), gp.perm.numpy())
+        if weights and n_edges:
+            assert np.array_equal(hp.array('edge_w'), gp.edge_w.numpy().view(np.int32))
+        if hubs:
+            assert int((gp.items[:, 3] & 4).ne(0).sum()) > 0                # some row was split
+    finally:
+        hp.free()

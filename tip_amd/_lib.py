@@ -165,6 +165,7 @@ SIGNATURES = {
     'tipk_plan_stream_rows': (_I, [_P, _P, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
     'tipk_plan_pair_bwd': (_I, [_P, _P, _P, _L, _L, _L, _P, _I, _I, _I, _I, _P]),
     'tipk_plan_link_words': (_I, [_P, _P, _L, _L, _P]),
+    'tipk_plan_gather': (_I, [_P, _P, _P, _L, _L, _L, _I, _I, _P]),
     'tipk_host_plan_array': (_I, [_P, C.c_char_p, _P, _P, _P]),
     'tipk_host_plan_scalar': (_L, [_P, C.c_char_p]),
     'tipk_host_plan_free': (None, [_P]),

@@ -56,6 +56,13 @@ struct PairRoute {
 
 struct HostEdges { std::vector<int32_t> src, dst, rel; };
 
+// a grouped gather plan of tipk_gather_sum on the device (G = 128: rows of 4 .. 32 floats), built in C++ (tipk_pairplan.hip)
+struct GatherDev {
+    int32_t* row_id = nullptr; float* edge_w = nullptr; int32_t* items = nullptr;
+    int64_t n_items = 0, n_table = 0;
+    int G = 0;
+};
+
 }  // namespace
 
 struct tipk_graph {
@@ -72,6 +79,8 @@ struct tipk_graph {
     HostEdges* host;                       // kind 0: the edge list on the host until tipk_graph_release_host (plans are built from it)
     std::vector<PairRoute*>* routes;       // kind 0: prepared pair-form routes
     int symmetric_known, symmetric;        // kind 0: every relation links u -> v as often as v -> u (computed on first use)
+    GatherDev* pf;                         // work-item plans of the two CSRs for rows of <= 32 floats (hub rows cut into pieces that one
+    GatherDev* pb;                         // workgroup combines): the wavefront-per-row kernel below is the route for everything else
 };
 
 namespace {
@@ -87,6 +96,7 @@ struct GrArgs {
     const float* bias;                         // nullable: per column, added before the ReLU
     int relu, d;
     float* out; int64_t ld_out;
+    const GatherDev* plan;                     // nullable: the same sums as work items of tipk_gather_sum (used when it applies)
 };
 
 // one wavefront per output row, lane = column (blocks of 64 columns), the row's edges in list order, 4 rows of the table in flight
@@ -137,8 +147,17 @@ __global__ __launch_bounds__(256) void graph_gate_kernel(const float* in, int64_
     out[i] = gate[r * ld_gate + c] > 0.f ? v : 0.f;
 }
 
+// the work-item plan applies: rows of 4 .. 32 floats, 16-byte aligned, no epilogue beyond row scale / bias / ReLU
+bool plan_applies(const GrArgs& a) {
+    return a.plan && !a.addend && !a.gate && !a.table_scale && a.d % 4 == 0 && a.d <= 32 && tipk_plan::group_slots_for(a.d) == a.plan->G &&
+           a.ld_t % 4 == 0 && a.ld_out % 4 == 0 && !(reinterpret_cast<uintptr_t>(a.table) & 15) && !(reinterpret_cast<uintptr_t>(a.out) & 15);
+}
+
 int gr_launch(const GrArgs& a, hipStream_t st) {
     if (a.n_out <= 0) return TIPK_OK;
+    if (plan_applies(a))
+        return tipk_gather_sum(a.table, a.ld_t, a.plan->n_table, a.plan->row_id, a.edge_w ? a.plan->edge_w : nullptr, a.plan->items,
+                               a.plan->n_items, a.out, a.ld_out, nullptr, a.out_scale, a.bias, a.relu, a.d, a.plan->G, (tipk_stream_t)st);
     const int64_t blocks = tipk_ceil_div(a.n_out, (int64_t)4);
     if (blocks > 0x7fffffffLL) return TIPK_EUNSUPPORTED;
     hipLaunchKernelGGL(graph_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -156,6 +175,57 @@ tipk_gemm_desc gemm_desc(int64_t m, int64_t n, int64_t k, const float* a, int64_
 }
 
 inline int64_t align256(int64_t bytes) { return (bytes + 255) / 256 * 256; }
+
+// C [m x n] (rows contiguous) = A . B with a LONG reduction and few output tiles (weight gradients: K = the node count): the k
+// range is cut into slabs that fill the chip, added in order afterwards (tipk_gemm_f32 ksplit + tipk_sum_slabs_ex) -- one
+// workgroup walking 19 081 terms took 0.8 ms.  reduce_slabs = slabs of the split (0: the plain product), `slabs` = that many
+// m x n blocks of the caller's workspace
+int64_t reduce_slabs(int64_t m, int64_t n, int64_t k) {
+    const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
+    const int64_t want = std::min((k + 63) / 64, (512 + tiles - 1) / tiles);
+    if (want < 2 || tiles >= 256 || m * n > 65536) return 0;
+    return std::min<int64_t>(320, want);
+}
+
+int reduce_gemm(tipk_gemm_desc d, float* slabs, tipk_stream_t stream) {
+    const int64_t ns = reduce_slabs(d.m, d.n, d.k);
+    if (!ns || d.c_sm != d.n || d.batch != 1 || d.kbatch != 1 || d.c_in || d.relu || d.alpha != 1.f) return tipk_gemm_f32(&d, stream);
+    float* out = d.c;
+    d.ksplit = ns; d.c = slabs; d.c_ss = d.m * d.n;
+    const int st = tipk_gemm_f32(&d, stream);
+    if (st != TIPK_OK) return st;
+    return tipk_sum_slabs_ex(slabs, ns, d.m * d.n, d.m * d.n, 1.f, 0, nullptr, d.n, nullptr, 0, out, stream);
+}
+
+void free_gather(GatherDev* p) {
+    if (!p) return;
+    if (p->row_id) (void)hipFree(p->row_id);
+    if (p->edge_w) (void)hipFree(p->edge_w);
+    if (p->items) (void)hipFree(p->items);
+    delete p;
+}
+
+// work items for out[o] = sum_e w[e] table[t_e] (grouped plan, G = 128), uploaded; *out stays null when the graph is too large
+// for 32-bit plans or an allocation fails (the wavefront-per-row kernel then runs)
+void build_gather_dev(const std::vector<int64_t>& orow, const std::vector<int64_t>& trow, const float* w, int64_t n_out, int64_t n_table,
+                      GatherDev** out) {
+    *out = nullptr;
+    const int64_t e = (int64_t)orow.size();
+    if (e >= 0x7fffffffLL || n_out >= (1 << 26) || n_table >= 0x7fffffffLL) return;
+    tipk_plan::GatherPlanH gp;
+    tipk_plan::build_gather_plan(orow.data(), trow.data(), w, e, n_out, n_table, 0, 128, gp);
+    GatherDev* d = new (std::nothrow) GatherDev;
+    if (!d) return;
+    auto up = [&](void** dev, const void* host, size_t bytes) {
+        if (hipMalloc(dev, bytes ? bytes : 4) != hipSuccess) { *dev = nullptr; return false; }
+        return !bytes || hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    bool ok = up((void**)&d->row_id, gp.row_id.data(), gp.row_id.size() * 4) && up((void**)&d->items, gp.items.data(), gp.items.size() * 4);
+    if (ok && w) ok = up((void**)&d->edge_w, gp.edge_w.data(), gp.edge_w.size() * 4);
+    if (!ok) { free_gather(d); return; }
+    d->n_items = gp.n_items; d->n_table = n_table; d->G = 128;
+    *out = d;
+}
 
 // workspace layout (floats): XB [nb][N][d_out] | Y or dY [R N][d_out] | xroot / g' [N][d_out] | d XB [nb][N][d_out]
 struct Ws { float* xb; float* y; float* t; float* dxb; int64_t bytes; };
@@ -253,6 +323,18 @@ extern "C" int tipk_graph_build(const void* edge_index, const void* edge_type, c
     if (st == TIPK_OK) st = up((void**)&g->bwd_row, brow.data(), brow.size() * 4);
     if (st == TIPK_OK) st = up((void**)&g->inv_deg, inv.data(), inv.size() * 4);
     if (st != TIPK_OK) { tipk_graph_destroy(g); return st; }
+    // work-item plans of the same two gathers (rows of <= 32 floats): few destination rows with thousands of edges each -- BioSNAP:
+    // 645 rows of 12 900 -- are 645 wavefronts on the per-row kernel; 1 / deg of the destination is folded into the transposed
+    // plan's edge weights.  Not for (relation, node) spaces beyond 4 M rows (config 5: the plan would outweigh the CSR)
+    if (n_rel * n_nodes <= (1 << 22) && n_edges > 0) {
+        std::vector<int64_t> orow((size_t)n_edges), trow((size_t)n_edges);
+        std::vector<float> w((size_t)n_edges);
+        for (int64_t i = 0; i < n_edges; ++i) {
+            orow[(size_t)i] = dst[i]; trow[(size_t)i] = rel[(size_t)i] * n_nodes + src[i]; w[(size_t)i] = inv[(size_t)dst[i]];
+        }
+        build_gather_dev(orow, trow, nullptr, n_nodes, n_rel * n_nodes, &g->pf);
+        build_gather_dev(trow, orow, w.data(), n_rel * n_nodes, n_nodes, &g->pb);
+    }
     // the edge list stays on the host (12 bytes per edge) for tipk_graph_prepare_rgcn, until tipk_graph_release_host
     g->host = new (std::nothrow) HostEdges;
     g->routes = new (std::nothrow) std::vector<PairRoute*>;
@@ -279,6 +361,8 @@ extern "C" int tipk_graph_destroy(tipk_graph* g) {
         }
         delete g->routes;
     }
+    free_gather(g->pf);
+    free_gather(g->pb);
     delete g->host;
     delete g;
     return st;
@@ -525,7 +609,15 @@ extern "C" int tipk_rgcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, 
     GrArgs a;
     memset(&a, 0, sizeof(a));
     a.table = w.y; a.ld_t = d_out; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = n;
-    a.out_scale = g->inv_deg; a.addend = w.t; a.ld_add = d_out; a.relu = relu; a.d = d_out; a.out = out; a.ld_out = ld_out;
+    a.out_scale = g->inv_deg; a.d = d_out; a.plan = g->pf;
+    a.out = w.dxb; a.ld_out = d_out;                                            // (d XB's place is free in the forward pass)
+    if (ld_out == d_out && plan_applies(a)) {
+        // work items: the scaled aggregate first, then + X root and the ReLU in the ordered-sum kernel (one "slab")
+        if ((st = gr_launch(a, (hipStream_t)stream)) != TIPK_OK) return st;
+        return tipk_sum_slabs_ex(w.dxb, 1, n * d_out, n * d_out, 1.f, 0, nullptr, d_out, w.t, relu, out, stream);
+    }
+    a.plan = nullptr;
+    a.addend = w.t; a.ld_add = d_out; a.relu = relu; a.out = out; a.ld_out = ld_out;
     return gr_launch(a, (hipStream_t)stream);
 }
 
@@ -595,8 +687,10 @@ extern "C" int tipk_rgcn_bwd_ex(const tipk_graph* g, const float* x, int64_t ld_
         // dY[(r, u)] = sum over the edges (r, u) -> v of g'[v] / deg[v]
         GrArgs a;
         memset(&a, 0, sizeof(a));
-        a.table = gp; a.ld_t = ld_gp; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = r * n; a.table_scale = g->inv_deg;
-        a.d = d_out; a.out = w.y; a.ld_out = d_out;
+        a.table = gp; a.ld_t = ld_gp; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = r * n;
+        a.d = d_out; a.out = w.y; a.ld_out = d_out; a.plan = g->pb;
+        if (plan_applies(a)) a.edge_w = g->inv_deg;                            // (non-null = "weighted": the plan carries 1 / deg per edge)
+        else { a.plan = nullptr; a.table_scale = g->inv_deg; }
         if ((st = gr_launch(a, hs)) != TIPK_OK) return st;
         // d att = dY . XB^T  [R, bases],  d XB = att^T . dY  [bases, N d_out]
         d = gemm_desc(r, n_bases, n * d_out, w.y, n * d_out, 1, w.xb, 1, n * d_out, g_att, n_bases);
@@ -641,6 +735,10 @@ int build_weighted(tipk_graph* g, const std::vector<int64_t>& orow, const std::v
     if (st == TIPK_OK) st = up((void**)&g->fwd_w, fw.data(), e * 4);
     if (st == TIPK_OK) st = up((void**)&g->bwd_w, bw.data(), e * 4);
     g->n_out = n_out; g->n_table = n_table; g->n_edges = (int64_t)e;
+    if (st == TIPK_OK && e > 0) {
+        build_gather_dev(orow, trow, w.data(), n_out, n_table, &g->pf);
+        build_gather_dev(trow, orow, w.data(), n_table, n_out, &g->pb);
+    }
     return st;
 }
 
@@ -699,7 +797,9 @@ extern "C" int tipk_gcn_graph_build(const void* edge_index, int idx_bytes, int64
 
 extern "C" int64_t tipk_gcn_workspace_bytes(const tipk_graph* g, int d_in, int d_out) {
     if (!g || g->kind != 1 || d_out <= 0) return -1;
-    return 2 * align256(g->n_nodes * (int64_t)d_out * 4) + align256(256 * (int64_t)d_out * 4);
+    // [g' | d lin | column-sum scratch | slabs of the split d W product (dense features of modest width)]
+    const int64_t slabs = d_in > 0 ? reduce_slabs(d_out, d_in, g->n_nodes) : 0;
+    return 2 * align256(g->n_nodes * (int64_t)d_out * 4) + align256(256 * (int64_t)d_out * 4) + align256(slabs * d_out * (int64_t)d_in * 4);
 }
 
 // out = relu?( A_hat (x W^T) + bias );  x = NULL: identity features (lin(I) = W^T: d_in = n_nodes); weight element (o, i) at
@@ -725,7 +825,7 @@ extern "C" int tipk_gcn_fwd(const tipk_graph* g, const float* x, int64_t ld_x, i
         if (w_so != 1) return TIPK_EUNSUPPORTED;
         a.table = weight; a.ld_t = w_si;
     }
-    a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = n; a.edge_w = g->fwd_w; a.bias = bias; a.relu = relu; a.d = d_out;
+    a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = n; a.edge_w = g->fwd_w; a.bias = bias; a.relu = relu; a.d = d_out; a.plan = g->pf;
     a.out = out; a.ld_out = ld_out;
     return gr_launch(a, (hipStream_t)stream);
 }
@@ -758,14 +858,14 @@ extern "C" int tipk_gcn_bwd(const tipk_graph* g, const float* x, int64_t ld_x, i
     if (!x && gw_so == 1) { gxl_out = g_weight; ld_gxl = gw_si; }              // identity features: d W = (d lin)^T, written in place
     GrArgs a;
     memset(&a, 0, sizeof(a));
-    a.table = gp; a.ld_t = ld_gp; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = n; a.edge_w = g->bwd_w; a.d = d_out;
+    a.table = gp; a.ld_t = ld_gp; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = n; a.edge_w = g->bwd_w; a.d = d_out; a.plan = g->pb;
     a.out = gxl_out; a.ld_out = ld_gxl;
     if ((st = gr_launch(a, hs)) != TIPK_OK) return st;
     if (!x) return gw_so == 1 ? TIPK_OK : TIPK_EUNSUPPORTED;
     // d W (o, i) = sum_v gxl[v, o] x[v, i];  d x = gxl W
     tipk_gemm_desc d = gemm_desc(d_out, d_in, n, gxl, 1, d_out, x, ld_x, 1, g_weight, gw_so);
     if (gw_si != 1) return TIPK_EUNSUPPORTED;
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    if ((st = reduce_gemm(d, scratch + align256(256 * (int64_t)d_out * 4) / 4, stream)) != TIPK_OK) return st;
     if (g_x) {
         d = gemm_desc(n, d_in, d_out, gxl, d_out, 1, weight, w_so, w_si, g_x, ld_gx);
         if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
@@ -807,7 +907,7 @@ extern "C" int tipk_hier_graph_build(const void* edge_index, int idx_bytes, int6
 
 extern "C" int64_t tipk_hier_workspace_bytes(const tipk_graph* g, int d_in, int d_out) {
     if (!g || g->kind != 2 || d_in <= 0 || d_out <= 0) return -1;
-    return 2 * align256(g->n_out * (int64_t)d_in * 4);
+    return 2 * align256(g->n_out * (int64_t)d_in * 4) + align256(reduce_slabs(d_in, d_out, g->n_out) * d_in * (int64_t)d_out * 4);
 }
 
 // out [n_target x d_out] = mean(x over incoming edges) . weight;  x [n_all x d_in], weight [d_in x d_out] contiguous
@@ -818,7 +918,7 @@ extern "C" int tipk_hier_fwd(const tipk_graph* g, const float* x, int64_t ld_x, 
     float* mean = (float*)workspace;
     GrArgs a;
     memset(&a, 0, sizeof(a));
-    a.table = x; a.ld_t = ld_x; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = g->n_out; a.edge_w = g->fwd_w; a.d = d_in;
+    a.table = x; a.ld_t = ld_x; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = g->n_out; a.edge_w = g->fwd_w; a.d = d_in; a.plan = g->pf;
     a.out = mean; a.ld_out = d_in;
     int st = gr_launch(a, (hipStream_t)stream);
     if (st != TIPK_OK) return st;
@@ -838,17 +938,17 @@ extern "C" int tipk_hier_bwd(const tipk_graph* g, const float* x, int64_t ld_x, 
     float* g_mean = (float*)((char*)workspace + align256(g->n_out * (int64_t)d_in * 4));
     GrArgs a;
     memset(&a, 0, sizeof(a));
-    a.table = x; a.ld_t = ld_x; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = g->n_out; a.edge_w = g->fwd_w; a.d = d_in;
+    a.table = x; a.ld_t = ld_x; a.ptr = g->fwd_ptr; a.row = g->fwd_row; a.n_out = g->n_out; a.edge_w = g->fwd_w; a.d = d_in; a.plan = g->pf;
     a.out = mean; a.ld_out = d_in;
     int st = gr_launch(a, hs);                                                 // the mean again (nothing is kept between the calls)
     if (st != TIPK_OK) return st;
     tipk_gemm_desc d = gemm_desc(d_in, d_out, g->n_out, mean, 1, d_in, grad_out, ld_g, 1, g_weight, d_out);     // mean^T g
-    if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
+    if ((st = reduce_gemm(d, g_mean + align256(g->n_out * (int64_t)d_in * 4) / 4, stream)) != TIPK_OK) return st;
     if (!g_x) return TIPK_OK;
     d = gemm_desc(g->n_out, d_in, d_out, grad_out, ld_g, 1, weight, 1, d_out, g_mean, d_in);                     // g W^T
     if ((st = tipk_gemm_f32(&d, stream)) != TIPK_OK) return st;
     memset(&a, 0, sizeof(a));
-    a.table = g_mean; a.ld_t = d_in; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = g->n_table; a.edge_w = g->bwd_w; a.d = d_in;
+    a.table = g_mean; a.ld_t = d_in; a.ptr = g->bwd_ptr; a.row = g->bwd_row; a.n_out = g->n_table; a.edge_w = g->bwd_w; a.d = d_in; a.plan = g->pb;
     a.out = g_x; a.ld_out = ld_gx;
     return gr_launch(a, hs);                                                   // rows nobody reads from: zeros
 }

@@ -30,6 +30,16 @@ struct PairBwdH {
     StreamPlanH gather;
 };
 
+// arrays of tipk_gather_sum on a GROUPED plan (include/tipk.h section 1; tip_amd/plan.py `build_gather_plan` with group_slots > 0)
+struct GatherPlanH {
+    int64_t n_out = 0, n_table = 0, n_edges = 0, n_items = 0;
+    int chunk = 0, group_slots = 0;
+    std::vector<int32_t> row_id;            // [n_edges] table row per edge, edges sorted by output row (stable)
+    std::vector<float> edge_w;              // [n_edges] in the same order (empty: no weights)
+    std::vector<int32_t> items;             // [n_items][4] {begin, end, target, flags}
+    std::vector<int64_t> perm;              // plan order -> caller's edge order
+};
+
 constexpr int STREAM_WIDE_STEPS = 16;
 constexpr int PAIR_PART_ROWS = 1016, PAIR_PART_WGS = 4, PAIR_PART_EDGES_PER_WG = 16384;
 
@@ -41,6 +51,12 @@ void build_stream_plan_rows(const int64_t* out_row, const int64_t* tab_row, int6
 // graph was declared symmetric and is not
 bool build_pair_bwd_plan(const int64_t* src, const int64_t* dst, const int64_t* rel, int64_t n_edges, int64_t n_nodes, int64_t n_rel,
                          const float* scale, bool symmetric, int n_wg, int lanes, int piece, PairBwdH& pb);
+
+// out[o] = sum over the edges with out_row[e] == o of edge_w[e] * table[table_row[e]]; chunk 0 = chosen from the edge count;
+// group_slots = the block size G (split rows are combined inside one workgroup): `group_slots_for(d)`
+void build_gather_plan(const int64_t* out_row, const int64_t* table_row, const float* edge_w /* nullable */, int64_t n_edges, int64_t n_out,
+                       int64_t n_table, int chunk, int group_slots, GatherPlanH& gp);
+int group_slots_for(int d);
 
 // uint32 [n_nodes padded to 8][ceil(n_nodes / 32)]: bit r of word (u, t) = some edge links u -> 32 t + r
 void pair_link_words(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n_nodes, std::vector<uint32_t>& words);

@@ -441,6 +441,101 @@ bool build_pair_bwd_plan(const int64_t* src, const int64_t* dst, const int64_t* 
     return true;
 }
 
+int group_slots_for(int d) {
+    int lanes = 1;
+    const int need = d % 4 == 0 ? d / 4 : d;
+    while (lanes < need) lanes *= 2;
+    return std::max(std::min(128, 1024 / lanes), 64 / lanes);
+}
+
+void build_gather_plan(const int64_t* out_row, const int64_t* table_row, const float* edge_w, int64_t E, int64_t n_out, int64_t n_table,
+                       int chunk, int G, GatherPlanH& gp) {
+    enum { ITEM_DIRECT = 1, ITEM_PIECE = 2, ITEM_LEADER = 4, ITEM_NULL = 8 };
+    if (chunk <= 0) {                                                          // plan.py auto_chunk
+        const int64_t target = E <= (1 << 22) ? 65536 * 2 : 65536;
+        chunk = 16;
+        while (chunk < 128 && E / chunk > target) chunk *= 2;
+    }
+    // edges by output row, stable
+    std::vector<int64_t> row_ptr((size_t)n_out + 1, 0);
+    for (int64_t e = 0; e < E; ++e) ++row_ptr[(size_t)out_row[e] + 1];
+    for (int64_t r = 0; r < n_out; ++r) row_ptr[(size_t)r + 1] += row_ptr[(size_t)r];
+    gp.perm.resize((size_t)E); gp.row_id.resize((size_t)E);
+    gp.edge_w.clear();
+    if (edge_w) gp.edge_w.resize((size_t)E);
+    {
+        std::vector<int64_t> pos(row_ptr.begin(), row_ptr.end() - 1);
+        for (int64_t e = 0; e < E; ++e) {
+            const int64_t p = pos[(size_t)out_row[e]]++;
+            gp.perm[(size_t)p] = e;
+            gp.row_id[(size_t)p] = (int32_t)table_row[e];
+            if (edge_w) gp.edge_w[(size_t)p] = edge_w[e];
+        }
+    }
+    // pieces per row (hub rows: at most G balanced pieces, one workgroup)
+    std::vector<int64_t> n_chunks((size_t)n_out), piece_len((size_t)n_out);
+    for (int64_t r = 0; r < n_out; ++r) {
+        const int64_t cnt = row_ptr[(size_t)r + 1] - row_ptr[(size_t)r];
+        int64_t nc = std::max<int64_t>(cdiv(cnt, chunk), 1);
+        nc = std::min<int64_t>(nc, G);
+        n_chunks[(size_t)r] = nc;
+        piece_len[(size_t)r] = std::max<int64_t>(cdiv(cnt, nc), 1);
+    }
+    auto piece = [&](int64_t r, int64_t local, int64_t& begin, int64_t& end) {
+        const int64_t row_end = row_ptr[(size_t)r + 1];
+        begin = std::min(row_ptr[(size_t)r] + local * piece_len[(size_t)r], row_end);
+        end = std::min(begin + piece_len[(size_t)r], row_end);
+    };
+    // split rows: best-fit-decreasing packing of their pieces into blocks of G consecutive slots (plan.py pack_blocks)
+    std::vector<int64_t> split;
+    for (int64_t r = 0; r < n_out; ++r)
+        if (n_chunks[(size_t)r] > 1) split.push_back(r);
+    std::vector<int64_t> order(split.size());
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return n_chunks[(size_t)split[(size_t)a]] > n_chunks[(size_t)split[(size_t)b]]; });
+    std::vector<std::vector<int64_t>> free_((size_t)G + 1);
+    std::vector<int64_t> used, block(split.size()), offset(split.size());
+    for (int64_t i : order) {
+        const int64_t pc = n_chunks[(size_t)split[(size_t)i]];
+        int64_t b = -1;
+        for (int64_t c = pc; c <= G; ++c)
+            if (!free_[(size_t)c].empty()) { b = free_[(size_t)c].back(); free_[(size_t)c].pop_back(); break; }
+        if (b < 0) { b = (int64_t)used.size(); used.push_back(0); }
+        block[(size_t)i] = b; offset[(size_t)i] = used[(size_t)b];
+        used[(size_t)b] += pc;
+        if (G - used[(size_t)b] > 0) free_[(size_t)(G - used[(size_t)b])].push_back(b);
+    }
+    const int64_t n_blocks = (int64_t)used.size();
+    // direct rows, longest first (stable)
+    std::vector<int64_t> direct;
+    for (int64_t r = 0; r < n_out; ++r)
+        if (n_chunks[(size_t)r] == 1) direct.push_back(r);
+    std::stable_sort(direct.begin(), direct.end(), [&](int64_t a, int64_t b) {
+        return row_ptr[(size_t)a + 1] - row_ptr[(size_t)a] > row_ptr[(size_t)b + 1] - row_ptr[(size_t)b];
+    });
+    gp.n_items = n_blocks * G + (int64_t)direct.size();
+    gp.items.assign((size_t)gp.n_items * 4, 0);
+    for (int64_t i = 0; i < n_blocks * G; ++i) gp.items[(size_t)i * 4 + 3] = ITEM_NULL;
+    for (size_t i = 0; i < split.size(); ++i) {
+        const int64_t r = split[i], pc = n_chunks[(size_t)r], base = block[i] * G + offset[i];
+        for (int64_t l = 0; l < pc; ++l) {
+            int64_t b, e;
+            piece(r, l, b, e);
+            int32_t* it = &gp.items[(size_t)(base + l) * 4];
+            it[0] = (int32_t)b; it[1] = (int32_t)e; it[2] = (int32_t)r;
+            it[3] = (int32_t)(l == 0 ? (ITEM_PIECE | ITEM_LEADER | (pc << 8)) : ITEM_PIECE);
+        }
+    }
+    for (size_t i = 0; i < direct.size(); ++i) {
+        const int64_t r = direct[i];
+        int64_t b, e;
+        piece(r, 0, b, e);
+        int32_t* it = &gp.items[(size_t)(n_blocks * G + (int64_t)i) * 4];
+        it[0] = (int32_t)b; it[1] = (int32_t)e; it[2] = (int32_t)r; it[3] = ITEM_DIRECT;
+    }
+    gp.n_out = n_out; gp.n_table = n_table; gp.n_edges = E; gp.chunk = chunk; gp.group_slots = G;
+}
+
 void pair_link_words(const int64_t* src, const int64_t* dst, int64_t n_edges, int64_t n, std::vector<uint32_t>& words) {
     const int64_t n8 = cdiv(n, 8) * 8, lw = cdiv(n, 32);
     words.assign((size_t)(n8 * lw), 0u);
@@ -531,6 +626,26 @@ extern "C" int tipk_plan_pair_bwd(const int64_t* src, const int64_t* dst, const 
     h->scalars["n_slots"] = pb.n_slots; h->scalars["n_parts"] = pb.n_parts; h->scalars["part_len"] = pb.part_len;
     h->scalars["n_alloc"] = pb.n_alloc; h->scalars["symmetric"] = pb.symmetric;
     put_stream(h, pb.gather, "gather.");
+    *out = h;
+    return TIPK_OK;
+}
+
+extern "C" int tipk_plan_gather(const int64_t* out_row, const int64_t* table_row, const float* edge_w, int64_t n_edges, int64_t n_out,
+                                int64_t n_table, int chunk, int group_slots, tipk_host_plan** out) {
+    if (!out) return TIPK_EINVAL;
+    *out = nullptr;
+    if (n_edges < 0 || (n_edges > 0 && (!out_row || !table_row)) || n_out <= 0 || n_table <= 0 || chunk < 0 || group_slots <= 0 ||
+        group_slots > 1024 || n_edges >= 0x7fffffffLL || n_out >= 0x7fffffffLL || n_table >= 0x7fffffffLL)
+        return TIPK_EINVAL;
+    for (int64_t e = 0; e < n_edges; ++e)
+        if (out_row[e] < 0 || out_row[e] >= n_out || table_row[e] < 0 || table_row[e] >= n_table) return TIPK_EINVAL;
+    tipk_host_plan* h = new (std::nothrow) tipk_host_plan;
+    if (!h) return TIPK_EINVAL;
+    tipk_plan::GatherPlanH gp;
+    tipk_plan::build_gather_plan(out_row, table_row, edge_w, n_edges, n_out, n_table, chunk, group_slots, gp);
+    h->put("row_id", gp.row_id); h->put("edge_w", gp.edge_w); h->put("items", gp.items); h->put("perm", gp.perm);
+    h->scalars["n_items"] = gp.n_items; h->scalars["chunk"] = gp.chunk; h->scalars["group_slots"] = gp.group_slots;
+    h->scalars["n_edges"] = gp.n_edges; h->scalars["n_out"] = gp.n_out; h->scalars["n_table"] = gp.n_table;
     *out = h;
     return TIPK_OK;
 }
