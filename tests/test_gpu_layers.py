@@ -488,6 +488,60 @@ def biosnap_full():
     return build_data_dict()
 
 
+def test_graph_handle_full_biosnap_both_layers_match_the_modules(biosnap_full):
+    """BASELINE config 2's D-D graph at full size (645 drugs, 1 097 relations, 8.3 M edges) through the op-level handle: both
+    R-GCN layers (64 -> 32 with the ReLU inside, 32 -> 16) forward + backward on plans the library built in C++, against the
+    PyTorch modules on `plan.py`'s plans -- the same bits -- and the handle's GENERIC route (work-item gathers) within tolerance."""
+    import ctypes as C
+    from tip_amd import _lib
+    from tip_amd.layers import MyRGCNConv2
+    L = _lib.lib()
+    dd = biosnap_full
+    n, r = dd['n_drug'], dd['n_dd_et']
+    ei, rg = dd['dd_train_idx'].to(DEV), dd['dd_train_range'].to(DEV)
+    torch.manual_seed(3)
+    m1, m2 = MyRGCNConv2(64, 32, r, 32, after_relu=False).to(DEV), MyRGCNConv2(32, 16, r, 32, after_relu=True).to(DEV)
+    x = torch.randn(n, 64, device=DEV).requires_grad_(True)
+    up = torch.randn(n, 16, device=DEV)
+    h1 = torch.relu(m1(x, ei, None, rg))
+    h1.retain_grad()
+    z = m2(h1, ei, None, rg)
+    z.backward(up)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(h, prepared):
+        par = [[t.detach().contiguous() for t in (m.basis, m.att, m.root)] for m in (m1, m2)]
+        ws = [torch.empty(L.tipk_rgcn_workspace_bytes(h, di, do, 32), dtype=torch.uint8, device=DEV) for di, do in ((64, 32), (32, 16))]
+        o1, o2 = torch.empty(n, 32, device=DEV), torch.empty(n, 16, device=DEV)
+        xd = x.detach()
+        assert L.tipk_rgcn_fwd(h, ptr(xd), 64, 64, ptr(par[0][0]), ptr(par[0][1]), ptr(par[0][2]), 32, 32, 1, ptr(o1), 32, ptr(ws[0]),
+                               ws[0].numel(), st) == 0
+        assert L.tipk_rgcn_fwd(h, ptr(o1), 32, 32, ptr(par[1][0]), ptr(par[1][1]), ptr(par[1][2]), 32, 16, 0, ptr(o2), 16, ptr(ws[1]),
+                               ws[1].numel(), st) == 0
+        g2 = [torch.empty_like(t) for t in [o1] + par[1]]
+        assert L.tipk_rgcn_bwd_ex(h, ptr(o1), 32, 32, ptr(par[1][0]), ptr(par[1][1]), ptr(par[1][2]), 32, 16, ptr(up), 16, None, 0,
+                                  ptr(g2[0]), 32, ptr(g2[1]), ptr(g2[2]), ptr(g2[3]), ptr(ws[1]), ws[1].numel(), int(prepared), st) == 0
+        g1 = [torch.empty_like(t) for t in [xd] + par[0]]
+        assert L.tipk_rgcn_bwd_ex(h, ptr(xd), 64, 64, ptr(par[0][0]), ptr(par[0][1]), ptr(par[0][2]), 32, 32, ptr(g2[0]), 32, ptr(o1), 32,
+                                  ptr(g1[0]), 64, ptr(g1[1]), ptr(g1[2]), ptr(g1[3]), ptr(ws[0]), ws[0].numel(), int(prepared), st) == 0
+        return [o1, o2] + g2 + g1
+
+    want = [h1.detach(), z.detach(), h1.grad, m2.basis.grad, m2.att.grad, m2.root.grad, x.grad, m1.basis.grad, m1.att.grad, m1.root.grad]
+    h = C.c_void_p()
+    assert L.tipk_graph_build(ptr(ei), None, ptr(rg), 8, ei.shape[1], n, r, None, C.byref(h)) == 0
+    try:
+        generic = run(h, False)
+        for got, ref in zip(generic, want):
+            close(got, ref, rtol=1e-4, atol=2e-5 * float(ref.abs().max()))
+        assert L.tipk_graph_prepare_rgcn(h, 32, 32) == 0 and L.tipk_graph_prepare_rgcn(h, 32, 16) == 0
+        assert L.tipk_graph_rgcn_route(h, 32, 32) == 2 and L.tipk_graph_rgcn_route(h, 32, 16) == 2
+        for got, ref in zip(run(h, True), want):
+            assert torch.equal(got, ref)
+    finally:
+        assert L.tipk_graph_destroy(h) == 0
+
+
 @pytest.mark.parametrize('mod,generic', [('cat', False), ('add', False), ('cat', True)])
 def test_full_biosnap_encoder_vs_oracle(biosnap_full, mod, generic, monkeypatch):
     """BASELINE configs 2 and 3 at full size: z and all parameter gradients vs the CPU oracle.
