@@ -1123,10 +1123,17 @@ def main():
     # measured 0.377 ms/step with the order reversed against 0.36 here and for --steps 100 either way)
     launches = [] if args.step_only else dd_launches(enc, dev)
     launch_us = {l['label']: time_launch_us(l['fn']) for l in launches if l['work'] is not None}
-    settle = args.settle if launch == 'graph' else 0
-    for _ in range(settle):                                    # (untimed; the contract's W warm-up steps and K timed steps follow)
-        run()
-    fence()
+    settle = 0
+    if launch == 'graph' and args.settle > 0:                  # (untimed; the contract's W warm-up steps and K timed steps follow)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run()
+        fence()
+        per = (time.perf_counter() - t0) / 3
+        settle = 3 + max(0, min(args.settle - 3, int(0.05 / max(per, 1e-6))))     # at most ~50 ms of them (config 5, oversubscribed ranks)
+        for _ in range(settle - 3):
+            run()
+        fence()
     elapsed = timed(run, args.steps, args.warmup, fence)
     replay_stats = None
     if world == 1 and not args.step_only:
