@@ -1131,6 +1131,10 @@ def main():
         fence()
         per = (time.perf_counter() - t0) / 3
         settle = 3 + max(0, min(args.settle - 3, int(0.05 / max(per, 1e-6))))     # at most ~50 ms of them (config 5, oversubscribed ranks)
+        if world > 1:                                          # every rank replays the SAME number of steps (they hold collectives)
+            agreed = torch.tensor([settle], dtype=torch.int64, device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            settle = int(agreed.item())
         for _ in range(settle - 3):
             run()
         fence()
