@@ -1124,23 +1124,13 @@ def main():
     launches = [] if args.step_only else dd_launches(enc, dev)
     launch_us = {l['label']: time_launch_us(l['fn']) for l in launches if l['work'] is not None}
     settle = 0
-    do_settle = launch == 'graph' and args.settle > 0
-    if world > 1:                                              # (a rank whose capture fell back to eager steps: nobody settles)
-        tdev = dev if dist.get_backend() == 'nccl' else torch.device('cpu')
-        flag = torch.tensor([int(do_settle)], dtype=torch.int64, device=tdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        do_settle = bool(flag.item())
-    if do_settle:                                              # (untimed; the contract's W warm-up steps and K timed steps follow)
-        t0 = time.perf_counter()
-        for _ in range(3):
+    if launch == 'graph' and args.settle > 0 and world == 1:   # (untimed; the contract's W warm-up steps and K timed steps follow.
+        t0 = time.perf_counter()                               # One rank only: an N-rank step holds collectives, and nothing that
+        for _ in range(3):                                     # could make the ranks disagree on a count belongs in front of them)
             run()
         fence()
         per = (time.perf_counter() - t0) / 3
-        settle = 3 + max(0, min(args.settle - 3, int(0.05 / max(per, 1e-6))))     # at most ~50 ms of them (config 5, oversubscribed ranks)
-        if world > 1:                                          # every rank replays the SAME number of steps (they hold collectives)
-            agreed = torch.tensor([settle], dtype=torch.int64, device=tdev)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-            settle = int(agreed.item())
+        settle = 3 + max(0, min(args.settle - 3, int(0.05 / max(per, 1e-6))))     # at most ~50 ms of them (config 5)
         for _ in range(settle - 3):
             run()
         fence()
